@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own code.
+
+Run only in the build container (needs /root/reference; never on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What is reference code and what is not:
+  * imported unmodified from /root/reference: ``core_functions.vision.{fast_adapt,accuracy}``,
+    ``utils.data_pre.prepare_batch``, ``core_functions.vision_models.{MiniImagenetCNN,OmniglotCNN,ConvBase}``,
+    ``core_functions.policies.{DiagNormalPolicy,DiagNormalPolicyANIL}``;
+  * absent third-party packages (learn2learn, cherry, torchvision, gym, ...) are replaced by inert module stubs so the
+    imports succeed; none of their code is executed;
+  * the learn2learn learner (``MAML.clone/adapt``) is replaced by ``StandInLearner`` below, a duck type restating l2l's
+    published semantics (parity UNPINNED at that boundary -- see oracle/__init__.py).
+Inputs/weights come from the build's hash generator (exploring_meta_amd/utils/synthetic.py), so fixtures store seeds
+plus the expected outputs only.
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from exploring_meta_amd.utils import synthetic  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, '/root/reference')
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith('__'):
+                raise AttributeError(k)
+            return sys.modules.get(self.__name__ + '.' + k) or type(k, (), {})
+
+    names = ['learn2learn', 'learn2learn.data', 'learn2learn.data.transforms', 'learn2learn.vision',
+             'learn2learn.vision.transforms', 'learn2learn.algorithms', 'learn2learn.algorithms.maml',
+             'learn2learn.utils', 'learn2learn.gym', 'learn2learn.gym.envs', 'learn2learn.gym.envs.meta_env',
+             'torchvision', 'torchvision.transforms', 'cherry', 'cherry.algorithms', 'cherry.pg', 'cherry._utils',
+             'cherry.envs', 'cherry.envs.base', 'gym', 'torchsummary', 'wandb', 'metaworld', 'metaworld.envs',
+             'metaworld.envs.mujoco', 'metaworld.envs.mujoco.multitask_env', 'metaworld.benchmarks', 'PIL', 'PIL.Image']
+    for n in names:
+        try:                       # keep anything that is really installed (PIL is, via matplotlib)
+            __import__(n)
+            continue
+        except Exception:
+            pass
+        m = _Any(n)
+        m.__path__ = []
+        sys.modules.setdefault(n, m)
+    from core_functions.vision import fast_adapt, accuracy
+    from core_functions.vision_models import MiniImagenetCNN, OmniglotCNN, ConvBase
+    from core_functions.policies import DiagNormalPolicy, DiagNormalPolicyANIL
+    from utils.data_pre import prepare_batch
+    return dict(fast_adapt=fast_adapt, accuracy=accuracy, MiniImagenetCNN=MiniImagenetCNN, OmniglotCNN=OmniglotCNN,
+                ConvBase=ConvBase, DiagNormalPolicy=DiagNormalPolicy, DiagNormalPolicyANIL=DiagNormalPolicyANIL,
+                prepare_batch=prepare_batch)
+
+
+class StandInLearner:
+    """Duck type of an l2l ``MAML`` clone: ``__call__`` + ``adapt`` (vision.py:11,13).  clone_module = per-parameter
+    ``clone()``; buffers stay those of the wrapped module (shared, mutated in place by BN like l2l)."""
+
+    def __init__(self, module, lr, first_order):
+        self.module, self.lr, self.first_order = module, lr, first_order
+        self.params = {k: p.clone() for k, p in module.named_parameters()}
+
+    def __call__(self, x):
+        return torch.func.functional_call(self.module, self.params, (x,))
+
+    def adapt(self, loss):
+        so = not self.first_order
+        g = torch.autograd.grad(loss, list(self.params.values()), retain_graph=so, create_graph=so)
+        self.params = {k: p - self.lr * gi for (k, p), gi in zip(self.params.items(), g)}
+
+
+def load_hash_weights(module, seed, dtype):
+    shapes = {k: tuple(v.shape) for k, v in module.named_parameters()}
+    w = synthetic.hash_weights(shapes, seed)
+    module.to(dtype)
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            p.copy_(torch.from_numpy(w[k]).to(dtype))
+    return module
+
+
+def g1_prepare_batch(ref, out):
+    for ways, shots in [(5, 1), (5, 5), (20, 1), (20, 5)]:
+        n = 2 * shots * ways
+        data = torch.arange(n, dtype=torch.float32).view(n, 1, 1, 1).expand(n, 1, 2, 2).contiguous()
+        labels = torch.from_numpy(synthetic.task_labels(ways, shots))
+        ad, al, ed, el = ref['prepare_batch']((data, labels), shots, ways, torch.device('cpu'))
+        out[f'g1_{ways}w{shots}s_support_rows'] = ad[:, 0, 0, 0].numpy().astype(np.int64)
+        out[f'g1_{ways}w{shots}s_query_rows'] = ed[:, 0, 0, 0].numpy().astype(np.int64)
+        out[f'g1_{ways}w{shots}s_support_labels'] = al.numpy()
+        out[f'g1_{ways}w{shots}s_query_labels'] = el.numpy()
+
+
+def g2_forward(ref, out):
+    cases = {
+        'min32': (lambda: ref['MiniImagenetCNN'](5), 'min', 5),
+        'omni64': (lambda: ref['OmniglotCNN'](5), 'omni', 1),
+        'base_min64': (lambda: ref['ConvBase'](output_size=64, channels=3, max_pool=True), 'min', 5),
+        'base_omni32': (lambda: ref['ConvBase'](output_size=64, hidden=32, channels=1, max_pool=False), 'omni', 1),
+    }
+    for name, (ctor, dataset, shots) in cases.items():
+        for dt, tag in [(torch.float64, 'f64'), (torch.float32, 'f32')]:
+            torch.manual_seed(0)
+            m = load_hash_weights(ctor(), seed=7, dtype=dt)
+            data, _ = synthetic.make_task(dataset, 3, 5, shots, seed=42)
+            x = torch.from_numpy(data).to(dt)
+            with torch.no_grad():
+                y = m(x)
+                out[f'g2_{name}_{tag}_out'] = y.reshape(y.shape[0], -1).numpy().astype(np.float64 if dt == torch.float64 else np.float32) \
+                    if y.numel() <= 4096 else np.array([])
+                out[f'g2_{name}_{tag}_out_sum'] = np.array([y.double().sum().item(), y.double().abs().sum().item()])
+                blocks = m.base if hasattr(m, 'base') else m
+                h = x.view(-1, 1, 28, 28) if dataset == 'omni' else x
+                sums = []
+                for blk in blocks:
+                    h = blk(h)
+                    sums.append([h.double().sum().item(), h.double().abs().sum().item(), float(h.shape[-1])])
+                out[f'g2_{name}_{tag}_block_sums'] = np.array(sums)
+
+
+def run_maml_case(ref, model_name, dataset, ways, shots, K, lr, first_order, task_ids, dt):
+    ctor = {'min32': lambda: ref['MiniImagenetCNN'](ways), 'omni64': lambda: ref['OmniglotCNN'](ways)}[model_name]
+    torch.manual_seed(0)
+    model = load_hash_weights(ctor(), seed=11, dtype=dt)
+    loss_fn = torch.nn.CrossEntropyLoss(reduction='mean')
+    losses, accs = [], []
+    for p in model.parameters():
+        p.grad = None
+    for t in task_ids:
+        data, labels = synthetic.make_task(dataset, t, ways, shots, seed=42)
+        batch = (torch.from_numpy(data).to(dt), torch.from_numpy(labels))
+        learner = StandInLearner(model, lr, first_order)
+        vl, va = ref['fast_adapt'](batch, learner, loss_fn, K, shots, ways, torch.device('cpu'))
+        vl.backward()                      # maml_vision.py:112 -- accumulates (sums) over tasks
+        losses.append(vl.item())
+        accs.append(va.item())
+    grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    return np.array(losses), np.array(accs), grad.numpy()
+
+
+def g3_fast_adapt(ref, out):
+    cases = [
+        # tag, model, dataset, ways, shots, K, lr, first_order, tasks
+        ('cfg1_omni_5w1s_K1_fo', 'omni64', 'omni', 5, 1, 1, 0.5, True, [0, 1]),
+        ('cfg2_min_5w5s_K5_so', 'min32', 'min', 5, 5, 5, 0.5, False, [0, 1]),
+        ('cfg2_min_5w5s_K1_so', 'min32', 'min', 5, 5, 1, 0.5, False, [0]),
+        ('cfg2_min_5w5s_K2_so_lr01', 'min32', 'min', 5, 5, 2, 0.1, False, [0]),
+        ('cfg2_min_5w5s_K5_fo', 'min32', 'min', 5, 5, 5, 0.5, True, [0]),
+        ('cfg4_min_5w1s_K1_so', 'min32', 'min', 5, 1, 1, 0.5, False, [0, 1, 2]),
+        ('omni_5w1s_K2_so', 'omni64', 'omni', 5, 1, 2, 0.4, False, [0]),
+    ]
+    for tag, model, dataset, ways, shots, K, lr, fo, tasks in cases:
+        for dt, dtag in [(torch.float64, 'f64'), (torch.float32, 'f32')]:
+            losses, accs, grad = run_maml_case(ref, model, dataset, ways, shots, K, lr, fo, tasks, dt)
+            out[f'g3_{tag}_{dtag}_loss'] = losses
+            out[f'g3_{tag}_{dtag}_acc'] = accs
+            if dtag == 'f64':
+                out[f'g3_{tag}_{dtag}_grad'] = grad.astype(np.float32)   # fp64 result stored as fp32 (fixture size)
+            out[f'g3_{tag}_{dtag}_grad_norm'] = np.array([np.linalg.norm(grad.astype(np.float64))])
+        out[f'g3_{tag}_meta'] = np.array([ways, shots, K, int(fo)] + tasks, dtype=np.int64)
+        out[f'g3_{tag}_lr'] = np.array([lr])
+        print('g3', tag, out[f'g3_{tag}_f64_loss'], out[f'g3_{tag}_f32_loss'], flush=True)
+
+
+def g3_anil(ref, out):
+    """anil_vision.py:86-94,116-122 with the intended Mini-ImageNet sizes (64 filters, 1600 features)."""
+    ways, shots, lr = 5, 5, 0.5
+    for K in (1, 5):
+        for dt, dtag in [(torch.float64, 'f64'), (torch.float32, 'f32')]:
+            torch.manual_seed(0)
+            base = load_hash_weights(ref['ConvBase'](output_size=64, channels=3, max_pool=True), seed=13, dtype=dt)
+            features = torch.nn.Sequential(base)
+            feat = lambda x: features(x).view(-1, 1600)
+            head = load_hash_weights(torch.nn.Linear(1600, ways), seed=17, dtype=dt)
+            loss_fn = torch.nn.CrossEntropyLoss(reduction='mean')
+            losses, accs = [], []
+            for t in [0, 1]:
+                data, labels = synthetic.make_task('min', t, ways, shots, seed=42)
+                batch = (torch.from_numpy(data).to(dt), torch.from_numpy(labels))
+                learner = StandInLearner(head, lr, False)
+                vl, va = ref['fast_adapt'](batch, learner, loss_fn, K, shots, ways, torch.device('cpu'), features=feat)
+                vl.backward()
+                losses.append(vl.item())
+                accs.append(va.item())
+            gf = torch.cat([p.grad.reshape(-1) for p in features.parameters()]).numpy()
+            gh = torch.cat([p.grad.reshape(-1) for p in head.parameters()]).numpy()
+            tag = f'g3_cfg3_anil_min_5w5s_K{K}_{dtag}'
+            out[f'{tag}_loss'] = np.array(losses)
+            out[f'{tag}_acc'] = np.array(accs)
+            if dtag == 'f64':
+                out[f'{tag}_grad_feat'] = gf.astype(np.float32)
+                out[f'{tag}_grad_head'] = gh.astype(np.float32)
+            out[f'{tag}_grad_norm'] = np.array([np.linalg.norm(gf.astype(np.float64)), np.linalg.norm(gh.astype(np.float64))])
+            print('g3 anil', K, dtag, losses, flush=True)
+
+
+def g4_accuracy(ref, out):
+    preds = torch.tensor([[1.0, 1.0, 0.0], [0.0, 2.0, 2.0], [3.0, 1.0, 3.0], [0.5, 0.5, 0.5], [0.1, 0.9, 0.3]])
+    targets = torch.tensor([0, 1, 0, 0, 2])
+    out['g4_preds'] = preds.numpy()
+    out['g4_targets'] = targets.numpy()
+    out['g4_acc'] = np.array([ref['accuracy'](preds, targets).item()])
+
+
+def g5_policy(ref, out):
+    st = torch.from_numpy(synthetic.hash_uniform(5, (64, 2)) * 2 - 1)
+    ac = torch.from_numpy(synthetic.hash_uniform(6, (64, 2)) * 0.2 - 0.1)
+    for dt, dtag in [(torch.float64, 'f64'), (torch.float32, 'f32')]:
+        pol = load_hash_weights(ref['DiagNormalPolicy'](2, 2), seed=19, dtype=dt)
+        with torch.no_grad():
+            pol.sigma.copy_(torch.tensor([-0.3, 0.2], dtype=dt))
+        lp = pol.log_prob(st.to(dt), ac.to(dt))
+        d = pol.density(st.to(dt))
+        out[f'g5_policy_{dtag}_logp'] = lp.detach().numpy()
+        out[f'g5_policy_{dtag}_loc'] = d.loc.detach().numpy()
+        out[f'g5_policy_{dtag}_scale'] = d.scale.detach().numpy()
+        g = torch.autograd.grad(lp.sum(), list(pol.parameters()))
+        out[f'g5_policy_{dtag}_grad'] = torch.cat([x.reshape(-1) for x in g]).numpy()
+        anil = load_hash_weights(ref['DiagNormalPolicyANIL'](2, 2, 100), seed=23, dtype=dt)
+        for off in (False, True):
+            if off:
+                anil.turn_off_body_grads()
+            else:
+                anil.turn_on_body_grads()
+            lp = anil.log_prob(st.to(dt), ac.to(dt))
+            g = torch.autograd.grad(lp.sum(), list(anil.parameters()), allow_unused=True)
+            out[f'g5_anil_{dtag}_bodyoff{int(off)}_logp'] = lp.detach().numpy()
+            out[f'g5_anil_{dtag}_bodyoff{int(off)}_grad'] = torch.cat(
+                [(x if x is not None else torch.zeros_like(p)).reshape(-1) for x, p in zip(g, anil.parameters())]).numpy()
+    out['g5_states'] = st.numpy()
+    out['g5_actions'] = ac.numpy()
+    out['g5_param_names'] = np.array([k for k, _ in ref['DiagNormalPolicy'](2, 2).named_parameters()])
+
+
+def main():
+    torch.set_num_threads(8)
+    ref = import_reference()
+    small, big = {}, {}
+    g1_prepare_batch(ref, small)
+    g4_accuracy(ref, small)
+    g5_policy(ref, small)
+    g2_forward(ref, small)
+    np.savez_compressed(os.path.join(HERE, 'golden_small.npz'), **small)
+    g3_fast_adapt(ref, big)
+    g3_anil(ref, big)
+    np.savez_compressed(os.path.join(HERE, 'golden_fast_adapt.npz'), **big)
+    for f in ('golden_small.npz', 'golden_fast_adapt.npz'):
+        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    main()
