@@ -1,0 +1,86 @@
+"""ctypes binding of libmi_maml.so (include/mi_maml.h).  There is no CPU fallback: if the HIP library is missing or a call
+fails, this raises."""
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libmi_maml.so')
+
+_lib = None
+
+
+class MiModelDesc(C.Structure):
+    _fields_ = [('n_layers', C.c_int32), ('in_channels', C.c_int32), ('in_h', C.c_int32), ('in_w', C.c_int32),
+                ('hidden', C.c_int32), ('max_pool', C.c_int32), ('ways', C.c_int32), ('head_mean_pool', C.c_int32)]
+
+
+class MiError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(['make', '-C', CSRC, '-j4'], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise MiError('building libmi_maml.so failed')
+    return LIB_PATH
+
+
+_SIGS = {
+    'mi_engine_create': (C.c_int, [C.POINTER(MiModelDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    'mi_engine_destroy': (None, [C.c_void_p]),
+    'mi_last_error': (C.c_char_p, [C.c_void_p]),
+    'mi_version': (C.c_char_p, []),
+    'mi_param_count': (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    'mi_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    'mi_meta_batch_maml': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t]),
+    'mi_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float,
+                               C.c_float, C.c_float, C.c_float, C.c_float]),
+    'mi_prepare_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mi_conv3x3_bn_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'mi_bn_relu_pool': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'mi_bn_relu_pool_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'mi_conv3x3_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    'mi_head_fwd_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mi_kernel_scratch_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def load():
+    """Load libmi_maml.so (built in-tree by ``build()`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MiError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                      '(hipcc --offload-arch=gfx950). There is no CPU fallback for the MAML hot path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = load().mi_last_error(handle)
+        raise MiError(f'libmi_maml error {rc}: {msg.decode() if msg else "?"}')

@@ -1,0 +1,419 @@
+// Batch-stat BatchNorm + ReLU + MaxPool2d(2,2) for a whole meta-batch: forward, backward, and their tangents
+// (R-operator) -- the elementwise / per-channel-reduction half of ConvBlock.forward
+// (reference core_functions/vision_models.py:188-193: normalize -> relu -> max_pool; BatchNorm2d always in TRAIN mode,
+// SURVEY.md section 0.4), replacing ATen batch_norm / threshold_backward / max_pool2d_with_indices and their
+// backward / double-backward.
+//
+// All kernels are HBM-streaming: NHWC, one thread owns a 2x2 pooling window (or one pixel without pooling) x 4 channels
+// (one 16-B load per position), 8 (C=32) or 16 (C=64) consecutive lanes cover one pixel's channel vector, consecutive
+// lane groups walk consecutive windows => fully coalesced 128/256-B segments.  Nothing but z (conv output) is stored by
+// the forward: the ReLU mask and pooling argmax are re-derived from z in every backward/tangent kernel with bit-identical
+// arithmetic (bn_zh/bn_u).  Per-channel reductions accumulate in fp64 per thread, reduce through LDS and leave one
+// deterministic partial per workgroup; bn_finalize_kernel folds the partials in a fixed order.
+#include "mi_common.h"
+#include "kernels.h"
+
+struct ChanConst {
+  float mu[4], r[4], g[4], b[4];
+};
+
+__device__ __forceinline__ void load4(const float* p, float* o) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void store4(float* p, const float* o) {
+  *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__device__ __forceinline__ ChanConst load_consts(const BnArgs& a, int task, int c0) {
+  ChanConst k;
+  load4(a.mu + (size_t)task * a.c + c0, k.mu);
+  load4(a.rstd + (size_t)task * a.c + c0, k.r);
+  load4(a.gamma + (size_t)task * a.pstride + c0, k.g);
+  load4(a.beta + (size_t)task * a.pstride + c0, k.b);
+  return k;
+}
+
+// Window geometry shared by all kernels.  POOL: windows tile ceil(ho/2) x ceil(wo/2) (so the dropped odd row/column of
+// floor pooling is still visited for dz); !POOL: one position per "window".
+template <int POOL>
+struct WinIter {
+  int hw2, ww2, nwin, hp, wp;
+  __device__ WinIter(const BnArgs& a) {
+    if (POOL) {
+      hw2 = (a.ho + 1) >> 1; ww2 = (a.wo + 1) >> 1; hp = a.ho >> 1; wp = a.wo >> 1;
+    } else {
+      hw2 = a.ho; ww2 = a.wo; hp = a.ho; wp = a.wo;
+    }
+    nwin = a.n * hw2 * ww2;
+  }
+};
+
+// Analyse one window for 4 channels: zh and u at its (up to 4) positions, first-max argmax.
+template <int POOL>
+struct Window {
+  static constexpr int NP = POOL ? 4 : 1;
+  size_t off[NP];     // element offset of each position's channel quad inside the task's z
+  bool exists[NP];
+  bool pooled;        // window produces a pooled output (inside the floor-pooled grid)
+  size_t poff;        // offset of the pooled output quad
+  float zh[NP][4], u[NP][4];
+  int arg[4];
+  float umax[4];
+
+  __device__ __forceinline__ void locate(const BnArgs& a, const WinIter<POOL>& it, int win, int c0) {
+    const int n = win / (it.hw2 * it.ww2);
+    const int rem = win - n * it.hw2 * it.ww2;
+    const int wy = rem / it.ww2, wx = rem - wy * it.ww2;
+    if (POOL) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int y = 2 * wy + (k >> 1), x = 2 * wx + (k & 1);
+        exists[k] = (y < a.ho) && (x < a.wo);
+        off[k] = ((size_t)(n * a.ho + y) * a.wo + x) * a.c + c0;
+      }
+      pooled = (wy < it.hp) && (wx < it.wp);
+      poff = ((size_t)(n * it.hp + wy) * it.wp + wx) * a.c + c0;
+    } else {
+      exists[0] = true;
+      off[0] = ((size_t)(n * a.ho + wy) * a.wo + wx) * a.c + c0;
+      pooled = true;
+      poff = off[0];
+    }
+  }
+  __device__ __forceinline__ void analyse(const float* __restrict__ z_t, const ChanConst& k) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      float zv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (exists[p]) load4(z_t + off[p], zv);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        zh[p][c] = bn_zh(zv[c], k.mu[c], k.r[c]);
+        u[p][c] = bn_u(zh[p][c], k.g[c], k.b[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int best = 0;
+      float bu = u[0][c];
+#pragma unroll
+      for (int p = 1; p < NP; ++p)
+        if (u[p][c] > bu) { bu = u[p][c]; best = p; }   // strict '>' keeps the first maximum (torch max_pool2d order)
+      arg[c] = best;
+      umax[c] = bu;
+    }
+  }
+  // value of a per-position quantity at the argmax position of channel c
+  __device__ __forceinline__ float at_arg(const float (*v)[4], int c) const {
+    float r = v[0][c];
+#pragma unroll
+    for (int p = 1; p < NP; ++p) r = (arg[c] == p) ? v[p][c] : r;
+    return r;
+  }
+};
+
+#define BN_THREAD_SETUP(POOL)                                                                   \
+  const int quads = a.c >> 2;                                                                   \
+  const int quad = threadIdx.x % quads, wl = threadIdx.x / quads, wpb = 256 / quads;            \
+  const int task = blockIdx.y, c0 = quad * 4;                                                   \
+  const WinIter<POOL> it(a);                                                                    \
+  const size_t z_task = (size_t)a.n * a.ho * a.wo * a.c;                                        \
+  const size_t p_task = (size_t)a.n * it.hp * it.wp * a.c;                                      \
+  const ChanConst k = load_consts(a, task, c0);                                                 \
+  const float* z_t = a.z + (size_t)task * z_task;                                               \
+  (void)p_task; (void)z_t;
+
+// fp64 block reduction of 8 per-thread accumulators (4 channels x 2 quantities) -> partial[task][blk][2][c]
+__device__ __forceinline__ void block_reduce_write(const double* acc0, const double* acc1, const BnArgs& a, int quads,
+                                                   int task) {
+  __shared__ double red[256 * 8];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    red[threadIdx.x * 8 + c] = acc0[c];
+    red[threadIdx.x * 8 + 4 + c] = acc1[c];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.c) {
+    const int q = threadIdx.x >> 2, comp = threadIdx.x & 3, wpb = 256 / quads;
+    double s0 = 0.0, s1 = 0.0;
+    for (int w = 0; w < wpb; ++w) {
+      s0 += red[(w * quads + q) * 8 + comp];
+      s1 += red[(w * quads + q) * 8 + 4 + comp];
+    }
+    double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * a.c;
+    pb[threadIdx.x] = s0;
+    pb[a.c + threadIdx.x] = s1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
+  BN_THREAD_SETUP(POOL)
+  float* out_t = a.out + (size_t)task * p_task;
+  Window<POOL> w;
+  for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
+    w.locate(a, it, win, c0);
+    if (!w.pooled) continue;
+    w.analyse(z_t, k);
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = fmaxf(w.umax[c], 0.f);
+    store4(out_t + w.poff, o);
+  }
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnArgs a) {
+  BN_THREAD_SETUP(POOL)
+  const float* dp_t = a.dp + (size_t)task * p_task;
+  double dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+  Window<POOL> w;
+  for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
+    w.locate(a, it, win, c0);
+    if (!w.pooled) continue;
+    w.analyse(z_t, k);
+    float d[4];
+    load4(dp_t + w.poff, d);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (w.umax[c] > 0.f) {
+        db[c] += (double)d[c];
+        dg[c] += (double)d[c] * (double)w.at_arg(w.zh, c);
+      }
+    }
+  }
+  block_reduce_write(dg, db, a, quads, task);
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnArgs a) {
+  BN_THREAD_SETUP(POOL)
+  const float* dp_t = a.dp + (size_t)task * p_task;
+  float* out_t = a.out + (size_t)task * z_task;
+  float dgm[4], dbm[4], gr[4];
+  load4(a.dgamma + (size_t)task * a.gstride + c0, dgm);
+  load4(a.dbeta + (size_t)task * a.gstride + c0, dbm);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { dgm[c] *= a.inv_m; dbm[c] *= a.inv_m; gr[c] = k.g[c] * k.r[c]; }
+  Window<POOL> w;
+  for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
+    w.locate(a, it, win, c0);
+    w.analyse(z_t, k);
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    if (w.pooled) load4(dp_t + w.poff, d);
+#pragma unroll
+    for (int p = 0; p < Window<POOL>::NP; ++p) {
+      if (!w.exists[p]) continue;
+      float o[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float du = (w.pooled && w.arg[c] == p && w.umax[c] > 0.f) ? d[c] : 0.f;
+        o[c] = gr[c] * (du - dbm[c] - w.zh[p][c] * dgm[c]);
+      }
+      store4(out_t + w.off[p], o);
+    }
+  }
+}
+
+// tangent forward: pd = [u>0 at argmax] * (gammad*zh + gamma*zhd + betad),  zhd = r (zd - m1 - zh m2)
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_tan_fwd_kernel(BnArgs a) {
+  BN_THREAD_SETUP(POOL)
+  const float* zd_t = a.zd + (size_t)task * z_task;
+  float* out_t = a.out + (size_t)task * p_task;
+  float m1[4], m2[4], gd[4], bd[4];
+  load4(a.m1 + (size_t)task * a.c + c0, m1);
+  load4(a.m2 + (size_t)task * a.c + c0, m2);
+  load4(a.gammad + (size_t)task * a.vstride + c0, gd);
+  load4(a.betad + (size_t)task * a.vstride + c0, bd);
+  Window<POOL> w;
+  for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
+    w.locate(a, it, win, c0);
+    if (!w.pooled) continue;
+    w.analyse(z_t, k);
+    float zdv[Window<POOL>::NP][4];
+#pragma unroll
+    for (int p = 0; p < Window<POOL>::NP; ++p) load4(zd_t + w.off[p], zdv[p]);
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float zh = w.at_arg(w.zh, c), zd = w.at_arg(zdv, c);
+      const float zhd = k.r[c] * (zd - m1[c] - zh * m2[c]);
+      const float ud = gd[c] * zh + k.g[c] * zhd + bd[c];
+      o[c] = (w.umax[c] > 0.f) ? ud : 0.f;
+    }
+    store4(out_t + w.poff, o);
+  }
+}
+
+// tangent backward reductions: R{dbeta} = sum dud ; R{dgamma} = sum (dud zh + du zhd)   (argmax positions only)
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_tan_bwd_reduce_kernel(BnArgs a) {
+  BN_THREAD_SETUP(POOL)
+  const float* zd_t = a.zd + (size_t)task * z_task;
+  const float* dp_t = a.dp + (size_t)task * p_task;
+  const float* dpd_t = a.dpd + (size_t)task * p_task;
+  float m1[4], m2[4];
+  load4(a.m1 + (size_t)task * a.c + c0, m1);
+  load4(a.m2 + (size_t)task * a.c + c0, m2);
+  double rg[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
+  Window<POOL> w;
+  for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
+    w.locate(a, it, win, c0);
+    if (!w.pooled) continue;
+    w.analyse(z_t, k);
+    float zdv[Window<POOL>::NP][4];
+#pragma unroll
+    for (int p = 0; p < Window<POOL>::NP; ++p) load4(zd_t + w.off[p], zdv[p]);
+    float d[4], dd[4];
+    load4(dp_t + w.poff, d);
+    load4(dpd_t + w.poff, dd);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (w.umax[c] > 0.f) {
+        const float zh = w.at_arg(w.zh, c), zd = w.at_arg(zdv, c);
+        const float zhd = k.r[c] * (zd - m1[c] - zh * m2[c]);
+        rb[c] += (double)dd[c];
+        rg[c] += (double)dd[c] * (double)zh + (double)d[c] * (double)zhd;
+      }
+    }
+  }
+  block_reduce_write(rg, rb, a, quads, task);
+}
+
+// tangent backward apply:
+//   E = du - dbeta/M - zh dgamma/M
+//   R{dz} = (gammad r + gamma rd) E + gamma r (dud - R{dbeta}/M - zhd dgamma/M - zh R{dgamma}/M),  rd = -r^2 m2
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_tan_bwd_apply_kernel(BnArgs a) {
+  BN_THREAD_SETUP(POOL)
+  const float* zd_t = a.zd + (size_t)task * z_task;
+  const float* dp_t = a.dp + (size_t)task * p_task;
+  const float* dpd_t = a.dpd + (size_t)task * p_task;
+  float* out_t = a.out + (size_t)task * z_task;
+  float m1[4], m2[4], gd[4], dgm[4], dbm[4], rgm[4], rbm[4], c1[4], gr[4];
+  load4(a.m1 + (size_t)task * a.c + c0, m1);
+  load4(a.m2 + (size_t)task * a.c + c0, m2);
+  load4(a.gammad + (size_t)task * a.vstride + c0, gd);
+  load4(a.dgamma + (size_t)task * a.gstride + c0, dgm);
+  load4(a.dbeta + (size_t)task * a.gstride + c0, dbm);
+  load4(a.rdgamma + (size_t)task * a.hstride + c0, rgm);
+  load4(a.rdbeta + (size_t)task * a.hstride + c0, rbm);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    dgm[c] *= a.inv_m; dbm[c] *= a.inv_m; rgm[c] *= a.inv_m; rbm[c] *= a.inv_m;
+    const float rd = -k.r[c] * k.r[c] * m2[c];
+    c1[c] = gd[c] * k.r[c] + k.g[c] * rd;
+    gr[c] = k.g[c] * k.r[c];
+  }
+  Window<POOL> w;
+  for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
+    w.locate(a, it, win, c0);
+    w.analyse(z_t, k);
+    float d[4] = {0.f, 0.f, 0.f, 0.f}, dd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (w.pooled) { load4(dp_t + w.poff, d); load4(dpd_t + w.poff, dd); }
+#pragma unroll
+    for (int p = 0; p < Window<POOL>::NP; ++p) {
+      if (!w.exists[p]) continue;
+      float zdv[4], o[4];
+      load4(zd_t + w.off[p], zdv);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool sel = w.pooled && w.arg[c] == p && w.umax[c] > 0.f;
+        const float du = sel ? d[c] : 0.f, dud = sel ? dd[c] : 0.f;
+        const float zh = w.zh[p][c];
+        const float zhd = k.r[c] * (zdv[c] - m1[c] - zh * m2[c]);
+        const float e = du - dbm[c] - zh * dgm[c];
+        o[c] = c1[c] * e + gr[c] * (dud - rbm[c] - zhd * dgm[c] - zh * rgm[c]);
+      }
+      store4(out_t + w.off[p], o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fold per-workgroup fp64 partials [T][nblk][2][c] in block order.
+//  FIN_STATS : (sum z, sum z^2)        -> out0 = mean, out1 = 1/sqrt(biased var + eps)
+//  FIN_TSTATS: (sum zd, sum zh zd)     -> out0 = m1,   out1 = m2
+//  FIN_SUMS  : (first, second)         -> out0 = first, out1 = second (e.g. dgamma, dbeta)
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int c, double inv_m, int mode,
+                                   float* __restrict__ out0, size_t stride0, float* __restrict__ out1, size_t stride1) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  const int task = blockIdx.y;
+  if (ch >= c) return;
+  const double* p = partial + (size_t)task * nblk * 2 * c;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += p[(size_t)b * 2 * c + ch];
+    q += p[(size_t)b * 2 * c + c + ch];
+  }
+  float o0, o1;
+  if (mode == FIN_STATS) {
+    const double mean = s * inv_m;
+    double var = q * inv_m - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    o0 = (float)mean;
+    o1 = (float)(1.0 / sqrt(var + MI_BN_EPS));
+  } else if (mode == FIN_TSTATS) {
+    o0 = (float)(s * inv_m);
+    o1 = (float)(q * inv_m);
+  } else {
+    o0 = (float)s;
+    o1 = (float)q;
+  }
+  out0[(size_t)task * stride0 + ch] = o0;
+  out1[(size_t)task * stride1 + ch] = o1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int bn_blocks_per_task(int n, int ho, int wo, int c, int pool, int tasks) {
+  const int nwin = pool ? n * ((ho + 1) / 2) * ((wo + 1) / 2) : n * ho * wo;
+  const int wpb = 256 / (c / 4);
+  int blocks = ceil_div(nwin, wpb);
+  // cap the grid near 8 workgroups per CU over the whole launch, grid-stride the rest
+  const int cap = ceil_div(2048, tasks);
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return blocks;
+}
+
+hipError_t launch_bn_finalize(hipStream_t st, const double* partial, int nblk, int tasks, int c, double inv_m, int mode,
+                              float* out0, size_t stride0, float* out1, size_t stride1) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 64), tasks), dim3(64), 0, st, partial, nblk, c, inv_m, mode, out0,
+                     stride0, out1, stride1);
+  return hipGetLastError();
+}
+
+#define BN_LAUNCH(KERNEL)                                                                          \
+  const int blocks = bn_blocks_per_task(a.n, a.ho, a.wo, a.c, pool, tasks);                        \
+  dim3 grid(blocks, tasks);                                                                        \
+  if (pool) hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), 0, st, a);                              \
+  else hipLaunchKernelGGL(KERNEL<0>, grid, dim3(256), 0, st, a);
+
+hipError_t launch_bn_fwd(hipStream_t st, const BnArgs& a, int tasks, int pool) {
+  BN_LAUNCH(bn_fwd_kernel)
+  return hipGetLastError();
+}
+hipError_t launch_bn_bwd_reduce(hipStream_t st, const BnArgs& a, int tasks, int pool, int* nblk) {
+  BN_LAUNCH(bn_bwd_reduce_kernel)
+  *nblk = blocks;
+  return hipGetLastError();
+}
+hipError_t launch_bn_bwd_apply(hipStream_t st, const BnArgs& a, int tasks, int pool) {
+  BN_LAUNCH(bn_bwd_apply_kernel)
+  return hipGetLastError();
+}
+hipError_t launch_bn_tan_fwd(hipStream_t st, const BnArgs& a, int tasks, int pool) {
+  BN_LAUNCH(bn_tan_fwd_kernel)
+  return hipGetLastError();
+}
+hipError_t launch_bn_tan_bwd_reduce(hipStream_t st, const BnArgs& a, int tasks, int pool, int* nblk) {
+  BN_LAUNCH(bn_tan_bwd_reduce_kernel)
+  *nblk = blocks;
+  return hipGetLastError();
+}
+hipError_t launch_bn_tan_bwd_apply(hipStream_t st, const BnArgs& a, int tasks, int pool) {
+  BN_LAUNCH(bn_tan_bwd_apply_kernel)
+  return hipGetLastError();
+}

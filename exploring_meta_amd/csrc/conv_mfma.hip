@@ -1,0 +1,469 @@
+// conv3x3 (pad 1) forward / dgrad / wgrad for a whole meta-batch in one launch, per-task weights.
+//
+// Replaces the implicit ATen conv2d forward / backward / double-backward launches behind ConvBlock.conv
+// (reference core_functions/vision_models.py:177-185,189) for every task of the meta-batch at once.
+//
+// Design (gfx950): implicit GEMM on the exact-fp32 matrix pipe, v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, so the
+// fp32 parity budget is untouched).  One wave owns a 32-pixel x 32-channel output tile (M = pixels of the task in
+// (n,y,x) raster order, N = output channels): 32 filters -- the reference's hidden size -- is exactly one MFMA tile.
+// K = 9 taps x Ci; the K order is free, so lane half h = lane>>5 takes input channels [16h,16h+16) of each 32-channel
+// chunk: one lane's A operands for 16 consecutive MFMAs are 16 contiguous NHWC floats (4 x 16-B loads), no shuffles.
+// Per-task weights are staged once per workgroup into LDS as [term][tap][ci][32] (B operand reads are conflict-free,
+// 32 consecutive dwords per lane half) and re-used for every pixel tile the workgroup walks.
+// "terms": the tangent (R-operator) passes need conv(x,Wd)+conv(xd,W) / dgrad(Rdz,W)+dgrad(dz,Wd); both products
+// accumulate into the same MFMA accumulators in one launch.
+// Epilogues: per-(task,channel) fp64 partial sums for batch-stat BN (sum z, sum z^2) or its tangent (sum zd, sum zh*zd),
+// reduced wave -> workgroup in LDS and written as one deterministic partial per workgroup (no atomics).
+#include "mi_common.h"
+#include "kernels.h"
+
+#define EPI_NONE 0
+#define EPI_STATS 1
+#define EPI_TSTATS 2
+
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stats_block_reduce(double s, double q, double* ldsd, int lane, int wave, int nwaves,
+                                                   double* partial_blk, int co_total, int cbase) {
+  // lanes l and l^32 hold the same channel
+  s += __shfl_xor(s, 32, 64);
+  q += __shfl_xor(q, 32, 64);
+  __syncthreads();  // weights in LDS are dead from here on
+  if (lane < 32) {
+    ldsd[(wave * 2 + 0) * 32 + lane] = s;
+    ldsd[(wave * 2 + 1) * 32 + lane] = q;
+  }
+  __syncthreads();
+  if (wave == 0 && lane < 32) {
+    double ts = 0.0, tq = 0.0;
+    for (int w = 0; w < nwaves; ++w) {
+      ts += ldsd[(w * 2 + 0) * 32 + lane];
+      tq += ldsd[(w * 2 + 1) * 32 + lane];
+    }
+    partial_blk[cbase + lane] = ts;
+    partial_blk[co_total + cbase + lane] = tq;
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void conv_epilogue(const floatx16& acc, int tile, int lane, int mpix, int co_total, int cbase,
+                                              float* __restrict__ out_t, const float* __restrict__ z_t, float mu_c,
+                                              float r_c, double& s, double& q) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int pix = tile * 32 + m;
+    if (pix < mpix) {
+      const size_t o = (size_t)pix * co_total + cbase + j;
+      const float v = acc[r];
+      out_t[o] = v;
+      if (EPI == EPI_STATS) {
+        const double dv = (double)v;
+        s += dv;
+        q = fma(dv, dv, q);
+      } else if (EPI == EPI_TSTATS) {
+        const float zh = bn_zh(z_t[o], mu_c, r_c);
+        s += (double)v;
+        q = fma((double)zh, (double)v, q);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Generic conv: CI multiple of 32 (template), CO multiple of 32 (grid.z tiles).
+// MODE 0: forward   out[o] = sum_tap in[o*S + d - 1] * W[tap]            weights [9][CI][CO]
+// MODE 1: dgrad     out[i] = sum_tap in[(i + 1 - d)/S] * W[tap]^T        weights [9][CO_op][CI_op] (the forward layout)
+template <int CI, int NTERMS, int EPI, int MODE, int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y, ct = blockIdx.z;
+  const int H = a.g.h, W = a.g.w, HO = a.g.ho, WO = a.g.wo, CO = a.g.co;
+  const int cbase = ct * 32;
+
+  // ---- stage this task's weights: lds[((term*9+tap)*CI + k)*32 + nl]
+  for (int idx = tid; idx < NTERMS * 9 * CI * 32; idx += 256) {
+    const int nl = idx & 31;
+    const int k = (idx >> 5) % CI;
+    const int tt = idx / (CI * 32);  // term*9 + tap
+    const int term = tt / 9, tap = tt - term * 9;
+    const float* wsrc = a.wt[term] + (size_t)task * a.wstride;
+    float v;
+    if (MODE == 0)
+      v = wsrc[((size_t)tap * CI + k) * CO + cbase + nl];
+    else
+      v = wsrc[((size_t)tap * CO + cbase + nl) * CI + k];
+    lds[idx] = v;
+  }
+  __syncthreads();
+
+  const int mpix = a.mpix;
+  const size_t in_task = (size_t)a.g.n * H * W * CI;
+  const size_t out_task = (size_t)mpix * CO;
+  float* out_t = a.out + (size_t)task * out_task;
+  const float* z_t = (EPI == EPI_TSTATS) ? a.z + (size_t)task * out_task : nullptr;
+  float mu_c = 0.f, r_c = 0.f;
+  if (EPI == EPI_TSTATS) {
+    mu_c = a.mu[(size_t)task * CO + cbase + j];
+    r_c = a.rstd[(size_t)task * CO + cbase + j];
+  }
+  double s = 0.0, q = 0.0;
+
+  const int tile0 = (blockIdx.x * 4 + wave) * a.tiles_per_wave;
+  const int tile1 = min(tile0 + a.tiles_per_wave, a.ntiles);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int pix = tile * 32 + j;
+    const bool valid = pix < mpix;
+    const int n = pix / (HO * WO);
+    const int rem = pix - n * (HO * WO);
+    const int oy = rem / WO, ox = rem - oy * WO;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+#pragma unroll
+    for (int term = 0; term < NTERMS; ++term) {
+      const float* in_t = a.in[term] + (size_t)task * in_task;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        int iy, ix;
+        bool inb = valid;
+        if (MODE == 0) {
+          iy = oy * STRIDE + dy - 1;
+          ix = ox * STRIDE + dx - 1;
+        } else {
+          iy = oy + 1 - dy;
+          ix = ox + 1 - dx;
+          if (STRIDE == 2) {
+            inb = inb && ((iy & 1) == 0) && ((ix & 1) == 0);
+            iy >>= 1;
+            ix >>= 1;
+          }
+        }
+        inb = inb && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float* src = in_t + ((size_t)(n * H + iy) * W + ix) * CI + h * 16;
+#pragma unroll
+        for (int cc = 0; cc < CI / 32; ++cc) {
+          float av[16];
+          if (inb) {
+            const float4* s4 = reinterpret_cast<const float4*>(src + cc * 32);
+            const float4 v0 = s4[0], v1 = s4[1], v2 = s4[2], v3 = s4[3];
+            av[0] = v0.x; av[1] = v0.y; av[2] = v0.z; av[3] = v0.w;
+            av[4] = v1.x; av[5] = v1.y; av[6] = v1.z; av[7] = v1.w;
+            av[8] = v2.x; av[9] = v2.y; av[10] = v2.z; av[11] = v2.w;
+            av[12] = v3.x; av[13] = v3.y; av[14] = v3.z; av[15] = v3.w;
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) av[kk] = 0.f;
+          }
+          const float* bl = lds + ((size_t)((term * 9 + tap) * CI + cc * 32 + h * 16)) * 32 + j;
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bl[kk * 32], acc, 0, 0, 0);
+        }
+      }
+    }
+    conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, z_t, mu_c, r_c, s, q);
+  }
+  if (EPI != EPI_NONE) {
+    double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
+    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, 4, pb, CO, cbase);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// First-layer conv: CI0 in {1,3}.  K = 9*CI0 padded to an even KP; lane half h takes k in [h*KP/2, (h+1)*KP/2).
+template <int CI0, int EPI, int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_first_mfma_kernel(ConvArgs a) {
+  constexpr int K = 9 * CI0, KP = (K + 1) & ~1, KH = KP / 2;
+  constexpr int LDS_FLOATS = KP * 32 > 512 ? KP * 32 : 512;  // weights, later 4 waves x 2 x 32 doubles for the stats
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y, ct = blockIdx.z;
+  const int H = a.g.h, W = a.g.w, HO = a.g.ho, WO = a.g.wo, CO = a.g.co;
+  const int cbase = ct * 32;
+  const float* wsrc = a.wt[0] + (size_t)task * a.wstride;  // [9][CI0][CO] == [k][CO]
+  for (int idx = tid; idx < KP * 32; idx += 256) {
+    const int k = idx >> 5, nl = idx & 31;
+    lds[idx] = (k < K) ? wsrc[(size_t)k * CO + cbase + nl] : 0.f;
+  }
+  __syncthreads();
+
+  // per-lane tap table
+  int kdy[KH], kdx[KH], kci[KH];
+  bool kok[KH];
+#pragma unroll
+  for (int kk = 0; kk < KH; ++kk) {
+    const int k = h * KH + kk;
+    kok[kk] = k < K;
+    const int tap = k / CI0;
+    kci[kk] = k - tap * CI0;
+    kdy[kk] = tap / 3 - 1;
+    kdx[kk] = tap % 3 - 1;
+  }
+
+  const int mpix = a.mpix;
+  const size_t in_task = (size_t)a.g.n * H * W * CI0;
+  const size_t out_task = (size_t)mpix * CO;
+  const float* in_t = a.in[0] + (size_t)task * in_task;
+  float* out_t = a.out + (size_t)task * out_task;
+  const float* z_t = (EPI == EPI_TSTATS) ? a.z + (size_t)task * out_task : nullptr;
+  float mu_c = 0.f, r_c = 0.f;
+  if (EPI == EPI_TSTATS) {
+    mu_c = a.mu[(size_t)task * CO + cbase + j];
+    r_c = a.rstd[(size_t)task * CO + cbase + j];
+  }
+  double s = 0.0, q = 0.0;
+  const int tile0 = (blockIdx.x * 4 + wave) * a.tiles_per_wave;
+  const int tile1 = min(tile0 + a.tiles_per_wave, a.ntiles);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int pix = tile * 32 + j;
+    const bool valid = pix < mpix;
+    const int n = pix / (HO * WO);
+    const int rem = pix - n * (HO * WO);
+    const int oy = rem / WO, ox = rem - oy * WO;
+    float av[KH];
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+      const int iy = oy * STRIDE + kdy[kk], ix = ox * STRIDE + kdx[kk];
+      const bool inb = valid && kok[kk] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      av[kk] = inb ? in_t[((size_t)(n * H + iy) * W + ix) * CI0 + kci[kk]] : 0.f;
+    }
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], lds[(h * KH + kk) * 32 + j], acc, 0, 0, 0);
+    conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, z_t, mu_c, r_c, s, q);
+  }
+  if (EPI != EPI_NONE) {
+    double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
+    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, 4, pb, CO, cbase);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// wgrad: dW[tap][ci][co] = sum over output pixels of x[pixin(pix,tap)][ci] * dz[pix][co].
+// M = ci (32-chunk), N = co (32-tile), K = pixels.  Each wave owns a pixel chunk and 9 tap accumulators; lane half h takes
+// every second pixel.  Partials [task][chunk][9][CI][CO] are summed in a fixed order by reduce_partials_kernel.
+template <int NTERMS, int STRIDE>
+__global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y;
+  const int H = a.g.h, W = a.g.w, HO = a.g.ho, WO = a.g.wo, CI = a.g.ci, CO = a.g.co;
+  const int ncot = CO / 32;
+  const int cit = blockIdx.z / ncot, cot = blockIdx.z - cit * ncot;
+  const int chunk = blockIdx.x * 4 + wave;
+  if (chunk >= a.nchunks) return;
+  const int p0 = chunk * a.chunk_pix, p1 = min(p0 + a.chunk_pix, a.mpix);
+  const size_t x_task = (size_t)a.g.n * H * W * CI, dz_task = (size_t)a.mpix * CO;
+
+  floatx16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+#pragma unroll
+  for (int term = 0; term < NTERMS; ++term) {
+    const float* x_t = a.x[term] + (size_t)task * x_task + cit * 32 + j;
+    const float* dz_t = a.dz[term] + (size_t)task * dz_task + cot * 32 + j;
+    for (int p = p0 + h; p < p1 + h; p += 2) {  // both halves run the same trip count; the odd tail lane-half feeds zeros
+      const bool valid = p < p1;
+      const int n = p / (HO * WO);
+      const int rem = p - n * (HO * WO);
+      const int oy = rem / WO, ox = rem - oy * WO;
+      const float b = valid ? dz_t[(size_t)p * CO] : 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy * STRIDE + tap / 3 - 1, ix = ox * STRIDE + tap % 3 - 1;
+        const bool inb = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float av = inb ? x_t[((size_t)(n * H + iy) * W + ix) * CI] : 0.f;
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+  float* pt = a.partial + ((size_t)task * a.nchunks + chunk) * 9 * CI * CO;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      pt[((size_t)tap * CI + cit * 32 + row) * CO + cot * 32 + j] = acc[tap][r];
+    }
+}
+
+// First-layer wgrad: rows m = tap*CI0 + ci (27 or 9 of 32), one accumulator.
+template <int CI0, int STRIDE>
+__global__ __launch_bounds__(256) void wgrad3x3_first_mfma_kernel(WgradArgs a) {
+  constexpr int K = 9 * CI0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y, cot = blockIdx.z;
+  const int H = a.g.h, W = a.g.w, HO = a.g.ho, WO = a.g.wo, CO = a.g.co;
+  const int chunk = blockIdx.x * 4 + wave;
+  if (chunk >= a.nchunks) return;
+  const int p0 = chunk * a.chunk_pix, p1 = min(p0 + a.chunk_pix, a.mpix);
+  const size_t x_task = (size_t)a.g.n * H * W * CI0, dz_task = (size_t)a.mpix * CO;
+  const bool mok = j < K;
+  const int tap = j / CI0, ci = j - tap * CI0;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const float* x_t = a.x[0] + (size_t)task * x_task + ci;
+  const float* dz_t = a.dz[0] + (size_t)task * dz_task + cot * 32 + j;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int p = p0 + h; p < p1 + h; p += 2) {
+    const bool valid = p < p1;
+    const int n = p / (HO * WO);
+    const int rem = p - n * (HO * WO);
+    const int oy = rem / WO, ox = rem - oy * WO;
+    const float b = valid ? dz_t[(size_t)p * CO] : 0.f;
+    const int iy = oy * STRIDE + dy, ix = ox * STRIDE + dx;
+    const bool inb = valid && mok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float av = inb ? x_t[((size_t)(n * H + iy) * W + ix) * CI0] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc, 0, 0, 0);
+  }
+  float* pt = a.partial + ((size_t)task * a.nchunks + chunk) * K * CO;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (row < K) pt[(size_t)row * CO + cot * 32 + j] = acc[r];
+  }
+}
+
+// out[task*ostride + e] = sum_chunk partial[task][chunk][e]   (fixed order => deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nchunks, int nelem,
+                                                              float* __restrict__ out, size_t ostride) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int task = blockIdx.y;
+  if (e >= nelem) return;
+  const float* p = partial + (size_t)task * nchunks * nelem + e;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += p[(size_t)c * nelem];
+  out[(size_t)task * ostride + e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host launchers
+static inline void conv_grid(int mpix, int tasks, int cot, int& ntiles, int& tpw, dim3& grid) {
+  ntiles = ceil_div(mpix, 32);
+  long total = (long)ntiles * tasks * cot;
+  tpw = (int)(total / (4L * 2048));
+  if (tpw < 1) tpw = 1;
+  if (tpw > 16) tpw = 16;
+  grid = dim3(ceil_div(ntiles, 4 * tpw), tasks, cot);
+}
+
+int conv_max_blocks_per_task(const ConvGeom& g) {  // tiles_per_wave == 1 is the finest split any launch uses
+  return ceil_div(ceil_div(g.n * g.ho * g.wo, 32), 4);
+}
+
+template <int CI, int NTERMS, int EPI, int MODE, int STRIDE>
+static hipError_t launch_conv_t(hipStream_t st, ConvArgs& a, dim3 grid) {
+  const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);
+  auto k = conv3x3_mfma_kernel<CI, NTERMS, EPI, MODE, STRIDE>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+template <int CI, int NTERMS, int EPI>
+static hipError_t launch_conv_ms(hipStream_t st, ConvArgs& a, dim3 grid, int mode, int stride) {
+  if (mode == 0 && stride == 1) return launch_conv_t<CI, NTERMS, EPI, 0, 1>(st, a, grid);
+  if (mode == 0 && stride == 2) return launch_conv_t<CI, NTERMS, EPI, 0, 2>(st, a, grid);
+  if (EPI == EPI_NONE) {
+    if (mode == 1 && stride == 1) return launch_conv_t<CI, NTERMS, EPI_NONE, 1, 1>(st, a, grid);
+    if (mode == 1 && stride == 2) return launch_conv_t<CI, NTERMS, EPI_NONE, 1, 2>(st, a, grid);
+  }
+  return hipErrorInvalidValue;
+}
+
+// Generic conv launcher.  mode 0 = forward, 1 = dgrad.  epi as EPI_*.  Returns blocks per task (partials written).
+hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int epi, int mode, int* blocks_per_task) {
+  const int cot = a.g.co / 32;
+  int ntiles, tpw;
+  dim3 grid;
+  conv_grid(a.mpix, tasks, cot, ntiles, tpw, grid);
+  a.ntiles = ntiles;
+  a.tiles_per_wave = tpw;
+  if (blocks_per_task) *blocks_per_task = grid.x;
+  if (a.g.co % 32 != 0) return hipErrorInvalidValue;
+  const int s = a.g.stride;
+  if (a.g.ci == 1 || a.g.ci == 3) {
+    if (mode != 0 || nterms != 1) return hipErrorInvalidValue;
+#define FIRST(CI0, E, S) hipLaunchKernelGGL((conv3x3_first_mfma_kernel<CI0, E, S>), grid, dim3(256), 0, st, a)
+    if (a.g.ci == 3 && s == 1) { if (epi == EPI_STATS) FIRST(3, EPI_STATS, 1); else if (epi == EPI_TSTATS) FIRST(3, EPI_TSTATS, 1); else FIRST(3, EPI_NONE, 1); }
+    else if (a.g.ci == 3 && s == 2) { if (epi == EPI_STATS) FIRST(3, EPI_STATS, 2); else if (epi == EPI_TSTATS) FIRST(3, EPI_TSTATS, 2); else FIRST(3, EPI_NONE, 2); }
+    else if (a.g.ci == 1 && s == 1) { if (epi == EPI_STATS) FIRST(1, EPI_STATS, 1); else if (epi == EPI_TSTATS) FIRST(1, EPI_TSTATS, 1); else FIRST(1, EPI_NONE, 1); }
+    else if (a.g.ci == 1 && s == 2) { if (epi == EPI_STATS) FIRST(1, EPI_STATS, 2); else if (epi == EPI_TSTATS) FIRST(1, EPI_TSTATS, 2); else FIRST(1, EPI_NONE, 2); }
+    else return hipErrorInvalidValue;
+#undef FIRST
+    return hipGetLastError();
+  }
+#define DISPATCH(CI)                                                                              \
+  if (nterms == 1) {                                                                              \
+    if (epi == EPI_NONE) return launch_conv_ms<CI, 1, EPI_NONE>(st, a, grid, mode, s);             \
+    if (epi == EPI_STATS) return launch_conv_ms<CI, 1, EPI_STATS>(st, a, grid, mode, s);           \
+    return launch_conv_ms<CI, 1, EPI_TSTATS>(st, a, grid, mode, s);                                \
+  } else {                                                                                        \
+    if (epi == EPI_NONE) return launch_conv_ms<CI, 2, EPI_NONE>(st, a, grid, mode, s);             \
+    if (epi == EPI_TSTATS) return launch_conv_ms<CI, 2, EPI_TSTATS>(st, a, grid, mode, s);         \
+    return hipErrorInvalidValue;                                                                  \
+  }
+  if (a.g.ci == 32) { DISPATCH(32) }
+  if (a.g.ci == 64) { DISPATCH(64) }
+#undef DISPATCH
+  return hipErrorInvalidValue;
+}
+
+// wgrad launcher: writes dW (tap-major [9][ci][co]) for every task at out + task*ostride.
+int wgrad_chunks(int mpix, int tasks) {
+  // aim for >= ~2048 waves in flight, chunks of at least 256 pixels and at most 2048
+  int chunk = 1024;
+  while (chunk > 256 && (long)ceil_div(mpix, chunk) * tasks < 2048) chunk >>= 1;
+  return chunk;
+}
+
+size_t wgrad_partial_floats(const ConvGeom& g, int tasks) {
+  const int mpix = g.n * g.ho * g.wo;
+  const int chunk = wgrad_chunks(mpix, tasks);
+  return (size_t)tasks * ceil_div(mpix, chunk) * 9 * g.ci * g.co;
+}
+
+hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, float* out, size_t ostride) {
+  a.chunk_pix = wgrad_chunks(a.mpix, tasks);
+  a.nchunks = ceil_div(a.mpix, a.chunk_pix);
+  const int s = a.g.stride;
+  const int nelem = 9 * a.g.ci * a.g.co;
+  if (a.g.ci == 1 || a.g.ci == 3) {
+    if (nterms != 1) return hipErrorInvalidValue;
+    dim3 grid(ceil_div(a.nchunks, 4), tasks, a.g.co / 32);
+    if (a.g.ci == 3 && s == 1) hipLaunchKernelGGL((wgrad3x3_first_mfma_kernel<3, 1>), grid, dim3(256), 0, st, a);
+    else if (a.g.ci == 3 && s == 2) hipLaunchKernelGGL((wgrad3x3_first_mfma_kernel<3, 2>), grid, dim3(256), 0, st, a);
+    else if (a.g.ci == 1 && s == 1) hipLaunchKernelGGL((wgrad3x3_first_mfma_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_first_mfma_kernel<1, 2>), grid, dim3(256), 0, st, a);
+  } else {
+    if (a.g.ci % 32 || a.g.co % 32) return hipErrorInvalidValue;
+    dim3 grid(ceil_div(a.nchunks, 4), tasks, (a.g.ci / 32) * (a.g.co / 32));
+    if (nterms == 1 && s == 1) hipLaunchKernelGGL((wgrad3x3_mfma_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    else if (nterms == 1 && s == 2) hipLaunchKernelGGL((wgrad3x3_mfma_kernel<1, 2>), grid, dim3(256), 0, st, a);
+    else if (nterms == 2 && s == 1) hipLaunchKernelGGL((wgrad3x3_mfma_kernel<2, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_mfma_kernel<2, 2>), grid, dim3(256), 0, st, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nelem, 256), tasks), dim3(256), 0, st, a.partial, a.nchunks, nelem,
+                     out, ostride);
+  return hipGetLastError();
+}

@@ -1,0 +1,570 @@
+// Engine: orchestrates one whole meta-batch (all tasks, all inner steps, query pass, second-order adjoint recursion) as
+// a fixed sequence of batched-over-tasks kernel launches on the caller's stream, and exports the C ABI (include/mi_maml.h).
+//
+// Algorithm (per task t, identical to the reference's clone -> fast_adapt -> eval_loss.backward()):
+//   theta_0 = theta;  for k < K:  g_k = grad L_support(theta_k);  theta_{k+1} = theta_k - alpha g_k      (l2l MAML.adapt)
+//   lam = grad L_query(theta_K);   second order:  for k = K-1..0:  lam <- lam - alpha * H_support(theta_k) lam
+//   meta_grad = sum_t lam_t.        H v is a forward-over-reverse tangent sweep over the SAVED step-k activations.
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cmath>
+#include "mi_common.h"
+#include "kernels.h"
+#include "../../include/mi_maml.h"
+
+#define EPI_NONE 0
+#define EPI_STATS 1
+#define EPI_TSTATS 2
+
+static thread_local std::string g_err;
+
+struct Layer {
+  int ci, co, h, w, ho, wo, stride, pool, hp, wp;
+  size_t off_gamma, off_beta, off_w, off_b;
+};
+
+struct mi_engine {
+  mi_model_desc d;
+  int device;
+  std::vector<Layer> L;
+  int head_c, head_hw, feat;
+  size_t off_wl, off_bl, P;
+  size_t PS;  // per-task stride of parameter-shaped buffers (P padded so every task's vectors stay 16-B aligned)
+  int32_t* perm_dev;
+  std::string err;
+};
+
+static int fail(mi_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(e, call)                                                                            \
+  do {                                                                                             \
+    hipError_t _s = (call);                                                                        \
+    if (_s != hipSuccess)                                                                          \
+      return fail(e, MI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s) + " @" + std::to_string(__LINE__)); \
+  } while (0)
+
+static ConvGeom geom(const Layer& l, int n) { return ConvGeom{n, l.h, l.w, l.ho, l.wo, l.ci, l.co, l.stride}; }
+static ConvGeom geom_dgrad(const Layer& l, int n) {  // op input = dz (ho,wo,co), op output = dx (h,w,ci)
+  return ConvGeom{n, l.ho, l.wo, l.h, l.w, l.co, l.ci, l.stride};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" const char* mi_version(void) { return "mi_maml 0.1 (gfx950)"; }
+extern "C" const char* mi_last_error(const mi_engine* e) { return e ? e->err.c_str() : g_err.c_str(); }
+
+extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** out) {
+  if (!d || !out) return fail(nullptr, MI_ERR_ARG, "null argument");
+  if (d->n_layers < 1 || d->n_layers > 8) return fail(nullptr, MI_ERR_ARG, "n_layers must be 1..8");
+  if (d->hidden != 32 && d->hidden != 64) return fail(nullptr, MI_ERR_ARG, "hidden must be 32 or 64");
+  if (d->in_channels != 1 && d->in_channels != 3 && d->in_channels != 32 && d->in_channels != 64)
+    return fail(nullptr, MI_ERR_ARG, "in_channels must be 1, 3, 32 or 64");
+  if (d->ways < 1 || d->ways > 64) return fail(nullptr, MI_ERR_ARG, "ways must be 1..64");
+  mi_engine* e = new mi_engine();
+  e->d = *d;
+  e->device = device;
+  e->perm_dev = nullptr;
+  int ci = d->in_channels, h = d->in_h, w = d->in_w;
+  size_t off = 0;
+  std::vector<int32_t> perm;
+  for (int i = 0; i < d->n_layers; ++i) {
+    Layer l;
+    l.ci = ci; l.co = d->hidden; l.h = h; l.w = w;
+    l.stride = d->max_pool ? 1 : 2;
+    l.pool = d->max_pool ? 1 : 0;
+    l.ho = (h + 2 - 3) / l.stride + 1;
+    l.wo = (w + 2 - 3) / l.stride + 1;
+    l.hp = l.pool ? l.ho / 2 : l.ho;
+    l.wp = l.pool ? l.wo / 2 : l.wo;
+    if (l.hp < 1 || l.wp < 1) { delete e; return fail(nullptr, MI_ERR_ARG, "input too small for this many blocks"); }
+    l.off_gamma = off; off += l.co;
+    l.off_beta = off; off += l.co;
+    l.off_w = off; off += (size_t)9 * l.ci * l.co;
+    l.off_b = off; off += l.co;
+    for (size_t k = perm.size(); k < l.off_w; ++k) perm.push_back((int32_t)k);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int c1 = 0; c1 < l.ci; ++c1)
+        for (int c2 = 0; c2 < l.co; ++c2) perm.push_back((int32_t)(l.off_w + ((size_t)c2 * l.ci + c1) * 9 + tap));
+    for (size_t k = perm.size(); k < off; ++k) perm.push_back((int32_t)k);
+    e->L.push_back(l);
+    ci = l.co; h = l.hp; w = l.wp;
+  }
+  e->head_c = ci;
+  e->head_hw = h * w;
+  e->feat = d->head_mean_pool ? ci : ci * h * w;
+  e->off_wl = off; off += (size_t)d->ways * e->feat;
+  e->off_bl = off; off += d->ways;
+  e->P = off;
+  e->PS = align_up(off, 64);
+  for (int wy = 0; wy < d->ways; ++wy)
+    for (int i = 0; i < e->feat; ++i) {
+      size_t ref;
+      if (d->head_mean_pool) ref = (size_t)wy * e->feat + i;
+      else { const int s = i / e->head_c, c = i % e->head_c; ref = (size_t)wy * e->feat + (size_t)c * e->head_hw + s; }
+      perm.push_back((int32_t)(e->off_wl + ref));
+    }
+  for (size_t k = perm.size(); k < off; ++k) perm.push_back((int32_t)k);
+  if (hipSetDevice(device) != hipSuccess) { delete e; return fail(nullptr, MI_ERR_HIP, "hipSetDevice failed"); }
+  if (hipMalloc(&e->perm_dev, perm.size() * sizeof(int32_t)) != hipSuccess ||
+      hipMemcpy(e->perm_dev, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+    delete e;
+    return fail(nullptr, MI_ERR_HIP, "allocating the parameter permutation table failed");
+  }
+  *out = e;
+  return MI_OK;
+}
+
+extern "C" void mi_engine_destroy(mi_engine* e) {
+  if (!e) return;
+  if (e->perm_dev) (void)hipFree(e->perm_dev);
+  delete e;
+}
+
+extern "C" int mi_param_count(const mi_engine* e, size_t* n) {
+  if (!e || !n) return MI_ERR_ARG;
+  *n = e->P;
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct Bump {
+  char* base;
+  size_t off;
+  template <class T> T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+struct ActSet {
+  float *z[8], *p[8], *dz[8], *dp[8], *mu[8], *rstd[8];
+  float *f, *df, *prob, *dl;
+};
+struct TanSet {
+  float *zd[8], *pd[8], *m1[8], *m2[8];
+  float *rdz, *dpd[2], *fd, *rdf;
+};
+struct Plan {
+  float *theta, *g, *lam, *hv;
+  float *xs, *xq;
+  int32_t *ys, *yq;
+  std::vector<ActSet> sup;
+  ActSet qry;
+  TanSet tan;
+  double* bnpart;
+  float* wgpart;
+  float *tmp_loss, *tmp_acc;
+  size_t bytes;
+};
+
+static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bool with_bwd) {
+  const int nl = (int)e->L.size();
+  for (int l = 0; l < nl; ++l) {
+    const Layer& L = e->L[l];
+    const size_t zs = (size_t)T * n * L.ho * L.wo * L.co, ps = (size_t)T * n * L.hp * L.wp * L.co;
+    A.z[l] = b.take<float>(zs);
+    A.p[l] = b.take<float>(ps);
+    A.dz[l] = with_bwd ? b.take<float>(zs) : nullptr;
+    A.dp[l] = with_bwd ? b.take<float>(ps) : nullptr;
+    A.mu[l] = b.take<float>((size_t)T * L.co);
+    A.rstd[l] = b.take<float>((size_t)T * L.co);
+  }
+  if (e->d.head_mean_pool) {
+    A.f = b.take<float>((size_t)T * n * e->feat);
+    A.df = with_bwd ? b.take<float>((size_t)T * n * e->feat) : nullptr;
+  } else {
+    A.f = A.p[nl - 1];
+    A.df = A.dp[nl - 1];
+  }
+  A.prob = b.take<float>((size_t)T * n * e->d.ways);
+  A.dl = b.take<float>((size_t)T * n * e->d.ways);
+}
+
+static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K, int second_order, Plan& pl) {
+  Bump b{reinterpret_cast<char*>(ws), 0};
+  const int nl = (int)e->L.size();
+  const size_t TP = (size_t)T * e->PS;
+  pl.theta = b.take<float>(TP * (K + 1));
+  pl.g = b.take<float>(TP * (K > 0 ? K : 1));
+  pl.lam = b.take<float>(TP);
+  pl.hv = b.take<float>(TP);
+  const size_t img = (size_t)e->d.in_h * e->d.in_w * e->d.in_channels;
+  pl.xs = b.take<float>((size_t)T * ns * img);
+  pl.xq = b.take<float>((size_t)T * nq * img);
+  pl.ys = b.take<int32_t>((size_t)T * ns);
+  pl.yq = b.take<int32_t>((size_t)T * nq);
+  pl.tmp_loss = b.take<float>(T);
+  pl.tmp_acc = b.take<float>(T);
+  const int nsets = (second_order && K > 0) ? K : 1;
+  pl.sup.resize(nsets);
+  for (int k = 0; k < nsets; ++k) plan_actset(e, b, pl.sup[k], T, ns, true);
+  plan_actset(e, b, pl.qry, T, nq, true);
+  // partial buffers (sized for the larger of support / query passes)
+  const int nmax = ns > nq ? ns : nq;
+  size_t bnp = 0, wgp = 0, zmax = 0, pmax = 0;
+  for (int l = 0; l < nl; ++l) {
+    const Layer& L = e->L[l];
+    const ConvGeom gg = geom(L, nmax);
+    int blk = conv_max_blocks_per_task(gg);
+    const int bb = bn_blocks_per_task(nmax, L.ho, L.wo, L.co, L.pool, 1);
+    if (bb > blk) blk = bb;
+    const size_t need = (size_t)T * blk * 2 * L.co;
+    if (need > bnp) bnp = need;
+    const size_t w = wgrad_partial_floats(gg, T);
+    if (w > wgp) wgp = w;
+    const size_t zs = (size_t)T * nmax * L.ho * L.wo * L.co, ps = (size_t)T * nmax * L.hp * L.wp * L.co;
+    if (zs > zmax) zmax = zs;
+    if (ps > pmax) pmax = ps;
+  }
+  pl.bnpart = b.take<double>(bnp);
+  pl.wgpart = b.take<float>(wgp);
+  if (second_order && K > 0) {
+    TanSet& X = pl.tan;
+    for (int l = 0; l < nl; ++l) {
+      const Layer& L = e->L[l];
+      X.zd[l] = b.take<float>((size_t)T * ns * L.ho * L.wo * L.co);
+      X.pd[l] = b.take<float>((size_t)T * ns * L.hp * L.wp * L.co);
+      X.m1[l] = b.take<float>((size_t)T * L.co);
+      X.m2[l] = b.take<float>((size_t)T * L.co);
+    }
+    X.rdz = b.take<float>(zmax);
+    X.dpd[0] = b.take<float>(pmax);
+    X.dpd[1] = b.take<float>(pmax);
+    if (e->d.head_mean_pool) {
+      X.fd = b.take<float>((size_t)T * ns * e->feat);
+      X.rdf = b.take<float>((size_t)T * ns * e->feat);
+    } else {
+      X.fd = nullptr;
+      X.rdf = nullptr;
+    }
+  }
+  pl.bytes = align_up(b.off, 256);
+}
+
+extern "C" int mi_workspace_bytes(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, int second_order,
+                                  size_t* bytes) {
+  if (!e || !bytes || tasks < 1 || ways < 1 || shots < 1 || adapt_steps < 0) return MI_ERR_ARG;
+  Plan pl;
+  make_plan(e, nullptr, tasks, ways * shots, ways * shots, adapt_steps, second_order, pl);
+  *bytes = pl.bytes;
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One forward (+ backward) pass of the whole net on n images per task.
+static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, const int32_t* y, int n, int T,
+                        const float* theta, float* g, float* loss, float* acc, float* logits, bool with_grad) {
+  const int nl = (int)e->L.size();
+  const size_t P = e->PS;  // task stride
+  for (int l = 0; l < nl; ++l) {
+    const Layer& L = e->L[l];
+    ConvArgs ca{};
+    ca.in[0] = l == 0 ? x0 : A.p[l - 1];
+    ca.wt[0] = theta + L.off_w;
+    ca.wstride = P;
+    ca.out = A.z[l];
+    ca.partial = pl.bnpart;
+    ca.g = geom(L, n);
+    ca.mpix = n * L.ho * L.wo;
+    int blk = 0;
+    HIPCHK(e, launch_conv3x3(st, ca, T, 1, EPI_STATS, 0, &blk));
+    HIPCHK(e, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co));
+    BnArgs ba{};
+    ba.z = A.z[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l];
+    ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
+    ba.out = A.p[l];
+    ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
+    HIPCHK(e, launch_bn_fwd(st, ba, T, L.pool));
+  }
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
+  if (with_grad) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * P * sizeof(float), st));
+  HeadArgs ha{};
+  ha.f = A.f;
+  ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
+  ha.y = y; ha.loss = loss; ha.acc = acc; ha.logits = logits; ha.prob = A.prob; ha.dl = A.dl;
+  ha.dwl = with_grad ? g + e->off_wl : nullptr; ha.dbl = with_grad ? g + e->off_bl : nullptr; ha.gstride = P;
+  ha.df = with_grad ? A.df : nullptr;
+  ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+  HIPCHK(e, launch_head_fwd_bwd(st, ha, T, with_grad ? 1 : 0));
+  if (!with_grad) return MI_OK;
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], T * n, e->head_hw, e->head_c));
+  for (int l = nl - 1; l >= 0; --l) {
+    const Layer& L = e->L[l];
+    const int mpix = n * L.ho * L.wo;
+    BnArgs ba{};
+    ba.z = A.z[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l];
+    ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
+    ba.dp = A.dp[l];
+    ba.partial = pl.bnpart;
+    ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
+    ba.inv_m = 1.f / (float)mpix;
+    int blk = 0;
+    HIPCHK(e, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
+    HIPCHK(e, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
+    ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
+    ba.out = A.dz[l];
+    HIPCHK(e, launch_bn_bwd_apply(st, ba, T, L.pool));
+    WgradArgs wa{};
+    wa.x[0] = l == 0 ? x0 : A.p[l - 1];
+    wa.dz[0] = A.dz[l];
+    wa.partial = pl.wgpart;
+    wa.g = geom(L, n);
+    wa.mpix = mpix;
+    HIPCHK(e, launch_wgrad3x3(st, wa, T, 1, g + L.off_w, P));
+    if (l > 0) {
+      ConvArgs ca{};
+      ca.in[0] = A.dz[l];
+      ca.wt[0] = theta + L.off_w;
+      ca.wstride = P;
+      ca.out = A.dp[l - 1];
+      ca.g = geom_dgrad(L, n);
+      ca.mpix = n * L.h * L.w;
+      HIPCHK(e, launch_conv3x3(st, ca, T, 1, EPI_NONE, 1, nullptr));
+    }
+  }
+  return MI_OK;
+}
+
+// hv = H(theta) v for the saved support pass A (activations) / g (its gradient): forward-over-reverse.
+static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
+                    const float* g, const float* v, float* hv) {
+  const int nl = (int)e->L.size();
+  const size_t P = e->PS;  // task stride
+  TanSet& X = pl.tan;
+  HIPCHK(e, hipMemsetAsync(hv, 0, (size_t)T * P * sizeof(float), st));
+  for (int l = 0; l < nl; ++l) {
+    const Layer& L = e->L[l];
+    const int mpix = n * L.ho * L.wo;
+    ConvArgs ca{};
+    ca.in[0] = l == 0 ? x0 : A.p[l - 1];
+    ca.wt[0] = v + L.off_w;
+    if (l > 0) { ca.in[1] = X.pd[l - 1]; ca.wt[1] = theta + L.off_w; }
+    ca.wstride = P;
+    ca.out = X.zd[l];
+    ca.z = A.z[l]; ca.mu = A.mu[l]; ca.rstd = A.rstd[l];
+    ca.partial = pl.bnpart;
+    ca.g = geom(L, n);
+    ca.mpix = mpix;
+    int blk = 0;
+    HIPCHK(e, launch_conv3x3(st, ca, T, l > 0 ? 2 : 1, EPI_TSTATS, 0, &blk));
+    HIPCHK(e, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co));
+    BnArgs ba{};
+    ba.z = A.z[l]; ba.zd = X.zd[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l]; ba.m1 = X.m1[l]; ba.m2 = X.m2[l];
+    ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
+    ba.gammad = v + L.off_gamma; ba.betad = v + L.off_beta; ba.vstride = P;
+    ba.out = X.pd[l];
+    ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
+    HIPCHK(e, launch_bn_tan_fwd(st, ba, T, L.pool));
+  }
+  const float* fd = X.pd[nl - 1];
+  if (e->d.head_mean_pool) {
+    HIPCHK(e, launch_spatial_mean(st, X.pd[nl - 1], X.fd, T * n, e->head_hw, e->head_c));
+    fd = X.fd;
+  }
+  int cur = 0;
+  HeadArgs ha{};
+  ha.f = A.f; ha.fd = fd;
+  ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
+  ha.wld = v + e->off_wl; ha.bld = v + e->off_bl; ha.vstride = P;
+  ha.prob = A.prob; ha.dl = A.dl;
+  ha.dwl = hv + e->off_wl; ha.dbl = hv + e->off_bl; ha.gstride = P;
+  ha.df = e->d.head_mean_pool ? X.rdf : X.dpd[cur];
+  ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+  HIPCHK(e, launch_head_tangent(st, ha, T));
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, X.rdf, X.dpd[cur], T * n, e->head_hw, e->head_c));
+  for (int l = nl - 1; l >= 0; --l) {
+    const Layer& L = e->L[l];
+    const int mpix = n * L.ho * L.wo;
+    BnArgs ba{};
+    ba.z = A.z[l]; ba.zd = X.zd[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l]; ba.m1 = X.m1[l]; ba.m2 = X.m2[l];
+    ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
+    ba.gammad = v + L.off_gamma; ba.betad = v + L.off_beta; ba.vstride = P;
+    ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
+    ba.dp = A.dp[l]; ba.dpd = X.dpd[cur];
+    ba.partial = pl.bnpart;
+    ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
+    ba.inv_m = 1.f / (float)mpix;
+    int blk = 0;
+    HIPCHK(e, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
+    HIPCHK(e, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
+    ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
+    ba.out = X.rdz;
+    HIPCHK(e, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
+    WgradArgs wa{};
+    wa.x[0] = l == 0 ? x0 : A.p[l - 1];
+    wa.dz[0] = X.rdz;
+    if (l > 0) { wa.x[1] = X.pd[l - 1]; wa.dz[1] = A.dz[l]; }
+    wa.partial = pl.wgpart;
+    wa.g = geom(L, n);
+    wa.mpix = mpix;
+    HIPCHK(e, launch_wgrad3x3(st, wa, T, l > 0 ? 2 : 1, hv + L.off_w, P));
+    if (l > 0) {
+      ConvArgs ca{};
+      ca.in[0] = X.rdz; ca.wt[0] = theta + L.off_w;
+      ca.in[1] = A.dz[l]; ca.wt[1] = v + L.off_w;
+      ca.wstride = P;
+      ca.out = X.dpd[cur ^ 1];
+      ca.g = geom_dgrad(L, n);
+      ca.mpix = n * L.h * L.w;
+      HIPCHK(e, launch_conv3x3(st, ca, T, 2, EPI_NONE, 1, nullptr));
+      cur ^= 1;
+    }
+  }
+  return MI_OK;
+}
+
+extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
+                                  int tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order,
+                                  int with_grad, float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
+                                  void* workspace, size_t workspace_bytes) {
+  if (!e) return fail(nullptr, MI_ERR_ARG, "null engine");
+  if (!theta || !data || !labels || !loss_out || !acc_out || !workspace) return fail(e, MI_ERR_ARG, "null pointer argument");
+  if (with_grad && !meta_grad_out) return fail(e, MI_ERR_ARG, "meta_grad_out is NULL but with_grad != 0");
+  if (tasks < 1 || shots < 1 || adapt_steps < 0) return fail(e, MI_ERR_ARG, "tasks/shots must be >= 1, adapt_steps >= 0");
+  if (ways != e->d.ways) return fail(e, MI_ERR_ARG, "ways differs from the engine's classifier width");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int T = tasks, K = adapt_steps, ns = ways * shots, nq = ways * shots;
+  const int so = (second_order && with_grad) ? 1 : 0;
+  Plan pl;
+  make_plan(e, workspace, T, ns, nq, K, so, pl);
+  if (pl.bytes > workspace_bytes)
+    return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
+  const size_t TP = (size_t)T * e->PS;
+  HIPCHK(e, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
+  HIPCHK(e, launch_gather_params(st, theta, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
+  for (int k = 0; k < K; ++k) {
+    ActSet& A = so ? pl.sup[k] : pl.sup[0];
+    float* th = pl.theta + (size_t)k * TP;
+    float* gk = pl.g + (size_t)k * TP;
+    int rc = pass_fwd_bwd(e, st, pl, A, pl.xs, pl.ys, ns, T, th, gk, pl.tmp_loss, pl.tmp_acc, nullptr, true);
+    if (rc) return rc;
+    HIPCHK(e, launch_axpy(st, th, gk, inner_lr, TP, th + TP));
+  }
+  float* thK = pl.theta + (size_t)K * TP;
+  int rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, nq, T, thK, pl.lam, loss_out, acc_out, logits_out, with_grad != 0);
+  if (rc) return rc;
+  if (!with_grad) return MI_OK;
+  if (so) {
+    for (int k = K - 1; k >= 0; --k) {
+      rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, T, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv);
+      if (rc) return rc;
+      HIPCHK(e, launch_axpy(st, pl.lam, pl.hv, inner_lr, TP, pl.lam));
+    }
+  }
+  HIPCHK(e, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, meta_grad_out));
+  return MI_OK;
+}
+
+extern "C" int mi_adam_step(void* stream, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                            int step, float lr, float beta1, float beta2, float eps, float grad_scale) {
+  if (!theta || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(nullptr, MI_ERR_ARG, "bad adam arguments");
+  hipError_t s = launch_adam(reinterpret_cast<hipStream_t>(stream), theta, grad, exp_avg, exp_avg_sq, n, step, lr, beta1,
+                             beta2, eps, grad_scale);
+  return s == hipSuccess ? MI_OK : fail(nullptr, MI_ERR_HIP, hipGetErrorString(s));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-kernel entry points (unit parity tests).
+#define HIPCHK0(call)                                                                     \
+  do {                                                                                    \
+    hipError_t _s = (call);                                                               \
+    if (_s != hipSuccess) return fail(nullptr, MI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s)); \
+  } while (0)
+
+extern "C" size_t mi_kernel_scratch_bytes(int tasks, int n, int h, int w, int c) {
+  // generous: covers bn partials and wgrad partials for one layer with <= 64 input channels
+  ConvGeom g{n, h, w, h, w, 64, c, 1};
+  size_t bn = (size_t)tasks * (size_t)conv_max_blocks_per_task(g) * 2 * c * sizeof(double);
+  size_t wg = wgrad_partial_floats(g, tasks) * sizeof(float);
+  return align_up(bn, 256) + align_up(wg, 256) + 4096;
+}
+
+extern "C" int mi_prepare_batch(void* stream, const float* data, const int64_t* labels, int tasks, int n2, int c, int h, int w,
+                                float* xs, float* xq, int32_t* ys, int32_t* yq) {
+  if (n2 % 2) return fail(nullptr, MI_ERR_ARG, "task batch must hold 2*shots*ways rows");
+  HIPCHK0(launch_prepare_batch(reinterpret_cast<hipStream_t>(stream), data, labels, tasks, n2, c, h, w, xs, xq, ys, yq));
+  return MI_OK;
+}
+
+extern "C" int mi_conv3x3_bn_stats(void* stream, const float* x, const float* w9, size_t pstride, int tasks, int n, int h,
+                                   int wd, int ci, int co, int stride, float* z, float* mu, float* rstd, void* scratch,
+                                   size_t scratch_bytes) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  ConvArgs ca{};
+  ca.in[0] = x; ca.wt[0] = w9; ca.wstride = pstride; ca.out = z;
+  ca.partial = reinterpret_cast<double*>(scratch);
+  ca.g = ConvGeom{n, h, wd, (h - 1) / stride + 1, (wd - 1) / stride + 1, ci, co, stride};
+  ca.mpix = n * ca.g.ho * ca.g.wo;
+  if ((size_t)tasks * conv_max_blocks_per_task(ca.g) * 2 * co * sizeof(double) > scratch_bytes)
+    return fail(nullptr, MI_ERR_WORKSPACE, "scratch too small");
+  int blk = 0;
+  HIPCHK0(launch_conv3x3(st, ca, tasks, 1, EPI_STATS, 0, &blk));
+  HIPCHK0(launch_bn_finalize(st, ca.partial, blk, tasks, co, 1.0 / (double)ca.mpix, FIN_STATS, mu, co, rstd, co));
+  return MI_OK;
+}
+
+extern "C" int mi_bn_relu_pool(void* stream, const float* z, const float* mu, const float* rstd, const float* gamma,
+                               const float* beta, size_t pstride, int tasks, int n, int ho, int wo, int c, int pool, float* p) {
+  BnArgs ba{};
+  ba.z = z; ba.mu = mu; ba.rstd = rstd; ba.gamma = gamma; ba.beta = beta; ba.pstride = pstride; ba.out = p;
+  ba.n = n; ba.ho = ho; ba.wo = wo; ba.c = c;
+  HIPCHK0(launch_bn_fwd(reinterpret_cast<hipStream_t>(stream), ba, tasks, pool));
+  return MI_OK;
+}
+
+extern "C" int mi_bn_relu_pool_bwd(void* stream, const float* z, const float* mu, const float* rstd, const float* gamma,
+                                   const float* beta, size_t pstride, const float* dp, int tasks, int n, int ho, int wo, int c,
+                                   int pool, float* dgamma, float* dbeta, size_t gstride, float* dz, void* scratch,
+                                   size_t scratch_bytes) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  BnArgs ba{};
+  ba.z = z; ba.mu = mu; ba.rstd = rstd; ba.gamma = gamma; ba.beta = beta; ba.pstride = pstride; ba.dp = dp;
+  ba.partial = reinterpret_cast<double*>(scratch);
+  ba.n = n; ba.ho = ho; ba.wo = wo; ba.c = c;
+  ba.inv_m = 1.f / (float)(n * ho * wo);
+  if ((size_t)tasks * bn_blocks_per_task(n, ho, wo, c, pool, tasks) * 2 * c * sizeof(double) > scratch_bytes)
+    return fail(nullptr, MI_ERR_WORKSPACE, "scratch too small");
+  int blk = 0;
+  HIPCHK0(launch_bn_bwd_reduce(st, ba, tasks, pool, &blk));
+  HIPCHK0(launch_bn_finalize(st, ba.partial, blk, tasks, c, 1.0, FIN_SUMS, dgamma, gstride, dbeta, gstride));
+  ba.dgamma = dgamma; ba.dbeta = dbeta; ba.gstride = gstride; ba.out = dz;
+  HIPCHK0(launch_bn_bwd_apply(st, ba, tasks, pool));
+  return MI_OK;
+}
+
+extern "C" int mi_conv3x3_bwd(void* stream, const float* x, const float* dz, const float* w9, size_t pstride, int tasks, int n,
+                              int h, int wd, int ci, int co, int stride, float* dx, float* dw9, size_t gstride, void* scratch,
+                              size_t scratch_bytes) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ho = (h - 1) / stride + 1, wo = (wd - 1) / stride + 1;
+  WgradArgs wa{};
+  wa.x[0] = x; wa.dz[0] = dz; wa.partial = reinterpret_cast<float*>(scratch);
+  wa.g = ConvGeom{n, h, wd, ho, wo, ci, co, stride};
+  wa.mpix = n * ho * wo;
+  if (wgrad_partial_floats(wa.g, tasks) * sizeof(float) > scratch_bytes) return fail(nullptr, MI_ERR_WORKSPACE, "scratch too small");
+  HIPCHK0(launch_wgrad3x3(st, wa, tasks, 1, dw9, gstride));
+  if (dx) {
+    ConvArgs ca{};
+    ca.in[0] = dz; ca.wt[0] = w9; ca.wstride = pstride; ca.out = dx;
+    ca.g = ConvGeom{n, ho, wo, h, wd, co, ci, stride};
+    ca.mpix = n * h * wd;
+    HIPCHK0(launch_conv3x3(st, ca, tasks, 1, EPI_NONE, 1, nullptr));
+  }
+  return MI_OK;
+}
+
+extern "C" int mi_head_fwd_bwd(void* stream, const float* f, const float* wl, const float* bl, size_t pstride, const int32_t* y,
+                               int tasks, int n, int feat, int ways, float* loss, float* acc, float* logits, float* prob,
+                               float* dl, float* dwl, float* dbl, size_t gstride, float* df) {
+  HeadArgs ha{};
+  ha.f = f; ha.wl = wl; ha.bl = bl; ha.pstride = pstride; ha.y = y; ha.loss = loss; ha.acc = acc; ha.logits = logits;
+  ha.prob = prob; ha.dl = dl; ha.dwl = dwl; ha.dbl = dbl; ha.gstride = gstride; ha.df = df;
+  ha.n = n; ha.feat = feat; ha.ways = ways;
+  HIPCHK0(launch_head_fwd_bwd(reinterpret_cast<hipStream_t>(stream), ha, tasks, dwl != nullptr));
+  return MI_OK;
+}

@@ -1,0 +1,91 @@
+// Internal launcher interface between the kernel files and the engine (not part of the C ABI).
+#pragma once
+#include "mi_common.h"
+
+struct ConvArgs {
+  const float* in[2];   // [T][n][h][w][ci] per term
+  const float* wt[2];   // per-task weights per term (forward layout [9][Ci_fwd][Co_fwd]), advance wstride floats per task
+  size_t wstride;
+  float* out;           // [T][n][ho][wo][co]
+  const float* z;       // EPI_TSTATS: primal conv output (same shape as out)
+  const float* mu;      // EPI_TSTATS: [T][co]
+  const float* rstd;    // EPI_TSTATS: [T][co]
+  double* partial;      // EPI_*STATS: [T][blocks_per_task][2][co]
+  ConvGeom g;
+  int mpix;             // n*ho*wo
+  int ntiles, tiles_per_wave;
+};
+
+struct WgradArgs {
+  const float* x[2];    // [T][n][h][w][ci] per term
+  const float* dz[2];   // [T][n][ho][wo][co] per term
+  float* partial;       // [T][nchunks][9][ci][co]
+  ConvGeom g;
+  int mpix, chunk_pix, nchunks;
+};
+
+struct BnArgs {
+  const float* z;       // [T][n][ho][wo][c]
+  const float* zd;      // tangent of z
+  const float* mu;      // [T][c]
+  const float* rstd;
+  const float* m1;      // [T][c] mean(zd)
+  const float* m2;      // [T][c] mean(zh*zd)
+  const float* gamma; const float* beta; size_t pstride;     // theta (per task)
+  const float* gammad; const float* betad; size_t vstride;   // tangent direction (per task)
+  const float* dgamma; const float* dbeta; size_t gstride;   // primal gradient (per task)
+  const float* rdgamma; const float* rdbeta; size_t hstride; // tangent gradient (per task)
+  const float* dp;      // [T][n][hp][wp][c]
+  const float* dpd;
+  float* out;
+  double* partial;      // [T][nblk][2][c]
+  int n, ho, wo, c;
+  float inv_m;
+};
+
+enum { FIN_STATS = 0, FIN_TSTATS = 1, FIN_SUMS = 2 };
+
+// conv_mfma.hip
+hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int epi, int mode, int* blocks_per_task);
+hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, float* out, size_t ostride);
+size_t wgrad_partial_floats(const ConvGeom& g, int tasks);
+int conv_max_blocks_per_task(const ConvGeom& g);
+
+// bn_pool.hip
+int bn_blocks_per_task(int n, int ho, int wo, int c, int pool, int tasks);
+hipError_t launch_bn_finalize(hipStream_t st, const double* partial, int nblk, int tasks, int c, double inv_m, int mode,
+                              float* out0, size_t stride0, float* out1, size_t stride1);
+hipError_t launch_bn_fwd(hipStream_t st, const BnArgs& a, int tasks, int pool);
+hipError_t launch_bn_bwd_reduce(hipStream_t st, const BnArgs& a, int tasks, int pool, int* nblk);
+hipError_t launch_bn_bwd_apply(hipStream_t st, const BnArgs& a, int tasks, int pool);
+hipError_t launch_bn_tan_fwd(hipStream_t st, const BnArgs& a, int tasks, int pool);
+hipError_t launch_bn_tan_bwd_reduce(hipStream_t st, const BnArgs& a, int tasks, int pool, int* nblk);
+hipError_t launch_bn_tan_bwd_apply(hipStream_t st, const BnArgs& a, int tasks, int pool);
+
+// head.hip
+struct HeadArgs {
+  const float* f;       // [T][n][F]
+  const float* fd;      // tangent
+  const float* wl; const float* bl; size_t pstride;      // theta
+  const float* wld; const float* bld; size_t vstride;    // direction
+  const int32_t* y;     // [T][n]
+  float* loss; float* acc;          // [T]
+  float* logits;        // [T][n][ways] (may be null)
+  float* prob; float* dl;           // [T][n][ways] saved (tangent pass reads them)
+  float* dwl; float* dbl; size_t gstride;   // outputs (primal grads or tangent grads)
+  float* df;            // [T][n][F] output (df or R{df}); may be null
+  int n, feat, ways;
+};
+hipError_t launch_head_fwd_bwd(hipStream_t st, const HeadArgs& a, int tasks, int with_grad);
+hipError_t launch_head_tangent(hipStream_t st, const HeadArgs& a, int tasks);
+hipError_t launch_spatial_mean(hipStream_t st, const float* p, float* f, int rows, int hw, int c);
+hipError_t launch_spatial_mean_bwd(hipStream_t st, const float* df, float* dp, int rows, int hw, int c);
+
+// misc.hip
+hipError_t launch_prepare_batch(hipStream_t st, const float* data, const int64_t* labels, int tasks, int n2, int c, int h,
+                                int w, float* xs, float* xq, int32_t* ys, int32_t* yq);
+hipError_t launch_gather_params(hipStream_t st, const float* theta_ref, const int32_t* perm, int p, int pstride, int tasks, float* theta_eng);
+hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* perm, int p, int pstride, int tasks, float* out_ref);
+hipError_t launch_axpy(hipStream_t st, const float* a, const float* b, float alpha, size_t n, float* out);
+hipError_t launch_adam(hipStream_t st, float* theta, const float* grad, float* m, float* v, size_t n, int step, float lr,
+                       float b1, float b2, float eps, float gscale);

@@ -1,0 +1,39 @@
+// Shared device/host helpers for libmi_maml (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define MI_WAVE 64
+#define MI_BN_EPS 1e-5
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---- launch geometry of one ConvBlock as the kernels see it
+struct ConvGeom {
+  int n;        // images per task
+  int h, w;     // conv input spatial size
+  int ho, wo;   // conv output spatial size
+  int ci, co;   // reduction / output channels of THIS op
+  int stride;   // 1 or 2 (pad is always 1, kernel 3x3)
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// u = gamma * ((z - mu) * rstd) + beta, written so that every kernel evaluates it with the same roundings
+// (the pooling argmax / ReLU mask is RE-computed from z in backward and tangent kernels, never stored).
+__device__ __forceinline__ float bn_zh(float z, float mu, float r) { return (z - mu) * r; }
+__device__ __forceinline__ float bn_u(float zh, float g, float b) { return fmaf(g, zh, b); }
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,98 @@
+// Boundary / bookkeeping kernels: the reference's prepare_batch split, parameter-layout gather/scatter, fast-weight SGD
+// update, Adam.
+#include "mi_common.h"
+#include "kernels.h"
+
+// utils/data_pre.py:115-129 (reference): support = rows {0,2,4,...} of the task batch, query = the complement (odd rows),
+// order preserved; here also NCHW -> NHWC and int64 -> int32 labels.  One thread per output pixel (all channels).
+__global__ void prepare_batch_kernel(const float* __restrict__ data, const int64_t* __restrict__ labels, int tasks, int n2,
+                                     int c, int h, int w, float* __restrict__ xs, float* __restrict__ xq,
+                                     int32_t* __restrict__ ys, int32_t* __restrict__ yq) {
+  const size_t hw = (size_t)h * w;
+  const size_t total = (size_t)tasks * n2 * hw;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const size_t pix = e % hw;
+  const size_t img = e / hw;  // task*n2 + row
+  const size_t task = img / n2, row = img - task * n2;
+  const size_t half = row >> 1;
+  float* dst = ((row & 1) ? xq : xs) + ((task * (n2 >> 1) + half) * hw + pix) * c;
+  const float* src = data + img * c * hw + pix;
+  for (int ch = 0; ch < c; ++ch) dst[ch] = src[(size_t)ch * hw];
+  if (pix == 0) {
+    int32_t* yd = (row & 1) ? yq : ys;
+    yd[task * (n2 >> 1) + half] = (int32_t)labels[img];
+  }
+}
+
+// theta_eng[t][i] = theta_ref[perm[i]] for every task (learn2learn clone_module: each task starts from the meta-parameters)
+__global__ void gather_params_kernel(const float* __restrict__ theta_ref, const int32_t* __restrict__ perm, int p, int pstride,
+                                     float* __restrict__ theta_eng) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pstride) return;
+  theta_eng[(size_t)blockIdx.y * pstride + i] = i < p ? theta_ref[perm[i]] : 0.f;
+}
+
+// out_ref[perm[i]] = sum_t lam[t][i]   (eval_loss.backward() accumulates over tasks, maml_vision.py:112); fixed task order.
+__global__ void scatter_sum_kernel(const float* __restrict__ lam, const int32_t* __restrict__ perm, int p, int pstride,
+                                   int tasks, float* __restrict__ out_ref) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  float s = 0.f;
+  for (int t = 0; t < tasks; ++t) s += lam[(size_t)t * pstride + i];
+  out_ref[perm[i]] = s;
+}
+
+// out = a - alpha*b : learn2learn maml_update (p <- p - lr*g) and the adjoint recursion lam <- lam - alpha*H lam.
+__global__ void axpy_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha, size_t n,
+                            float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] - alpha * b[i];
+}
+
+// torch.optim.Adam (defaults, no weight decay / amsgrad) on the flat meta-parameters; grad scaled by 1/meta_batch first
+// (maml_vision.py:139-141).
+__global__ void adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float gscale,
+                            float bc1, float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = grad[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * g;
+  const float vi = b2 * v[i] + (1.f - b2) * g * g;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  theta[i] -= (lr / bc1) * (mi / denom);
+}
+
+hipError_t launch_prepare_batch(hipStream_t st, const float* data, const int64_t* labels, int tasks, int n2, int c, int h,
+                                int w, float* xs, float* xq, int32_t* ys, int32_t* yq) {
+  const size_t total = (size_t)tasks * n2 * h * w;
+  hipLaunchKernelGGL(prepare_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, data, labels, tasks, n2, c,
+                     h, w, xs, xq, ys, yq);
+  return hipGetLastError();
+}
+hipError_t launch_gather_params(hipStream_t st, const float* theta_ref, const int32_t* perm, int p, int pstride, int tasks,
+                                float* theta_eng) {
+  hipLaunchKernelGGL(gather_params_kernel, dim3(ceil_div(pstride, 256), tasks), dim3(256), 0, st, theta_ref, perm, p, pstride,
+                     theta_eng);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* perm, int p, int pstride, int tasks,
+                              float* out_ref) {
+  hipLaunchKernelGGL(scatter_sum_kernel, dim3(ceil_div(p, 256)), dim3(256), 0, st, lam, perm, p, pstride, tasks, out_ref);
+  return hipGetLastError();
+}
+hipError_t launch_axpy(hipStream_t st, const float* a, const float* b, float alpha, size_t n, float* out) {
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, alpha, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_adam(hipStream_t st, float* theta, const float* grad, float* m, float* v, size_t n, int step, float lr,
+                       float b1, float b2, float eps, float gscale) {
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  const float bc2 = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, grad, m, v, n, lr, b1, b2, eps,
+                     gscale, bc1, bc2);
+  return hipGetLastError();
+}

@@ -1,0 +1,144 @@
+"""Batched MAML engine: Python host over the C ABI (include/mi_maml.h).
+
+``MetaEngine.meta_batch`` processes a whole meta-batch of tasks in one call -- what the reference does with a sequential
+Python loop of ``maml.clone()`` / ``fast_adapt`` / ``eval_loss.backward()`` (vision/maml_vision.py:102-114).  PyTorch is
+used only for device memory and streams; all arithmetic runs in libmi_maml's HIP kernels.
+"""
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class ModelSpec:
+    """Architecture of the reference's few-shot classifiers (core_functions/vision_models.py)."""
+    n_layers: int
+    in_channels: int
+    in_h: int
+    in_w: int
+    hidden: int
+    max_pool: bool
+    ways: int
+    head_mean_pool: bool
+
+    @staticmethod
+    def mini_imagenet(ways, hidden=32, layers=4):
+        """MiniImagenetCNN(output_size=ways, hidden_size=32, layers=4) (vision_models.py:93-105)."""
+        return ModelSpec(layers, 3, 84, 84, hidden, True, ways, False)
+
+    @staticmethod
+    def omniglot(ways, hidden=64, layers=4):
+        """OmniglotCNN(output_size=ways, hidden_size=64, layers=4) (vision_models.py:39-49)."""
+        return ModelSpec(layers, 1, 28, 28, hidden, False, ways, True)
+
+    def param_shapes(self):
+        """(name, shape) in the reference's parameters() order / state_dict naming."""
+        out, ci = [], self.in_channels
+        for i in range(self.n_layers):
+            out += [(f'base.{i}.normalize.weight', (self.hidden,)), (f'base.{i}.normalize.bias', (self.hidden,)),
+                    (f'base.{i}.conv.weight', (self.hidden, ci, 3, 3)), (f'base.{i}.conv.bias', (self.hidden,))]
+            ci = self.hidden
+        h, w = self.in_h, self.in_w
+        for _ in range(self.n_layers):
+            if self.max_pool:
+                h, w = h // 2, w // 2
+            else:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        feat = self.hidden if self.head_mean_pool else self.hidden * h * w
+        out += [('linear.weight', (self.ways, feat)), ('linear.bias', (self.ways,))]
+        return out
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class MetaEngine:
+    """One engine per (model spec, device).  Not re-entrant (one host thread per GPU / rank)."""
+
+    def __init__(self, spec, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.MiError('MetaEngine needs a GPU: the MAML hot path has no CPU implementation in this package '
+                               '(the CPU restatement under oracle/ is test infrastructure only).')
+        self.spec = spec
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        desc = _lib.MiModelDesc(spec.n_layers, spec.in_channels, spec.in_h, spec.in_w, spec.hidden, int(spec.max_pool),
+                                spec.ways, int(spec.head_mean_pool))
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.mi_engine_create(C.byref(desc), idx, C.byref(self._h)))
+        n = C.c_size_t()
+        _lib.check(self.lib.mi_param_count(self._h, C.byref(n)), self._h)
+        self.param_count = n.value
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self.lib.mi_engine_destroy(h)
+            self._h = C.c_void_p()
+
+    def workspace_bytes(self, tasks, shots, adapt_steps, second_order):
+        b = C.c_size_t()
+        _lib.check(self.lib.mi_workspace_bytes(self._h, tasks, self.spec.ways, shots, adapt_steps, int(second_order),
+                                               C.byref(b)), self._h)
+        return b.value
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def meta_batch(self, theta, data, labels, shots, adapt_steps, inner_lr, first_order=False, with_grad=True,
+                   return_logits=False):
+        """theta [P] fp32; data [T, 2*shots*ways, C, H, W] fp32 (the reference's task batches, stacked); labels [T, 2*S*W]
+        int64.  Returns (loss[T], acc[T], meta_grad[P] summed over tasks or None, logits [T, S*W, ways] or None)."""
+        s = self.spec
+        T = data.shape[0]
+        n2 = 2 * shots * s.ways
+        if tuple(data.shape) != (T, n2, s.in_channels, s.in_h, s.in_w) and \
+                not (s.in_channels == 1 and data.numel() == T * n2 * s.in_h * s.in_w):
+            raise ValueError(f'data shape {tuple(data.shape)} does not match [T, {n2}, {s.in_channels}, {s.in_h}, {s.in_w}]')
+        if tuple(labels.shape) != (T, n2):
+            raise ValueError(f'labels shape {tuple(labels.shape)} != {(T, n2)}')
+        if theta.numel() != self.param_count:
+            raise ValueError(f'theta has {theta.numel()} elements, the model has {self.param_count}')
+        for t, dt in ((theta, torch.float32), (data, torch.float32), (labels, torch.int64)):
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+                raise ValueError('theta/data must be contiguous fp32 CUDA tensors and labels contiguous int64 CUDA')
+        so = (not first_order) and with_grad
+        ws = self._workspace(self.workspace_bytes(T, shots, adapt_steps, so))
+        loss = torch.empty(T, dtype=torch.float32, device=self.device)
+        acc = torch.empty(T, dtype=torch.float32, device=self.device)
+        grad = torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None
+        logits = torch.empty(T, shots * s.ways, s.ways, dtype=torch.float32, device=self.device) if return_logits else None
+        rc = self.lib.mi_meta_batch_maml(self._h, _stream(), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
+                                         adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
+                                         _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
+        _lib.check(rc, self._h)
+        return loss, acc, grad, logits
+
+    def adam_step(self, theta, grad, state, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+        """torch.optim.Adam defaults on the flat meta-parameters (vision/maml_vision.py:85,139-141)."""
+        if 'm' not in state:
+            state['m'] = torch.zeros_like(theta)
+            state['v'] = torch.zeros_like(theta)
+            state['step'] = 0
+        state['step'] += 1
+        _lib.check(self.lib.mi_adam_step(_stream(), _ptr(theta), _ptr(grad), _ptr(state['m']), _ptr(state['v']),
+                                         theta.numel(), state['step'], lr, betas[0], betas[1], eps, grad_scale))
+
+
+def flatten_parameters(module):
+    """Flat fp32 vector in module.parameters() order (what the C ABI calls theta)."""
+    return torch.cat([p.detach().reshape(-1) for p in module.parameters()]).float().contiguous()

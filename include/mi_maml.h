@@ -1,0 +1,116 @@
+/* mi_maml.h -- C ABI of the MI355X-native MAML/ANIL inner/outer-loop engine (libmi_maml.so).
+ *
+ * Drop-in boundary for the reference's hot path (Kostis-S-Z/exploring_meta).  The reference is pure Python with no FFI of
+ * its own; each entry point below names the reference interface it replaces (file:line under /root/reference).  A
+ * maintainer binds these with ctypes; exploring_meta_amd/_lib.py is that binding.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no torch types.  Every function returns 0 on success and a negative
+ * code on error; mi_last_error() returns a message for the last failing call on that engine (or the global message when
+ * engine is NULL).  All tensor pointers are caller-owned DEVICE memory (fp32 unless noted), the engine keeps nothing
+ * across calls except its model description; work is enqueued on `stream` (a hipStream_t passed as void*), stream
+ * ordered, with no internal synchronisation.  One engine per device; a handle is not re-entrant.
+ *
+ * Parameter vectors ("theta", gradients) are FLAT fp32 vectors in the reference's `module.parameters()` order and
+ * layouts: per ConvBlock  normalize.weight[C], normalize.bias[C], conv.weight[Co,Ci,3,3], conv.bias[Co]
+ * (vision_models.py:168-186), then linear.weight[ways,F], linear.bias[ways] (vision_models.py:47,103).
+ */
+#ifndef MI_MAML_H
+#define MI_MAML_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_ERR_ARG (-1)      /* invalid argument / unsupported shape */
+#define MI_ERR_HIP (-2)      /* HIP runtime error */
+#define MI_ERR_WORKSPACE (-3) /* workspace too small */
+
+typedef struct mi_engine mi_engine;
+
+/* Model family of core_functions/vision_models.py: ConvBase (:121-146) + optional classifier head.
+ *   MiniImagenetCNN(ways)   (:66-118): {4, 3,84,84, 32, max_pool=1, ways, head_mean_pool=0}
+ *   OmniglotCNN(ways)       (:10-63) : {4, 1,28,28, 64, max_pool=0, ways, head_mean_pool=1}
+ *   ANIL trunk ConvBase(...)(anil_vision.py:86-91): ways=0 is not a classifier; see mi_anil_* below. */
+typedef struct {
+  int32_t n_layers;       /* ConvBlocks */
+  int32_t in_channels, in_h, in_w;
+  int32_t hidden;         /* filters per block (32 or 64) */
+  int32_t max_pool;       /* 1: stride-1 conv + MaxPool2d(2,2,floor); 0: stride-2 conv, no pooling (vision_models.py:157-165) */
+  int32_t ways;           /* classifier outputs */
+  int32_t head_mean_pool; /* 1: x.mean(dim=[2,3]) then Linear(hidden,ways) (:53-54); 0: view(-1, hw*hidden) then Linear (:109) */
+} mi_model_desc;
+
+int mi_engine_create(const mi_model_desc* desc, int device, mi_engine** out);
+void mi_engine_destroy(mi_engine* e);
+const char* mi_last_error(const mi_engine* e);
+const char* mi_version(void);
+
+/* Number of fp32 parameters (= sum(p.numel() for p in model.parameters())). */
+int mi_param_count(const mi_engine* e, size_t* n);
+
+/* Bytes of caller-provided scratch for one mi_meta_batch_* call with these sizes. */
+int mi_workspace_bytes(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, int second_order, size_t* bytes);
+
+/* One meta-batch of MAML tasks: replaces, for `tasks` tasks at once, the body of the reference's per-task loop
+ *   learner = maml.clone(); fast_adapt(batch, learner, loss, adapt_steps, shots, ways, device); eval_loss.backward()
+ * (vision/maml_vision.py:102-114; core_functions/vision.py:6-18; utils/data_pre.py:115-129; learn2learn MAML.clone/adapt)
+ * with loss = CrossEntropyLoss(reduction='mean') (maml_vision.py:86).
+ *   theta       [P]                      meta-parameters (read only)
+ *   data        [tasks, 2*shots*ways, C, H, W]  NCHW fp32, exactly the reference's task batches stacked
+ *   labels      [tasks, 2*shots*ways]    int64, as sampled by the reference (sorted by class)
+ *   inner_lr    MAML(model, lr=...)      (maml_vision.py:84)
+ *   second_order 1 = create_graph inner updates (the reference's hard-coded first_order=False), 0 = first-order MAML
+ *   with_grad   0 = evaluation only (core_functions/vision.py:26-42 evaluate, and the validation half :117-124)
+ * Outputs:
+ *   loss_out    [tasks]  query loss per task          (valid_loss, vision.py:16)
+ *   acc_out     [tasks]  query accuracy per task      (valid_accuracy, vision.py:17,21-23)
+ *   meta_grad_out [P]    SUM over tasks of d valid_loss / d theta  (what .backward() accumulates, maml_vision.py:112);
+ *                        the caller applies 1/meta_batch_size (:139-140).  May be NULL when with_grad == 0.
+ *   logits_out  [tasks, shots*ways, ways] query predictions, or NULL. */
+int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
+                       int tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order, int with_grad,
+                       float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
+                       void* workspace, size_t workspace_bytes);
+
+/* Adam step on the flat meta-parameters with torch.optim.Adam defaults (maml_vision.py:85,139-141):
+ * grad is first scaled by grad_scale (= 1/meta_batch_size). step is the 1-based step count after increment. */
+int mi_adam_step(void* stream, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step,
+                 float lr, float beta1, float beta2, float eps, float grad_scale);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Per-kernel entry points (unit parity tests against oracle/kernels_ref.py).  Engine-internal layouts:
+ * activations NHWC [tasks, N, H, W, C]; conv weights tap-major [9, Ci, Co]; all per-task parameter pointers advance by
+ * `pstride` floats per task. */
+
+/* utils/data_pre.py:115-129 prepare_batch: even rows -> support, odd rows -> query, NCHW -> NHWC, labels -> int32. */
+int mi_prepare_batch(void* stream, const float* data, const int64_t* labels, int tasks, int n2, int c, int h, int w,
+                     float* xs, float* xq, int32_t* ys, int32_t* yq);
+
+/* conv3x3 pad 1 (ConvBlock.conv, vision_models.py:177-185, bias dropped: batch-stat BN cancels it) + per-channel
+ * sum / sum-of-squares partials; then finalize -> mu, rstd (BatchNorm2d train mode, eps 1e-5, biased variance). */
+int mi_conv3x3_bn_stats(void* stream, const float* x, const float* w9, size_t pstride, int tasks, int n, int h, int wd,
+                        int ci, int co, int stride, float* z, float* mu, float* rstd, void* scratch, size_t scratch_bytes);
+/* BN-apply + ReLU + MaxPool2d(2,2) (or identity). */
+int mi_bn_relu_pool(void* stream, const float* z, const float* mu, const float* rstd, const float* gamma, const float* beta,
+                    size_t pstride, int tasks, int n, int ho, int wo, int c, int pool, float* p);
+/* backward of BN+ReLU+pool: dgamma, dbeta, dz. */
+int mi_bn_relu_pool_bwd(void* stream, const float* z, const float* mu, const float* rstd, const float* gamma, const float* beta,
+                        size_t pstride, const float* dp, int tasks, int n, int ho, int wo, int c, int pool,
+                        float* dgamma, float* dbeta, size_t gstride, float* dz, void* scratch, size_t scratch_bytes);
+/* conv backward: dx = dgrad(dz, w9) (may be NULL), dw9 = wgrad(x, dz). */
+int mi_conv3x3_bwd(void* stream, const float* x, const float* dz, const float* w9, size_t pstride, int tasks, int n, int h,
+                   int wd, int ci, int co, int stride, float* dx, float* dw9, size_t gstride, void* scratch, size_t scratch_bytes);
+/* Linear + CrossEntropy(mean) forward/backward on features f [tasks, n, F]. */
+int mi_head_fwd_bwd(void* stream, const float* f, const float* wl, const float* bl, size_t pstride, const int32_t* y,
+                    int tasks, int n, int feat, int ways, float* loss, float* acc, float* logits, float* prob, float* dl,
+                    float* dwl, float* dbl, size_t gstride, float* df);
+size_t mi_kernel_scratch_bytes(int tasks, int n, int h, int w, int c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_MAML_H */
