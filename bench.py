@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the MAML hot path on MI355X: tasks/sec for BASELINE.json's headline configuration.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one meta-iteration of the train half of the reference loop (vision/maml_vision.py:93-141): every rank
+processes its shard of the meta-batch (K inner steps on support, query forward, second-order outer backward) through
+mi_meta_batch_maml, the flat meta-gradient is all-reduced over RCCL, and the identical Adam step is applied on every rank.
+Inputs (synthetic tasks) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from exploring_meta_amd.engine import MetaEngine, ModelSpec  # noqa: E402
+from exploring_meta_amd.utils import synthetic  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on (fits one GPU)
+    'cfg2': dict(name='Mini-ImageNet 5-way 5-shot second-order MAML, 4-conv-32, 5 adapt steps, meta-batch 32 per GPU',
+                 dataset='min', ways=5, shots=5, steps=5, lr=0.5, first_order=False, tasks=32),
+    'cfg4': dict(name='Mini-ImageNet 5-way 1-shot second-order MAML, 1 adapt step, 32 tasks per GPU',
+                 dataset='min', ways=5, shots=1, steps=1, lr=0.5, first_order=False, tasks=32),
+    'cfg1': dict(name='Omniglot 5-way 1-shot first-order MAML, meta-batch 4', dataset='omni', ways=5, shots=1, steps=1,
+                 lr=0.5, first_order=True, tasks=4),
+}
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+
+# MiniImagenetCNN-32 conv geometry (input hw, ci) per block; co = 32 everywhere
+MIN_LAYERS = [(84, 3), (42, 32), (21, 32), (10, 32)]
+
+
+def conv_launch_flops(layer, n_img):
+    """Algorithmic FLOPs of one conv launch over n_img images (2*9*ci*co per output pixel; SURVEY.md 8d per-image figures)."""
+    hw, ci = MIN_LAYERS[layer]
+    return 2.0 * 9 * ci * 32 * hw * hw * n_img
+
+
+def conv_launch_bytes(layer, n_img):
+    """Algorithmic HBM bytes of one conv+stats launch: read the layer input once, write the conv output once."""
+    hw, ci = MIN_LAYERS[layer]
+    return 4.0 * hw * hw * (ci + 32) * n_img
+
+
+def init_theta(spec, seed=42):
+    shapes = dict(spec.param_shapes())
+    w = synthetic.hash_weights(shapes, seed)
+    for k in w:                      # reference initialisers: biases / BN beta start at zero (vision_models.py:204-207)
+        if k.endswith('bias'):
+            w[k] = np.zeros_like(w[k])
+    return torch.from_numpy(np.concatenate([w[k].ravel() for k in shapes])).float()
+
+
+def cpu_baseline(wl, budget_s=20.0, max_tasks=16):
+    """The oracle (CPU restatement of the reference loop, fp32, all host cores) on a bounded sample of the same workload."""
+    from collections import OrderedDict
+    from oracle import vision_ref as R
+    spec = R.mini_imagenet_spec(wl['ways']) if wl['dataset'] == 'min' else R.omniglot_spec(wl['ways'])
+    host_cores = os.cpu_count() or 1
+    w = synthetic.hash_weights(R.param_shapes(spec), 42)
+    theta = OrderedDict((k, torch.from_numpy(v).float()) for k, v in w.items())
+
+    def run(task_ids):
+        datas, labels = [], []
+        for t in task_ids:
+            d, l = synthetic.make_task(wl['dataset'], t, wl['ways'], wl['shots'])
+            datas.append(torch.from_numpy(d))
+            labels.append(torch.from_numpy(l))
+        t0 = time.perf_counter()
+        R.maml_meta_batch(theta, spec, datas, labels, wl['steps'], wl['shots'], wl['ways'], wl['lr'], wl['first_order'])
+        return time.perf_counter() - t0
+
+    # PyTorch-CPU autograd on 5..25-image batches does not scale to hundreds of threads: pick the fastest intra-op thread
+    # count on a small probe (one first-order single-step task) and use that for the baseline.
+    probe = dict(wl, steps=1, first_order=True)
+
+    def probe_time(nthreads):
+        torch.set_num_threads(nthreads)
+        d, l = synthetic.make_task(probe['dataset'], 0, probe['ways'], probe['shots'])
+        args = (theta, spec, [torch.from_numpy(d)], [torch.from_numpy(l)], 1, probe['shots'], probe['ways'], probe['lr'], True)
+        R.maml_meta_batch(*args)
+        t0 = time.perf_counter()
+        R.maml_meta_batch(*args)
+        return time.perf_counter() - t0
+
+    cands = sorted({c for c in (4, 8, 16, 32, 64) if c <= host_cores} | {min(host_cores, 8)})
+    cores = min(cands, key=probe_time)
+    torch.set_num_threads(cores)
+    run([0])                                   # warm-up (thread pools, oneDNN primitives)
+    done, elapsed = 0, 0.0
+    while done < max_tasks and elapsed < budget_s:
+        elapsed += run([done])
+        done += 1
+    return dict(value=done / elapsed, unit='tasks/s', cores=cores, kind='port',
+                sample=f'{done} tasks of the same workload, sequential per-task loop, PyTorch-CPU autograd fp32 '
+                       f'(oracle/vision_ref.py), {cores} intra-op threads (fastest of {cands} on a probe; host has '
+                       f'{host_cores} logical cores)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', default='', help='write a per-kernel event-time breakdown (one extra untimed step) to this file')
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    T = wl['tasks']
+    spec = ModelSpec.mini_imagenet(wl['ways']) if wl['dataset'] == 'min' else ModelSpec.omniglot(wl['ways'])
+    eng = MetaEngine(spec)
+    theta = init_theta(spec).cuda()
+    task_ids = [rank * T + i for i in range(T)]          # shard by global task id: rank r owns tasks [rT, (r+1)T)
+    data, labels = synthetic.make_meta_batch(wl['dataset'], task_ids, wl['ways'], wl['shots'])
+    data = torch.from_numpy(data).cuda()
+    labels = torch.from_numpy(labels).cuda()
+    adam = {}
+    out = {}
+
+    def step():
+        loss, acc, grad, _ = eng.meta_batch(theta, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
+        if dist is not None:
+            dist.all_reduce(grad)                                   # one flat fp32 all-reduce of the meta-gradient (RCCL)
+        eng.adam_step(theta, grad, adam, 0.003, grad_scale=1.0 / (T * world))   # maml_vision.py:139-141
+        out['loss'], out['acc'] = loss, acc
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    dom = ('tangent_wgrad', 1)                 # dominant kernel (profiles/): 2-term weight-gradient GEMM of block 2 (42x42)
+    eng.profile(True, *dom)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_collect()
+    eng.profile(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+
+    roofline = None
+    if dom in prof and args.workload == 'cfg2':
+        ms, cnt = prof[dom]
+        n_img = T * wl['ways'] * wl['shots']
+        flops = 2 * conv_launch_flops(dom[1], n_img)            # two (activation, gradient) products per launch
+        achieved = flops / (ms / cnt * 1e-3) / 1e12
+        roofline = dict(kernel='wgrad3x3_mfma_kernel<2,1> (tangent weight gradient, block 2, 42x42, 32x32 filters)', bound='mfma',
+                        achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
+                        frac=round(achieved / FP32_MFMA_PEAK_TF, 4), traffic=None, launches=int(cnt),
+                        avg_launch_ms=round(ms / cnt, 4), flops_per_launch=flops,
+                        algorithmic_bytes_per_launch=2 * conv_launch_bytes(dom[1], n_img))
+
+    if args.breakdown and rank == 0:
+        eng.profile(True)
+        step()
+        torch.cuda.synchronize()
+        full = eng.profile_collect()
+        eng.profile(False)
+        tot = sum(v[0] for v in full.values())
+        with open(args.breakdown, 'w') as f:
+            f.write(f'# per-kernel HIP-event time of ONE meta-iteration, workload {args.workload} (T={T} tasks), total {tot:.3f} ms\n')
+            f.write('op,layer,launches,total_ms,avg_ms,share\n')
+            for (op, layer), (ms, cnt) in sorted(full.items(), key=lambda kv: -kv[1][0]):
+                f.write(f'{op},{layer},{cnt},{ms:.4f},{ms / cnt:.4f},{ms / tot:.4f}\n')
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wl)
+
+    if rank == 0:
+        value = world * T * args.steps / dt
+        line = {
+            'metric': 'tasks/sec', 'value': round(value, 2), 'unit': 'tasks/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': wl['name'], 'tasks_per_gpu': T, 'global_meta_batch': T * world, 'ways': wl['ways'],
+                       'shots': wl['shots'], 'adapt_steps': wl['steps'], 'inner_lr': wl['lr'],
+                       'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter'},
+            'post_adapt': {'query_loss_mean': round(out['loss'].mean().item(), 5),
+                           'query_acc_mean': round(out['acc'].mean().item(), 5)},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -58,6 +58,10 @@ _SIGS = {
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     'mi_kernel_scratch_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'mi_profile_enable': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    'mi_profile_kinds': (C.c_int, []),
+    'mi_profile_op_name': (C.c_char_p, [C.c_int]),
+    'mi_profile_collect': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -71,6 +75,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MiError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                       '(hipcc --offload-arch=gfx950). There is no CPU fallback for the MAML hot path.')
+    import torch  # noqa: F401  -- torch's bundled HIP runtime must be the one in the process before ours is resolved
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

@@ -441,11 +441,11 @@ size_t wgrad_partial_floats(const ConvGeom& g, int tasks) {
   return (size_t)tasks * ceil_div(mpix, chunk) * 9 * g.ci * g.co;
 }
 
-hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, float* out, size_t ostride) {
+hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out) {
   a.chunk_pix = wgrad_chunks(a.mpix, tasks);
   a.nchunks = ceil_div(a.mpix, a.chunk_pix);
+  *nchunks_out = a.nchunks;
   const int s = a.g.stride;
-  const int nelem = 9 * a.g.ci * a.g.co;
   if (a.g.ci == 1 || a.g.ci == 3) {
     if (nterms != 1) return hipErrorInvalidValue;
     dim3 grid(ceil_div(a.nchunks, 4), tasks, a.g.co / 32);
@@ -461,9 +461,13 @@ hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, f
     else if (nterms == 2 && s == 1) hipLaunchKernelGGL((wgrad3x3_mfma_kernel<2, 1>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad3x3_mfma_kernel<2, 2>), grid, dim3(256), 0, st, a);
   }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nelem, 256), tasks), dim3(256), 0, st, a.partial, a.nchunks, nelem,
-                     out, ostride);
+  return hipGetLastError();
+}
+
+// dW[task] = sum over chunks of the wgrad partials, written at out + task*ostride (tap-major [9][ci][co]).
+hipError_t launch_wgrad_reduce(hipStream_t st, const float* partial, int nchunks, int nelem, int tasks, float* out,
+                               size_t ostride) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nelem, 256), tasks), dim3(256), 0, st, partial, nchunks, nelem, out,
+                     ostride);
   return hipGetLastError();
 }

@@ -33,13 +33,51 @@ struct mi_engine {
   size_t PS;  // per-task stride of parameter-shaped buffers (P padded so every task's vectors stay 16-B aligned)
   int32_t* perm_dev;
   std::string err;
+  // optional per-launch HIP-event profiling (bench.py's roofline leg): kind = op*8 + layer
+  int prof_on = 0, prof_filter = -1;
+  std::vector<hipEvent_t> ev0, ev1;
+  std::vector<int> ev_kind;
+  size_t ev_used = 0;
 };
+
+enum ProfOp { OP_CONV_FWD = 0, OP_BN_FINALIZE, OP_BN_FWD, OP_HEAD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_WGRAD, OP_WGRAD_REDUCE,
+              OP_DGRAD, OP_TAN_CONV, OP_BN_TAN_FWD, OP_HEAD_TAN, OP_BN_TAN_BWD_REDUCE, OP_BN_TAN_BWD_APPLY, OP_TAN_WGRAD,
+              OP_TAN_DGRAD, OP_MISC, OP_COUNT };
+static const char* kOpNames[OP_COUNT] = {"conv_fwd_stats", "bn_finalize", "bn_relu_pool_fwd", "head_fwd_bwd", "bn_bwd_reduce",
+                                         "bn_bwd_apply", "wgrad", "wgrad_reduce", "dgrad", "tangent_conv_fwd", "bn_tangent_fwd",
+                                         "head_tangent", "bn_tangent_bwd_reduce", "bn_tangent_bwd_apply", "tangent_wgrad",
+                                         "tangent_dgrad", "misc"};
+
+static bool prof_begin(mi_engine* e, hipStream_t st, int kind) {
+  if (!e || !e->prof_on || (e->prof_filter >= 0 && e->prof_filter != kind)) return false;
+  if (e->ev_used == e->ev0.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+    e->ev0.push_back(a); e->ev1.push_back(b); e->ev_kind.push_back(0);
+  }
+  e->ev_kind[e->ev_used] = kind;
+  (void)hipEventRecord(e->ev0[e->ev_used], st);
+  return true;
+}
+static void prof_end(mi_engine* e, hipStream_t st, bool active) {
+  if (!active) return;
+  (void)hipEventRecord(e->ev1[e->ev_used], st);
+  e->ev_used++;
+}
 
 static int fail(mi_engine* e, int code, const std::string& msg) {
   if (e) e->err = msg;
   g_err = msg;
   return code;
 }
+#define LAUNCH(e, st, op, layer, call)                                                             \
+  do {                                                                                             \
+    const bool _pa = prof_begin(e, st, (op) * 8 + (layer));                                        \
+    hipError_t _s = (call);                                                                        \
+    prof_end(e, st, _pa);                                                                          \
+    if (_s != hipSuccess)                                                                          \
+      return fail(e, MI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s) + " @" + std::to_string(__LINE__)); \
+  } while (0)
 #define HIPCHK(e, call)                                                                            \
   do {                                                                                             \
     hipError_t _s = (call);                                                                        \
@@ -120,6 +158,8 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
 extern "C" void mi_engine_destroy(mi_engine* e) {
   if (!e) return;
   if (e->perm_dev) (void)hipFree(e->perm_dev);
+  for (auto ev : e->ev0) (void)hipEventDestroy(ev);
+  for (auto ev : e->ev1) (void)hipEventDestroy(ev);
   delete e;
 }
 
@@ -272,14 +312,14 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
     ca.g = geom(L, n);
     ca.mpix = n * L.ho * L.wo;
     int blk = 0;
-    HIPCHK(e, launch_conv3x3(st, ca, T, 1, EPI_STATS, 0, &blk));
-    HIPCHK(e, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co));
+    LAUNCH(e, st, OP_CONV_FWD, l, launch_conv3x3(st, ca, T, 1, EPI_STATS, 0, &blk));
+    LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co));
     BnArgs ba{};
     ba.z = A.z[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
     ba.out = A.p[l];
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
-    HIPCHK(e, launch_bn_fwd(st, ba, T, L.pool));
+    LAUNCH(e, st, OP_BN_FWD, l, launch_bn_fwd(st, ba, T, L.pool));
   }
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
   if (with_grad) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * P * sizeof(float), st));
@@ -290,7 +330,7 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
   ha.dwl = with_grad ? g + e->off_wl : nullptr; ha.dbl = with_grad ? g + e->off_bl : nullptr; ha.gstride = P;
   ha.df = with_grad ? A.df : nullptr;
   ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
-  HIPCHK(e, launch_head_fwd_bwd(st, ha, T, with_grad ? 1 : 0));
+  LAUNCH(e, st, OP_HEAD, 0, launch_head_fwd_bwd(st, ha, T, with_grad ? 1 : 0));
   if (!with_grad) return MI_OK;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], T * n, e->head_hw, e->head_c));
   for (int l = nl - 1; l >= 0; --l) {
@@ -304,18 +344,20 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
-    HIPCHK(e, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
-    HIPCHK(e, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
+    LAUNCH(e, st, OP_BN_BWD_REDUCE, l, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
+    LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
     ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
     ba.out = A.dz[l];
-    HIPCHK(e, launch_bn_bwd_apply(st, ba, T, L.pool));
+    LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = A.dz[l];
     wa.partial = pl.wgpart;
     wa.g = geom(L, n);
     wa.mpix = mpix;
-    HIPCHK(e, launch_wgrad3x3(st, wa, T, 1, g + L.off_w, P));
+    int nch = 0;
+    LAUNCH(e, st, OP_WGRAD, l, launch_wgrad3x3(st, wa, T, 1, &nch));
+    LAUNCH(e, st, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(st, pl.wgpart, nch, 9 * L.ci * L.co, T, g + L.off_w, P));
     if (l > 0) {
       ConvArgs ca{};
       ca.in[0] = A.dz[l];
@@ -324,7 +366,7 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
       ca.out = A.dp[l - 1];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
-      HIPCHK(e, launch_conv3x3(st, ca, T, 1, EPI_NONE, 1, nullptr));
+      LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_NONE, 1, nullptr));
     }
   }
   return MI_OK;
@@ -351,15 +393,15 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ca.g = geom(L, n);
     ca.mpix = mpix;
     int blk = 0;
-    HIPCHK(e, launch_conv3x3(st, ca, T, l > 0 ? 2 : 1, EPI_TSTATS, 0, &blk));
-    HIPCHK(e, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co));
+    LAUNCH(e, st, OP_TAN_CONV, l, launch_conv3x3(st, ca, T, l > 0 ? 2 : 1, EPI_TSTATS, 0, &blk));
+    LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co));
     BnArgs ba{};
     ba.z = A.z[l]; ba.zd = X.zd[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l]; ba.m1 = X.m1[l]; ba.m2 = X.m2[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
     ba.gammad = v + L.off_gamma; ba.betad = v + L.off_beta; ba.vstride = P;
     ba.out = X.pd[l];
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
-    HIPCHK(e, launch_bn_tan_fwd(st, ba, T, L.pool));
+    LAUNCH(e, st, OP_BN_TAN_FWD, l, launch_bn_tan_fwd(st, ba, T, L.pool));
   }
   const float* fd = X.pd[nl - 1];
   if (e->d.head_mean_pool) {
@@ -375,7 +417,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   ha.dwl = hv + e->off_wl; ha.dbl = hv + e->off_bl; ha.gstride = P;
   ha.df = e->d.head_mean_pool ? X.rdf : X.dpd[cur];
   ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
-  HIPCHK(e, launch_head_tangent(st, ha, T));
+  LAUNCH(e, st, OP_HEAD_TAN, 0, launch_head_tangent(st, ha, T));
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, X.rdf, X.dpd[cur], T * n, e->head_hw, e->head_c));
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
@@ -390,11 +432,11 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
-    HIPCHK(e, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
-    HIPCHK(e, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
+    LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, l, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
+    LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
     ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
     ba.out = X.rdz;
-    HIPCHK(e, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
+    LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = X.rdz;
@@ -402,7 +444,9 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     wa.partial = pl.wgpart;
     wa.g = geom(L, n);
     wa.mpix = mpix;
-    HIPCHK(e, launch_wgrad3x3(st, wa, T, l > 0 ? 2 : 1, hv + L.off_w, P));
+    int nch = 0;
+    LAUNCH(e, st, OP_TAN_WGRAD, l, launch_wgrad3x3(st, wa, T, l > 0 ? 2 : 1, &nch));
+    LAUNCH(e, st, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(st, pl.wgpart, nch, 9 * L.ci * L.co, T, hv + L.off_w, P));
     if (l > 0) {
       ConvArgs ca{};
       ca.in[0] = X.rdz; ca.wt[0] = theta + L.off_w;
@@ -411,7 +455,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       ca.out = X.dpd[cur ^ 1];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
-      HIPCHK(e, launch_conv3x3(st, ca, T, 2, EPI_NONE, 1, nullptr));
+      LAUNCH(e, st, OP_TAN_DGRAD, l, launch_conv3x3(st, ca, T, 2, EPI_NONE, 1, nullptr));
       cur ^= 1;
     }
   }
@@ -435,15 +479,15 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
   if (pl.bytes > workspace_bytes)
     return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
   const size_t TP = (size_t)T * e->PS;
-  HIPCHK(e, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
-  HIPCHK(e, launch_gather_params(st, theta, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
+  LAUNCH(e, st, OP_MISC, 0, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
   for (int k = 0; k < K; ++k) {
     ActSet& A = so ? pl.sup[k] : pl.sup[0];
     float* th = pl.theta + (size_t)k * TP;
     float* gk = pl.g + (size_t)k * TP;
     int rc = pass_fwd_bwd(e, st, pl, A, pl.xs, pl.ys, ns, T, th, gk, pl.tmp_loss, pl.tmp_acc, nullptr, true);
     if (rc) return rc;
-    HIPCHK(e, launch_axpy(st, th, gk, inner_lr, TP, th + TP));
+    LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, th, gk, inner_lr, TP, th + TP));
   }
   float* thK = pl.theta + (size_t)K * TP;
   int rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, nq, T, thK, pl.lam, loss_out, acc_out, logits_out, with_grad != 0);
@@ -453,10 +497,10 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
     for (int k = K - 1; k >= 0; --k) {
       rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, T, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv);
       if (rc) return rc;
-      HIPCHK(e, launch_axpy(st, pl.lam, pl.hv, inner_lr, TP, pl.lam));
+      LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, pl.lam, pl.hv, inner_lr, TP, pl.lam));
     }
   }
-  HIPCHK(e, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, meta_grad_out));
+  LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, meta_grad_out));
   return MI_OK;
 }
 
@@ -547,7 +591,9 @@ extern "C" int mi_conv3x3_bwd(void* stream, const float* x, const float* dz, con
   wa.g = ConvGeom{n, h, wd, ho, wo, ci, co, stride};
   wa.mpix = n * ho * wo;
   if (wgrad_partial_floats(wa.g, tasks) * sizeof(float) > scratch_bytes) return fail(nullptr, MI_ERR_WORKSPACE, "scratch too small");
-  HIPCHK0(launch_wgrad3x3(st, wa, tasks, 1, dw9, gstride));
+  int nch = 0;
+  HIPCHK0(launch_wgrad3x3(st, wa, tasks, 1, &nch));
+  HIPCHK0(launch_wgrad_reduce(st, wa.partial, nch, 9 * ci * co, tasks, dw9, gstride));
   if (dx) {
     ConvArgs ca{};
     ca.in[0] = dz; ca.wt[0] = w9; ca.wstride = pstride; ca.out = dx;
@@ -566,5 +612,31 @@ extern "C" int mi_head_fwd_bwd(void* stream, const float* f, const float* wl, co
   ha.prob = prob; ha.dl = dl; ha.dwl = dwl; ha.dbl = dbl; ha.gstride = gstride; ha.df = df;
   ha.n = n; ha.feat = feat; ha.ways = ways;
   HIPCHK0(launch_head_fwd_bwd(reinterpret_cast<hipStream_t>(stream), ha, tasks, dwl != nullptr));
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-launch profiling with HIP events on the caller's stream (used by bench.py for the roofline figures).
+extern "C" int mi_profile_enable(mi_engine* e, int on, int kind_filter) {
+  if (!e) return MI_ERR_ARG;
+  e->prof_on = on;
+  e->prof_filter = kind_filter;
+  e->ev_used = 0;
+  return MI_OK;
+}
+extern "C" int mi_profile_kinds(void) { return OP_COUNT * 8; }
+extern "C" const char* mi_profile_op_name(int op) { return (op >= 0 && op < OP_COUNT) ? kOpNames[op] : "?"; }
+// Sums elapsed ms / launch counts per kind (= op*8 + layer) since the last collect; blocks until the events completed.
+extern "C" int mi_profile_collect(mi_engine* e, double* total_ms, int64_t* count, int n_kinds) {
+  if (!e || !total_ms || !count || n_kinds < OP_COUNT * 8) return MI_ERR_ARG;
+  for (int i = 0; i < n_kinds; ++i) { total_ms[i] = 0.0; count[i] = 0; }
+  for (size_t i = 0; i < e->ev_used; ++i) {
+    if (hipEventSynchronize(e->ev1[i]) != hipSuccess) return fail(e, MI_ERR_HIP, "hipEventSynchronize failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]) != hipSuccess) return fail(e, MI_ERR_HIP, "hipEventElapsedTime failed");
+    total_ms[e->ev_kind[i]] += ms;
+    count[e->ev_kind[i]] += 1;
+  }
+  e->ev_used = 0;
   return MI_OK;
 }

@@ -47,7 +47,8 @@ enum { FIN_STATS = 0, FIN_TSTATS = 1, FIN_SUMS = 2 };
 
 // conv_mfma.hip
 hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int epi, int mode, int* blocks_per_task);
-hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, float* out, size_t ostride);
+hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out);
+hipError_t launch_wgrad_reduce(hipStream_t st, const float* partial, int nchunks, int nelem, int tasks, float* out, size_t ostride);
 size_t wgrad_partial_floats(const ConvGeom& g, int tasks);
 int conv_max_blocks_per_task(const ConvGeom& g);
 

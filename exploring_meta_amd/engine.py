@@ -128,6 +128,22 @@ class MetaEngine:
         _lib.check(rc, self._h)
         return loss, acc, grad, logits
 
+    def profile(self, on, op=None, layer=0):
+        """Record HIP events around every launch (or only launches of one (op name, layer)) until switched off."""
+        kind = -1
+        if op is not None:
+            names = [self.lib.mi_profile_op_name(i).decode() for i in range(self.lib.mi_profile_kinds() // 8)]
+            kind = names.index(op) * 8 + layer
+        _lib.check(self.lib.mi_profile_enable(self._h, int(on), kind), self._h)
+
+    def profile_collect(self):
+        """{(op name, layer): (total_ms, launches)} since the last collect; synchronises on the recorded events."""
+        n = self.lib.mi_profile_kinds()
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        _lib.check(self.lib.mi_profile_collect(self._h, ms, cnt, n), self._h)
+        return {(self.lib.mi_profile_op_name(k // 8).decode(), k % 8): (ms[k], cnt[k]) for k in range(n) if cnt[k]}
+
     def adam_step(self, theta, grad, state, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
         """torch.optim.Adam defaults on the flat meta-parameters (vision/maml_vision.py:85,139-141)."""
         if 'm' not in state:

@@ -110,6 +110,14 @@ int mi_head_fwd_bwd(void* stream, const float* f, const float* wl, const float* 
                     float* dwl, float* dbl, size_t gstride, float* df);
 size_t mi_kernel_scratch_bytes(int tasks, int n, int h, int w, int c);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Per-launch profiling with HIP events on the caller's stream (the reference has no profiler hooks, SURVEY.md section 5;
+ * bench.py uses this for its roofline figures).  kind = op * 8 + layer; kind_filter < 0 profiles every launch. */
+int mi_profile_enable(mi_engine* e, int on, int kind_filter);
+int mi_profile_kinds(void);
+const char* mi_profile_op_name(int op);
+int mi_profile_collect(mi_engine* e, double* total_ms, int64_t* count, int n_kinds);
+
 #ifdef __cplusplus
 }
 #endif
