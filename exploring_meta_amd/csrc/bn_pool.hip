@@ -60,6 +60,7 @@ struct Window {
   float zh[NP][4], u[NP][4];
   int arg[4];
   float umax[4];
+  bool better[NP][4];
 
   __device__ __forceinline__ void locate(const BnArgs& a, const WinIter<POOL>& it, int win, int c0) {
     const int n = win / (it.hw2 * it.ww2);
@@ -97,20 +98,50 @@ struct Window {
       int best = 0;
       float bu = u[0][c];
 #pragma unroll
-      for (int p = 1; p < NP; ++p)
-        if (u[p][c] > bu) { bu = u[p][c]; best = p; }   // strict '>' keeps the first maximum (torch max_pool2d order)
+      for (int p = 1; p < NP; ++p) {
+        better[p][c] = u[p][c] > bu;                      // strict '>' keeps the first maximum (torch max_pool2d order)
+        if (better[p][c]) { bu = u[p][c]; best = p; }
+      }
       arg[c] = best;
       umax[c] = bu;
     }
   }
-  // value of a per-position quantity at the argmax position of channel c
-  __device__ __forceinline__ float at_arg(const float (*v)[4], int c) const {
+  // value of a per-position quantity at the argmax position of channel c.  A chain of selects on the comparison flags
+  // (the last position that beat the running maximum wins); selecting on `arg[c] == p` instead lets LLVM re-roll the
+  // chain into a dynamically indexed scratch array.
+  __device__ __forceinline__ float at_arg(const float (&v)[NP][4], int c) const {
     float r = v[0][c];
 #pragma unroll
-    for (int p = 1; p < NP; ++p) r = (arg[c] == p) ? v[p][c] : r;
+    for (int p = 1; p < NP; ++p) r = better[p][c] ? v[p][c] : r;
     return r;
   }
 };
+
+// Streaming scan of one window: running maximum of u and the values of zh (and zd) AT the running maximum, carried as
+// plain SSA values (no per-position arrays: selecting among stored positions by index makes LLVM spill them to scratch).
+template <int POOL, bool WITH_ZD>
+__device__ __forceinline__ void scan_window(const Window<POOL>& w, const float* __restrict__ z_t, const float* __restrict__ zd_t,
+                                            const ChanConst& k, floatx4& umax, floatx4& zh_at, floatx4& zd_at) {
+#pragma unroll
+  for (int p = 0; p < Window<POOL>::NP; ++p) {
+    const floatx4 z = *reinterpret_cast<const floatx4*>(z_t + w.off[p]);
+    floatx4 zd = {0.f, 0.f, 0.f, 0.f};
+    if (WITH_ZD) zd = *reinterpret_cast<const floatx4*>(zd_t + w.off[p]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float zh = bn_zh(z[c], k.mu[c], k.r[c]);
+      const float u = bn_u(zh, k.g[c], k.b[c]);
+      if (p == 0) {
+        umax[c] = u; zh_at[c] = zh; zd_at[c] = zd[c];
+      } else {
+        const bool gt = u > umax[c];                      // strict '>' keeps the first maximum (torch max_pool2d order)
+        umax[c] = gt ? u : umax[c];
+        zh_at[c] = gt ? zh : zh_at[c];
+        zd_at[c] = gt ? zd[c] : zd_at[c];
+      }
+    }
+  }
+}
 
 #define BN_THREAD_SETUP(POOL)                                                                   \
   const int quads = a.c >> 2;                                                                   \
@@ -171,16 +202,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnArgs a) {
   Window<POOL> w;
   for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
     w.locate(a, it, win, c0);
-    if (!w.pooled) continue;
-    w.analyse(z_t, k);
-    float d[4];
-    load4(dp_t + w.poff, d);
+    if (!w.pooled) continue;                              // pooled windows have all their positions inside the image
+    floatx4 umax, zh_at, zd_at;
+    scan_window<POOL, false>(w, z_t, nullptr, k, umax, zh_at, zd_at);
+    const floatx4 d = *reinterpret_cast<const floatx4*>(dp_t + w.poff);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (w.umax[c] > 0.f) {
-        db[c] += (double)d[c];
-        dg[c] += (double)d[c] * (double)w.at_arg(w.zh, c);
-      }
+      const float du = umax[c] > 0.f ? d[c] : 0.f;
+      db[c] += (double)du;
+      dg[c] += (double)du * (double)zh_at[c];
     }
   }
   block_reduce_write(dg, db, a, quads, task);
@@ -231,19 +261,16 @@ __global__ __launch_bounds__(256) void bn_tan_fwd_kernel(BnArgs a) {
   for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
     w.locate(a, it, win, c0);
     if (!w.pooled) continue;
-    w.analyse(z_t, k);
-    float zdv[Window<POOL>::NP][4];
-#pragma unroll
-    for (int p = 0; p < Window<POOL>::NP; ++p) load4(zd_t + w.off[p], zdv[p]);
-    float o[4];
+    floatx4 umax, zh_at, zd_at;
+    scan_window<POOL, true>(w, z_t, zd_t, k, umax, zh_at, zd_at);
+    floatx4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float zh = w.at_arg(w.zh, c), zd = w.at_arg(zdv, c);
-      const float zhd = k.r[c] * (zd - m1[c] - zh * m2[c]);
-      const float ud = gd[c] * zh + k.g[c] * zhd + bd[c];
-      o[c] = (w.umax[c] > 0.f) ? ud : 0.f;
+      const float zhd = k.r[c] * (zd_at[c] - m1[c] - zh_at[c] * m2[c]);
+      const float ud = gd[c] * zh_at[c] + k.g[c] * zhd + bd[c];
+      o[c] = (umax[c] > 0.f) ? ud : 0.f;
     }
-    store4(out_t + w.poff, o);
+    *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
   }
 }
 
@@ -262,21 +289,17 @@ __global__ __launch_bounds__(256) void bn_tan_bwd_reduce_kernel(BnArgs a) {
   for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
     w.locate(a, it, win, c0);
     if (!w.pooled) continue;
-    w.analyse(z_t, k);
-    float zdv[Window<POOL>::NP][4];
-#pragma unroll
-    for (int p = 0; p < Window<POOL>::NP; ++p) load4(zd_t + w.off[p], zdv[p]);
-    float d[4], dd[4];
-    load4(dp_t + w.poff, d);
-    load4(dpd_t + w.poff, dd);
+    floatx4 umax, zh_at, zd_at;
+    scan_window<POOL, true>(w, z_t, zd_t, k, umax, zh_at, zd_at);
+    const floatx4 d = *reinterpret_cast<const floatx4*>(dp_t + w.poff);
+    const floatx4 dd = *reinterpret_cast<const floatx4*>(dpd_t + w.poff);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (w.umax[c] > 0.f) {
-        const float zh = w.at_arg(w.zh, c), zd = w.at_arg(zdv, c);
-        const float zhd = k.r[c] * (zd - m1[c] - zh * m2[c]);
-        rb[c] += (double)dd[c];
-        rg[c] += (double)dd[c] * (double)zh + (double)d[c] * (double)zhd;
-      }
+      const bool on = umax[c] > 0.f;
+      const float du = on ? d[c] : 0.f, dud = on ? dd[c] : 0.f;
+      const float zhd = k.r[c] * (zd_at[c] - m1[c] - zh_at[c] * m2[c]);
+      rb[c] += (double)dud;
+      rg[c] += (double)dud * (double)zh_at[c] + (double)du * (double)zhd;
     }
   }
   block_reduce_write(rg, rb, a, quads, task);

@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-#pragma unroll
-    for (int term = 0; term < NTERMS; ++term) {
-      const float* in_t = a.in[term] + (size_t)task * in_task;
+#pragma unroll 1
+    for (int term = 0; term < NTERMS; ++term) {   // not unrolled: the 2-term variants keep the 1-term register footprint
+      const float* in_t = (term == 0 ? a.in[0] : a.in[1]) + (size_t)task * in_task;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
@@ -298,6 +298,116 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-1 wgrad, register-tiled over image rows (the hot weight-gradient kernel).
+// Work unit = (image n, row pair yp, column segment s): lane half h owns output row y = 2*yp + h, columns
+// [s*RH, s*RH+RH).  Per unit a lane loads RH values of dz (B operand, its co) and a 3 x (RH+2) halo patch of x (A operand,
+// its ci): 4*RH+6 coalesced dword loads feed 9*RH MFMAs (each x value is re-used by up to 9 (tap, pixel) pairs from
+// registers).  Units are software-pipelined through two register sets so the next unit's loads fly under the current
+// unit's MFMAs.  The 4 waves of a workgroup interleave units, reduce their 9 accumulators through LDS tap by tap and leave
+// ONE partial per workgroup; reduce_partials_kernel folds workgroups in a fixed order (deterministic, no atomics).
+template <int RH>
+struct WgUnit {
+  float xa[3][RH + 2];
+  float b[RH];
+};
+
+template <int RH>
+__device__ __forceinline__ void wg_load_unit(WgUnit<RH>& u, int unit, const float* __restrict__ x_t,
+                                             const float* __restrict__ dz_t, int H, int W, int CI, int CO, int hp2, int nseg,
+                                             int h) {
+  const int n = unit / (hp2 * nseg);
+  const int rem = unit - n * hp2 * nseg;
+  const int yp = rem / nseg, s = rem - yp * nseg;
+  const int y = 2 * yp + h, x0 = s * RH;
+  const bool rowok = y < H;
+#pragma unroll
+  for (int i = 0; i < RH; ++i) {
+    const bool ok = rowok && (x0 + i) < W;
+    u.b[i] = ok ? dz_t[((size_t)(n * H + y) * W + x0 + i) * CO] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int iy = y + r - 1;
+    const bool rok = rowok && iy >= 0 && iy < H;
+#pragma unroll
+    for (int c = 0; c < RH + 2; ++c) {
+      const int ix = x0 + c - 1;
+      const bool ok = rok && ix >= 0 && ix < W;
+      u.xa[r][c] = ok ? x_t[((size_t)(n * H + iy) * W + ix) * CI] : 0.f;
+    }
+  }
+}
+
+template <int RH>
+__device__ __forceinline__ void wg_compute_unit(const WgUnit<RH>& u, floatx16* acc) {
+#pragma unroll
+  for (int i = 0; i < RH; ++i)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.xa[tap / 3][i + tap % 3], u.b[i], acc[tap], 0, 0, 0);
+}
+
+template <int RH>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_rows_mfma_kernel(WgradArgs a) {
+  __shared__ float red[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y;
+  const int H = a.g.h, W = a.g.w, CI = a.g.ci, CO = a.g.co;   // stride 1: conv output is H x W as well
+  const int ncot = CO / 32;
+  const int cit = blockIdx.z / ncot, cot = blockIdx.z - cit * ncot;
+  const int hp2 = (H + 1) >> 1, nseg = (W + RH - 1) / RH;
+  const int nunits = a.g.n * hp2 * nseg;                     // per term; the unit stream is [term][unit]
+  const int total = nunits * a.nterms;
+  const int ub0 = blockIdx.x * a.chunk_pix;                  // chunk_pix = units per workgroup here
+  const int ub1 = min(ub0 + a.chunk_pix, total);
+  const size_t x_off = (size_t)task * a.g.n * H * W * CI + cit * 32 + j;
+  const size_t dz_off = (size_t)task * a.g.n * H * W * CO + cot * 32 + j;
+  const float* x0 = a.x[0] + x_off;
+  const float* d0 = a.dz[0] + dz_off;
+  const float* x1 = a.nterms > 1 ? a.x[1] + x_off : x0;
+  const float* d1 = a.nterms > 1 ? a.dz[1] + dz_off : d0;
+
+  floatx16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto load = [&](WgUnit<RH>& un, int v) {
+    const bool second = v >= nunits;                          // wave-uniform
+    wg_load_unit<RH>(un, second ? v - nunits : v, second ? x1 : x0, second ? d1 : d0, H, W, CI, CO, hp2, nseg, h);
+  };
+  WgUnit<RH> u0, u1;
+  int u = ub0 + wave;
+  if (u < ub1) load(u0, u);
+  for (; u < ub1; u += 8) {
+    if (u + 4 < ub1) load(u1, u + 4);
+    wg_compute_unit<RH>(u0, acc);
+    if (u + 8 < ub1) load(u0, u + 8);
+    if (u + 4 < ub1) wg_compute_unit<RH>(u1, acc);
+  }
+
+  // cross-wave reduction, one tap at a time: red[wave][r*64 + lane]
+  float* pt = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 9 * CI * CO;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[tap][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      const int r = e >> 6, l = e & 63;
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+      pt[((size_t)tap * CI + cit * 32 + row) * CO + cot * 32 + col] = v;
+    }
+    __syncthreads();
+  }
+}
+
 // First-layer wgrad: rows m = tap*CI0 + ci (27 or 9 of 32), one accumulator.
 template <int CI0, int STRIDE>
 __global__ __launch_bounds__(256) void wgrad3x3_first_mfma_kernel(WgradArgs a) {
@@ -435,17 +545,63 @@ int wgrad_chunks(int mpix, int tasks) {
   return chunk;
 }
 
+// ---- stride-1 row-tiled wgrad: segment length and work split
+static int rows_pick_rh(int w) {
+  const int cand[4] = {7, 8, 5, 4};
+  int best = 7, best_waste = 1 << 30;
+  for (int i = 0; i < 4; ++i) {
+    const int waste = ceil_div(w, cand[i]) * cand[i] - w;
+    if (waste < best_waste) { best_waste = waste; best = cand[i]; }
+  }
+  return best;
+}
+static bool use_rows_kernel(const ConvGeom& g) { return g.stride == 1 && g.ci % 32 == 0 && g.co % 32 == 0; }
+static void rows_split(const ConvGeom& g, int tasks, int& rh, int& nunits, int& upb, int& blocks) {
+  rh = rows_pick_rh(g.w);
+  nunits = g.n * ((g.h + 1) / 2) * ceil_div(g.w, rh);
+  const int nz = (g.ci / 32) * (g.co / 32);
+  int bpt = ceil_div(1024, tasks * nz);               // ~2 workgroups per CU, twice over
+  const int max_bpt = ceil_div(nunits, 32);           // >= 8 units per wave so the LDS reduction epilogue stays small
+  if (bpt > max_bpt) bpt = max_bpt;
+  if (bpt < 1) bpt = 1;
+  upb = ceil_div(nunits, bpt);
+  blocks = ceil_div(nunits, upb);
+}
+
 size_t wgrad_partial_floats(const ConvGeom& g, int tasks) {
+  if (use_rows_kernel(g)) {
+    int rh, nunits, upb, blocks;
+    rows_split(g, tasks, rh, nunits, upb, blocks);
+    return (size_t)tasks * blocks * 9 * g.ci * g.co;
+  }
   const int mpix = g.n * g.ho * g.wo;
   const int chunk = wgrad_chunks(mpix, tasks);
   return (size_t)tasks * ceil_div(mpix, chunk) * 9 * g.ci * g.co;
 }
 
+static void launch_rows(hipStream_t st, const WgradArgs& a, dim3 grid, int rh) {
+  if (rh == 7) hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<7>), grid, dim3(256), 0, st, a);
+  else if (rh == 8) hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<8>), grid, dim3(256), 0, st, a);
+  else if (rh == 5) hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<5>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<4>), grid, dim3(256), 0, st, a);
+}
+
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out) {
+  const int s = a.g.stride;
+  if (use_rows_kernel(a.g)) {
+    int rh, nunits, upb, blocks;
+    rows_split(a.g, tasks, rh, nunits, upb, blocks);
+    a.nterms = nterms;
+    a.chunk_pix = upb * nterms;                            // the unit stream is nterms x nunits long, same workgroup count
+    a.nchunks = blocks;
+    *nchunks_out = blocks;
+    dim3 grid(blocks, tasks, (a.g.ci / 32) * (a.g.co / 32));
+    launch_rows(st, a, grid, rh);
+    return hipGetLastError();
+  }
   a.chunk_pix = wgrad_chunks(a.mpix, tasks);
   a.nchunks = ceil_div(a.mpix, a.chunk_pix);
   *nchunks_out = a.nchunks;
-  const int s = a.g.stride;
   if (a.g.ci == 1 || a.g.ci == 3) {
     if (nterms != 1) return hipErrorInvalidValue;
     dim3 grid(ceil_div(a.nchunks, 4), tasks, a.g.co / 32);
@@ -456,9 +612,7 @@ hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, i
   } else {
     if (a.g.ci % 32 || a.g.co % 32) return hipErrorInvalidValue;
     dim3 grid(ceil_div(a.nchunks, 4), tasks, (a.g.ci / 32) * (a.g.co / 32));
-    if (nterms == 1 && s == 1) hipLaunchKernelGGL((wgrad3x3_mfma_kernel<1, 1>), grid, dim3(256), 0, st, a);
-    else if (nterms == 1 && s == 2) hipLaunchKernelGGL((wgrad3x3_mfma_kernel<1, 2>), grid, dim3(256), 0, st, a);
-    else if (nterms == 2 && s == 1) hipLaunchKernelGGL((wgrad3x3_mfma_kernel<2, 1>), grid, dim3(256), 0, st, a);
+    if (nterms == 1) hipLaunchKernelGGL((wgrad3x3_mfma_kernel<1, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad3x3_mfma_kernel<2, 2>), grid, dim3(256), 0, st, a);
   }
   return hipGetLastError();

@@ -21,7 +21,7 @@ struct WgradArgs {
   const float* dz[2];   // [T][n][ho][wo][co] per term
   float* partial;       // [T][nchunks][9][ci][co]
   ConvGeom g;
-  int mpix, chunk_pix, nchunks;
+  int mpix, chunk_pix, nchunks, nterms;
 };
 
 struct BnArgs {
