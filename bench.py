@@ -139,13 +139,19 @@ def main():
     labels = torch.from_numpy(labels).cuda()
     adam = {}
     out = {}
+    from exploring_meta_amd.sharding import MetaTrainer
+
+    def compute(th, _task_ids):                 # this rank's shard is already resident in HBM (data, labels)
+        loss, acc, grad, _ = eng.meta_batch(th, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
+        return loss, acc, grad
+
+    def adam_fn(th, grad, scale):               # maml_vision.py:139-141
+        eng.adam_step(th, grad, adam, 0.003, grad_scale=scale)
+
+    trainer = MetaTrainer(compute, adam_fn, T * world)     # one flat all-reduce (RCCL) of the meta-gradient per iteration
 
     def step():
-        loss, acc, grad, _ = eng.meta_batch(theta, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
-        if dist is not None:
-            dist.all_reduce(grad)                                   # one flat fp32 all-reduce of the meta-gradient (RCCL)
-        eng.adam_step(theta, grad, adam, 0.003, grad_scale=1.0 / (T * world))   # maml_vision.py:139-141
-        out['loss'], out['acc'] = loss, acc
+        out['loss'], out['acc'], _ = trainer.step(theta)
 
     def fence():
         torch.cuda.synchronize()
@@ -208,8 +214,7 @@ def main():
             'config': {'workload': wl['name'], 'tasks_per_gpu': T, 'global_meta_batch': T * world, 'ways': wl['ways'],
                        'shots': wl['shots'], 'adapt_steps': wl['steps'], 'inner_lr': wl['lr'],
                        'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter'},
-            'post_adapt': {'query_loss_mean': round(out['loss'].mean().item(), 5),
-                           'query_acc_mean': round(out['acc'].mean().item(), 5)},
+            'post_adapt': {'query_loss_mean': round(float(out['loss']), 5), 'query_acc_mean': round(float(out['acc']), 5)},
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)

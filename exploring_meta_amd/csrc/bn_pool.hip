@@ -360,16 +360,28 @@ __global__ __launch_bounds__(256) void bn_tan_bwd_apply_kernel(BnArgs a) {
 //  FIN_STATS : (sum z, sum z^2)        -> out0 = mean, out1 = 1/sqrt(biased var + eps)
 //  FIN_TSTATS: (sum zd, sum zh zd)     -> out0 = m1,   out1 = m2
 //  FIN_SUMS  : (first, second)         -> out0 = first, out1 = second (e.g. dgamma, dbeta)
-__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int c, double inv_m, int mode,
-                                   float* __restrict__ out0, size_t stride0, float* __restrict__ out1, size_t stride1) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  const int task = blockIdx.y;
-  if (ch >= c) return;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int c, double inv_m,
+                                                          int mode, float* __restrict__ out0, size_t stride0,
+                                                          float* __restrict__ out1, size_t stride1) {
+  // one workgroup per task: thread (slice, channel) folds every `slices`-th partial, slices are then folded in order
+  __shared__ double red[2 * 256];
+  const int task = blockIdx.x;
+  const int slices = 256 / c, sl = threadIdx.x / c, ch = threadIdx.x - sl * c;
   const double* p = partial + (size_t)task * nblk * 2 * c;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += p[(size_t)b * 2 * c + ch];
-    q += p[(size_t)b * 2 * c + c + ch];
+  if (sl < slices)
+    for (int b = sl; b < nblk; b += slices) {
+      s += p[(size_t)b * 2 * c + ch];
+      q += p[(size_t)b * 2 * c + c + ch];
+    }
+  red[threadIdx.x] = s;
+  red[256 + threadIdx.x] = q;
+  __syncthreads();
+  if ((int)threadIdx.x >= c) return;
+  s = 0.0; q = 0.0;
+  for (int k = 0; k < slices; ++k) {
+    s += red[k * c + ch];
+    q += red[256 + k * c + ch];
   }
   float o0, o1;
   if (mode == FIN_STATS) {
@@ -403,8 +415,9 @@ int bn_blocks_per_task(int n, int ho, int wo, int c, int pool, int tasks) {
 
 hipError_t launch_bn_finalize(hipStream_t st, const double* partial, int nblk, int tasks, int c, double inv_m, int mode,
                               float* out0, size_t stride0, float* out1, size_t stride1) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 64), tasks), dim3(64), 0, st, partial, nblk, c, inv_m, mode, out0,
-                     stride0, out1, stride1);
+  if (c > 256 || 256 % c != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(tasks), dim3(256), 0, st, partial, nblk, c, inv_m, mode, out0, stride0, out1,
+                     stride1);
   return hipGetLastError();
 }
 

@@ -504,6 +504,31 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
   return MI_OK;
 }
 
+// Plain forward of the classifier (BatchNorm in train mode, i.e. statistics of the n images of each task batch), no
+// adaptation: `learner(x)` / `model(x)` of the reference (vision_models.py:51-55,107-110).
+extern "C" int mi_forward_logits(mi_engine* e, void* stream, const float* theta, const float* x, int tasks, int n,
+                                 float* logits_out, void* workspace, size_t workspace_bytes) {
+  if (!e) return fail(nullptr, MI_ERR_ARG, "null engine");
+  if (!theta || !x || !logits_out || !workspace || tasks < 1 || n < 1) return fail(e, MI_ERR_ARG, "bad forward arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  Plan pl;
+  make_plan(e, workspace, tasks, n, n, 0, 0, pl);
+  if (pl.bytes > workspace_bytes)
+    return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
+  LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xq));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
+  HIPCHK(e, hipMemsetAsync(pl.yq, 0, (size_t)tasks * n * sizeof(int32_t), st));
+  return pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, n, tasks, pl.theta, pl.lam, pl.tmp_loss, pl.tmp_acc, logits_out, false);
+}
+
+extern "C" int mi_forward_workspace_bytes(const mi_engine* e, int tasks, int n, size_t* bytes) {
+  if (!e || !bytes || tasks < 1 || n < 1) return MI_ERR_ARG;
+  Plan pl;
+  make_plan(e, nullptr, tasks, n, n, 0, 0, pl);
+  *bytes = pl.bytes;
+  return MI_OK;
+}
+
 extern "C" int mi_adam_step(void* stream, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                             int step, float lr, float beta1, float beta2, float eps, float grad_scale) {
   if (!theta || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(nullptr, MI_ERR_ARG, "bad adam arguments");

@@ -25,6 +25,15 @@ __global__ void prepare_batch_kernel(const float* __restrict__ data, const int64
   }
 }
 
+// NCHW -> NHWC for plain forward calls (learner(x)): one thread per pixel.
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, size_t images, int c, int h, int w, float* __restrict__ dst) {
+  const size_t hw = (size_t)h * w;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= images * hw) return;
+  const size_t pix = e % hw, img = e / hw;
+  for (int ch = 0; ch < c; ++ch) dst[e * c + ch] = src[(img * c + ch) * hw + pix];
+}
+
 // theta_eng[t][i] = theta_ref[perm[i]] for every task (learn2learn clone_module: each task starts from the meta-parameters)
 __global__ void gather_params_kernel(const float* __restrict__ theta_ref, const int32_t* __restrict__ perm, int p, int pstride,
                                      float* __restrict__ theta_eng) {
@@ -71,6 +80,11 @@ hipError_t launch_prepare_batch(hipStream_t st, const float* data, const int64_t
   const size_t total = (size_t)tasks * n2 * h * w;
   hipLaunchKernelGGL(prepare_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, data, labels, tasks, n2, c,
                      h, w, xs, xq, ys, yq);
+  return hipGetLastError();
+}
+hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, size_t images, int c, int h, int w, float* dst) {
+  const size_t total = images * h * w;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, images, c, h, w, dst);
   return hipGetLastError();
 }
 hipError_t launch_gather_params(hipStream_t st, const float* theta_ref, const int32_t* perm, int p, int pstride, int tasks,

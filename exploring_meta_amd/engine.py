@@ -128,6 +128,17 @@ class MetaEngine:
         _lib.check(rc, self._h)
         return loss, acc, grad, logits
 
+    def forward_logits(self, theta, x):
+        """Plain forward (no adaptation): x [T, n, C, H, W] -> logits [T, n, ways]; BatchNorm uses each batch's statistics."""
+        T, n = x.shape[0], x.shape[1]
+        b = C.c_size_t()
+        _lib.check(self.lib.mi_forward_workspace_bytes(self._h, T, n, C.byref(b)), self._h)
+        ws = self._workspace(b.value)
+        logits = torch.empty(T, n, self.spec.ways, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mi_forward_logits(self._h, _stream(), _ptr(theta.contiguous()), _ptr(x.contiguous()), T, n,
+                                              _ptr(logits), _ptr(ws), ws.numel()), self._h)
+        return logits
+
     def profile(self, on, op=None, layer=0):
         """Record HIP events around every launch (or only launches of one (op name, layer)) until switched off."""
         kind = -1

@@ -1,0 +1,52 @@
+"""Task-sharded data parallelism for the meta-batch: tasks are independent given the meta-parameters
+(reference vision/maml_vision.py:102-124), so rank r owns a contiguous block of the global task list, runs them through its
+own engine, and ONE all-reduce of the flat fp32 meta-gradient (with the loss/accuracy sums appended, so logging needs no
+second collective) precedes the identical Adam step on every rank.  Backend "nccl" is RCCL over xGMI on the GPU box;
+"gloo" on CPU (tests).  No collective touches the per-task data path.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_tasks, rank, world):
+    """Contiguous block of the global task list owned by ``rank`` (sizes differ by at most one)."""
+    base, rem = divmod(num_tasks, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def reduce_meta_batch(meta_grad, loss_sum, acc_sum, group=None):
+    """Sum (meta_grad, loss_sum, acc_sum) over ranks with a single all-reduce.  Returns the reduced triple.
+    Single-process (no initialised process group): identity."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return meta_grad, loss_sum, acc_sum
+    flat = torch.cat([meta_grad.reshape(-1), torch.stack([loss_sum.reshape(()), acc_sum.reshape(())]).to(meta_grad.dtype)])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    n = meta_grad.numel()
+    return flat[:n].view_as(meta_grad), flat[n], flat[n + 1]
+
+
+class MetaTrainer:
+    """One meta-iteration = local shard through ``compute`` -> one all-reduce -> Adam (maml_vision.py:93-141, train half).
+
+    ``compute(theta, task_ids) -> (loss[T_local], acc[T_local], meta_grad_sum[P])`` is the engine call on this rank's shard
+    (``MetaEngine.meta_batch`` on the GPU; tests inject a CPU callable).  ``adam(theta, grad, grad_scale)`` applies the step
+    in place.  theta is replicated; since every rank applies the same step to the same reduced gradient it stays identical
+    without a broadcast.
+    """
+
+    def __init__(self, compute, adam, meta_batch_size, group=None):
+        self.compute, self.adam, self.meta_batch_size, self.group = compute, adam, meta_batch_size, group
+        init = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if init else 0
+        self.world = dist.get_world_size(group) if init else 1
+
+    def local_tasks(self, first_task_id=0):
+        a, b = shard_range(self.meta_batch_size, self.rank, self.world)
+        return list(range(first_task_id + a, first_task_id + b))
+
+    def step(self, theta, first_task_id=0):
+        loss, acc, grad = self.compute(theta, self.local_tasks(first_task_id))
+        grad, loss_sum, acc_sum = reduce_meta_batch(grad, loss.sum(), acc.sum(), self.group)
+        self.adam(theta, grad, 1.0 / self.meta_batch_size)            # maml_vision.py:139-141
+        return loss_sum / self.meta_batch_size, acc_sum / self.meta_batch_size, grad

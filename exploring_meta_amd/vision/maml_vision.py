@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's ``vision/maml_vision.py`` on the batched HIP engine.
+
+Same experiment (seeds, model, ``MAML(model, lr, first_order)``, Adam(outer_lr), CrossEntropy, per-iteration train +
+validation meta-batches, gradient / meta_batch_size, meta-test with ``evaluate``), same flags plus ``--first_order`` (the
+reference hard-codes second order, maml_vision.py:84) -- but the ``for task in range(meta_batch_size)`` loop
+(maml_vision.py:102-124) is ONE ``meta_batch_adapt`` call per half, and with ``torchrun`` the meta-batch is sharded over
+ranks with one RCCL all-reduce.  Datasets are not available offline: tasks come from the seeded synthetic generator
+(``utils/synthetic.py``) with the reference's batch layout.
+
+    python -m exploring_meta_amd.vision.maml_vision --dataset min --shots 5 --adapt_steps 5 --num_iterations 10
+"""
+import argparse
+import os
+import random
+
+import numpy as np
+import torch
+
+from ..core_functions import MAML, MiniImagenetCNN, OmniglotCNN, evaluate, meta_batch_adapt
+from ..sharding import reduce_meta_batch, shard_range
+from ..utils import synthetic
+
+params = {
+    "ways": 5, "shots": 1, "outer_lr": 0.003, "inner_lr": 0.5, "adapt_steps": 1, "meta_batch_size": 32,
+    "num_iterations": 10000, "save_every": 1000, "seed": 42,
+}
+
+
+class SyntheticTasks:
+    """Stand-in for an l2l TaskDataset: ``sample()`` returns (data [2*S*W,C,H,W], labels [2*S*W])."""
+
+    def __init__(self, dataset, ways, shots, first_id):
+        self.dataset, self.ways, self.shots, self.next = dataset, ways, shots, first_id
+
+    def sample(self):
+        d, l = synthetic.make_task(self.dataset, self.next, self.ways, self.shots)
+        self.next += 1
+        return torch.from_numpy(d), torch.from_numpy(l)
+
+    def sample_batch(self, ids):
+        d, l = synthetic.make_meta_batch(self.dataset, ids, self.ways, self.shots)
+        return torch.from_numpy(d), torch.from_numpy(l)
+
+
+def run(dataset, p, first_order=False, log=print):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    random.seed(p['seed']); np.random.seed(p['seed']); torch.manual_seed(p['seed']); torch.cuda.manual_seed(p['seed'])
+    device = torch.device('cuda', local)
+    model = (OmniglotCNN(p['ways']) if dataset == 'omni' else MiniImagenetCNN(p['ways'])).to(device)
+    maml = MAML(model, lr=p['inner_lr'], first_order=first_order)
+    opt = torch.optim.Adam(maml.parameters(), p['outer_lr'])
+    loss = torch.nn.CrossEntropyLoss(reduction='mean')
+    T = p['meta_batch_size']
+    lo, hi = shard_range(T, rank, world)
+    train, valid = SyntheticTasks(dataset, p['ways'], p['shots'], 0), SyntheticTasks(dataset, p['ways'], p['shots'], 10 ** 6)
+    metrics = {}
+    for it in range(p['num_iterations']):
+        opt.zero_grad()
+        ids = list(range(it * T + lo, it * T + hi))
+        d, l = train.sample_batch(ids)
+        total, losses, accs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
+        total.backward()                                                     # accumulates the SUM over this rank's tasks
+        with torch.no_grad():
+            d, l = valid.sample_batch([10 ** 6 + i for i in ids])
+            _, vlosses, vaccs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
+        flat = torch.cat([q.grad.reshape(-1) for q in maml.parameters()])
+        flat, lsum, asum = reduce_meta_batch(flat, losses.sum(), accs.sum())
+        off = 0
+        for q in maml.parameters():                                          # maml_vision.py:139-140
+            q.grad.copy_(flat[off:off + q.numel()].view_as(q) * (1.0 / T))
+            off += q.numel()
+        opt.step()
+        metrics = {'train_loss': (lsum / T).item(), 'train_acc': (asum / T).item(),
+                   'valid_loss': vlosses.mean().item(), 'valid_acc': vaccs.mean().item()}
+        if rank == 0:
+            log(f'iter {it}: {metrics}')
+    test = SyntheticTasks(dataset, p['ways'], p['shots'], 2 * 10 ** 6)
+    metrics['test_acc'] = evaluate(p, test, maml, loss, device)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return model, metrics
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser(description='MAML on Vision (MI355X engine)')
+    parser.add_argument('--dataset', type=str, default='min', help='omni or min')
+    for k, v in params.items():
+        parser.add_argument(f'--{k}', type=type(v), default=v)
+    parser.add_argument('--first_order', action='store_true')
+    args = parser.parse_args()
+    for k in params:
+        params[k] = getattr(args, k)
+    run(args.dataset, params, first_order=args.first_order)

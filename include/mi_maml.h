@@ -76,6 +76,12 @@ int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta, const flo
                        float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
                        void* workspace, size_t workspace_bytes);
 
+/* Plain classifier forward, no adaptation: `learner(x)` / `model(x)` (vision_models.py:51-55,107-110), BatchNorm in train
+ * mode over the n images of each of the `tasks` batches.  x [tasks, n, C, H, W] NCHW; logits_out [tasks, n, ways]. */
+int mi_forward_workspace_bytes(const mi_engine* e, int tasks, int n, size_t* bytes);
+int mi_forward_logits(mi_engine* e, void* stream, const float* theta, const float* x, int tasks, int n, float* logits_out,
+                      void* workspace, size_t workspace_bytes);
+
 /* Adam step on the flat meta-parameters with torch.optim.Adam defaults (maml_vision.py:85,139-141):
  * grad is first scaled by grad_scale (= 1/meta_batch_size). step is the 1-based step count after increment. */
 int mi_adam_step(void* stream, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step,

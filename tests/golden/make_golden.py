@@ -245,6 +245,16 @@ def g5_policy(ref, out):
     out['g5_param_names'] = np.array([k for k, _ in ref['DiagNormalPolicy'](2, 2).named_parameters()])
 
 
+def g6_state_dict(ref, out):
+    """state_dict layout a reference checkpoint has (utils/experiment.py:85-90 saves model.state_dict())."""
+    for name, m in (('min32', ref['MiniImagenetCNN'](5)), ('omni64', ref['OmniglotCNN'](5)),
+                    ('base_min64', ref['ConvBase'](output_size=64, channels=3, max_pool=True))):
+        sd = m.state_dict()
+        out[f'g6_{name}_keys'] = np.array(list(sd.keys()))
+        out[f'g6_{name}_shapes'] = np.array([','.join(str(d) for d in v.shape) for v in sd.values()])
+        out[f'g6_{name}_param_names'] = np.array([k for k, _ in m.named_parameters()])
+
+
 def main():
     torch.set_num_threads(8)
     ref = import_reference()
@@ -253,6 +263,7 @@ def main():
     g4_accuracy(ref, small)
     g5_policy(ref, small)
     g2_forward(ref, small)
+    g6_state_dict(ref, small)
     np.savez_compressed(os.path.join(HERE, 'golden_small.npz'), **small)
     g3_fast_adapt(ref, big)
     g3_anil(ref, big)
