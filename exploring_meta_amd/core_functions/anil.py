@@ -1,0 +1,72 @@
+"""ANIL through the reference's own call: ``fast_adapt(batch, learner, loss, K, shots, ways, device, features=features)``
+with ``features = Sequential(ConvBase, Lambda(view(-1, fc_neurons)))`` and ``learner = MAML(Linear(fc_neurons, ways)).clone()``
+(reference vision/anil_vision.py:86-94,116-122).  The fused HIP call runs the trunk once on all rows, adapts the head, and
+returns a loss whose ``.backward()`` fills ``.grad`` of both the trunk's and the head's parameters."""
+import torch
+
+from ..engine import MetaEngine, ModelSpec
+from .maml import MAML
+from .vision_models import ConvBase
+
+_engines = {}
+
+
+def _find_convbase(features):
+    if isinstance(features, ConvBase):
+        return features
+    for m in features.modules():
+        if isinstance(m, ConvBase):
+            return m
+    raise ValueError('features must contain an exploring_meta_amd ConvBase trunk (reference anil_vision.py:86-91)')
+
+
+class _FusedAnil(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, data, labels, shots, steps, lr, first_order, need_grad, *params):
+        theta = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
+        loss, acc, grad, _ = engine.meta_batch_anil(theta, data, labels, shots, steps, lr, first_order=first_order,
+                                                    with_grad=need_grad)
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(grad if grad is not None else torch.empty(0, device=data.device))
+        ctx.mark_non_differentiable(acc)
+        return loss.sum(), loss, acc
+
+    @staticmethod
+    def backward(ctx, gsum, gloss, gacc):
+        (grad,) = ctx.saved_tensors
+        if grad.numel() == 0:
+            raise RuntimeError('fast_adapt was run without gradients (torch.no_grad or no parameter requires grad)')
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            n = int(torch.Size(shp).numel())
+            outs.append((grad[off:off + n] * gsum).reshape(shp))
+            off += n
+        return (None,) * 8 + tuple(outs)
+
+
+def meta_batch_adapt_anil(learner, features, data, labels, adaptation_steps, shots, ways):
+    """Batched ANIL entry: data [T, 2*S*W, C, H, W], labels [T, 2*S*W] on the GPU -> (loss_sum, loss[T], acc[T])."""
+    head = learner.module if isinstance(learner, MAML) else learner
+    if not isinstance(head, torch.nn.Linear) or head.out_features != ways:
+        raise ValueError('ANIL learner must wrap torch.nn.Linear(fc_neurons, ways) (reference anil_vision.py:93)')
+    base = _find_convbase(features)
+    _, _, c, h, w = data.shape
+    spec = ModelSpec.anil(ways, base.hidden, base.channels, base.max_pool, base.layers, h)
+    dev = data.device
+    key = (spec, dev.index)
+    if key not in _engines:
+        _engines[key] = MetaEngine(spec, dev)
+    engine = _engines[key]
+    params = list(base.parameters()) + [head.weight, head.bias]          # reference optimizer order (anil_vision.py:97)
+    if head.in_features * ways + ways + sum(p.numel() for p in base.parameters()) != engine.param_count:
+        raise ValueError(f'head.in_features={head.in_features} does not match the trunk output for {h}x{w} inputs')
+    need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    fo = learner.first_order if isinstance(learner, MAML) else False
+    return _FusedAnil.apply(engine, data.float().contiguous(), labels.contiguous(), shots, adaptation_steps, learner.lr, fo,
+                            need, *params)
+
+
+def fast_adapt_anil(data, labels, learner, features, adaptation_steps, shots, ways):
+    total, losses, accs = meta_batch_adapt_anil(learner, features, data.unsqueeze(0), labels.unsqueeze(0), adaptation_steps,
+                                                shots, ways)
+    return total, accs[0]

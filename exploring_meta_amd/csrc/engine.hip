@@ -296,9 +296,8 @@ extern "C" int mi_workspace_bytes(const mi_engine* e, int tasks, int ways, int s
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One forward (+ backward) pass of the whole net on n images per task.
-static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, const int32_t* y, int n, int T,
-                        const float* theta, float* g, float* loss, float* acc, float* logits, bool with_grad) {
+// Trunk forward: ConvBlocks on n images per task (conv + BN-stat epilogue, finalize, BN+ReLU+pool).
+static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   for (int l = 0; l < nl; ++l) {
@@ -321,18 +320,14 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     LAUNCH(e, st, OP_BN_FWD, l, launch_bn_fwd(st, ba, T, L.pool));
   }
-  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
-  if (with_grad) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * P * sizeof(float), st));
-  HeadArgs ha{};
-  ha.f = A.f;
-  ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
-  ha.y = y; ha.loss = loss; ha.acc = acc; ha.logits = logits; ha.prob = A.prob; ha.dl = A.dl;
-  ha.dwl = with_grad ? g + e->off_wl : nullptr; ha.dbl = with_grad ? g + e->off_bl : nullptr; ha.gstride = P;
-  ha.df = with_grad ? A.df : nullptr;
-  ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
-  LAUNCH(e, st, OP_HEAD, 0, launch_head_fwd_bwd(st, ha, T, with_grad ? 1 : 0));
-  if (!with_grad) return MI_OK;
-  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], T * n, e->head_hw, e->head_c));
+  return MI_OK;
+}
+
+// Trunk backward from A.dp[last] (gradient w.r.t. the last block's output): writes gamma/beta/conv-weight gradients into g.
+static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
+                          float* g) {
+  const int nl = (int)e->L.size();
+  const size_t P = e->PS;
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
@@ -370,6 +365,35 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
     }
   }
   return MI_OK;
+}
+
+// Linear + CE on features f [T][n][feat]: loss/acc/logits, prob & dl saved, and (with_grad) dwl/dbl into g, df.
+static int head_pass(mi_engine* e, hipStream_t st, const float* f, const int32_t* y, int n, int T, const float* theta, float* g,
+                     float* loss, float* acc, float* logits, float* prob, float* dl, float* df, bool with_grad) {
+  const size_t P = e->PS;
+  HeadArgs ha{};
+  ha.f = f;
+  ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
+  ha.y = y; ha.loss = loss; ha.acc = acc; ha.logits = logits; ha.prob = prob; ha.dl = dl;
+  ha.dwl = with_grad ? g + e->off_wl : nullptr; ha.dbl = with_grad ? g + e->off_bl : nullptr; ha.gstride = P;
+  ha.df = with_grad ? df : nullptr;
+  ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+  LAUNCH(e, st, OP_HEAD, 0, launch_head_fwd_bwd(st, ha, T, with_grad ? 1 : 0));
+  return MI_OK;
+}
+
+// One forward (+ backward) pass of the whole net on n images per task.
+static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, const int32_t* y, int n, int T,
+                        const float* theta, float* g, float* loss, float* acc, float* logits, bool with_grad) {
+  const int nl = (int)e->L.size();
+  int rc = trunk_forward(e, st, pl, A, x0, n, T, theta);
+  if (rc) return rc;
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
+  if (with_grad) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * e->PS * sizeof(float), st));
+  rc = head_pass(e, st, A.f, y, n, T, theta, g, loss, acc, logits, A.prob, A.dl, A.df, with_grad);
+  if (rc || !with_grad) return rc;
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], T * n, e->head_hw, e->head_c));
+  return trunk_backward(e, st, pl, A, x0, n, T, theta, g);
 }
 
 // hv = H(theta) v for the saved support pass A (activations) / g (its gradient): forward-over-reverse.
@@ -501,6 +525,126 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
     }
   }
   LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, meta_grad_out));
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ANIL (reference vision/anil_vision.py:86-99,116-122 + utils/data_pre.py:118-119): the conv trunk runs ONCE per task on all
+// 2*shots*ways images (BatchNorm statistics over support and query together), the inner loop adapts only the Linear head,
+// the outer gradient reaches the trunk through the query features (directly) and through the support features (second-
+// order path:  d L_q / d f_s = -lr * sum_k  R_{lam_{k+1}}{ dL_s/df_s }(w_k), the head tangent kernel's R{df} output).
+struct AnilPlan {
+  float *theta, *g, *lam, *hv;
+  float* x;                 // [T][2n][H][W][C] NHWC
+  int32_t *ys, *yq;
+  ActSet act;               // trunk activations over 2n images
+  float *fs, *fq, *dfs, *dfq, *rdf;   // [T][n][feat]
+  float *prob, *dl;         // [K+1][T][n][ways]  (support steps 0..K-1, query at K)
+  float *tmp_loss, *tmp_acc;
+  Plan scratch;             // bnpart / wgpart live here
+  size_t bytes;
+};
+
+static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, AnilPlan& ap) {
+  Bump b{reinterpret_cast<char*>(ws), 0};
+  const size_t TP = (size_t)T * e->PS;
+  ap.theta = b.take<float>(TP * (K + 1));
+  ap.g = b.take<float>(TP * (K > 0 ? K : 1));
+  ap.lam = b.take<float>(TP);
+  ap.hv = b.take<float>(TP);
+  const size_t img = (size_t)e->d.in_h * e->d.in_w * e->d.in_channels;
+  ap.x = b.take<float>((size_t)T * 2 * n * img);
+  ap.ys = b.take<int32_t>((size_t)T * n);
+  ap.yq = b.take<int32_t>((size_t)T * n);
+  plan_actset(e, b, ap.act, T, 2 * n, true);
+  const size_t fsz = (size_t)T * n * e->feat;
+  ap.fs = b.take<float>(fsz); ap.fq = b.take<float>(fsz); ap.dfs = b.take<float>(fsz); ap.dfq = b.take<float>(fsz);
+  ap.rdf = b.take<float>(fsz);
+  ap.prob = b.take<float>((size_t)(K + 1) * T * n * e->d.ways);
+  ap.dl = b.take<float>((size_t)(K + 1) * T * n * e->d.ways);
+  ap.tmp_loss = b.take<float>(T);
+  ap.tmp_acc = b.take<float>(T);
+  size_t bnp = 0, wgp = 0;
+  for (const Layer& L : e->L) {
+    const ConvGeom gg = geom(L, 2 * n);
+    int blk = conv_max_blocks_per_task(gg);
+    const int bb = bn_blocks_per_task(2 * n, L.ho, L.wo, L.co, L.pool, 1);
+    if (bb > blk) blk = bb;
+    const size_t need = (size_t)T * blk * 2 * L.co;
+    if (need > bnp) bnp = need;
+    const size_t w = wgrad_partial_floats(gg, T);
+    if (w > wgp) wgp = w;
+  }
+  ap.scratch.bnpart = b.take<double>(bnp);
+  ap.scratch.wgpart = b.take<float>(wgp);
+  ap.bytes = align_up(b.off, 256);
+}
+
+extern "C" int mi_anil_workspace_bytes(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, size_t* bytes) {
+  if (!e || !bytes || tasks < 1 || ways < 1 || shots < 1 || adapt_steps < 0) return MI_ERR_ARG;
+  AnilPlan ap;
+  make_anil_plan(e, nullptr, tasks, ways * shots, adapt_steps, ap);
+  *bytes = ap.bytes;
+  return MI_OK;
+}
+
+extern "C" int mi_meta_batch_anil(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
+                                  int tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order,
+                                  int with_grad, float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
+                                  void* workspace, size_t workspace_bytes) {
+  if (!e) return fail(nullptr, MI_ERR_ARG, "null engine");
+  if (!theta || !data || !labels || !loss_out || !acc_out || !workspace) return fail(e, MI_ERR_ARG, "null pointer argument");
+  if (with_grad && !meta_grad_out) return fail(e, MI_ERR_ARG, "meta_grad_out is NULL but with_grad != 0");
+  if (e->d.head_mean_pool) return fail(e, MI_ERR_ARG, "ANIL features are flattened (view(-1, fc_neurons)), not mean-pooled");
+  if (tasks < 1 || shots < 1 || adapt_steps < 0 || ways != e->d.ways) return fail(e, MI_ERR_ARG, "bad tasks/shots/steps/ways");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int T = tasks, K = adapt_steps, n = ways * shots, nl = (int)e->L.size();
+  AnilPlan ap;
+  make_anil_plan(e, workspace, T, n, K, ap);
+  if (ap.bytes > workspace_bytes)
+    return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(ap.bytes) + " bytes");
+  const size_t TP = (size_t)T * e->PS, fsz = (size_t)T * n * e->feat, pw = (size_t)T * n * e->d.ways;
+  LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, data, (size_t)T * 2 * n, e->d.in_channels, e->d.in_h, e->d.in_w, ap.x));
+  LAUNCH(e, st, OP_MISC, 0, launch_split_labels(st, labels, T, 2 * n, ap.ys, ap.yq));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, e->perm_dev, (int)e->P, (int)e->PS, T, ap.theta));
+  int rc = trunk_forward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta);     // features(data) on all rows
+  if (rc) return rc;
+  LAUNCH(e, st, OP_MISC, 4, launch_split_rows(st, ap.act.p[nl - 1], T, 2 * n, e->feat, ap.fs, ap.fq));
+  for (int k = 0; k < K; ++k) {                                                    // head-only inner loop
+    float* th = ap.theta + (size_t)k * TP;
+    float* gk = ap.g + (size_t)k * TP;
+    HIPCHK(e, hipMemsetAsync(gk, 0, TP * sizeof(float), st));
+    rc = head_pass(e, st, ap.fs, ap.ys, n, T, th, gk, ap.tmp_loss, ap.tmp_acc, nullptr, ap.prob + k * pw, ap.dl + k * pw,
+                   nullptr, true);
+    if (rc) return rc;
+    LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, th, gk, inner_lr, TP, th + TP));
+  }
+  float* thK = ap.theta + (size_t)K * TP;
+  if (with_grad) HIPCHK(e, hipMemsetAsync(ap.lam, 0, TP * sizeof(float), st));
+  rc = head_pass(e, st, ap.fq, ap.yq, n, T, thK, ap.lam, loss_out, acc_out, logits_out, ap.prob + K * pw, ap.dl + K * pw, ap.dfq,
+                 with_grad != 0);
+  if (rc || !with_grad) return rc;
+  HIPCHK(e, hipMemsetAsync(ap.dfs, 0, fsz * sizeof(float), st));
+  if (second_order) {
+    for (int k = K - 1; k >= 0; --k) {
+      HIPCHK(e, hipMemsetAsync(ap.hv, 0, TP * sizeof(float), st));
+      HeadArgs ha{};
+      ha.f = ap.fs; ha.fd = nullptr;
+      ha.wl = ap.theta + (size_t)k * TP + e->off_wl; ha.bl = ap.theta + (size_t)k * TP + e->off_bl; ha.pstride = e->PS;
+      ha.wld = ap.lam + e->off_wl; ha.bld = ap.lam + e->off_bl; ha.vstride = e->PS;
+      ha.prob = ap.prob + k * pw; ha.dl = ap.dl + k * pw;
+      ha.dwl = ap.hv + e->off_wl; ha.dbl = ap.hv + e->off_bl; ha.gstride = e->PS;
+      ha.df = ap.rdf;
+      ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+      LAUNCH(e, st, OP_HEAD_TAN, 0, launch_head_tangent(st, ha, T));
+      LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, ap.dfs, ap.rdf, inner_lr, fsz, ap.dfs));   // dfs -= lr * R{df}
+      LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, ap.lam, ap.hv, inner_lr, TP, ap.lam));     // lam -= lr * H lam
+    }
+  }
+  LAUNCH(e, st, OP_MISC, 4, launch_interleave_rows(st, ap.dfs, ap.dfq, T, n, e->feat, ap.act.dp[nl - 1]));
+  rc = trunk_backward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta, ap.lam);  // trunk grads join the head part in lam
+  if (rc) return rc;
+  LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, ap.lam, e->perm_dev, (int)e->P, (int)e->PS, T, meta_grad_out));
   return MI_OK;
 }
 

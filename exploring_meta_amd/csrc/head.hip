@@ -100,14 +100,15 @@ __global__ __launch_bounds__(256) void head_tangent_kernel(HeadArgs a) {
   float* s_ld = sm;                 // [N][WY]  -> R{dl}
   float* s_dl = sm + N * WY;        // [N][WY]
   const float* f_t = a.f + (size_t)task * N * F;
-  const float* fd_t = a.fd + (size_t)task * N * F;
+  const bool has_fd = a.fd != nullptr;          // ANIL: features carry no tangent (only the head is adapted)
+  const float* fd_t = has_fd ? a.fd + (size_t)task * N * F : f_t;
   const float* wl_t = a.wl + (size_t)task * a.pstride;
   const float* wld_t = a.wld + (size_t)task * a.vstride;
   const float* bld_t = a.bld + (size_t)task * a.vstride;
   for (int pair = wave; pair < N * WY; pair += 4) {
     const int n = pair / WY, w = pair - n * WY;
-    const float d = wave_dot(fd_t + (size_t)n * F, wl_t + (size_t)w * F, F, lane) +
-                    wave_dot(f_t + (size_t)n * F, wld_t + (size_t)w * F, F, lane);
+    float d = wave_dot(f_t + (size_t)n * F, wld_t + (size_t)w * F, F, lane);
+    if (has_fd) d += wave_dot(fd_t + (size_t)n * F, wl_t + (size_t)w * F, F, lane);
     if (lane == 0) s_ld[pair] = d + bld_t[w];
   }
   for (int e = tid; e < N * WY; e += 256) s_dl[e] = a.dl[(size_t)task * N * WY + e];
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void head_tangent_kernel(HeadArgs a) {
     float s = 0.f;
     for (int n = 0; n < N; ++n) {
       s = fmaf(s_ld[n * WY + w], f_t[(size_t)n * F + i], s);
-      s = fmaf(s_dl[n * WY + w], fd_t[(size_t)n * F + i], s);
+      if (has_fd) s = fmaf(s_dl[n * WY + w], fd_t[(size_t)n * F + i], s);
     }
     dwl_t[e] = s;
   }

@@ -34,6 +34,28 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, size_t images
   for (int ch = 0; ch < c; ++ch) dst[e * c + ch] = src[(img * c + ch) * hw + pix];
 }
 
+// ANIL: prepare_batch's even/odd split applied to feature rows (data_pre.py:122-127 after :118-119) and its transpose.
+__global__ void split_rows_kernel(const float* __restrict__ src, size_t rows2, int f, float* __restrict__ even,
+                                  float* __restrict__ odd) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows2 * f) return;
+  const size_t row = e / f, col = e - row * f;
+  ((row & 1) ? odd : even)[(row >> 1) * f + col] = src[e];
+}
+__global__ void interleave_rows_kernel(const float* __restrict__ even, const float* __restrict__ odd, size_t rows2, int f,
+                                       float* __restrict__ dst) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows2 * f) return;
+  const size_t row = e / f, col = e - row * f;
+  dst[e] = ((row & 1) ? odd : even)[(row >> 1) * f + col];
+}
+__global__ void split_labels_kernel(const int64_t* __restrict__ labels, size_t rows2, int32_t* __restrict__ ys,
+                                    int32_t* __restrict__ yq) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows2) return;
+  ((e & 1) ? yq : ys)[e >> 1] = (int32_t)labels[e];
+}
+
 // theta_eng[t][i] = theta_ref[perm[i]] for every task (learn2learn clone_module: each task starts from the meta-parameters)
 __global__ void gather_params_kernel(const float* __restrict__ theta_ref, const int32_t* __restrict__ perm, int p, int pstride,
                                      float* __restrict__ theta_eng) {
@@ -85,6 +107,22 @@ hipError_t launch_prepare_batch(hipStream_t st, const float* data, const int64_t
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, size_t images, int c, int h, int w, float* dst) {
   const size_t total = images * h * w;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, images, c, h, w, dst);
+  return hipGetLastError();
+}
+hipError_t launch_split_rows(hipStream_t st, const float* src, int tasks, int n2, int f, float* even, float* odd) {
+  const size_t total = (size_t)tasks * n2 * f;   // n2 is even, so global row parity == row parity within the task
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, (size_t)tasks * n2, f, even, odd);
+  return hipGetLastError();
+}
+hipError_t launch_interleave_rows(hipStream_t st, const float* even, const float* odd, int tasks, int n, int f, float* dst) {
+  const size_t total = (size_t)tasks * 2 * n * f;
+  hipLaunchKernelGGL(interleave_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, even, odd,
+                     (size_t)tasks * 2 * n, f, dst);
+  return hipGetLastError();
+}
+hipError_t launch_split_labels(hipStream_t st, const int64_t* labels, int tasks, int n2, int32_t* ys, int32_t* yq) {
+  const size_t total = (size_t)tasks * n2;
+  hipLaunchKernelGGL(split_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, labels, total, ys, yq);
   return hipGetLastError();
 }
 hipError_t launch_gather_params(hipStream_t st, const float* theta_ref, const int32_t* perm, int p, int pstride, int tasks,

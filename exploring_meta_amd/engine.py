@@ -35,6 +35,12 @@ class ModelSpec:
         """OmniglotCNN(output_size=ways, hidden_size=64, layers=4) (vision_models.py:39-49)."""
         return ModelSpec(layers, 1, 28, 28, hidden, False, ways, True)
 
+    @staticmethod
+    def anil(ways, hidden=64, channels=3, max_pool=True, layers=4, in_hw=84):
+        """ANIL trunk ConvBase(output_size, hidden, channels, max_pool) + Linear(fc_neurons, ways) head
+        (vision/anil_vision.py:86-94): Mini-ImageNet (64 filters, 3x84x84, pooling) or Omniglot (32 filters, 1x28x28)."""
+        return ModelSpec(layers, channels, in_hw, in_hw, hidden, bool(max_pool), ways, False)
+
     def param_shapes(self):
         """(name, shape) in the reference's parameters() order / state_dict naming."""
         out, ci = [], self.in_channels
@@ -123,6 +129,33 @@ class MetaEngine:
         grad = torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None
         logits = torch.empty(T, shots * s.ways, s.ways, dtype=torch.float32, device=self.device) if return_logits else None
         rc = self.lib.mi_meta_batch_maml(self._h, _stream(), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
+                                         adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
+                                         _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
+        _lib.check(rc, self._h)
+        return loss, acc, grad, logits
+
+    def meta_batch_anil(self, theta, data, labels, shots, adapt_steps, inner_lr, first_order=False, with_grad=True,
+                        return_logits=False):
+        """ANIL (reference vision/anil_vision.py:116-122): theta = [features.parameters()..., head.weight, head.bias] flat;
+        the trunk sees all 2*shots*ways images of a task at once, only the head is adapted.  Same returns as meta_batch."""
+        s = self.spec
+        T = data.shape[0]
+        n2 = 2 * shots * s.ways
+        if tuple(data.shape) != (T, n2, s.in_channels, s.in_h, s.in_w) or tuple(labels.shape) != (T, n2):
+            raise ValueError(f'data/labels shapes {tuple(data.shape)}/{tuple(labels.shape)} do not match T x {n2} task rows')
+        if theta.numel() != self.param_count:
+            raise ValueError(f'theta has {theta.numel()} elements, trunk + head have {self.param_count}')
+        for t, dt in ((theta, torch.float32), (data, torch.float32), (labels, torch.int64)):
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+                raise ValueError('theta/data must be contiguous fp32 CUDA tensors and labels contiguous int64 CUDA')
+        b = C.c_size_t()
+        _lib.check(self.lib.mi_anil_workspace_bytes(self._h, T, s.ways, shots, adapt_steps, C.byref(b)), self._h)
+        ws = self._workspace(b.value)
+        loss = torch.empty(T, dtype=torch.float32, device=self.device)
+        acc = torch.empty(T, dtype=torch.float32, device=self.device)
+        grad = torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None
+        logits = torch.empty(T, shots * s.ways, s.ways, dtype=torch.float32, device=self.device) if return_logits else None
+        rc = self.lib.mi_meta_batch_anil(self._h, _stream(), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
                                          adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
                                          _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
         _lib.check(rc, self._h)

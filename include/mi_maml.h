@@ -76,6 +76,18 @@ int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta, const flo
                        float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
                        void* workspace, size_t workspace_bytes);
 
+/* One meta-batch of ANIL tasks (vision/anil_vision.py:116-122 with features = Sequential(ConvBase, view(-1, fc_neurons)),
+ * head = MAML(Linear(fc_neurons, ways)), :86-94): the trunk runs once per task on all 2*shots*ways images (BatchNorm over
+ * support and query together, utils/data_pre.py:118-119), only the head is adapted, and the outer gradient reaches both.
+ * The engine is created with the trunk's ConvBase geometry and `ways`; theta / meta_grad_out are
+ * [features.parameters() ..., head.weight[ways, fc_neurons], head.bias[ways]] -- the order of the reference's optimizer list
+ * (anil_vision.py:97).  Other arguments as mi_meta_batch_maml. */
+int mi_anil_workspace_bytes(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, size_t* bytes);
+int mi_meta_batch_anil(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
+                       int tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order, int with_grad,
+                       float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
+                       void* workspace, size_t workspace_bytes);
+
 /* Plain classifier forward, no adaptation: `learner(x)` / `model(x)` (vision_models.py:51-55,107-110), BatchNorm in train
  * mode over the n images of each of the `tasks` batches.  x [tasks, n, C, H, W] NCHW; logits_out [tasks, n, ways]. */
 int mi_forward_workspace_bytes(const mi_engine* e, int tasks, int n, size_t* bytes);

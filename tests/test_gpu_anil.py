@@ -1,0 +1,97 @@
+"""ANIL (BASELINE config 3) on the GPU against the reference-generated fixtures and the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from exploring_meta_amd import core_functions as cf
+from exploring_meta_amd.core_functions.anil import meta_batch_adapt_anil
+from exploring_meta_amd.engine import MetaEngine, ModelSpec
+from exploring_meta_amd.utils import synthetic
+from oracle import vision_ref as R
+from helpers import hash_params, task_tensors
+from gpu_utils import rel_err, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _params():
+    base = R.convbase_spec(64, 3, True)
+    spec = dict(kind='min', in_shape=(3, 84, 84), base=base)
+    tf = hash_params(R.param_shapes(spec, prefix_base='0.'), 13)
+    th = hash_params({'weight': (5, 1600), 'bias': (5,)}, 17)
+    return base, tf, th
+
+
+@pytest.mark.parametrize('K', [1, 5])
+def test_anil_engine_vs_golden_and_oracle(golden_fa, K):
+    ways, shots, lr, tasks = 5, 5, 0.5, [0, 1]
+    base, tf, th = _params()
+    theta = torch.cat([R.flatten_params(tf), R.flatten_params(th)]).float().cuda()
+    eng = MetaEngine(ModelSpec.anil(ways))
+    data, labels = synthetic.make_meta_batch('min', tasks, ways, shots)
+    loss, acc, grad, _ = eng.meta_batch_anil(theta, torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda(), shots, K, lr)
+    torch.cuda.synchronize()
+    tag = f'g3_cfg3_anil_min_5w5s_K{K}'
+    l64 = golden_fa[f'{tag}_f64_loss']
+    g64 = np.concatenate([golden_fa[f'{tag}_f64_grad_feat'], golden_fa[f'{tag}_f64_grad_head']])
+    l32 = golden_fa[f'{tag}_f32_loss']
+    ref_err = np.abs(l32 - l64) / np.abs(l64)
+    err = np.abs(loss.cpu().numpy() - l64) / np.abs(l64)
+    nf = golden_fa[f'{tag}_f64_grad_feat'].size
+    g = grad.cpu().numpy()
+    ef, eh = rel_err(g[:nf], g64[:nf]), rel_err(g[nf:], g64[nf:])
+    report(f'anil[K={K}]', loss_rel_err=float(err.max()), ref_fp32_loss_rel_err=float(ref_err.max()), grad_feat_rel=ef,
+           grad_head_rel=eh, loss=[float(x) for x in loss.cpu()])
+    assert np.all(err <= np.maximum(1e-4, 2 * ref_err))
+    assert np.array_equal(acc.cpu().numpy().astype(np.float64), golden_fa[f'{tag}_f64_acc'])
+    assert ef < 2e-3 and eh < 2e-3
+
+
+def test_anil_reference_call_surface(golden_fa):
+    """fast_adapt(..., features=features) + eval_loss.backward() as in vision/anil_vision.py:116-122."""
+    ways, shots, K, lr = 5, 5, 1, 0.5
+    base, tf, th = _params()
+    trunk = cf.ConvBase(output_size=64, channels=3, max_pool=True)
+    with torch.no_grad():
+        for (k, p) in trunk.named_parameters():
+            p.copy_(tf['0.' + k].float())
+    features = torch.nn.Sequential(trunk).cuda()
+    head = torch.nn.Linear(1600, ways)
+    with torch.no_grad():
+        head.weight.copy_(th['weight'].float())
+        head.bias.copy_(th['bias'].float())
+    head = cf.MAML(head, lr=lr).cuda()
+    loss_fn = torch.nn.CrossEntropyLoss(reduction='mean')
+    for t in [0, 1]:
+        d, l = synthetic.make_task('min', t, ways, shots)
+        eval_loss, eval_acc = cf.fast_adapt((torch.from_numpy(d), torch.from_numpy(l)), head.clone(), loss_fn, K, shots, ways,
+                                            torch.device('cuda'), features=features)
+        eval_loss.backward()
+    gf = torch.cat([p.grad.reshape(-1) for p in features.parameters()]).cpu().numpy()
+    gh = torch.cat([p.grad.reshape(-1) for p in head.parameters()]).cpu().numpy()
+    tag = f'g3_cfg3_anil_min_5w5s_K{K}_f64'
+    assert rel_err(gf, golden_fa[f'{tag}_grad_feat']) < 2e-3 and rel_err(gh, golden_fa[f'{tag}_grad_head']) < 2e-3
+
+
+def test_anil_first_order_and_omniglot_trunk():
+    """First-order ANIL (support features get no gradient) and the Omniglot trunk (32 filters, stride-2, fc 128)."""
+    ways, shots, K, lr = 5, 1, 2, 0.4
+    base = R.convbase_spec(32, 1, False)
+    spec = dict(kind='omni', in_shape=(1, 28, 28), base=base)
+    tf = hash_params(R.param_shapes(spec, prefix_base='0.'), 13)
+    th = hash_params({'weight': (ways, 128), 'bias': (ways,)}, 17)
+    datas, labels = task_tensors('omni', [0, 1], ways, shots)
+    datas = [d.view(-1, 1, 28, 28) for d in datas]
+    for fo in (False, True):
+        l64, a64, gf, gh = R.anil_meta_batch(tf, th, base, 128, datas, labels, K, shots, ways, lr, first_order=fo)
+        g64 = torch.cat([R.flatten_params(gf), R.flatten_params(gh)]).numpy()
+        eng = MetaEngine(ModelSpec.anil(ways, hidden=32, channels=1, max_pool=False, in_hw=28))
+        theta = torch.cat([R.flatten_params(tf), R.flatten_params(th)]).float().cuda()
+        data, lab = synthetic.make_meta_batch('omni', [0, 1], ways, shots)
+        loss, acc, grad, _ = eng.meta_batch_anil(theta, torch.from_numpy(data).cuda(), torch.from_numpy(lab).cuda(), shots, K, lr,
+                                                 first_order=fo)
+        torch.cuda.synchronize()
+        e = rel_err(grad.cpu().numpy(), g64)
+        report(f'anil_omni[fo={fo}]', grad_rel=e, loss_err=float(np.abs(loss.cpu().numpy() - l64.numpy()).max()))
+        assert np.allclose(loss.cpu().numpy(), l64.numpy(), rtol=1e-4) and np.array_equal(acc.cpu().numpy(), a64.numpy())
+        assert e < 1e-3
