@@ -17,6 +17,11 @@ class MiModelDesc(C.Structure):
                 ('hidden', C.c_int32), ('max_pool', C.c_int32), ('ways', C.c_int32), ('head_mean_pool', C.c_int32)]
 
 
+class MiPolicyDesc(C.Structure):
+    _fields_ = [('state_size', C.c_int32), ('action_size', C.c_int32), ('hidden1', C.c_int32), ('hidden2', C.c_int32),
+                ('activation', C.c_int32)]
+
+
 class MiError(RuntimeError):
     pass
 
@@ -65,6 +70,19 @@ _SIGS = {
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     'mi_kernel_scratch_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'mi_policy_create': (C.c_int, [C.POINTER(MiPolicyDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    'mi_policy_destroy': (None, [C.c_void_p]),
+    'mi_policy_last_error': (C.c_char_p, [C.c_void_p]),
+    'mi_policy_param_count': (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    'mi_trpo_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    'mi_policy_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_size_t]),
+    'mi_policy_adapt': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'mi_trpo_surrogate': (C.c_int, [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                         C.c_void_p, C.c_size_t]),
+    'mi_trpo_fvp': (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_size_t]),
     'mi_profile_enable': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     'mi_profile_kinds': (C.c_int, []),
     'mi_profile_op_name': (C.c_char_p, [C.c_int]),

@@ -1,0 +1,249 @@
+"""MAML-TRPO functions with the reference's names (core_functions/rl.py TRPO part, lines 95-110 and 346-473) on the batched
+HIP policy engine.  Replays are plain dicts of tensors (the reference uses cherry ExperienceReplay objects, out of scope):
+``states [N,S], actions [N,A], rewards [N,1], dones [N,1], next_states [N,S]`` with episodes concatenated.
+Host side (tiny): discounting, the LinearValue least-squares baseline, GAE, normalisation.
+Device side: policy forward, the inner ``trpo_update``, the meta surrogate loss / KL, its gradient, and the Fisher-vector
+products inside conjugate gradient -- for ALL tasks of the meta-batch per call.
+"""
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+device = torch.device('cuda')
+
+
+def set_device(dev):
+    """reference rl.py:44-46"""
+    global device
+    device = dev
+
+
+# ---------------------------------------------------------------------------------------------- host-side pieces (cherry semantics)
+def _np(x):
+    return x.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(x) else np.asarray(x, dtype=np.float64)
+
+
+def discount(gamma, rewards, dones):
+    """cherry.td.discount: R_t = r_t + gamma (1 - d_t) R_{t+1}."""
+    out = np.zeros_like(rewards)
+    run = 0.0
+    for t in range(rewards.shape[0] - 1, -1, -1):
+        run = rewards[t, 0] + gamma * (1.0 - dones[t, 0]) * run
+        out[t, 0] = run
+    return out
+
+
+class LinearValue:
+    """cherry.models.robotics.LinearValue(input_size, reg): features [s, s^2, t, t^2, t^3, 1], t = arange(N)/100; ridge
+    normal equations solved by least squares (rl/maml_trpo.py:85 passes env.action_size as ``reg``)."""
+
+    def __init__(self, input_size, reg=1e-5):
+        self.input_size, self.reg = input_size, reg
+        self.weight = np.zeros((2 * input_size + 4, 1))
+
+    def _features(self, states):
+        n = states.shape[0]
+        al = (np.arange(n, dtype=np.float64) / 100.0).reshape(-1, 1)
+        return np.concatenate([states, states ** 2, al, al ** 2, al ** 3, np.ones((n, 1))], axis=1)
+
+    def fit(self, states, returns):
+        f = self._features(_np(states))
+        a = f.T @ f + self.reg * np.eye(f.shape[1])
+        self.weight = np.linalg.lstsq(a, f.T @ _np(returns), rcond=None)[0]
+
+    def __call__(self, states):
+        return self._features(_np(states)) @ self.weight
+
+
+def compute_advantages(baseline, tau, gamma, rewards, dones, states, next_states, update_vf=True):
+    """reference rl.py:95-110 (GAE with cherry semantics).  numpy float64 [N,1]."""
+    rewards, dones = _np(rewards), _np(dones)
+    returns = discount(gamma, rewards, dones)
+    if update_vf:
+        baseline.fit(states, returns)
+    values, next_values = baseline(states), baseline(next_states)
+    bootstraps = values * (1.0 - dones) + next_values * dones
+    nxt = np.concatenate([bootstraps[1:], np.zeros((1, 1))], axis=0)
+    td = rewards + gamma * (1.0 - dones) * nxt - bootstraps
+    return discount(gamma * tau, td, dones)
+
+
+def normalize(x, epsilon=1e-8):
+    """cherry.normalize"""
+    return (x - x.mean()) / (x.std(ddof=1) + epsilon) if x.size > 1 else x
+
+
+def _advantages(ep, baseline, gamma, tau, update_vf=True):
+    adv = compute_advantages(baseline, tau, gamma, ep['rewards'], ep['dones'], ep['states'], ep['next_states'], update_vf)
+    return normalize(adv)
+
+
+def _pad(eps_list, advs, S, A, dev):
+    """List of replays (one per task) -> padded device batch {states [T,B,S], actions, adv, count}."""
+    T = len(eps_list)
+    B = max(int(e['states'].shape[0]) for e in eps_list)
+    st, ac = torch.zeros(T, B, S), torch.zeros(T, B, A)
+    ad, cnt = torch.zeros(T, B), torch.zeros(T, dtype=torch.int32)
+    for t, (e, a) in enumerate(zip(eps_list, advs)):
+        n = int(e['states'].shape[0])
+        st[t, :n], ac[t, :n] = e['states'].detach().cpu().float(), e['actions'].detach().cpu().float()
+        ad[t, :n] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(-1))
+        cnt[t] = n
+    return dict(states=st.to(dev), actions=ac.to(dev), adv=ad.to(dev), count=cnt.to(dev))
+
+
+# ---------------------------------------------------------------------------------------------- reference functions
+def trpo_a2c_loss(episodes, learner, baseline, gamma, tau, update_vf=True):
+    """reference rl.py:346-358: -mean(log_prob * normalised advantages) (value only; the gradient path is trpo_update)."""
+    adv = _advantages(episodes, baseline, gamma, tau, update_vf)
+    lp = learner.log_prob(episodes['states'].to(device), episodes['actions'].to(device))
+    return -(lp * torch.from_numpy(adv).to(lp)).mean()
+
+
+def trpo_update(episodes, learner, baseline, inner_lr, gamma, tau, anil=False, first_order=False):
+    """reference rl.py:361-374: one MAML update of the policy on ``episodes``; returns the adapted policy (a new object; the
+    second-order dependence on the original parameters is handled inside meta_optimize_trpo's fused calls)."""
+    if anil:
+        raise NotImplementedError('ANIL-TRPO (tanh body) is not part of this build (SURVEY.md 8f rank 3)')
+    adv = _advantages(episodes, baseline, gamma, tau)
+    eng = learner.engine()
+    batch = _pad([episodes], [adv], learner.input_size, learner.output_size, learner.sigma.device)
+    theta_new, _ = eng.adapt(learner.flat(), batch['states'], batch['actions'], batch['adv'], batch['count'], inner_lr)
+    new = deepcopy(learner)
+    new.load_flat(theta_new[0])
+    return new
+
+
+def fast_adapt_trpo(task, learner, baseline, params, anil=False, first_order=False, render=False):
+    """reference rl.py:377-406.  ``task.run(policy, episodes=n)`` returns a replay dict."""
+    task_replay = []
+    for step in range(params['adapt_steps']):
+        support_episodes = task.run(learner, episodes=params['adapt_batch_size'])
+        task_replay.append(support_episodes)
+        learner = trpo_update(support_episodes, learner, baseline, params['inner_lr'], params['gamma'], params['tau'],
+                              anil=anil, first_order=first_order)
+    query_episodes = task.run(learner, episodes=params['adapt_batch_size'])
+    task_replay.append(query_episodes)
+    valid_loss = trpo_a2c_loss(query_episodes, learner, baseline, params['gamma'], params['tau'], update_vf=False)
+    query_rew = query_episodes['rewards'].sum().item() / params['adapt_batch_size']
+    return learner, valid_loss, task_replay, query_rew, 0.0
+
+
+class _SurrogateContext:
+    """Everything meta_surrogate_loss needs that does not depend on the candidate parameters (advantages are functions of
+    the replays only -- the reference re-fits the baseline to the same data on every call, rl.py:99,465)."""
+
+    def __init__(self, iter_replays, iter_policies, policy, baseline, params):
+        if any(len(r) != 2 for r in iter_replays):
+            raise NotImplementedError('the fused second-order TRPO path implements adapt_steps == 1 (the reference default)')
+        S, A, dev = policy.input_size, policy.output_size, policy.sigma.device
+        sup = [r[0] for r in iter_replays]
+        qry = [r[1] for r in iter_replays]
+        sadv = [_advantages(e, baseline, params['gamma'], params['tau']) for e in sup]
+        qadv = [_advantages(e, baseline, params['gamma'], params['tau']) for e in qry]
+        self.sup, self.qry = _pad(sup, sadv, S, A, dev), _pad(qry, qadv, S, A, dev)
+        B = max(self.sup['states'].shape[1], self.qry['states'].shape[1])
+        for d in (self.sup, self.qry):                           # one common padded length
+            if d['states'].shape[1] < B:
+                pad = B - d['states'].shape[1]
+                d['states'] = torch.nn.functional.pad(d['states'], (0, 0, 0, pad))
+                d['actions'] = torch.nn.functional.pad(d['actions'], (0, 0, 0, pad))
+                d['adv'] = torch.nn.functional.pad(d['adv'], (0, pad))
+            for k in ('states', 'actions', 'adv'):
+                d[k] = d[k].contiguous()
+        self.engine = policy.engine()
+        thetas = torch.stack([p.flat() for p in iter_policies])
+        self.old_loc = self.engine.forward(thetas, self.qry['states'])
+        self.old_scale = torch.stack([torch.exp(torch.clamp(p.sigma.detach(), min=np.log(1e-6))) for p in iter_policies]).float().contiguous()
+        self.inner_lr = params['inner_lr']
+
+    def evaluate(self, theta, want_grad=False):
+        return self.engine.surrogate(theta, self.sup, self.qry, self.old_loc, self.old_scale, self.inner_lr, want_grad)
+
+    def fvp(self, theta, v, damping=1e-5):
+        return self.engine.fvp(theta, self.sup, self.qry, self.inner_lr, damping, v)
+
+
+def meta_surrogate_loss(iter_replays, iter_policies, policy, baseline, params, anil=False):
+    """reference rl.py:441-473 -> (mean surrogate loss, mean KL) as 0-dim tensors."""
+    ctx = _SurrogateContext(iter_replays, iter_policies, policy, baseline, params)
+    loss, kl, _ = ctx.evaluate(policy.flat())
+    return loss[0], kl[0]
+
+
+def conjugate_gradient(Ax, b, num_iterations=10, tol=1e-10, eps=1e-8):
+    """cherry.algorithms.trpo.conjugate_gradient (reference rl.py:418)."""
+    x = torch.zeros_like(b)
+    r, p = b.clone(), b.clone()
+    r_dot_old = torch.dot(r, r)
+    for _ in range(num_iterations):
+        Ap = Ax(p)
+        alpha = r_dot_old / (torch.dot(p, Ap) + eps)
+        x += alpha * p
+        r -= alpha * Ap
+        r_dot_new = torch.dot(r, r)
+        p = r + (r_dot_new / r_dot_old) * p
+        r_dot_old = r_dot_new
+        if r_dot_new.item() < tol:
+            break
+    return x
+
+
+def meta_optimize_trpo(params, policy, baseline, iter_replays, iter_policies, anil=False):
+    """reference rl.py:409-438: CG step direction from the Fisher-vector product of the mean KL, then backtracking line
+    search on (surrogate loss, KL); updates ``policy`` in place.  Returns diagnostics."""
+    ctx = _SurrogateContext(iter_replays, iter_policies, policy, baseline, params)
+    theta = policy.flat()
+    old_loss, old_kl, grad = ctx.evaluate(theta, want_grad=True)
+    Fvp = lambda v: ctx.fvp(theta, v)
+    step = conjugate_gradient(Fvp, grad)
+    shs = 0.5 * torch.dot(step, Fvp(step))
+    lagrange_multiplier = torch.sqrt(shs / params['max_kl'])
+    step = step / lagrange_multiplier
+    accepted, new_loss, kl = None, None, None
+    for ls_step in range(params['ls_max_steps']):
+        stepsize = params['backtrack_factor'] ** ls_step * params['outer_lr']
+        cand = (theta - stepsize * step).contiguous()
+        new_loss, kl, _ = ctx.evaluate(cand)
+        if new_loss.item() < old_loss.item() and kl.item() < params['max_kl']:
+            policy.load_flat(cand)
+            accepted = ls_step
+            break
+    return dict(grad=grad, step=step, old_loss=old_loss[0], old_kl=old_kl[0], accepted=accepted,
+                new_loss=None if new_loss is None else new_loss[0], kl=None if kl is None else kl[0], fvp=Fvp, context=ctx)
+
+
+# ---------------------------------------------------------------------------------------------- Particles2D rollouts (host loop, device math)
+class Particles2DRunner:
+    """Minimal stand-in for core_functions/runner.py + learn2learn's Particles2D (both out of scope):
+    all ``episodes`` of a task advance in lock-step on the device; ``run`` returns a replay dict with episodes concatenated."""
+
+    def __init__(self, goal, max_path_length, generator=None, dev=None):
+        self.dev = dev or device
+        self.goal = torch.as_tensor(goal, dtype=torch.float32, device=self.dev)
+        self.max_path_length, self.generator = max_path_length, generator
+
+    def run(self, policy, episodes):
+        E, L = episodes, self.max_path_length
+        state = torch.zeros(E, 2, device=self.dev)
+        active = torch.ones(E, dtype=torch.bool, device=self.dev)
+        S, A, R, D, NS, M = [], [], [], [], [], []
+        scale = torch.exp(torch.clamp(policy.sigma.detach(), min=np.log(1e-6)))
+        theta, eng = policy.flat(), policy.engine()
+        for t in range(L):
+            loc = eng.forward(theta, state.unsqueeze(0))[0]
+            action = loc + scale * torch.randn(loc.shape, device=self.dev, generator=self.generator)
+            nxt = state + action.clamp(-0.1, 0.1)
+            diff = nxt - self.goal
+            reward = -diff.norm(dim=1)
+            done = (diff.abs() < 0.01).all(dim=1)
+            last = done | (t == L - 1)
+            S.append(state); A.append(action); R.append(reward); D.append(last.float()); NS.append(nxt); M.append(active)
+            state = nxt
+            active = active & ~done
+        S, A, NS = torch.stack(S, 1), torch.stack(A, 1), torch.stack(NS, 1)          # [E, L, *]
+        R, D, M = torch.stack(R, 1), torch.stack(D, 1), torch.stack(M, 1)
+        keep = M.reshape(-1)
+        flat = lambda x: x.reshape(E * L, -1)[keep]
+        return dict(states=flat(S), actions=flat(A), rewards=flat(R), dones=flat(D), next_states=flat(NS))

@@ -202,3 +202,86 @@ class MetaEngine:
 def flatten_parameters(module):
     """Flat fp32 vector in module.parameters() order (what the C ABI calls theta)."""
     return torch.cat([p.detach().reshape(-1) for p in module.parameters()]).float().contiguous()
+
+
+class PolicyEngine:
+    """ctypes wrapper of the MAML-TRPO policy path (mi_policy_* / mi_trpo_*), batched over tasks."""
+
+    def __init__(self, state_size, action_size, hiddens=(100, 100), device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.MiError('PolicyEngine needs a GPU: there is no CPU implementation of the policy path in this package.')
+        if len(hiddens) != 2:
+            raise ValueError('the HIP policy path implements the reference default: two hidden layers (policies.py:33-34)')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.S, self.A, self.H = state_size, action_size, tuple(hiddens)
+        desc = _lib.MiPolicyDesc(state_size, action_size, hiddens[0], hiddens[1], 0)
+        self._h = C.c_void_p()
+        rc = self.lib.mi_policy_create(C.byref(desc), self.device.index or 0, C.byref(self._h))
+        if rc:
+            raise _lib.MiError(self.lib.mi_policy_last_error(None).decode())
+        n = C.c_size_t()
+        self.lib.mi_policy_param_count(self._h, C.byref(n))
+        self.param_count = n.value
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self.lib.mi_policy_destroy(h)
+            self._h = C.c_void_p()
+
+    def _check(self, rc):
+        if rc:
+            raise _lib.MiError(f'libmi_maml policy error {rc}: {self.lib.mi_policy_last_error(self._h).decode()}')
+
+    def _workspace(self, T, B):
+        b = C.c_size_t()
+        self._check(self.lib.mi_trpo_workspace_bytes(self._h, T, B, C.byref(b)))
+        if self._ws is None or self._ws.numel() < b.value:
+            self._ws = torch.empty(b.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, theta, states):
+        """loc of the policy density; theta [P] (shared) or [T, P]; states [T, B, S] -> loc [T, B, A]."""
+        T, B = states.shape[0], states.shape[1]
+        ws = self._workspace(T, B)
+        loc = torch.empty(T, B, self.A, device=self.device)
+        stride = 0 if theta.dim() == 1 else self.param_count
+        self._check(self.lib.mi_policy_forward(self._h, _stream(), _ptr(theta.contiguous()), stride, _ptr(states.contiguous()), T, B,
+                                               _ptr(loc), _ptr(ws), ws.numel()))
+        return loc
+
+    def adapt(self, theta, states, actions, adv, count, lr):
+        """trpo_update for T tasks: returns (theta_out [T, P], loss [T])."""
+        T, B = states.shape[0], states.shape[1]
+        ws = self._workspace(T, B)
+        out = torch.empty(T, self.param_count, device=self.device)
+        loss = torch.empty(T, device=self.device)
+        stride = 0 if theta.dim() == 1 else self.param_count
+        self._check(self.lib.mi_policy_adapt(self._h, _stream(), _ptr(theta.contiguous()), stride, _ptr(states), _ptr(actions),
+                                             _ptr(adv), _ptr(count), T, B, float(lr), _ptr(out), _ptr(loss), _ptr(ws), ws.numel()))
+        return out, loss
+
+    def surrogate(self, theta, sup, qry, old_loc, old_scale, inner_lr, want_grad):
+        """sup/qry: dicts with states [T,B,S], actions [T,B,A], adv [T,B], count [T] int32.  -> (loss, kl, grad or None)."""
+        T, B = sup['states'].shape[0], sup['states'].shape[1]
+        ws = self._workspace(T, B)
+        loss = torch.empty(1, device=self.device)
+        kl = torch.empty(1, device=self.device)
+        grad = torch.empty(self.param_count, device=self.device) if want_grad else None
+        self._check(self.lib.mi_trpo_surrogate(self._h, _stream(), _ptr(theta), _ptr(sup['states']), _ptr(sup['actions']),
+                                               _ptr(sup['adv']), _ptr(sup['count']), _ptr(qry['states']), _ptr(qry['actions']),
+                                               _ptr(qry['adv']), _ptr(qry['count']), _ptr(old_loc), _ptr(old_scale), T, B,
+                                               float(inner_lr), _ptr(loss), _ptr(kl), _ptr(grad), _ptr(ws), ws.numel()))
+        return loss, kl, grad
+
+    def fvp(self, theta, sup, qry, inner_lr, damping, v):
+        """Fisher-vector product at the theta of the preceding ``surrogate`` call (same batches)."""
+        T, B = sup['states'].shape[0], sup['states'].shape[1]
+        ws = self._workspace(T, B)
+        out = torch.empty(self.param_count, device=self.device)
+        self._check(self.lib.mi_trpo_fvp(self._h, _stream(), _ptr(theta), _ptr(sup['states']), _ptr(sup['actions']),
+                                         _ptr(sup['count']), _ptr(qry['states']), _ptr(qry['count']), T, B, float(inner_lr),
+                                         float(damping), _ptr(v.contiguous()), _ptr(out), _ptr(ws), ws.numel()))
+        return out

@@ -136,6 +136,45 @@ int mi_profile_kinds(void);
 const char* mi_profile_op_name(int op);
 int mi_profile_collect(mi_engine* e, double* total_ms, int64_t* count, int n_kinds);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * MAML-TRPO policy path (BASELINE config 5; core_functions/policies.py:30-67, core_functions/rl.py:346-473).
+ * Policy parameters are a flat fp32 vector in DiagNormalPolicy's named_parameters() order:
+ *   sigma[A], mean.0.weight[H1,S], mean.0.bias[H1], mean.2.weight[H2,H1], mean.2.bias[H2], mean.4.weight[A,H2], mean.4.bias[A].
+ * Replays are padded to `batch` rows per task: states [tasks,batch,S], actions [tasks,batch,A], advantages [tasks,batch]
+ * (already normalised, rl.py:354-355), count[tasks] = valid rows.  The baseline fit / GAE (rl.py:95-110) stay on the host. */
+typedef struct mi_policy mi_policy;
+typedef struct {
+  int32_t state_size, action_size, hidden1, hidden2;
+  int32_t activation; /* 0 = ReLU (DiagNormalPolicy default, policies.py:32-37) */
+} mi_policy_desc;
+
+int mi_policy_create(const mi_policy_desc* desc, int device, mi_policy** out);
+void mi_policy_destroy(mi_policy* p);
+const char* mi_policy_last_error(const mi_policy* p);
+int mi_policy_param_count(const mi_policy* p, size_t* n);
+int mi_trpo_workspace_bytes(const mi_policy* p, int tasks, int batch, size_t* bytes);
+
+/* density(state).loc (policies.py:49-52) for acting; theta shared (tstride 0) or one vector per task (tstride = P). */
+int mi_policy_forward(mi_policy* p, void* stream, const float* theta, size_t tstride, const float* states, int tasks, int batch,
+                      float* loc_out, void* workspace, size_t workspace_bytes);
+/* trpo_update (rl.py:361-374): theta_out[t] = theta[t] - lr * grad_t( a2c.policy_loss = -mean(log_prob * advantages) ). */
+int mi_policy_adapt(mi_policy* p, void* stream, const float* theta, size_t tstride, const float* states, const float* actions,
+                    const float* adv, const int32_t* count, int tasks, int batch, float lr, float* theta_out, float* loss_out,
+                    void* workspace, size_t workspace_bytes);
+/* meta_surrogate_loss (rl.py:441-473) with one second-order inner step per task: mean surrogate loss, mean KL(new||old),
+ * and (grad_out != NULL) the gradient w.r.t. theta (rl.py:413-416).  old_loc [tasks,batch,A], old_scale [tasks,A] are the
+ * stored adapted policies' densities on the query states.  Leaves the context mi_trpo_fvp needs in `workspace`. */
+int mi_trpo_surrogate(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
+                      const float* s_adv, const int32_t* s_count, const float* q_states, const float* q_actions,
+                      const float* q_adv, const int32_t* q_count, const float* old_loc, const float* old_scale, int tasks,
+                      int batch, float inner_lr, float* loss_out, float* kl_out, float* grad_out, void* workspace,
+                      size_t workspace_bytes);
+/* trpo.hessian_vector_product(old_kl, params, damping)(v) (rl.py:417) at the parameters mi_trpo_surrogate was last called
+ * with on this workspace (where the adapted policies equal the stored old policies). */
+int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
+                const int32_t* s_count, const float* q_states, const int32_t* q_count, int tasks, int batch, float inner_lr,
+                float damping, const float* v, float* out, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,120 @@
+"""MAML-TRPO (BASELINE config 5) on the GPU against the fp64 oracle (oracle/rl_ref.py): policy density vs the reference's
+own fixtures; trpo_update, meta surrogate loss / KL, its gradient, the Fisher-vector product and a whole
+meta_optimize_trpo step vs the oracle on the same Particles2D replays."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from exploring_meta_amd import core_functions as cf
+from oracle import rl_ref as RL
+from helpers import hash_params
+from gpu_utils import rel_err, report
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = dict(inner_lr=0.1, max_path_length=25, adapt_steps=1, adapt_batch_size=6, meta_batch_size=4, outer_lr=0.3,
+              backtrack_factor=0.5, ls_max_steps=15, max_kl=0.01, tau=1.0, gamma=0.99)
+
+
+def _theta64():
+    p = hash_params(RL.policy_param_shapes(), 19)
+    p['sigma'] = torch.tensor([-0.3, 0.2], dtype=torch.float64)
+    return p
+
+
+def _policy(theta):
+    pol = cf.DiagNormalPolicy(2, 2)
+    with torch.no_grad():
+        for k, p in pol.named_parameters():
+            p.copy_(theta[k].float())
+    return pol.cuda()
+
+
+def _replays():
+    env = RL.Particles2D(seed=1)
+    gen = torch.Generator().manual_seed(2)
+    theta = _theta64()
+    baseline = RL.LinearValue(2, 2)
+    replays, olds = [], []
+    for task in env.sample_tasks(PARAMS['meta_batch_size']):
+        env.set_task(task)
+        learner = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+        adapted, _, rep, _ = RL.fast_adapt_trpo(env, learner, baseline, PARAMS, gen, first_order=True)
+        replays.append(rep)
+        olds.append(OrderedDict((k, v.detach()) for k, v in adapted.items()))
+    return theta, replays, olds
+
+
+def test_policy_density_matches_reference(golden_small):
+    pol = _policy(_theta64())
+    st, ac = torch.from_numpy(golden_small['g5_states']).float().cuda(), torch.from_numpy(golden_small['g5_actions']).float().cuda()
+    d = pol.density(st)
+    assert np.allclose(d.loc.cpu().numpy(), golden_small['g5_policy_f64_loc'], atol=2e-6)
+    assert np.allclose(d.scale.cpu().numpy(), golden_small['g5_policy_f64_scale'], rtol=1e-6)
+    assert np.allclose(pol.log_prob(st, ac).cpu().numpy(), golden_small['g5_policy_f64_logp'], atol=5e-6)
+
+
+def test_trpo_update_matches_oracle():
+    theta, replays, olds = _replays()
+    pol = _policy(theta)
+    for t in range(len(replays)):
+        new = cf.trpo_update(replays[t][0], pol, cf.LinearValue(2, 2), PARAMS['inner_lr'], PARAMS['gamma'], PARAMS['tau'])
+        ref = torch.cat([v.reshape(-1) for v in olds[t].values()]).numpy()
+        e = rel_err(new.flat().cpu().numpy() - pol.flat().cpu().numpy(), ref - torch.cat([v.reshape(-1) for v in theta.values()]).numpy())
+        assert e < 1e-4, e
+
+
+def test_surrogate_grad_fvp_match_oracle():
+    theta, replays, olds = _replays()
+    p64 = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+    loss, kl = RL.meta_surrogate_loss(replays, olds, p64, RL.LinearValue(2, 2), PARAMS)
+    plist = list(p64.values())
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, plist, retain_graph=True)])
+    Fvp = RL.hessian_vector_product(kl, plist)
+    v = torch.randn(grad.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    fv = Fvp(v)
+
+    pol = _policy(theta)
+    old_pols = [_policy(o) for o in olds]
+    from exploring_meta_amd.core_functions.rl import _SurrogateContext
+    ctx = _SurrogateContext(replays, old_pols, pol, cf.LinearValue(2, 2), PARAMS)
+    l32, k32, g32 = ctx.evaluate(pol.flat(), want_grad=True)
+    f32 = ctx.fvp(pol.flat(), v.float().cuda())
+    torch.cuda.synchronize()
+    eg, ef = rel_err(g32.cpu().numpy(), grad.numpy()), rel_err(f32.cpu().numpy(), fv.detach().numpy())
+    report('trpo_surrogate', loss=float(l32), loss_ref=float(loss), kl=float(k32), kl_ref=float(kl), grad_rel=eg, fvp_rel=ef)
+    assert abs(float(l32) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    assert abs(float(k32) - float(kl)) < 1e-6          # both ~0: the adapted policy equals the stored old policy
+    assert eg < 1e-4 and ef < 1e-3
+    # a displaced candidate (line-search evaluation): values only
+    cand = OrderedDict((k, (v.detach() + 0.01 * torch.sin(torch.arange(v.numel(), dtype=torch.float64)).view_as(v)).requires_grad_(True))
+                       for k, v in theta.items())
+    l2, k2 = RL.meta_surrogate_loss(replays, olds, cand, RL.LinearValue(2, 2), PARAMS)
+    th2 = torch.cat([v.detach().reshape(-1) for v in cand.values()]).float().cuda()
+    l2g, k2g, _ = ctx.evaluate(th2)
+    assert abs(float(l2g) - float(l2)) < 2e-5 * max(1.0, abs(float(l2))) and abs(float(k2g) - float(k2)) < 1e-4 * max(float(k2), 1e-3)
+
+
+def test_meta_optimize_trpo_matches_oracle():
+    theta, replays, olds = _replays()
+    p64 = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+    ref = RL.meta_optimize_trpo(PARAMS, p64, RL.LinearValue(2, 2), replays, olds)
+    pol = _policy(theta)
+    out = cf.meta_optimize_trpo(PARAMS, pol, cf.LinearValue(2, 2), replays, [_policy(o) for o in olds])
+    es = rel_err(out['step'].cpu().numpy(), ref['step'].numpy())
+    et = rel_err(pol.flat().cpu().numpy(), torch.cat([v.detach().reshape(-1) for v in p64.values()]).numpy())
+    report('meta_optimize_trpo', step_rel=es, theta_rel=et, accepted=out['accepted'], accepted_ref=ref['accepted'])
+    assert out['accepted'] == ref['accepted']
+    assert es < 5e-3 and et < 1e-4
+
+
+def test_runner_and_fast_adapt_trpo_shapes():
+    pol = _policy(_theta64())
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    task = cf.Particles2DRunner([0.2, -0.3], PARAMS['max_path_length'], gen)
+    learner, valid_loss, replay, rew, _ = cf.fast_adapt_trpo(task, pol, cf.LinearValue(2, 2), PARAMS, first_order=True)
+    assert len(replay) == 2 and replay[0]['states'].shape[1] == 2 and replay[0]['dones'].sum().item() == PARAMS['adapt_batch_size']
+    assert torch.isfinite(valid_loss) and rew < 0
+    assert not torch.equal(learner.flat(), pol.flat())

@@ -1,0 +1,72 @@
+"""oracle/rl_ref.py: the policy against fixtures from the reference's own DiagNormalPolicy (G5), and self-consistency of the
+restated TRPO machinery (the cherry / learn2learn pieces have no reference-side fixtures: parity unpinned there)."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from oracle import rl_ref as RL
+from helpers import hash_params
+
+
+def _policy(dtype=torch.float64):
+    p = hash_params(RL.policy_param_shapes(), 19, dtype)
+    p['sigma'] = torch.tensor([-0.3, 0.2], dtype=dtype)
+    return p
+
+
+def test_param_order_matches_reference(golden_small):
+    assert list(RL.policy_param_shapes().keys()) == list(golden_small['g5_param_names'])
+
+
+def test_policy_log_prob_and_grad_match_reference(golden_small):
+    p = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in _policy().items())
+    st, ac = torch.from_numpy(golden_small['g5_states']), torch.from_numpy(golden_small['g5_actions'])
+    loc, scale = RL.policy_loc_scale(p, st)
+    lp = RL.policy_log_prob(p, st, ac)
+    assert np.allclose(loc.detach().numpy(), golden_small['g5_policy_f64_loc'], rtol=1e-12, atol=1e-14)
+    assert np.allclose(scale.detach().numpy(), golden_small['g5_policy_f64_scale'], rtol=1e-12)
+    assert np.allclose(lp.detach().numpy(), golden_small['g5_policy_f64_logp'], rtol=1e-11, atol=1e-13)
+    g = torch.autograd.grad(lp.sum(), list(p.values()))
+    assert np.allclose(torch.cat([x.reshape(-1) for x in g]).numpy(), golden_small['g5_policy_f64_grad'], rtol=1e-9, atol=1e-12)
+
+
+def test_discount_and_gae():
+    r = torch.tensor([[1.0], [1.0], [1.0], [2.0]], dtype=torch.float64)
+    d = torch.tensor([[0.0], [1.0], [0.0], [1.0]], dtype=torch.float64)
+    assert torch.allclose(RL.discount(0.5, r, d), torch.tensor([[1.5], [1.0], [2.0], [2.0]], dtype=torch.float64))
+    v = torch.zeros(4, 1, dtype=torch.float64)
+    adv = RL.generalized_advantage(0.5, 1.0, r, d, v, torch.zeros(1))
+    assert torch.allclose(adv, RL.discount(0.5, r, d))            # V == 0 and tau == 1: GAE reduces to the return
+
+
+def test_cg_solves_spd_system():
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(12, 12, generator=g, dtype=torch.float64)
+    a = a @ a.t() + 0.5 * torch.eye(12, dtype=torch.float64)
+    b = torch.randn(12, generator=g, dtype=torch.float64)
+    x = RL.conjugate_gradient(lambda v: a @ v, b, num_iterations=50)
+    assert torch.allclose(a @ x, b, atol=1e-6)
+
+
+def test_meta_iteration_runs_and_improves_surrogate():
+    torch.manual_seed(0)
+    env = RL.Particles2D(seed=1)
+    gen = torch.Generator().manual_seed(2)
+    params = dict(inner_lr=0.1, max_path_length=20, adapt_steps=1, adapt_batch_size=4, meta_batch_size=3, outer_lr=0.3,
+                  backtrack_factor=0.5, ls_max_steps=15, max_kl=0.01, tau=1.0, gamma=0.99)
+    p = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in _policy().items())
+    baseline = RL.LinearValue(2, 2)
+    replays, pols = [], []
+    for task in env.sample_tasks(params['meta_batch_size']):
+        env.set_task(task)
+        learner = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in p.items())
+        adapted, vloss, rep, rew = RL.fast_adapt_trpo(env, learner, baseline, params, gen, first_order=True)
+        replays.append(rep)
+        pols.append(OrderedDict((k, v.detach()) for k, v in adapted.items()))
+    out = RL.meta_optimize_trpo(params, p, baseline, replays, pols)
+    assert out['accepted'] is not None and out['new_loss'] < out['old_loss'] and out['kl'] < params['max_kl']
+    # at the old parameters the adapted policy equals the stored one: KL == 0 and its gradient vanishes, so the Fisher
+    # product is symmetric positive semi-definite
+    v = torch.randn(out['grad'].shape, dtype=torch.float64)
+    assert torch.dot(v, out['fvp'](v)) > 0
