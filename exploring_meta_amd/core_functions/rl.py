@@ -158,11 +158,33 @@ class _SurrogateContext:
         self.old_scale = torch.stack([torch.exp(torch.clamp(p.sigma.detach(), min=np.log(1e-6))) for p in iter_policies]).float().contiguous()
         self.inner_lr = params['inner_lr']
 
+    # Multi-GPU (TRPO): every rank holds a shard of the task list; the mean over tasks of (loss, kl, grad) and
+    # of each Fisher-vector product is completed by one small all-reduce per evaluation (RCCL; 42 KB for the 2x100 policy).
+    def _allmean(self, *tensors):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return tensors
+        n_local = float(self.sup['states'].shape[0])
+        flat = torch.cat([t.reshape(-1) for t in tensors] + [torch.ones(1, device=tensors[0].device)]) * n_local
+        dist.all_reduce(flat)
+        flat = flat / flat[-1]
+        out, off = [], 0
+        for t in tensors:
+            out.append(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        return tuple(out)
+
     def evaluate(self, theta, want_grad=False):
-        return self.engine.surrogate(theta, self.sup, self.qry, self.old_loc, self.old_scale, self.inner_lr, want_grad)
+        loss, kl, grad = self.engine.surrogate(theta, self.sup, self.qry, self.old_loc, self.old_scale, self.inner_lr, want_grad)
+        if grad is None:
+            loss, kl = self._allmean(loss, kl)
+        else:
+            loss, kl, grad = self._allmean(loss, kl, grad)
+        return loss, kl, grad
 
     def fvp(self, theta, v, damping=1e-5):
-        return self.engine.fvp(theta, self.sup, self.qry, self.inner_lr, damping, v)
+        # the damping term is linear in v, so averaging the per-rank results keeps it exact
+        return self._allmean(self.engine.fvp(theta, self.sup, self.qry, self.inner_lr, damping, v))[0]
 
 
 def meta_surrogate_loss(iter_replays, iter_policies, policy, baseline, params, anil=False):
