@@ -1,0 +1,303 @@
+// Fused first ConvBlock (Ci in {1,3}, stride 1, 2x2 max-pool, even H and W): conv1 is RE-COMPUTED inside every kernel
+// instead of being stored, so the block's large tensors -- the conv output z (903 KB per 84x84 image at 32 filters), dz, and
+// their tangents -- never touch HBM.  Replaces, for block 1, the conv+stats / BN+ReLU+pool / BN-backward / weight-gradient
+// kernels and their tangent versions (reference core_functions/vision_models.py:188-193 forward and the autograd
+// backward / double-backward through it).  conv1 costs 12 MFLOP per image on the fp32 matrix pipe; one pass over z costs
+// 0.9 MB of HBM traffic: recomputing is ~3x cheaper than streaming.
+//
+// Tiling: one wave = 8 pooling windows x 4 positions = 32 pixels, M index m = 4*window + q (q = 2*dy+dx).  With the MFMA
+// 32x32 C/D layout lane (co = lane&31, h = lane>>5) then owns, in registers 4g..4g+3, the four positions of window
+// wl = 2g+h (g = 0..3): BN-apply, ReLU, the pooling max/argmax and all backward/tangent formulas are pure in-register math.
+// For the weight gradient, dz (or R{dz}) in that same layout IS the B operand of dW[k=(tap,ci)][co] += x_col[pixel][k] * dz:
+// 16 more MFMAs per tile with one accumulator, no LDS traffic.
+#include "mi_common.h"
+#include "kernels.h"
+
+struct Win4 { int n, wy, wx; };
+__device__ __forceinline__ Win4 win_advance(Win4 w, int delta, int hp, int wp) {   // delta < wp
+  w.wx += delta;
+  if (w.wx >= wp) { w.wx -= wp; w.wy += 1; }
+  if (w.wy >= hp) { w.wy = 0; w.n += 1; }
+  return w;
+}
+
+template <int CI0, int MODE>
+__global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
+  // K index layout: lane half 0 feeds taps 0..4, half 1 taps 5..8 (+ one zero tap): KH = 5*CI0 MFMAs per tile; every tap's
+  // CI0 channels are contiguous in NHWC, so a lane needs 5 address computations (one 4*CI0-byte load each) per tile.
+  constexpr int K = 9 * CI0, NTH = 5, KH = NTH * CI0, KP = 2 * KH;
+  constexpr bool TAN = MODE >= B1_TSTATS;
+  constexpr bool WG = MODE == B1_BWD_WGRAD || MODE == B1_TBWD_WGRAD;
+  constexpr bool RED = MODE == B1_STATS || MODE == B1_BWD_REDUCE || MODE == B1_TSTATS || MODE == B1_TBWD_REDUCE;
+  __shared__ __attribute__((aligned(16))) float lds[4096];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y, ct = blockIdx.z, cbase = ct * 32;
+  const int H = a.hh, W = a.ww, HP = H >> 1, WP = W >> 1, CO = a.co;
+
+  // ---- weights -> LDS: [k][32] (and the tangent direction's weights behind them)
+  {
+    const float* w0 = a.w + (size_t)task * a.wstride;
+    const float* w1 = TAN ? a.wd + (size_t)task * a.vstride : nullptr;
+    for (int idx = tid; idx < KP * 32; idx += 256) {
+      const int k = idx >> 5, nl = idx & 31;          // LDS row k = h*KH + t*CI0 + c  <->  weight row (5h + t)*CI0 + c
+      lds[idx] = (k < K) ? w0[(size_t)k * CO + cbase + nl] : 0.f;
+      if (TAN) lds[KP * 32 + idx] = (k < K) ? w1[(size_t)k * CO + cbase + nl] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- per-lane tap tables: relative element offset and row/column displacement of every K index this lane feeds.
+  // Loads are UNCONDITIONAL: out-of-image lanes read mi_zero_word through an address select (mi_common.h).
+  int toff[NTH], tdy[NTH], tdx[NTH];
+  bool tok[NTH];
+#pragma unroll
+  for (int t = 0; t < NTH; ++t) {
+    const int tap = NTH * h + t;                // rows h*KH + t*CI0 + c == (5h + t)*CI0 + c: the natural weight-row order
+    tok[t] = tap < 9;
+    tdy[t] = tap / 3 - 1;
+    tdx[t] = tap % 3 - 1;
+    toff[t] = (tdy[t] * W + tdx[t]) * CI0;
+  }
+  const bool wrow_ok = j < K;                 // weight-gradient row owned by this lane: k = j -> (tap, ci)
+  const int wtap = j / CI0, wdy = wtap / 3 - 1, wdx = wtap % 3 - 1;
+  const int woff = (wdy * W + wdx) * CI0 + (j - wtap * CI0);
+
+  // ---- per-channel constants (this lane's output channel cbase + j)
+  const int ch = cbase + j;
+  float mu = 0.f, rs = 0.f, gm = 0.f, bt = 0.f, m1 = 0.f, m2 = 0.f, gmd = 0.f, btd = 0.f, dgm = 0.f, dbm = 0.f, rgm = 0.f, rbm = 0.f;
+  if (MODE != B1_STATS) {
+    mu = a.mu[(size_t)task * CO + ch];
+    rs = a.rstd[(size_t)task * CO + ch];
+    gm = a.gamma[(size_t)task * a.pstride + ch];
+    bt = a.beta[(size_t)task * a.pstride + ch];
+  }
+  if (MODE == B1_TFWD || MODE == B1_TBWD_REDUCE || MODE == B1_TBWD_WGRAD) {
+    m1 = a.m1[(size_t)task * CO + ch];
+    m2 = a.m2[(size_t)task * CO + ch];
+    gmd = a.gammad[(size_t)task * a.vstride + ch];
+    btd = a.betad[(size_t)task * a.vstride + ch];
+  }
+  if (WG) {
+    dgm = a.dgamma[(size_t)task * a.gstride + ch] * a.inv_m;
+    dbm = a.dbeta[(size_t)task * a.gstride + ch] * a.inv_m;
+  }
+  if (MODE == B1_TBWD_WGRAD) {
+    rgm = a.rdgamma[(size_t)task * a.hstride + ch] * a.inv_m;
+    rbm = a.rdbeta[(size_t)task * a.hstride + ch] * a.inv_m;
+  }
+  const float gr = gm * rs;
+  const float c1 = gmd * rs + gm * (-rs * rs * m2);     // gammad*r + gamma*rd, rd = -r^2 m2
+
+  const size_t x_task = (size_t)a.n * H * W * CI0;
+  const size_t p_task = (size_t)a.n * HP * WP * CO;
+  const float* x_t = a.x + (size_t)task * x_task;
+  const float* dp_t = a.dp ? a.dp + (size_t)task * p_task : nullptr;
+  const float* dpd_t = a.dpd ? a.dpd + (size_t)task * p_task : nullptr;
+  float* out_t = a.out ? a.out + (size_t)task * p_task : nullptr;
+  const int nwin = a.n * HP * WP;
+
+  double s0 = 0.0, s1 = 0.0;     // the two per-channel sums of the reduction modes
+  floatx16 accw;                 // weight-gradient accumulator [k rows][co]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+
+  const int tile0 = (blockIdx.x * 4 + wave) * a.tiles_per_wave;
+  const int tile1 = min(tile0 + a.tiles_per_wave, a.ntiles);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int wbase = tile * 8;
+    Win4 w0;
+    w0.n = wbase / (HP * WP);
+    const int rem = wbase - w0.n * (HP * WP);
+    w0.wy = rem / WP;
+    w0.wx = rem - w0.wy * WP;
+
+    // ---- conv1 (and its tangent with the direction's weights): A operand = this lane's pixel m = j
+    const Win4 wl = win_advance(w0, j >> 2, HP, WP);
+    const bool pvalid = (wbase + (j >> 2)) < nwin;
+    const int py = 2 * wl.wy + ((j >> 1) & 1), px = 2 * wl.wx + (j & 1);
+    const int pbase = ((wl.n * H + py) * W + px) * CI0;      // < 2^31: one task's input
+    float av[KH];
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) {
+      const bool inb = pvalid && tok[t] && (unsigned)(py + tdy[t]) < (unsigned)H && (unsigned)(px + tdx[t]) < (unsigned)W;
+      const float* src = inb ? x_t + (pbase + toff[t]) : mi_zero_word;
+#pragma unroll
+      for (int c = 0; c < CI0; ++c) av[t * CI0 + c] = src[c];
+    }
+    floatx16 z, zd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { z[r] = 0.f; zd[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+      z = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], lds[(h * KH + kk) * 32 + j], z, 0, 0, 0);
+      if (TAN) zd = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], lds[KP * 32 + (h * KH + kk) * 32 + j], zd, 0, 0, 0);
+    }
+
+    // ---- epilogue over this lane's four windows (g = 0..3; window index wbase + 2g + h, positions in regs 4g..4g+3)
+    floatx16 bz;                  // dz or R{dz} for the weight gradient
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int widx = wbase + 2 * g + h;
+      const bool wvalid = widx < nwin;
+      const size_t poff = (size_t)widx * CO + ch;
+      float zh[4], u[4], zhd[4];
+      float umax = 0.f, zh_at = 0.f, zhd_at = 0.f;
+      int arg = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float zv = z[4 * g + q];
+        if (MODE == B1_STATS) {
+          if (wvalid) { const double dv = (double)zv; s0 += dv; s1 = fma(dv, dv, s1); }
+          continue;
+        }
+        zh[q] = bn_zh(zv, mu, rs);
+        if (MODE == B1_TSTATS) {
+          if (wvalid) { s0 += (double)zd[4 * g + q]; s1 = fma((double)zh[q], (double)zd[4 * g + q], s1); }
+          continue;
+        }
+        u[q] = bn_u(zh[q], gm, bt);
+        if (TAN) zhd[q] = rs * (zd[4 * g + q] - m1 - zh[q] * m2);
+        const bool gt = (q == 0) || (u[q] > umax);          // strict '>' keeps the first maximum
+        umax = gt ? u[q] : umax;
+        zh_at = gt ? zh[q] : zh_at;
+        if (TAN) zhd_at = gt ? zhd[q] : zhd_at;
+        arg = gt ? q : arg;
+      }
+      if (MODE == B1_STATS || MODE == B1_TSTATS) continue;
+      const bool on = umax > 0.f;
+      if (MODE == B1_FWD) {
+        if (wvalid) out_t[poff] = on ? umax : 0.f;
+      } else if (MODE == B1_TFWD) {
+        const float ud = gmd * zh_at + gm * zhd_at + btd;
+        if (wvalid) out_t[poff] = on ? ud : 0.f;
+      } else {
+        const bool ld = wvalid && on;
+        const float d = *(ld ? dp_t + poff : mi_zero_word);
+        float dd = 0.f;
+        if (TAN) dd = *(ld ? dpd_t + poff : mi_zero_word);
+        if (MODE == B1_BWD_REDUCE) {
+          s0 += (double)d * (double)zh_at;                    // dgamma
+          s1 += (double)d;                                    // dbeta
+        } else if (MODE == B1_TBWD_REDUCE) {
+          s0 += (double)dd * (double)zh_at + (double)d * (double)zhd_at;   // R{dgamma}
+          s1 += (double)dd;                                                // R{dbeta}
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float du = (q == arg) ? d : 0.f;
+            const float e = du - dbm - zh[q] * dgm;
+            if (MODE == B1_BWD_WGRAD) {
+              bz[4 * g + q] = wvalid ? gr * e : 0.f;
+            } else {
+              const float dud = (q == arg) ? dd : 0.f;
+              bz[4 * g + q] = wvalid ? c1 * e + gr * (dud - rbm - zhd[q] * dgm - zh[q] * rgm) : 0.f;
+            }
+          }
+        }
+      }
+    }
+
+    if (WG) {
+      // dW[k][co] += sum over the tile's pixels of x[pixel + tap(k)][ci(k)] * bz[pixel][co]; K-step r pairs the pixels the two
+      // lane halves hold in register r: m = (r&3) + 8(r>>2) + 4h  ->  window 2(r>>2)+h, position r&3.
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const Win4 wg = win_advance(w0, 2 * g + h, HP, WP);
+        const bool wv = (wbase + 2 * g + h) < nwin;
+        const int gbase = ((wg.n * H + 2 * wg.wy) * W + 2 * wg.wx) * CI0 + woff;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int qy = 2 * wg.wy + (q >> 1), qx = 2 * wg.wx + (q & 1);
+          const bool inb = wv && wrow_ok && (unsigned)(qy + wdy) < (unsigned)H && (unsigned)(qx + wdx) < (unsigned)W;
+          const float aw = *(inb ? x_t + (gbase + ((q >> 1) * W + (q & 1)) * CI0) : mi_zero_word);
+          accw = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bz[4 * g + q], accw, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (RED) {
+    // lanes l and l^32 hold the same channel; 4 waves -> one fp64 partial per workgroup
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    __syncthreads();
+    double* ldsd = reinterpret_cast<double*>(lds);
+    if (lane < 32) { ldsd[(wave * 2 + 0) * 32 + lane] = s0; ldsd[(wave * 2 + 1) * 32 + lane] = s1; }
+    __syncthreads();
+    if (wave == 0 && lane < 32) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int w = 0; w < 4; ++w) { t0 += ldsd[(w * 2 + 0) * 32 + lane]; t1 += ldsd[(w * 2 + 1) * 32 + lane]; }
+      double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
+      pb[cbase + lane] = t0;
+      pb[CO + cbase + lane] = t1;
+    }
+  }
+  if (WG) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[wave * 1024 + r * 64 + lane] = accw[r];
+    __syncthreads();
+    float* pt = a.wpartial + ((size_t)task * gridDim.x + blockIdx.x) * K * CO;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int e = tid + 256 * qq;
+      const float v = lds[e] + lds[1024 + e] + lds[2048 + e] + lds[3072 + e];
+      const int r = e >> 6, l = e & 63;
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+      if (row < K) pt[(size_t)row * CO + cbase + col] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+bool block1_supported(int ci, int stride, int pool, int h, int w, int co) {
+  return (ci == 1 || ci == 3) && stride == 1 && pool && (h % 2 == 0) && (w % 2 == 0) && (w / 2 >= 8) && (co % 32 == 0);
+}
+
+static void block1_grid(const B1Args& a, int tasks, int& ntiles, int& tpw, dim3& grid) {
+  ntiles = ceil_div(a.n * (a.hh / 2) * (a.ww / 2), 8);
+  const int cot = a.co / 32;
+  long total = (long)ntiles * tasks * cot;
+  tpw = (int)(total / (4L * 2048));
+  if (tpw < 1) tpw = 1;
+  if (tpw > 32) tpw = 32;
+  grid = dim3(ceil_div(ntiles, 4 * tpw), tasks, cot);
+}
+
+int block1_blocks_per_task(int n, int h, int w, int co, int tasks) {
+  B1Args a{};
+  a.n = n; a.hh = h; a.ww = w; a.co = co;
+  int ntiles, tpw;
+  dim3 grid;
+  block1_grid(a, tasks, ntiles, tpw, grid);
+  return (int)grid.x;
+}
+
+hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task) {
+  int ntiles, tpw;
+  dim3 grid;
+  block1_grid(a, tasks, ntiles, tpw, grid);
+  a.ntiles = ntiles;
+  a.tiles_per_wave = tpw;
+  if (blocks_per_task) *blocks_per_task = grid.x;
+#define B1_LAUNCH(CI0, M) hipLaunchKernelGGL((block1_kernel<CI0, M>), grid, dim3(256), 0, st, a)
+#define B1_MODES(CI0)                                   \
+  switch (mode) {                                       \
+    case B1_STATS: B1_LAUNCH(CI0, B1_STATS); break;     \
+    case B1_FWD: B1_LAUNCH(CI0, B1_FWD); break;         \
+    case B1_BWD_REDUCE: B1_LAUNCH(CI0, B1_BWD_REDUCE); break;   \
+    case B1_BWD_WGRAD: B1_LAUNCH(CI0, B1_BWD_WGRAD); break;     \
+    case B1_TSTATS: B1_LAUNCH(CI0, B1_TSTATS); break;   \
+    case B1_TFWD: B1_LAUNCH(CI0, B1_TFWD); break;       \
+    case B1_TBWD_REDUCE: B1_LAUNCH(CI0, B1_TBWD_REDUCE); break; \
+    case B1_TBWD_WGRAD: B1_LAUNCH(CI0, B1_TBWD_WGRAD); break;   \
+    default: return hipErrorInvalidValue;               \
+  }
+  if (ci == 3) { B1_MODES(3) }
+  else if (ci == 1) { B1_MODES(1) }
+  else return hipErrorInvalidValue;
+#undef B1_MODES
+#undef B1_LAUNCH
+  return hipGetLastError();
+}

@@ -74,8 +74,12 @@ __device__ __forceinline__ void conv_epilogue(const floatx16& acc, int tile, int
 // Generic conv: CI multiple of 32 (template), CO multiple of 32 (grid.z tiles).
 // MODE 0: forward   out[o] = sum_tap in[o*S + d - 1] * W[tap]            weights [9][CI][CO]
 // MODE 1: dgrad     out[i] = sum_tap in[(i + 1 - d)/S] * W[tap]^T        weights [9][CO_op][CI_op] (the forward layout)
+// waves per workgroup: the 2-term variants stage 2 x 36 KB of weights, so 8 waves share one copy (2 workgroups = 4 waves/SIMD)
+template <int CI, int NTERMS> struct ConvWaves { static constexpr int value = (NTERMS == 2 && CI == 32) ? 8 : 4; };
+
 template <int CI, int NTERMS, int EPI, int MODE, int STRIDE>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_mfma_kernel(ConvArgs a) {
+  constexpr int NW = ConvWaves<CI, NTERMS>::value, NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   const int cbase = ct * 32;
 
   // ---- stage this task's weights: lds[((term*9+tap)*CI + k)*32 + nl]
-  for (int idx = tid; idx < NTERMS * 9 * CI * 32; idx += 256) {
+  for (int idx = tid; idx < NTERMS * 9 * CI * 32; idx += NT) {
     const int nl = idx & 31;
     const int k = (idx >> 5) % CI;
     const int tt = idx / (CI * 32);  // term*9 + tap
@@ -111,7 +115,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   }
   double s = 0.0, q = 0.0;
 
-  const int tile0 = (blockIdx.x * 4 + wave) * a.tiles_per_wave;
+  // Main loop: explicit software pipeline over the K steps (term, tap, 32-channel chunk).  Each step's A operand is 16
+  // contiguous NHWC floats of this lane's (shifted) pixel = 4 x 16-B loads, issued DEPTH steps ahead of the 16 MFMAs that
+  // consume them; padding lanes read mi_zero_word through an address select (no predicated loads, no post-load selects).
+  // sched_barriers pin the order so the compiler neither hoists every load to the top (register blow-up) nor sinks them.
+  constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC, DEPTH = 2, RING = DEPTH + 1;
+  const float* in_base[NTERMS];
+#pragma unroll
+  for (int term = 0; term < NTERMS; ++term) in_base[term] = a.in[term] + (size_t)task * in_task + h * 16;
+
+  const int tile0 = (blockIdx.x * NW + wave) * a.tiles_per_wave;
   const int tile1 = min(tile0 + a.tiles_per_wave, a.ntiles);
   for (int tile = tile0; tile < tile1; ++tile) {
     const int pix = tile * 32 + j;
@@ -123,53 +136,52 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-#pragma unroll 1
-    for (int term = 0; term < NTERMS; ++term) {   // not unrolled: the 2-term variants keep the 1-term register footprint
-      const float* in_t = (term == 0 ? a.in[0] : a.in[1]) + (size_t)task * in_task;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
-        int iy, ix;
-        bool inb = valid;
-        if (MODE == 0) {
-          iy = oy * STRIDE + dy - 1;
-          ix = ox * STRIDE + dx - 1;
-        } else {
-          iy = oy + 1 - dy;
-          ix = ox + 1 - dx;
-          if (STRIDE == 2) {
-            inb = inb && ((iy & 1) == 0) && ((ix & 1) == 0);
-            iy >>= 1;
-            ix >>= 1;
-          }
-        }
-        inb = inb && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const float* src = in_t + ((size_t)(n * H + iy) * W + ix) * CI + h * 16;
-#pragma unroll
-        for (int cc = 0; cc < CI / 32; ++cc) {
-          float av[16];
-          if (inb) {
-            const float4* s4 = reinterpret_cast<const float4*>(src + cc * 32);
-            const float4 v0 = s4[0], v1 = s4[1], v2 = s4[2], v3 = s4[3];
-            av[0] = v0.x; av[1] = v0.y; av[2] = v0.z; av[3] = v0.w;
-            av[4] = v1.x; av[5] = v1.y; av[6] = v1.z; av[7] = v1.w;
-            av[8] = v2.x; av[9] = v2.y; av[10] = v2.z; av[11] = v2.w;
-            av[12] = v3.x; av[13] = v3.y; av[14] = v3.z; av[15] = v3.w;
-          } else {
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) av[kk] = 0.f;
-          }
-          const float* bl = lds + ((size_t)((term * 9 + tap) * CI + cc * 32 + h * 16)) * 32 + j;
-#pragma unroll
-          for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bl[kk * 32], acc, 0, 0, 0);
+    float4 ring[RING][4];
+    auto issue = [&](int step, float4* dst) {
+      const int cc = step % NCC, tt = step / NCC, tap = tt % 9, term = tt / 9;
+      const int dy = tap / 3, dx = tap % 3;
+      int iy, ix;
+      bool inb = valid;
+      if (MODE == 0) {
+        iy = oy * STRIDE + dy - 1;
+        ix = ox * STRIDE + dx - 1;
+      } else {
+        iy = oy + 1 - dy;
+        ix = ox + 1 - dx;
+        if (STRIDE == 2) {
+          inb = inb && ((iy & 1) == 0) && ((ix & 1) == 0);
+          iy >>= 1;
+          ix >>= 1;
         }
       }
+      inb = inb && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const float* src = inb ? in_base[term] + (((n * H + iy) * W + ix) * CI + cc * 32) : mi_zero_word;
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      dst[0] = s4[0]; dst[1] = s4[1]; dst[2] = s4[2]; dst[3] = s4[3];
+    };
+#pragma unroll
+    for (int st = 0; st < DEPTH && st < NSTEP; ++st) issue(st, ring[st % RING]);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + DEPTH < NSTEP) issue(step + DEPTH, ring[(step + DEPTH) % RING]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int cc = step % NCC, tt = step / NCC;           // tt = term*9 + tap
+      const float4* av = ring[step % RING];
+      const float* bl = lds + ((size_t)(tt * CI + cc * 32 + h * 16)) * 32 + j;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v].x, bl[(4 * v + 0) * 32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v].y, bl[(4 * v + 1) * 32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v].z, bl[(4 * v + 2) * 32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v].w, bl[(4 * v + 3) * 32], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, z_t, mu_c, r_c, s, q);
   }
   if (EPI != EPI_NONE) {
     double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
-    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, 4, pb, CO, cbase);
+    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase);
   }
 }
 
@@ -321,20 +333,22 @@ __device__ __forceinline__ void wg_load_unit(WgUnit<RH>& u, int unit, const floa
   const int yp = rem / nseg, s = rem - yp * nseg;
   const int y = 2 * yp + h, x0 = s * RH;
   const bool rowok = y < H;
+  // unconditional loads; out-of-image lanes read mi_zero_word (address select, see mi_common.h)
+  const int dzrow = ((n * H + y) * W + x0) * CO;            // 32-bit: offsets inside one task's tensor
 #pragma unroll
   for (int i = 0; i < RH; ++i) {
     const bool ok = rowok && (x0 + i) < W;
-    u.b[i] = ok ? dz_t[((size_t)(n * H + y) * W + x0 + i) * CO] : 0.f;
+    u.b[i] = *(ok ? dz_t + (dzrow + i * CO) : mi_zero_word);
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int iy = y + r - 1;
-    const bool rok = rowok && iy >= 0 && iy < H;
+    const bool rok = rowok && (unsigned)iy < (unsigned)H;
+    const int xrow = ((n * H + iy) * W + x0 - 1) * CI;
 #pragma unroll
     for (int c = 0; c < RH + 2; ++c) {
-      const int ix = x0 + c - 1;
-      const bool ok = rok && ix >= 0 && ix < W;
-      u.xa[r][c] = ok ? x_t[((size_t)(n * H + iy) * W + ix) * CI] : 0.f;
+      const bool ok = rok && (unsigned)(x0 + c - 1) < (unsigned)W;
+      u.xa[r][c] = *(ok ? x_t + (xrow + c * CI) : mi_zero_word);
     }
   }
 }
@@ -461,13 +475,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host launchers
-static inline void conv_grid(int mpix, int tasks, int cot, int& ntiles, int& tpw, dim3& grid) {
+static inline void conv_grid(int mpix, int tasks, int cot, int nw, int& ntiles, int& tpw, dim3& grid) {
   ntiles = ceil_div(mpix, 32);
   long total = (long)ntiles * tasks * cot;
-  tpw = (int)(total / (4L * 2048));
+  tpw = (int)(total / (4L * 2048));          // ~8k waves in the launch
   if (tpw < 1) tpw = 1;
   if (tpw > 16) tpw = 16;
-  grid = dim3(ceil_div(ntiles, 4 * tpw), tasks, cot);
+  grid = dim3(ceil_div(ntiles, nw * tpw), tasks, cot);
 }
 
 int conv_max_blocks_per_task(const ConvGeom& g) {  // tiles_per_wave == 1 is the finest split any launch uses
@@ -484,7 +498,7 @@ static hipError_t launch_conv_t(hipStream_t st, ConvArgs& a, dim3 grid) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS>::value * 64), lds, st, a);
   return hipGetLastError();
 }
 
@@ -504,7 +518,8 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
   const int cot = a.g.co / 32;
   int ntiles, tpw;
   dim3 grid;
-  conv_grid(a.mpix, tasks, cot, ntiles, tpw, grid);
+  const int nw = (nterms == 2 && a.g.ci == 32) ? 8 : 4;     // ConvWaves<CI, NTERMS>
+  conv_grid(a.mpix, tasks, cot, nw, ntiles, tpw, grid);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   if (blocks_per_task) *blocks_per_task = grid.x;

@@ -32,6 +32,7 @@ struct mi_engine {
   size_t off_wl, off_bl, P;
   size_t PS;  // per-task stride of parameter-shaped buffers (P padded so every task's vectors stay 16-B aligned)
   int32_t* perm_dev;
+  bool fuse1 = false;   // block 1 runs through the conv-recompute kernels of block1.hip
   std::string err;
   // optional per-launch HIP-event profiling (bench.py's roofline leg): kind = op*8 + layer
   int prof_on = 0, prof_filter = -1;
@@ -130,6 +131,7 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
     e->L.push_back(l);
     ci = l.co; h = l.hp; w = l.wp;
   }
+  e->fuse1 = block1_supported(e->L[0].ci, e->L[0].stride, e->L[0].pool, e->L[0].ho, e->L[0].wo, e->L[0].co);
   e->head_c = ci;
   e->head_hw = h * w;
   e->feat = d->head_mean_pool ? ci : ci * h * w;
@@ -207,9 +209,10 @@ static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bo
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
     const size_t zs = (size_t)T * n * L.ho * L.wo * L.co, ps = (size_t)T * n * L.hp * L.wp * L.co;
-    A.z[l] = b.take<float>(zs);
+    const bool fused = (l == 0 && e->fuse1);   // conv output / its gradient are recomputed, never stored
+    A.z[l] = fused ? nullptr : b.take<float>(zs);
     A.p[l] = b.take<float>(ps);
-    A.dz[l] = with_bwd ? b.take<float>(zs) : nullptr;
+    A.dz[l] = (with_bwd && !fused) ? b.take<float>(zs) : nullptr;
     A.dp[l] = with_bwd ? b.take<float>(ps) : nullptr;
     A.mu[l] = b.take<float>((size_t)T * L.co);
     A.rstd[l] = b.take<float>((size_t)T * L.co);
@@ -255,9 +258,10 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
     if (bb > blk) blk = bb;
     const size_t need = (size_t)T * blk * 2 * L.co;
     if (need > bnp) bnp = need;
-    const size_t w = wgrad_partial_floats(gg, T);
+    size_t w = wgrad_partial_floats(gg, T);
+    if (l == 0 && e->fuse1) w = (size_t)T * block1_blocks_per_task(nmax, L.ho, L.wo, L.co, T) * 9 * L.ci * L.co;
     if (w > wgp) wgp = w;
-    const size_t zs = (size_t)T * nmax * L.ho * L.wo * L.co, ps = (size_t)T * nmax * L.hp * L.wp * L.co;
+    const size_t zs = (l == 0 && e->fuse1) ? 0 : (size_t)T * nmax * L.ho * L.wo * L.co, ps = (size_t)T * nmax * L.hp * L.wp * L.co;
     if (zs > zmax) zmax = zs;
     if (ps > pmax) pmax = ps;
   }
@@ -267,7 +271,7 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
     TanSet& X = pl.tan;
     for (int l = 0; l < nl; ++l) {
       const Layer& L = e->L[l];
-      X.zd[l] = b.take<float>((size_t)T * ns * L.ho * L.wo * L.co);
+      X.zd[l] = (l == 0 && e->fuse1) ? nullptr : b.take<float>((size_t)T * ns * L.ho * L.wo * L.co);
       X.pd[l] = b.take<float>((size_t)T * ns * L.hp * L.wp * L.co);
       X.m1[l] = b.take<float>((size_t)T * L.co);
       X.m2[l] = b.take<float>((size_t)T * L.co);
@@ -296,12 +300,34 @@ extern "C" int mi_workspace_bytes(const mi_engine* e, int tasks, int ways, int s
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+static B1Args b1_args(const mi_engine* e, Plan& pl, ActSet& A, const float* x0, int n, const float* theta) {
+  const Layer& L = e->L[0];
+  B1Args a{};
+  a.x = x0;
+  a.w = theta + L.off_w; a.wstride = e->PS;
+  a.mu = A.mu[0]; a.rstd = A.rstd[0];
+  a.gamma = theta + L.off_gamma; a.beta = theta + L.off_beta; a.pstride = e->PS;
+  a.partial = pl.bnpart; a.wpartial = pl.wgpart;
+  a.n = n; a.hh = L.ho; a.ww = L.wo; a.co = L.co;
+  a.inv_m = 1.f / (float)(n * L.ho * L.wo);
+  return a;
+}
+
 // Trunk forward: ConvBlocks on n images per task (conv + BN-stat epilogue, finalize, BN+ReLU+pool).
 static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
+    if (l == 0 && e->fuse1) {
+      B1Args ba = b1_args(e, pl, A, x0, n, theta);
+      int blk = 0;
+      LAUNCH(e, st, OP_CONV_FWD, 0, launch_block1(st, ba, T, L.ci, B1_STATS, &blk));
+      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, (double)ba.inv_m, FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co));
+      ba.out = A.p[0];
+      LAUNCH(e, st, OP_BN_FWD, 0, launch_block1(st, ba, T, L.ci, B1_FWD, nullptr));
+      continue;
+    }
     ConvArgs ca{};
     ca.in[0] = l == 0 ? x0 : A.p[l - 1];
     ca.wt[0] = theta + L.off_w;
@@ -331,6 +357,17 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
+    if (l == 0 && e->fuse1) {
+      B1Args b1 = b1_args(e, pl, A, x0, n, theta);
+      b1.dp = A.dp[0];
+      int blk = 0;
+      LAUNCH(e, st, OP_BN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_BWD_REDUCE, &blk));
+      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
+      b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
+      LAUNCH(e, st, OP_WGRAD, 0, launch_block1(st, b1, T, L.ci, B1_BWD_WGRAD, &blk));
+      LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_wgrad_reduce(st, pl.wgpart, blk, 9 * L.ci * L.co, T, g + L.off_w, P));
+      continue;
+    }
     BnArgs ba{};
     ba.z = A.z[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
@@ -406,6 +443,18 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
+    if (l == 0 && e->fuse1) {
+      B1Args b1 = b1_args(e, pl, A, x0, n, theta);
+      b1.wd = v + L.off_w; b1.vstride = P;
+      int blk = 0;
+      LAUNCH(e, st, OP_TAN_CONV, 0, launch_block1(st, b1, T, L.ci, B1_TSTATS, &blk));
+      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[0], L.co, X.m2[0], L.co));
+      b1.m1 = X.m1[0]; b1.m2 = X.m2[0];
+      b1.gammad = v + L.off_gamma; b1.betad = v + L.off_beta;
+      b1.out = X.pd[0];
+      LAUNCH(e, st, OP_BN_TAN_FWD, 0, launch_block1(st, b1, T, L.ci, B1_TFWD, nullptr));
+      continue;
+    }
     ConvArgs ca{};
     ca.in[0] = l == 0 ? x0 : A.p[l - 1];
     ca.wt[0] = v + L.off_w;
@@ -446,6 +495,21 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
+    if (l == 0 && e->fuse1) {
+      B1Args b1 = b1_args(e, pl, A, x0, n, theta);
+      b1.wd = v + L.off_w; b1.vstride = P;
+      b1.m1 = X.m1[0]; b1.m2 = X.m2[0];
+      b1.gammad = v + L.off_gamma; b1.betad = v + L.off_beta;
+      b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
+      b1.dp = A.dp[0]; b1.dpd = X.dpd[cur];
+      int blk = 0;
+      LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_REDUCE, &blk));
+      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
+      b1.rdgamma = hv + L.off_gamma; b1.rdbeta = hv + L.off_beta; b1.hstride = P;
+      LAUNCH(e, st, OP_TAN_WGRAD, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_WGRAD, &blk));
+      LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_wgrad_reduce(st, pl.wgpart, blk, 9 * L.ci * L.co, T, hv + L.off_w, P));
+      continue;
+    }
     BnArgs ba{};
     ba.z = A.z[l]; ba.zd = X.zd[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l]; ba.m1 = X.m1[l]; ba.m2 = X.m2[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
@@ -572,7 +636,8 @@ static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, An
     if (bb > blk) blk = bb;
     const size_t need = (size_t)T * blk * 2 * L.co;
     if (need > bnp) bnp = need;
-    const size_t w = wgrad_partial_floats(gg, T);
+    size_t w = wgrad_partial_floats(gg, T);
+    if (&L == &e->L[0] && e->fuse1) w = (size_t)T * block1_blocks_per_task(2 * n, L.ho, L.wo, L.co, T) * 9 * L.ci * L.co;
     if (w > wgp) wgp = w;
   }
   ap.scratch.bnpart = b.take<double>(bnp);

@@ -63,6 +63,29 @@ hipError_t launch_bn_tan_fwd(hipStream_t st, const BnArgs& a, int tasks, int poo
 hipError_t launch_bn_tan_bwd_reduce(hipStream_t st, const BnArgs& a, int tasks, int pool, int* nblk);
 hipError_t launch_bn_tan_bwd_apply(hipStream_t st, const BnArgs& a, int tasks, int pool);
 
+// block1.hip -- fused first ConvBlock with conv recompute
+struct B1Args {
+  const float* x;            // [T][n][H][W][Ci0]
+  const float* w; const float* wd;        // conv weights [9*Ci0][Co] of theta / of the tangent direction
+  size_t wstride, vstride;   // per-task strides of theta-shaped / direction-shaped vectors
+  const float *mu, *rstd, *m1, *m2;       // [T][Co]
+  const float *gamma, *beta; size_t pstride;
+  const float *gammad, *betad;            // direction (stride vstride)
+  const float *dgamma, *dbeta; size_t gstride;
+  const float *rdgamma, *rdbeta; size_t hstride;
+  const float* dp; const float* dpd;      // [T][n][H/2][W/2][Co]
+  float* out;                // p or pd
+  double* partial;           // [T][blocks][2][Co]
+  float* wpartial;           // [T][blocks][9*Ci0][Co]
+  int n, hh, ww, co;         // images per task, conv output height / width (= input, stride 1), filters
+  float inv_m;
+  int ntiles, tiles_per_wave;
+};
+enum { B1_STATS = 0, B1_FWD = 1, B1_BWD_REDUCE = 2, B1_BWD_WGRAD = 3, B1_TSTATS = 4, B1_TFWD = 5, B1_TBWD_REDUCE = 6, B1_TBWD_WGRAD = 7 };
+bool block1_supported(int ci, int stride, int pool, int h, int w, int co);
+int block1_blocks_per_task(int n, int h, int w, int co, int tasks);
+hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task);
+
 // head.hip
 struct HeadArgs {
   const float* f;       // [T][n][F]

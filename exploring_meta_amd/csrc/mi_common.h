@@ -35,5 +35,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ float bn_zh(float z, float mu, float r) { return (z - mu) * r; }
 __device__ __forceinline__ float bn_u(float zh, float g, float b) { return fmaf(g, zh, b); }
 
+// Out-of-image operands are fetched from this zero word by selecting the ADDRESS (never the loaded value): a predicated load
+// costs an exec-mask branch region, and a select on the loaded value makes the wave wait for the load before it can issue
+// the MFMAs of the previous, already loaded, tile.
+static __device__ __attribute__((aligned(64))) float mi_zero_word[16] = {0.f};   // not const: must live in the global address space
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
