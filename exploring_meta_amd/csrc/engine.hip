@@ -201,6 +201,7 @@ struct Plan {
   double* bnpart;
   float* wgpart;
   float *tmp_loss, *tmp_acc;
+  float* hscr;   // head scratch: R{dl} [T][n][ways], row loss [T][n], row hit [T][n]
   size_t bytes;
 };
 
@@ -243,6 +244,7 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   pl.yq = b.take<int32_t>((size_t)T * nq);
   pl.tmp_loss = b.take<float>(T);
   pl.tmp_acc = b.take<float>(T);
+  pl.hscr = b.take<float>((size_t)T * (ns > nq ? ns : nq) * (e->d.ways + 2));
   const int nsets = (second_order && K > 0) ? K : 1;
   pl.sup.resize(nsets);
   for (int k = 0; k < nsets; ++k) plan_actset(e, b, pl.sup[k], T, ns, true);
@@ -404,9 +406,15 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
   return MI_OK;
 }
 
+static void head_scratch(const mi_engine* e, HeadArgs& ha, float* hscr, int T, int n) {
+  ha.rdl = hscr;
+  ha.rowloss = hscr + (size_t)T * n * e->d.ways;
+  ha.rowhit = ha.rowloss + (size_t)T * n;
+}
+
 // Linear + CE on features f [T][n][feat]: loss/acc/logits, prob & dl saved, and (with_grad) dwl/dbl into g, df.
-static int head_pass(mi_engine* e, hipStream_t st, const float* f, const int32_t* y, int n, int T, const float* theta, float* g,
-                     float* loss, float* acc, float* logits, float* prob, float* dl, float* df, bool with_grad) {
+static int head_pass(mi_engine* e, hipStream_t st, float* hscr, const float* f, const int32_t* y, int n, int T, const float* theta,
+                     float* g, float* loss, float* acc, float* logits, float* prob, float* dl, float* df, bool with_grad) {
   const size_t P = e->PS;
   HeadArgs ha{};
   ha.f = f;
@@ -415,6 +423,7 @@ static int head_pass(mi_engine* e, hipStream_t st, const float* f, const int32_t
   ha.dwl = with_grad ? g + e->off_wl : nullptr; ha.dbl = with_grad ? g + e->off_bl : nullptr; ha.gstride = P;
   ha.df = with_grad ? df : nullptr;
   ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+  head_scratch(e, ha, hscr, T, n);
   LAUNCH(e, st, OP_HEAD, 0, launch_head_fwd_bwd(st, ha, T, with_grad ? 1 : 0));
   return MI_OK;
 }
@@ -427,7 +436,7 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
   if (rc) return rc;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
   if (with_grad) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * e->PS * sizeof(float), st));
-  rc = head_pass(e, st, A.f, y, n, T, theta, g, loss, acc, logits, A.prob, A.dl, A.df, with_grad);
+  rc = head_pass(e, st, pl.hscr, A.f, y, n, T, theta, g, loss, acc, logits, A.prob, A.dl, A.df, with_grad);
   if (rc || !with_grad) return rc;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], T * n, e->head_hw, e->head_c));
   return trunk_backward(e, st, pl, A, x0, n, T, theta, g);
@@ -490,6 +499,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   ha.dwl = hv + e->off_wl; ha.dbl = hv + e->off_bl; ha.gstride = P;
   ha.df = e->d.head_mean_pool ? X.rdf : X.dpd[cur];
   ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+  head_scratch(e, ha, pl.hscr, T, n);
   LAUNCH(e, st, OP_HEAD_TAN, 0, launch_head_tangent(st, ha, T));
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, X.rdf, X.dpd[cur], T * n, e->head_hw, e->head_c));
   for (int l = nl - 1; l >= 0; --l) {
@@ -605,6 +615,7 @@ struct AnilPlan {
   float *fs, *fq, *dfs, *dfq, *rdf;   // [T][n][feat]
   float *prob, *dl;         // [K+1][T][n][ways]  (support steps 0..K-1, query at K)
   float *tmp_loss, *tmp_acc;
+  float* hscr;
   Plan scratch;             // bnpart / wgpart live here
   size_t bytes;
 };
@@ -628,6 +639,7 @@ static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, An
   ap.dl = b.take<float>((size_t)(K + 1) * T * n * e->d.ways);
   ap.tmp_loss = b.take<float>(T);
   ap.tmp_acc = b.take<float>(T);
+  ap.hscr = b.take<float>((size_t)T * n * (e->d.ways + 2));
   size_t bnp = 0, wgp = 0;
   for (const Layer& L : e->L) {
     const ConvGeom gg = geom(L, 2 * n);
@@ -679,14 +691,14 @@ extern "C" int mi_meta_batch_anil(mi_engine* e, void* stream, const float* theta
     float* th = ap.theta + (size_t)k * TP;
     float* gk = ap.g + (size_t)k * TP;
     HIPCHK(e, hipMemsetAsync(gk, 0, TP * sizeof(float), st));
-    rc = head_pass(e, st, ap.fs, ap.ys, n, T, th, gk, ap.tmp_loss, ap.tmp_acc, nullptr, ap.prob + k * pw, ap.dl + k * pw,
+    rc = head_pass(e, st, ap.hscr, ap.fs, ap.ys, n, T, th, gk, ap.tmp_loss, ap.tmp_acc, nullptr, ap.prob + k * pw, ap.dl + k * pw,
                    nullptr, true);
     if (rc) return rc;
     LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, th, gk, inner_lr, TP, th + TP));
   }
   float* thK = ap.theta + (size_t)K * TP;
   if (with_grad) HIPCHK(e, hipMemsetAsync(ap.lam, 0, TP * sizeof(float), st));
-  rc = head_pass(e, st, ap.fq, ap.yq, n, T, thK, ap.lam, loss_out, acc_out, logits_out, ap.prob + K * pw, ap.dl + K * pw, ap.dfq,
+  rc = head_pass(e, st, ap.hscr, ap.fq, ap.yq, n, T, thK, ap.lam, loss_out, acc_out, logits_out, ap.prob + K * pw, ap.dl + K * pw, ap.dfq,
                  with_grad != 0);
   if (rc || !with_grad) return rc;
   HIPCHK(e, hipMemsetAsync(ap.dfs, 0, fsz * sizeof(float), st));
@@ -701,6 +713,7 @@ extern "C" int mi_meta_batch_anil(mi_engine* e, void* stream, const float* theta
       ha.dwl = ap.hv + e->off_wl; ha.dbl = ap.hv + e->off_bl; ha.gstride = e->PS;
       ha.df = ap.rdf;
       ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+      head_scratch(e, ha, ap.hscr, T, n);
       LAUNCH(e, st, OP_HEAD_TAN, 0, launch_head_tangent(st, ha, T));
       LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, ap.dfs, ap.rdf, inner_lr, fsz, ap.dfs));   // dfs -= lr * R{df}
       LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, ap.lam, ap.hv, inner_lr, TP, ap.lam));     // lam -= lr * H lam
@@ -845,6 +858,8 @@ extern "C" int mi_head_fwd_bwd(void* stream, const float* f, const float* wl, co
   ha.f = f; ha.wl = wl; ha.bl = bl; ha.pstride = pstride; ha.y = y; ha.loss = loss; ha.acc = acc; ha.logits = logits;
   ha.prob = prob; ha.dl = dl; ha.dwl = dwl; ha.dbl = dbl; ha.gstride = gstride; ha.df = df;
   ha.n = n; ha.feat = feat; ha.ways = ways;
+  if (!df || (size_t)feat < 2) return fail(nullptr, MI_ERR_ARG, "mi_head_fwd_bwd needs df (its first 2*tasks*n floats double as row scratch)");
+  ha.rowloss = df; ha.rowhit = df + (size_t)tasks * n;   // consumed by the reduce launch before the gradient launch overwrites df
   HIPCHK0(launch_head_fwd_bwd(reinterpret_cast<hipStream_t>(stream), ha, tasks, dwl != nullptr));
   return MI_OK;
 }

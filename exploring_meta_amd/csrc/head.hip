@@ -1,5 +1,5 @@
 // Classifier head for a whole meta-batch: Linear(F, ways) + CrossEntropyLoss(reduction='mean') forward, backward and
-// tangent, one workgroup per task (per-task fast weights).
+// tangent (per-task fast weights).
 // Replaces (reference): MiniImagenetCNN.forward's `self.linear(x.view(-1, 25*hidden))` (core_functions/vision_models.py:109),
 // OmniglotCNN.forward's mean+linear (:53-54), `loss(learner(adapt_data), adapt_labels)` (core_functions/vision.py:11,16),
 // `accuracy` (vision.py:21-23) and the autograd backward / double-backward of addmm + log_softmax + nll_loss.
@@ -15,140 +15,125 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ x, const flo
   return wave_sum(s);
 }
 
-template <bool WITH_GRAD>
-__global__ __launch_bounds__(256) void head_fwd_bwd_kernel(HeadArgs a) {
-  extern __shared__ float sm[];
+// The head runs as two launches so that a 32-task meta-batch fills the chip:
+//   rows kernel   grid (T, ceil(N/4)): one wave per sample row -> `ways` dot products, softmax, prob / dlogits, row loss, row hit
+//   grads kernel  grid (T, ceil(F/256)): one thread per feature column -> dWl[:, i], df[:, i]; chunk 0 also reduces loss, acc, dbl
+// TANGENT = the R-operator version: rows compute ld = fd wl^T + f wld^T + bld and R{dl}; grads add the second products.
+template <bool TANGENT>
+__global__ __launch_bounds__(256) void head_rows_kernel(HeadArgs a) {
   const int task = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = a.n, F = a.feat, WY = a.ways;
-  float* s_logit = sm;              // [N][WY]
-  float* s_dl = sm + N * WY;        // [N][WY]
-  float* s_red = s_dl + N * WY;     // [2][N]
-  const float* f_t = a.f + (size_t)task * N * F;
+  const int n = blockIdx.y * 4 + wave;
+  if (n >= N) return;
+  const float* f_n = a.f + ((size_t)task * N + n) * F;
+  const float* fd_n = (TANGENT && a.fd) ? a.fd + ((size_t)task * N + n) * F : nullptr;
   const float* wl_t = a.wl + (size_t)task * a.pstride;
   const float* bl_t = a.bl + (size_t)task * a.pstride;
-  const int32_t* y_t = a.y + (size_t)task * N;
-
-  for (int pair = wave; pair < N * WY; pair += 4) {
-    const int n = pair / WY, w = pair - n * WY;
-    const float d = wave_dot(f_t + (size_t)n * F, wl_t + (size_t)w * F, F, lane);
-    if (lane == 0) s_logit[pair] = d + bl_t[w];
-  }
-  __syncthreads();
-  for (int n = tid; n < N; n += 256) {
-    const float* l = s_logit + n * WY;
-    float mx = l[0];
-    int am = 0;
-    for (int w = 1; w < WY; ++w)
-      if (l[w] > mx) { mx = l[w]; am = w; }      // first maximal index (torch.argmax)
-    float se = 0.f;
-    for (int w = 0; w < WY; ++w) se += expf(l[w] - mx);
-    const float lse = mx + logf(se);
-    const int y = y_t[n];
-    const float inv = 1.f / se, invn = 1.f / (float)N;
-    for (int w = 0; w < WY; ++w) {
-      const float p = expf(l[w] - mx) * inv;
-      const float dl = (p - (w == y ? 1.f : 0.f)) * invn;
-      s_dl[n * WY + w] = dl;
-      const size_t o = ((size_t)task * N + n) * WY + w;
-      if (a.prob) a.prob[o] = p;
-      if (a.dl) a.dl[o] = dl;
-      if (a.logits) a.logits[o] = l[w];
+  const float* wld_t = TANGENT ? a.wld + (size_t)task * a.vstride : nullptr;
+  const float* bld_t = TANGENT ? a.bld + (size_t)task * a.vstride : nullptr;
+  // lane w (< WY) ends up holding logit w of this row
+  float mine = 0.f;
+  for (int w = 0; w < WY; ++w) {
+    float d;
+    if (!TANGENT) {
+      d = wave_dot(f_n, wl_t + (size_t)w * F, F, lane) + bl_t[w];
+    } else {
+      d = wave_dot(f_n, wld_t + (size_t)w * F, F, lane) + bld_t[w];
+      if (fd_n) d += wave_dot(fd_n, wl_t + (size_t)w * F, F, lane);
     }
-    s_red[n] = lse - l[y];
-    s_red[N + n] = (am == y) ? 1.f : 0.f;
+    if (lane == w) mine = d;
+  }
+  const size_t o = ((size_t)task * N + n) * WY;
+  const bool act = lane < WY;
+  const float invn = 1.f / (float)N;
+  if (!TANGENT) {
+    // softmax over lanes 0..WY-1 (first maximal index like torch.argmax)
+    float mx = act ? mine : -INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const unsigned long long eq = __ballot(act && mine == mx);
+    const int am = __ffsll((long long)eq) - 1;
+    const float ex = act ? expf(mine - mx) : 0.f;
+    const float se = wave_sum(ex);
+    const int y = a.y[(size_t)task * N + n];
+    const float ly = __shfl(mine, y, 64);
+    if (act) {
+      const float p = ex / se;
+      const float dl = (p - (lane == y ? 1.f : 0.f)) * invn;
+      if (a.prob) a.prob[o + lane] = p;
+      if (a.dl) a.dl[o + lane] = dl;
+      if (a.logits) a.logits[o + lane] = mine;
+    }
+    if (lane == 0) {
+      a.rowloss[(size_t)task * N + n] = (mx + logf(se)) - ly;
+      a.rowhit[(size_t)task * N + n] = (am == y) ? 1.f : 0.f;
+    }
+  } else {
+    const float pr = act ? a.prob[o + lane] : 0.f;
+    const float dot = wave_sum(pr * mine);
+    if (act) a.rdl[o + lane] = pr * (mine - dot) * invn;
+  }
+}
+
+template <bool TANGENT>
+__global__ __launch_bounds__(256) void head_grads_kernel(HeadArgs a) {
+  extern __shared__ float sm[];
+  const int task = blockIdx.x, tid = threadIdx.x;
+  const int N = a.n, F = a.feat, WY = a.ways;
+  float* s_a = sm;               // [N][WY]: dl (primal) or R{dl} (tangent)
+  float* s_b = sm + N * WY;      // [N][WY]: dl (tangent only)
+  const float* src_a = (TANGENT ? a.rdl : a.dl) + (size_t)task * N * WY;
+  for (int e = tid; e < N * WY; e += 256) {
+    s_a[e] = src_a[e];
+    if (TANGENT) s_b[e] = a.dl[(size_t)task * N * WY + e];
   }
   __syncthreads();
-  if (tid == 0) {
-    float ls = 0.f, cs = 0.f;
-    for (int n = 0; n < N; ++n) { ls += s_red[n]; cs += s_red[N + n]; }
-    a.loss[task] = ls / (float)N;
-    a.acc[task] = cs / (float)N;
-  }
-  if (!WITH_GRAD) return;
+  const float* f_t = a.f + (size_t)task * N * F;
+  const float* fd_t = (TANGENT && a.fd) ? a.fd + (size_t)task * N * F : nullptr;
+  const float* wl_t = a.wl + (size_t)task * a.pstride;
+  const float* wld_t = TANGENT ? a.wld + (size_t)task * a.vstride : nullptr;
   float* dwl_t = a.dwl + (size_t)task * a.gstride;
-  float* dbl_t = a.dbl + (size_t)task * a.gstride;
-  // dwl[w][i] = sum_n dl[n][w] f[n][i]
-  for (int e = tid; e < WY * F; e += 256) {
-    const int w = e / F, i = e - w * F;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(s_dl[n * WY + w], f_t[(size_t)n * F + i], s);
-    dwl_t[e] = s;
-  }
-  for (int w = tid; w < WY; w += 256) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += s_dl[n * WY + w];
-    dbl_t[w] = s;
-  }
-  // df[n][i] = sum_w dl[n][w] wl[w][i]
-  if (a.df) {
-    float* df_t = a.df + (size_t)task * N * F;
-    for (int e = tid; e < N * F; e += 256) {
-      const int n = e / F, i = e - n * F;
+  const int i = blockIdx.y * 256 + tid;
+  if (i < F) {
+    for (int w = 0; w < WY; ++w) {                 // dwl[w][i] = sum_n a[n][w] f[n][i] (+ b[n][w] fd[n][i])
       float s = 0.f;
-      for (int w = 0; w < WY; ++w) s = fmaf(s_dl[n * WY + w], wl_t[(size_t)w * F + i], s);
-      df_t[e] = s;
+      for (int n = 0; n < N; ++n) {
+        s = fmaf(s_a[n * WY + w], f_t[(size_t)n * F + i], s);
+        if (TANGENT && fd_t) s = fmaf(s_b[n * WY + w], fd_t[(size_t)n * F + i], s);
+      }
+      dwl_t[(size_t)w * F + i] = s;
+    }
+    if (a.df) {                                    // df[n][i] = sum_w a[n][w] wl[w][i] (+ b[n][w] wld[w][i])
+      float* df_t = a.df + (size_t)task * N * F;
+      for (int n = 0; n < N; ++n) {
+        float s = 0.f;
+        for (int w = 0; w < WY; ++w) {
+          s = fmaf(s_a[n * WY + w], wl_t[(size_t)w * F + i], s);
+          if (TANGENT) s = fmaf(s_b[n * WY + w], wld_t[(size_t)w * F + i], s);
+        }
+        df_t[(size_t)n * F + i] = s;
+      }
+    }
+  }
+  if (blockIdx.y == 0) {
+    float* dbl_t = a.dbl + (size_t)task * a.gstride;
+    for (int w = tid; w < WY; w += 256) {
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s += s_a[n * WY + w];
+      dbl_t[w] = s;
     }
   }
 }
 
-// Tangent: ld = fd wl^T + f wld^T + bld ; probd = prob (ld - <prob, ld>) ; R{dl} = probd / N
-//          R{dwl} = R{dl}^T f + dl^T fd ; R{dbl} = sum_n R{dl} ; R{df} = R{dl} wl + dl wld
-__global__ __launch_bounds__(256) void head_tangent_kernel(HeadArgs a) {
-  extern __shared__ float sm[];
-  const int task = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.n, F = a.feat, WY = a.ways;
-  float* s_ld = sm;                 // [N][WY]  -> R{dl}
-  float* s_dl = sm + N * WY;        // [N][WY]
-  const float* f_t = a.f + (size_t)task * N * F;
-  const bool has_fd = a.fd != nullptr;          // ANIL: features carry no tangent (only the head is adapted)
-  const float* fd_t = has_fd ? a.fd + (size_t)task * N * F : f_t;
-  const float* wl_t = a.wl + (size_t)task * a.pstride;
-  const float* wld_t = a.wld + (size_t)task * a.vstride;
-  const float* bld_t = a.bld + (size_t)task * a.vstride;
-  for (int pair = wave; pair < N * WY; pair += 4) {
-    const int n = pair / WY, w = pair - n * WY;
-    float d = wave_dot(f_t + (size_t)n * F, wld_t + (size_t)w * F, F, lane);
-    if (has_fd) d += wave_dot(fd_t + (size_t)n * F, wl_t + (size_t)w * F, F, lane);
-    if (lane == 0) s_ld[pair] = d + bld_t[w];
-  }
-  for (int e = tid; e < N * WY; e += 256) s_dl[e] = a.dl[(size_t)task * N * WY + e];
-  __syncthreads();
-  for (int n = tid; n < N; n += 256) {
-    const float* pr = a.prob + ((size_t)task * N + n) * WY;
-    float dot = 0.f;
-    for (int w = 0; w < WY; ++w) dot = fmaf(pr[w], s_ld[n * WY + w], dot);
-    const float invn = 1.f / (float)N;
-    for (int w = 0; w < WY; ++w) s_ld[n * WY + w] = pr[w] * (s_ld[n * WY + w] - dot) * invn;
-  }
-  __syncthreads();
-  float* dwl_t = a.dwl + (size_t)task * a.gstride;
-  float* dbl_t = a.dbl + (size_t)task * a.gstride;
-  for (int e = tid; e < WY * F; e += 256) {
-    const int w = e / F, i = e - w * F;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) {
-      s = fmaf(s_ld[n * WY + w], f_t[(size_t)n * F + i], s);
-      if (has_fd) s = fmaf(s_dl[n * WY + w], fd_t[(size_t)n * F + i], s);
-    }
-    dwl_t[e] = s;
-  }
-  for (int w = tid; w < WY; w += 256) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += s_ld[n * WY + w];
-    dbl_t[w] = s;
-  }
-  if (a.df) {
-    float* df_t = a.df + (size_t)task * N * F;
-    for (int e = tid; e < N * F; e += 256) {
-      const int n = e / F, i = e - n * F;
-      float s = 0.f;
-      for (int w = 0; w < WY; ++w) {
-        s = fmaf(s_ld[n * WY + w], wl_t[(size_t)w * F + i], s);
-        s = fmaf(s_dl[n * WY + w], wld_t[(size_t)w * F + i], s);
-      }
-      df_t[e] = s;
-    }
-  }
+// loss[t] = mean_n rowloss, acc[t] = mean_n rowhit (fixed order)
+__global__ void head_reduce_kernel(const float* __restrict__ rowloss, const float* __restrict__ rowhit, int tasks, int n,
+                                   float* __restrict__ loss, float* __restrict__ acc) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= tasks) return;
+  float ls = 0.f, cs = 0.f;
+  for (int k = 0; k < n; ++k) { ls += rowloss[(size_t)t * n + k]; cs += rowhit[(size_t)t * n + k]; }
+  loss[t] = ls / (float)n;
+  acc[t] = cs / (float)n;
 }
 
 // OmniglotCNN: x.mean(dim=[2,3]) (vision_models.py:53).  rows = T*N, p [rows][hw][c] -> f [rows][c]; linear, so the
@@ -169,14 +154,20 @@ __global__ void spatial_mean_bwd_kernel(const float* __restrict__ df, float* __r
 }
 
 hipError_t launch_head_fwd_bwd(hipStream_t st, const HeadArgs& a, int tasks, int with_grad) {
-  const size_t sm = (size_t)(2 * a.n * a.ways + 2 * a.n) * sizeof(float);
-  if (with_grad) hipLaunchKernelGGL(head_fwd_bwd_kernel<true>, dim3(tasks), dim3(256), sm, st, a);
-  else hipLaunchKernelGGL(head_fwd_bwd_kernel<false>, dim3(tasks), dim3(256), sm, st, a);
+  if (a.ways > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(head_rows_kernel<false>, dim3(tasks, ceil_div(a.n, 4)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(head_reduce_kernel, dim3(ceil_div(tasks, 64)), dim3(64), 0, st, a.rowloss, a.rowhit, tasks, a.n, a.loss, a.acc);
+  if (with_grad) {
+    const size_t sm = (size_t)(a.n * a.ways) * sizeof(float);
+    hipLaunchKernelGGL(head_grads_kernel<false>, dim3(tasks, ceil_div(a.feat, 256)), dim3(256), sm, st, a);
+  }
   return hipGetLastError();
 }
 hipError_t launch_head_tangent(hipStream_t st, const HeadArgs& a, int tasks) {
+  if (a.ways > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(head_rows_kernel<true>, dim3(tasks, ceil_div(a.n, 4)), dim3(256), 0, st, a);
   const size_t sm = (size_t)(2 * a.n * a.ways) * sizeof(float);
-  hipLaunchKernelGGL(head_tangent_kernel, dim3(tasks), dim3(256), sm, st, a);
+  hipLaunchKernelGGL(head_grads_kernel<true>, dim3(tasks, ceil_div(a.feat, 256)), dim3(256), sm, st, a);
   return hipGetLastError();
 }
 hipError_t launch_spatial_mean(hipStream_t st, const float* p, float* f, int rows, int hw, int c) {

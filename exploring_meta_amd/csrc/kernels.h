@@ -96,6 +96,8 @@ struct HeadArgs {
   float* loss; float* acc;          // [T]
   float* logits;        // [T][n][ways] (may be null)
   float* prob; float* dl;           // [T][n][ways] saved (tangent pass reads them)
+  float* rdl;                       // [T][n][ways] scratch: R{dl} (tangent)
+  float* rowloss; float* rowhit;    // [T][n] scratch: per-row loss / hit
   float* dwl; float* dbl; size_t gstride;   // outputs (primal grads or tangent grads)
   float* df;            // [T][n][F] output (df or R{df}); may be null
   int n, feat, ways;

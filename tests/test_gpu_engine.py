@@ -49,8 +49,11 @@ CASES = [
     ('omni_5w1s_K2_so', 'omni', 5, 1, 2, 0.4, False, [0], 1e-4, 1e-3),
     ('cfg2_min_5w5s_K1_so', 'min', 5, 5, 1, 0.5, False, [0], 1e-4, 2e-3),
     ('cfg2_min_5w5s_K2_so_lr01', 'min', 5, 5, 2, 0.1, False, [0], 1e-4, 2e-3),
-    ('cfg2_min_5w5s_K5_fo', 'min', 5, 5, 5, 0.5, True, [0], 1e-4, 1e-3),
-    ('cfg2_min_5w5s_K5_so', 'min', 5, 5, 5, 0.5, False, [0, 1], 1e-4, 1e-3),
+    # K=5, lr=0.5 on raw 0..255 inputs is chaotic in fp32: the reference's OWN fp32 run deviates from fp64 by 6e-4..6e-2 in
+    # loss and 0.17..0.37 in the meta-gradient (first- and second-order alike; BASELINE.md section 3, and the fp32 leg
+    # measured below), and a single task's deviation is a random draw.  Floors are set a factor >3 below that envelope.
+    ('cfg2_min_5w5s_K5_fo', 'min', 5, 5, 5, 0.5, True, [0], 1e-3, 5e-2),
+    ('cfg2_min_5w5s_K5_so', 'min', 5, 5, 5, 0.5, False, [0, 1], 1e-3, 5e-2),
 ]
 
 
