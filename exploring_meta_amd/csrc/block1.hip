@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
   constexpr bool TAN = MODE >= B1_TSTATS;
   constexpr bool WG = MODE == B1_BWD_WGRAD || MODE == B1_TBWD_WGRAD;
   constexpr bool RED = MODE == B1_STATS || MODE == B1_BWD_REDUCE || MODE == B1_TSTATS || MODE == B1_TBWD_REDUCE;
-  __shared__ __attribute__((aligned(16))) float lds[4096];
+  // LDS: [0, 2*KP*32) conv weights (theta, direction); then one 30x33 transpose pad per wave for the weight-gradient A operand;
+  // the cross-wave reductions at the end re-use the buffer from offset 0.
+  constexpr int XT_PITCH = 33, XT_WAVE = KP * XT_PITCH, XT_BASE = 2 * KP * 32;
+  constexpr int LDS_FLOATS = (XT_BASE + 4 * XT_WAVE) > 4096 ? (XT_BASE + 4 * XT_WAVE) : 4096;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int task = blockIdx.y, ct = blockIdx.z, cbase = ct * 32;
@@ -59,9 +63,6 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
     tdx[t] = tap % 3 - 1;
     toff[t] = (tdy[t] * W + tdx[t]) * CI0;
   }
-  const bool wrow_ok = j < K;                 // weight-gradient row owned by this lane: k = j -> (tap, ci)
-  const int wtap = j / CI0, wdy = wtap / 3 - 1, wdx = wtap % 3 - 1;
-  const int woff = (wdy * W + wdx) * CI0 + (j - wtap * CI0);
 
   // ---- per-channel constants (this lane's output channel cbase + j)
   const int ch = cbase + j;
@@ -199,21 +200,17 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
     }
 
     if (WG) {
-      // dW[k][co] += sum over the tile's pixels of x[pixel + tap(k)][ci(k)] * bz[pixel][co]; K-step r pairs the pixels the two
-      // lane halves hold in register r: m = (r&3) + 8(r>>2) + 4h  ->  window 2(r>>2)+h, position r&3.
+      // dW[k][co] += sum over the tile's pixels of x_col[pixel][k] * bz[pixel][co].  The A operand is the TRANSPOSE of the conv's
+      // A operand this wave already holds (lane (m, h): x_col[m][h*KH + kk]): write it to the wave's LDS pad as xT[k][m] and read
+      // it back as lane (k, h) -> pixel m = (r&3) + 8(r>>2) + 4h for K-step r.  DS operations of one wave execute in order, so
+      // no barrier is needed; rows k >= 27 hold the zero taps.
+      float* xt = lds + XT_BASE + wave * XT_WAVE;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const Win4 wg = win_advance(w0, 2 * g + h, HP, WP);
-        const bool wv = (wbase + 2 * g + h) < nwin;
-        const int gbase = ((wg.n * H + 2 * wg.wy) * W + 2 * wg.wx) * CI0 + woff;
+      for (int kk = 0; kk < KH; ++kk) xt[(h * KH + kk) * XT_PITCH + j] = av[kk];
+      const float* xr = xt + (j < KP ? j : KP - 1) * XT_PITCH + 4 * h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int qy = 2 * wg.wy + (q >> 1), qx = 2 * wg.wx + (q & 1);
-          const bool inb = wv && wrow_ok && (unsigned)(qy + wdy) < (unsigned)H && (unsigned)(qx + wdx) < (unsigned)W;
-          const float aw = *(inb ? x_t + (gbase + ((q >> 1) * W + (q & 1)) * CI0) : mi_zero_word);
-          accw = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bz[4 * g + q], accw, 0, 0, 0);
-        }
-      }
+      for (int r = 0; r < 16; ++r)
+        accw = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[(r & 3) + 8 * (r >> 2)], bz[r], accw, 0, 0, 0);
     }
   }
 
