@@ -252,13 +252,16 @@ bool block1_supported(int ci, int stride, int pool, int h, int w, int co) {
   return (ci == 1 || ci == 3) && stride == 1 && pool && (h % 2 == 0) && (w % 2 == 0) && (w / 2 >= 8) && (co % 32 == 0);
 }
 
-static void block1_grid(const B1Args& a, int tasks, int& ntiles, int& tpw, dim3& grid) {
+static void block1_grid(const B1Args& a, int tasks, int mode, int& ntiles, int& tpw, dim3& grid) {
   ntiles = ceil_div(a.n * (a.hh / 2) * (a.ww / 2), 8);
   const int cot = a.co / 32;
+  // one balanced round of resident waves: 1024 SIMDs x the waves/SIMD this mode's register count allows
+  static const int occ[8] = {4, 4, 4, 3, 4, 3, 3, 2};
+  const long slots = 1024L * occ[mode & 7];
   long total = (long)ntiles * tasks * cot;
-  tpw = (int)(total / (4L * 2048));
+  tpw = (int)((total + slots - 1) / slots);
   if (tpw < 1) tpw = 1;
-  if (tpw > 32) tpw = 32;
+  if (tpw > 256) tpw = 256;
   grid = dim3(ceil_div(ntiles, 4 * tpw), tasks, cot);
 }
 
@@ -267,14 +270,18 @@ int block1_blocks_per_task(int n, int h, int w, int co, int tasks) {
   a.n = n; a.hh = h; a.ww = w; a.co = co;
   int ntiles, tpw;
   dim3 grid;
-  block1_grid(a, tasks, ntiles, tpw, grid);
-  return (int)grid.x;
+  int mx = 0;
+  for (int mode = 0; mode < 8; ++mode) {
+    block1_grid(a, tasks, mode, ntiles, tpw, grid);
+    if ((int)grid.x > mx) mx = (int)grid.x;
+  }
+  return mx;
 }
 
 hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task) {
   int ntiles, tpw;
   dim3 grid;
-  block1_grid(a, tasks, ntiles, tpw, grid);
+  block1_grid(a, tasks, mode, ntiles, tpw, grid);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   if (blocks_per_task) *blocks_per_task = grid.x;

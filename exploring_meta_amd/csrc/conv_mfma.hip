@@ -87,7 +87,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
   const int H = a.g.h, W = a.g.w, HO = a.g.ho, WO = a.g.wo, CO = a.g.co;
   const int cbase = ct * 32;
 
-  // ---- stage this task's weights: lds[((term*9+tap)*CI + k)*32 + nl]
+  // ---- stage this task's weights: lds[((term*9+tap)*CI + k)*32 + nl]   (unrolled: several loads in flight per thread)
+#pragma unroll 6
   for (int idx = tid; idx < NTERMS * 9 * CI * 32; idx += NT) {
     const int nl = idx & 31;
     const int k = (idx >> 5) % CI;
@@ -477,10 +478,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // host launchers
 static inline void conv_grid(int mpix, int tasks, int cot, int nw, int& ntiles, int& tpw, dim3& grid) {
   ntiles = ceil_div(mpix, 32);
+  // One balanced round: the chip holds 256 CUs x 4 SIMDs x 4 waves of this kernel (LDS-limited), so give every wave
+  // ceil(tiles / 4096) tiles -- more, shorter waves would run as 2.x rounds whose last round is mostly idle.
   long total = (long)ntiles * tasks * cot;
-  tpw = (int)(total / (4L * 2048));          // ~8k waves in the launch
+  tpw = (int)((total + 4095) / 4096);
   if (tpw < 1) tpw = 1;
-  if (tpw > 16) tpw = 16;
+  if (tpw > 32) tpw = 32;
   grid = dim3(ceil_div(ntiles, nw * tpw), tasks, cot);
 }
 
