@@ -70,6 +70,15 @@ __device__ __forceinline__ void conv_epilogue(const floatx16& acc, int tile, int
   }
 }
 
+// Operands come through raw buffer loads: one descriptor per (tensor, task), 32-bit byte offsets, and the hardware range
+// check returns 0 for any offset >= the task's tensor size -- so image padding costs no predicated loads and no selects:
+// an invalid ROW poisons the lane's row offset with OOB, an invalid COLUMN poisons the (wave-uniform, scalar) column addend.
+#define MI_OOB 0x40000000u   // >= any per-task tensor size; OOB + OOB does not wrap
+typedef __amdgpu_buffer_rsrc_t mi_rsrc;
+__device__ __forceinline__ float buf_ld(mi_rsrc r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Generic conv: CI multiple of 32 (template), CO multiple of 32 (grid.z tiles).
 // MODE 0: forward   out[o] = sum_tap in[o*S + d - 1] * W[tap]            weights [9][CI][CO]
@@ -81,7 +90,8 @@ template <int CI, int NTERMS, int EPI, int MODE, int STRIDE>
 __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_mfma_kernel(ConvArgs a) {
   constexpr int NW = ConvWaves<CI, NTERMS>::value, NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int task = blockIdx.y, ct = blockIdx.z;
   const int H = a.g.h, W = a.g.w, HO = a.g.ho, WO = a.g.wo, CO = a.g.co;
@@ -121,6 +131,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
   // consume them; padding lanes read mi_zero_word through an address select (no predicated loads, no post-load selects).
   // sched_barriers pin the order so the compiler neither hoists every load to the top (register blow-up) nor sinks them.
   constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC, DEPTH = 2, RING = DEPTH + 1;
+  // (16-B operands use global loads with an address select: __builtin_amdgcn_raw_buffer_load_b128 is miscompiled by hipcc 7.2
+  //  for gfx950 -- it emits buffer_load_dword and leaves three result registers undefined.)
   const float* in_base[NTERMS];
 #pragma unroll
   for (int term = 0; term < NTERMS; ++term) in_base[term] = a.in[term] + (size_t)task * in_task + h * 16;
@@ -326,30 +338,30 @@ struct WgUnit {
 };
 
 template <int RH>
-__device__ __forceinline__ void wg_load_unit(WgUnit<RH>& u, int unit, const float* __restrict__ x_t,
-                                             const float* __restrict__ dz_t, int H, int W, int CI, int CO, int hp2, int nseg,
-                                             int h) {
+__device__ __forceinline__ void wg_load_unit(WgUnit<RH>& u, int unit, mi_rsrc rx, mi_rsrc rdz, unsigned lane_x, unsigned lane_dz,
+                                             int H, int W, int CI, int CO, int hp2, int nseg, int h) {
+  // unit, and everything decoded from it, is wave-uniform (scalar unit)
   const int n = unit / (hp2 * nseg);
   const int rem = unit - n * hp2 * nseg;
   const int yp = rem / nseg, s = rem - yp * nseg;
-  const int y = 2 * yp + h, x0 = s * RH;
+  const int x0 = s * RH;
+  const int y = 2 * yp + h;                                  // per lane half
   const bool rowok = y < H;
-  // unconditional loads; out-of-image lanes read mi_zero_word (address select, see mi_common.h)
-  const int dzrow = ((n * H + y) * W + x0) * CO;            // 32-bit: offsets inside one task's tensor
+  const unsigned dzoff = rowok ? lane_dz + (unsigned)(((n * H + y) * W + x0) * CO) * 4u : MI_OOB;
 #pragma unroll
   for (int i = 0; i < RH; ++i) {
-    const bool ok = rowok && (x0 + i) < W;
-    u.b[i] = *(ok ? dz_t + (dzrow + i * CO) : mi_zero_word);
+    const unsigned col = (x0 + i) < W ? (unsigned)(i * CO) * 4u : MI_OOB;          // scalar select
+    u.b[i] = buf_ld(rdz, dzoff + col);
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int iy = y + r - 1;
     const bool rok = rowok && (unsigned)iy < (unsigned)H;
-    const int xrow = ((n * H + iy) * W + x0 - 1) * CI;
+    const unsigned xoff = rok ? lane_x + (unsigned)(((n * H + iy) * W + x0 - 1) * CI) * 4u : MI_OOB;
 #pragma unroll
     for (int c = 0; c < RH + 2; ++c) {
-      const bool ok = rok && (unsigned)(x0 + c - 1) < (unsigned)W;
-      u.xa[r][c] = *(ok ? x_t + (xrow + c * CI) : mi_zero_word);
+      const unsigned col = (unsigned)(x0 + c - 1) < (unsigned)W ? (unsigned)(c * CI) * 4u : MI_OOB;   // scalar select
+      u.xa[r][c] = buf_ld(rx, xoff + col);
     }
   }
 }
@@ -366,7 +378,8 @@ __device__ __forceinline__ void wg_compute_unit(const WgUnit<RH>& u, floatx16* a
 template <int RH>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_rows_mfma_kernel(WgradArgs a) {
   __shared__ float red[4 * 1024];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: unit decode runs on the scalar unit
   const int j = lane & 31, h = lane >> 5;
   const int task = blockIdx.y;
   const int H = a.g.h, W = a.g.w, CI = a.g.ci, CO = a.g.co;   // stride 1: conv output is H x W as well
@@ -377,12 +390,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_rows_mfma_kernel(WgradArgs a)
   const int total = nunits * a.nterms;
   const int ub0 = blockIdx.x * a.chunk_pix;                  // chunk_pix = units per workgroup here
   const int ub1 = min(ub0 + a.chunk_pix, total);
-  const size_t x_off = (size_t)task * a.g.n * H * W * CI + cit * 32 + j;
-  const size_t dz_off = (size_t)task * a.g.n * H * W * CO + cot * 32 + j;
-  const float* x0 = a.x[0] + x_off;
-  const float* d0 = a.dz[0] + dz_off;
-  const float* x1 = a.nterms > 1 ? a.x[1] + x_off : x0;
-  const float* d1 = a.nterms > 1 ? a.dz[1] + dz_off : d0;
+  const size_t x_task = (size_t)a.g.n * H * W * CI, dz_task = (size_t)a.g.n * H * W * CO;
+  const unsigned xb = (unsigned)(x_task * 4), db = (unsigned)(dz_task * 4);
+  const mi_rsrc rx0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x[0] + (size_t)task * x_task), 0, xb, 0x00020000);
+  const mi_rsrc rd0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dz[0] + (size_t)task * dz_task), 0, db, 0x00020000);
+  const float* x1p = a.nterms > 1 ? a.x[1] : a.x[0];
+  const float* d1p = a.nterms > 1 ? a.dz[1] : a.dz[0];
+  const mi_rsrc rx1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1p + (size_t)task * x_task), 0, xb, 0x00020000);
+  const mi_rsrc rd1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d1p + (size_t)task * dz_task), 0, db, 0x00020000);
+  const unsigned lane_x = (unsigned)(cit * 32 + j) * 4u, lane_dz = (unsigned)(cot * 32 + j) * 4u;
 
   floatx16 acc[9];
 #pragma unroll
@@ -391,8 +407,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_rows_mfma_kernel(WgradArgs a)
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   auto load = [&](WgUnit<RH>& un, int v) {
-    const bool second = v >= nunits;                          // wave-uniform
-    wg_load_unit<RH>(un, second ? v - nunits : v, second ? x1 : x0, second ? d1 : d0, H, W, CI, CO, hp2, nseg, h);
+    if (v >= nunits) wg_load_unit<RH>(un, v - nunits, rx1, rd1, lane_x, lane_dz, H, W, CI, CO, hp2, nseg, h);   // wave-uniform branch
+    else wg_load_unit<RH>(un, v, rx0, rd0, lane_x, lane_dz, H, W, CI, CO, hp2, nseg, h);
   };
   WgUnit<RH> u0, u1;
   int u = ub0 + wave;
