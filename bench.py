@@ -161,15 +161,31 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    dom = ('tangent_wgrad', 1)                 # dominant kernel (profiles/): 2-term weight-gradient GEMM of block 2 (42x42)
-    eng.profile(True, *dom)
+
+    # Dominant kernel = the conv-family (op, block) with the largest share of one meta-iteration's HIP-event time (blocks 2-4:
+    # the kernels with a clean algorithmic FLOP count).  Found on one untimed, fully profiled step; the timed region then
+    # records events around exactly that kernel's launches.
+    n_img = T * wl['ways'] * wl['shots']
+    CONV_OPS = {'conv_fwd_stats': (1, 'conv3x3_mfma_kernel<32,1,EPI_STATS,fwd>'), 'dgrad': (1, 'conv3x3_mfma_kernel<32,1,EPI_NONE,dgrad>'),
+                'wgrad': (1, 'wgrad3x3_rows_mfma_kernel (1 term)'), 'tangent_conv_fwd': (2, 'conv3x3_mfma_kernel<32,2,EPI_TSTATS,fwd>'),
+                'tangent_dgrad': (2, 'conv3x3_mfma_kernel<32,2,EPI_NONE,dgrad>'), 'tangent_wgrad': (2, 'wgrad3x3_rows_mfma_kernel (2 terms)')}
+    dom = None
+    if args.workload == 'cfg2':
+        eng.profile(True)
+        step()
+        torch.cuda.synchronize()
+        first = eng.profile_collect()
+        eng.profile(False)
+        cands = {k: v for k, v in first.items() if k[0] in CONV_OPS and k[1] >= 1}
+        dom = max(cands, key=lambda k: cands[k][0])
+        eng.profile(True, *dom)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    prof = eng.profile_collect()
+    prof = eng.profile_collect() if dom else {}
     eng.profile(False)
     if dist is not None:
         tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
@@ -177,16 +193,21 @@ def main():
         dt = tmax.item()
 
     roofline = None
-    if dom in prof and args.workload == 'cfg2':
+    if dom in prof:
         ms, cnt = prof[dom]
-        n_img = T * wl['ways'] * wl['shots']
-        flops = 2 * conv_launch_flops(dom[1], n_img)            # two (activation, gradient) products per launch
+        terms, kname = CONV_OPS[dom[0]]
+        hw = MIN_LAYERS[dom[1]][0]
+        flops = terms * conv_launch_flops(dom[1], n_img)
         achieved = flops / (ms / cnt * 1e-3) / 1e12
-        roofline = dict(kernel='wgrad3x3_mfma_kernel<2,1> (tangent weight gradient, block 2, 42x42, 32x32 filters)', bound='mfma',
+        traffic = None
+        tpath = os.path.join(REPO, 'profiles', 'pmc_traffic.json')       # HBM bytes/launch from rocprofv3 --pmc passes (profiles/README.md)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f'{dom[0]},{dom[1]}')
+        roofline = dict(kernel=f'{kname}, block {dom[1] + 1} ({hw}x{hw}, 32->32 filters)', op=dom[0], bound='mfma',
                         achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
-                        frac=round(achieved / FP32_MFMA_PEAK_TF, 4), traffic=None, launches=int(cnt),
+                        frac=round(achieved / FP32_MFMA_PEAK_TF, 4), traffic=traffic, launches=int(cnt),
                         avg_launch_ms=round(ms / cnt, 4), flops_per_launch=flops,
-                        algorithmic_bytes_per_launch=2 * conv_launch_bytes(dom[1], n_img))
+                        algorithmic_bytes_per_launch=terms * conv_launch_bytes(dom[1], n_img))
 
     if args.breakdown and rank == 0:
         eng.profile(True)

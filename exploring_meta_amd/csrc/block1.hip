@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
   constexpr int XT_PITCH = 33, XT_WAVE = KP * XT_PITCH, XT_BASE = 2 * KP * 32;
   constexpr int LDS_FLOATS = (XT_BASE + 4 * XT_WAVE) > 4096 ? (XT_BASE + 4 * XT_WAVE) : 4096;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: tile decode on the scalar unit
   const int j = lane & 31, h = lane >> 5;
   const int task = blockIdx.y, ct = blockIdx.z, cbase = ct * 32;
   const int H = a.hh, W = a.ww, HP = H >> 1, WP = W >> 1, CO = a.co;
@@ -103,9 +104,9 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) accw[r] = 0.f;
 
-  const int tile0 = (blockIdx.x * 4 + wave) * a.tiles_per_wave;
-  const int tile1 = min(tile0 + a.tiles_per_wave, a.ntiles);
-  for (int tile = tile0; tile < tile1; ++tile) {
+  const int tile_base = blockIdx.x * 4 * a.tiles_per_wave;       // tiles interleaved over the 4 waves (shared halo rows in L1)
+  const int tile_end = min(tile_base + 4 * a.tiles_per_wave, a.ntiles);
+  for (int tile = tile_base + wave; tile < tile_end; tile += 4) {
     const int wbase = tile * 8;
     Win4 w0;
     w0.n = wbase / (HP * WP);

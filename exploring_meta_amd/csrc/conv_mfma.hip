@@ -137,9 +137,11 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
 #pragma unroll
   for (int term = 0; term < NTERMS; ++term) in_base[term] = a.in[term] + (size_t)task * in_task + h * 16;
 
-  const int tile0 = (blockIdx.x * NW + wave) * a.tiles_per_wave;
-  const int tile1 = min(tile0 + a.tiles_per_wave, a.ntiles);
-  for (int tile = tile0; tile < tile1; ++tile) {
+  // tiles are interleaved over the workgroup's waves (wave w takes tiles base + w, base + w + NW, ...): at any time the waves
+  // work on adjacent image rows and share the 3x3 halo in L1/L2 instead of each sweeping its own far-apart chunk.
+  const int tile_base = blockIdx.x * NW * a.tiles_per_wave;
+  const int tile_end = min(tile_base + NW * a.tiles_per_wave, a.ntiles);
+  for (int tile = tile_base + wave; tile < tile_end; tile += NW) {
     const int pix = tile * 32 + j;
     const bool valid = pix < mpix;
     const int n = pix / (HO * WO);

@@ -105,7 +105,9 @@ def test_eval_only_and_batching_equivalence():
         gsum += g1
     e = rel_err(grad, gsum)
     report('batching_equivalence', grad_rel=e)
-    assert e < 1e-4
+    # not bit-equal: the number of workgroups (hence the fp32/fp64 partial-sum order) is sized from the whole launch, and this
+    # config's gradient is itself conditioned at ~1e-2 in fp32 (reference fp32 vs fp64 on the same tasks, test above)
+    assert e < 1e-3
 
 
 def test_determinism_and_task_permutation():
