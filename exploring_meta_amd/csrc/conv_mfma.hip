@@ -46,8 +46,8 @@ __device__ __forceinline__ void stats_block_reduce(double s, double q, double* l
 
 template <int EPI>
 __device__ __forceinline__ void conv_epilogue(const floatx16& acc, int tile, int lane, int mpix, int co_total, int cbase,
-                                              float* __restrict__ out_t, const float* __restrict__ z_t, float mu_c,
-                                              float r_c, double& s, double& q) {
+                                              float* __restrict__ out_t, const float* zpre, float mu_c, float r_c, double& s,
+                                              double& q) {
   const int j = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -62,11 +62,22 @@ __device__ __forceinline__ void conv_epilogue(const floatx16& acc, int tile, int
         s += dv;
         q = fma(dv, dv, q);
       } else if (EPI == EPI_TSTATS) {
-        const float zh = bn_zh(z_t[o], mu_c, r_c);
+        const float zh = bn_zh(zpre[r], mu_c, r_c);      // z was prefetched at the top of the tile, under the MFMAs
         s += (double)v;
         q = fma((double)zh, (double)v, q);
       }
     }
+  }
+}
+
+// z values of this lane's 16 output positions (tangent-stat epilogue), issued before the MFMA loop of the tile
+__device__ __forceinline__ void conv_prefetch_z(float* zpre, const float* __restrict__ z_t, int tile, int lane, int mpix,
+                                                int co_total, int cbase) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int pix = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    zpre[r] = *(pix < mpix ? z_t + ((size_t)pix * co_total + cbase + j) : mi_zero_word);
   }
 }
 
@@ -151,6 +162,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    float zpre[16];
+    if (EPI == EPI_TSTATS) conv_prefetch_z(zpre, z_t, tile, lane, mpix, CO, cbase);
     float4 ring[RING][4];
     auto issue = [&](int step, float4* dst) {
       const int cc = step % NCC, tt = step / NCC, tap = tt % 9, term = tt / 9;
@@ -192,7 +205,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, z_t, mu_c, r_c, s, q);
+    conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, zpre, mu_c, r_c, s, q);
   }
   if (EPI != EPI_NONE) {
     double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
@@ -265,7 +278,9 @@ __global__ __launch_bounds__(256) void conv3x3_first_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], lds[(h * KH + kk) * 32 + j], acc, 0, 0, 0);
-    conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, z_t, mu_c, r_c, s, q);
+    float zpre[16];
+    if (EPI == EPI_TSTATS) conv_prefetch_z(zpre, z_t, tile, lane, mpix, CO, cbase);
+    conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, zpre, mu_c, r_c, s, q);
   }
   if (EPI != EPI_NONE) {
     double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;

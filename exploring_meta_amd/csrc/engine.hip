@@ -165,6 +165,13 @@ extern "C" void mi_engine_destroy(mi_engine* e) {
   delete e;
 }
 
+// Ablation / test switch: run block 1 through the generic conv + BN kernels (z stored) instead of the conv-recompute kernels.
+extern "C" int mi_engine_set_fused_block1(mi_engine* e, int on) {
+  if (!e) return MI_ERR_ARG;
+  e->fuse1 = on && block1_supported(e->L[0].ci, e->L[0].stride, e->L[0].pool, e->L[0].ho, e->L[0].wo, e->L[0].co);
+  return MI_OK;
+}
+
 extern "C" int mi_param_count(const mi_engine* e, size_t* n) {
   if (!e || !n) return MI_ERR_ARG;
   *n = e->P;

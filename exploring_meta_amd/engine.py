@@ -93,6 +93,10 @@ class MetaEngine:
             self.lib.mi_engine_destroy(h)
             self._h = C.c_void_p()
 
+    def set_fused_block1(self, on):
+        """Ablation/test switch for the conv-recompute kernels of block 1."""
+        _lib.check(self.lib.mi_engine_set_fused_block1(self._h, int(on)), self._h)
+
     def workspace_bytes(self, tasks, shots, adapt_steps, second_order):
         b = C.c_size_t()
         _lib.check(self.lib.mi_workspace_bytes(self._h, tasks, self.spec.ways, shots, adapt_steps, int(second_order),

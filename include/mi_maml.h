@@ -49,6 +49,10 @@ void mi_engine_destroy(mi_engine* e);
 const char* mi_last_error(const mi_engine* e);
 const char* mi_version(void);
 
+/* Ablation/test switch: 0 = block 1 through the generic (z-storing) kernels, 1 = fused conv-recompute kernels (default when
+ * the geometry allows: Ci in {1,3}, stride-1 conv + pooling, even H/W). */
+int mi_engine_set_fused_block1(mi_engine* e, int on);
+
 /* Number of fp32 parameters (= sum(p.numel() for p in model.parameters())). */
 int mi_param_count(const mi_engine* e, size_t* n);
 
