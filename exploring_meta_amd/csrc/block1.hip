@@ -104,29 +104,39 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) accw[r] = 0.f;
 
-  const int tile_base = blockIdx.x * 4 * a.tiles_per_wave;       // tiles interleaved over the 4 waves (shared halo rows in L1)
-  const int tile_end = min(tile_base + 4 * a.tiles_per_wave, a.ntiles);
-  for (int tile = tile_base + wave; tile < tile_end; tile += 4) {
+  // conv A operand of one tile: this lane's pixel m = j (window j>>2, position j&3), NTH taps of CI0 contiguous channels each
+  auto load_tile = [&](int tile, float* dst) {
     const int wbase = tile * 8;
     Win4 w0;
     w0.n = wbase / (HP * WP);
     const int rem = wbase - w0.n * (HP * WP);
     w0.wy = rem / WP;
     w0.wx = rem - w0.wy * WP;
-
-    // ---- conv1 (and its tangent with the direction's weights): A operand = this lane's pixel m = j
     const Win4 wl = win_advance(w0, j >> 2, HP, WP);
     const bool pvalid = (wbase + (j >> 2)) < nwin;
     const int py = 2 * wl.wy + ((j >> 1) & 1), px = 2 * wl.wx + (j & 1);
     const int pbase = ((wl.n * H + py) * W + px) * CI0;      // < 2^31: one task's input
-    float av[KH];
 #pragma unroll
     for (int t = 0; t < NTH; ++t) {
       const bool inb = pvalid && tok[t] && (unsigned)(py + tdy[t]) < (unsigned)H && (unsigned)(px + tdx[t]) < (unsigned)W;
       const float* src = inb ? x_t + (pbase + toff[t]) : mi_zero_word;
 #pragma unroll
-      for (int c = 0; c < CI0; ++c) av[t * CI0 + c] = src[c];
+      for (int c = 0; c < CI0; ++c) dst[t * CI0 + c] = src[c];
     }
+  };
+
+  // tiles interleaved over the 4 waves (shared halo rows in L1); the next tile's operands are loaded under this tile's MFMAs
+  const int tile_base = blockIdx.x * 4 * a.tiles_per_wave;
+  const int tile_end = min(tile_base + 4 * a.tiles_per_wave, a.ntiles);
+  float av_next[KH];
+  if (tile_base + wave < tile_end) load_tile(tile_base + wave, av_next);
+  for (int tile = tile_base + wave; tile < tile_end; tile += 4) {
+    const int wbase = tile * 8;
+    float av[KH];
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) av[kk] = av_next[kk];
+    if (tile + 4 < tile_end) load_tile(tile + 4, av_next);
+    __builtin_amdgcn_sched_barrier(0);
     floatx16 z, zd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { z[r] = 0.f; zd[r] = 0.f; }
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
 
     // ---- epilogue over this lane's four windows (g = 0..3; window index wbase + 2g + h, positions in regs 4g..4g+3)
     floatx16 bz;                  // dz or R{dz} for the weight gradient
+    float t0 = 0.f, t1 = 0.f;     // per-tile fp32 partial sums of the two statistics modes
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int widx = wbase + 2 * g + h;
@@ -149,13 +160,17 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float zv = z[4 * g + q];
+        // statistics: windows past the end have zero operands, hence z = zd = 0 exactly -- no validity select needed; the 16
+        // values of a tile are summed in fp32 and folded into the fp64 running sums once per tile (below)
         if (MODE == B1_STATS) {
-          if (wvalid) { const double dv = (double)zv; s0 += dv; s1 = fma(dv, dv, s1); }
+          t0 += zv;
+          t1 = fmaf(zv, zv, t1);
           continue;
         }
         zh[q] = bn_zh(zv, mu, rs);
         if (MODE == B1_TSTATS) {
-          if (wvalid) { s0 += (double)zd[4 * g + q]; s1 = fma((double)zh[q], (double)zd[4 * g + q], s1); }
+          t0 += zd[4 * g + q];
+          t1 = fmaf(zh[q], zd[4 * g + q], t1);
           continue;
         }
         u[q] = bn_u(zh[q], gm, bt);
@@ -199,6 +214,8 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
         }
       }
     }
+
+    if (MODE == B1_STATS || MODE == B1_TSTATS) { s0 += (double)t0; s1 += (double)t1; }
 
     if (WG) {
       // dW[k][co] += sum over the tile's pixels of x_col[pixel][k] * bz[pixel][co].  The A operand is the TRANSPOSE of the conv's
