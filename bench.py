@@ -125,7 +125,7 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run always go through RCCL (also exercised at N=1)
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 

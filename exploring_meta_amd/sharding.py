@@ -18,7 +18,7 @@ def shard_range(num_tasks, rank, world):
 def reduce_meta_batch(meta_grad, loss_sum, acc_sum, group=None):
     """Sum (meta_grad, loss_sum, acc_sum) over ranks with a single all-reduce.  Returns the reduced triple.
     Single-process (no initialised process group): identity."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return meta_grad, loss_sum, acc_sum
     flat = torch.cat([meta_grad.reshape(-1), torch.stack([loss_sum.reshape(()), acc_sum.reshape(())]).to(meta_grad.dtype)])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

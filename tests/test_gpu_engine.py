@@ -161,3 +161,25 @@ def test_fused_block1_matches_generic_kernels():
     assert np.allclose(outs[0][0], outs[1][0], rtol=1e-5) and np.array_equal(outs[0][1], outs[1][1])
     assert np.allclose(outs[0][3], outs[1][3], rtol=1e-4, atol=1e-4)
     assert e < 1e-4
+
+
+@pytest.mark.parametrize('dataset,ways,shots,K,fo,tasks', [
+    ('omni', 20, 1, 1, True, [0, 1, 2]),          # 20-way (reference CLI --ways 20), first order
+    ('omni', 20, 5, 1, False, [3]),               # 100 support / 100 query rows per task
+    ('min', 5, 2, 0, False, [0, 1, 2, 3, 4]),     # K = 0: no adaptation, meta-gradient = plain query gradient; odd task count
+    ('min', 5, 1, 3, False, [7]),                 # three second-order steps at a small lr
+])
+def test_edge_shapes_vs_oracle(dataset, ways, shots, K, fo, tasks):
+    spec, mspec = _spec(dataset, ways)
+    theta = model_params(spec, 5)
+    lr = 0.05
+    loss, acc, grad, logits = _run_engine(mspec, theta, dataset, tasks, ways, shots, K, lr, fo)
+    l64, a64, g64, lg64 = _oracle(spec, theta, dataset, tasks, ways, shots, K, lr, fo, torch.float64)
+    e = rel_err(grad, g64)
+    report(f'edge[{dataset},{ways}w{shots}s,K{K}]', loss_rel=float(np.max(np.abs(loss - l64) / np.abs(l64))), grad_rel=e)
+    assert np.allclose(loss, l64, rtol=2e-4)
+    assert e < 2e-3
+    for t in range(len(tasks)):
+        top2 = np.sort(lg64[t], axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-3 * max(1.0, np.abs(lg64[t]).max())
+        assert np.array_equal(logits[t].argmax(axis=1)[clear], lg64[t].argmax(axis=1)[clear])
