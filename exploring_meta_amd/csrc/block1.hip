@@ -148,7 +148,6 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
 
     // ---- epilogue over this lane's four windows (g = 0..3; window index wbase + 2g + h, positions in regs 4g..4g+3)
     floatx16 bz;                  // dz or R{dz} for the weight gradient
-    float t0 = 0.f, t1 = 0.f;     // per-tile fp32 partial sums of the two statistics modes
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int widx = wbase + 2 * g + h;
@@ -160,17 +159,19 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float zv = z[4 * g + q];
-        // statistics: windows past the end have zero operands, hence z = zd = 0 exactly -- no validity select needed; the 16
-        // values of a tile are summed in fp32 and folded into the fp64 running sums once per tile (below)
+        // statistics: windows past the end have zero operands, hence z = zd = 0 exactly -- no validity select needed.  Every value
+        // goes into the fp64 sums individually: after an SGD step on raw 0..255 inputs the conv-1 weights carry a large DC
+        // component, |mean z| >> std z, and E[z^2] - mean^2 cancels catastrophically if sum z^2 is pre-summed in fp32.
         if (MODE == B1_STATS) {
-          t0 += zv;
-          t1 = fmaf(zv, zv, t1);
+          const double dv = (double)zv;
+          s0 += dv;
+          s1 = fma(dv, dv, s1);
           continue;
         }
         zh[q] = bn_zh(zv, mu, rs);
         if (MODE == B1_TSTATS) {
-          t0 += zd[4 * g + q];
-          t1 = fmaf(zh[q], zd[4 * g + q], t1);
+          s0 += (double)zd[4 * g + q];
+          s1 = fma((double)zh[q], (double)zd[4 * g + q], s1);
           continue;
         }
         u[q] = bn_u(zh[q], gm, bt);
@@ -214,8 +215,6 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
         }
       }
     }
-
-    if (MODE == B1_STATS || MODE == B1_TSTATS) { s0 += (double)t0; s1 += (double)t1; }
 
     if (WG) {
       // dW[k][co] += sum over the tile's pixels of x_col[pixel][k] * bz[pixel][co].  The A operand is the TRANSPOSE of the conv's

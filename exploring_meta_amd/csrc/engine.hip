@@ -299,6 +299,21 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   pl.bytes = align_up(b.off, 256);
 }
 
+// Debug/test aid: byte offsets inside the workspace of a mi_meta_batch_maml call with these sizes.
+// out = {theta, g, xs, sup[0].p[0], sup[0].dp[0], sup[0].mu[0], sup[0].rstd[0], sup[0].p[1], qry.p[0], total bytes}
+extern "C" int mi_debug_plan_offsets(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, int second_order,
+                                     size_t* out) {
+  if (!e || !out) return MI_ERR_ARG;
+  Plan pl;
+  char* base = reinterpret_cast<char*>(4096);
+  make_plan(e, base, tasks, ways * shots, ways * shots, adapt_steps, second_order, pl);
+  auto off = [&](const void* p) { return (size_t)(reinterpret_cast<const char*>(p) - base); };
+  out[0] = off(pl.theta); out[1] = off(pl.g); out[2] = off(pl.xs); out[3] = off(pl.sup[0].p[0]); out[4] = off(pl.sup[0].dp[0]);
+  out[5] = off(pl.sup[0].mu[0]); out[6] = off(pl.sup[0].rstd[0]); out[7] = off(pl.sup[0].p[1]); out[8] = off(pl.qry.p[0]);
+  out[9] = pl.bytes;
+  return MI_OK;
+}
+
 extern "C" int mi_workspace_bytes(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, int second_order,
                                   size_t* bytes) {
   if (!e || !bytes || tasks < 1 || ways < 1 || shots < 1 || adapt_steps < 0) return MI_ERR_ARG;
@@ -332,7 +347,7 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
       B1Args ba = b1_args(e, pl, A, x0, n, theta);
       int blk = 0;
       LAUNCH(e, st, OP_CONV_FWD, 0, launch_block1(st, ba, T, L.ci, B1_STATS, &blk));
-      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, (double)ba.inv_m, FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co));
+      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / ((double)n * L.ho * L.wo), FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co));
       ba.out = A.p[0];
       LAUNCH(e, st, OP_BN_FWD, 0, launch_block1(st, ba, T, L.ci, B1_FWD, nullptr));
       continue;

@@ -53,6 +53,10 @@ const char* mi_version(void);
  * the geometry allows: Ci in {1,3}, stride-1 conv + pooling, even H/W). */
 int mi_engine_set_fused_block1(mi_engine* e, int on);
 
+/* Debug/test aid: byte offsets of {theta, g, xs, sup[0].p[0], sup[0].dp[0], sup[0].mu[0], sup[0].rstd[0], sup[0].p[1],
+ * qry.p[0], total} inside the workspace of a mi_meta_batch_maml call with these sizes (out: 10 entries). */
+int mi_debug_plan_offsets(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, int second_order, size_t* out);
+
 /* Number of fp32 parameters (= sum(p.numel() for p in model.parameters())). */
 int mi_param_count(const mi_engine* e, size_t* n);
 
