@@ -68,10 +68,59 @@ class _EngineModel(torch.nn.Module):
             _EngineModel._engines[key] = MetaEngine(self.spec(), dev)
         return _EngineModel._engines[key]
 
-    def forward(self, x):
+    def flat_parameters(self):
+        """parameters() as one flat tensor that is still connected to them in the autograd graph."""
+        return torch.cat([p.reshape(-1) for p in self.parameters()]).float()
+
+    def _images(self, x):
         s = self.spec()
-        x = x.reshape(-1, s.in_channels, s.in_h, s.in_w).float().contiguous()
-        return self.engine().forward_logits(flatten_parameters(self), x.unsqueeze(0))[0]
+        return x.reshape(-1, s.in_channels, s.in_h, s.in_w).float().contiguous()
+
+    def forward(self, x, theta=None):
+        """`model(x)` (reference vision_models.py:51-55,107-110).  `theta` (flat, parameters() order) overrides the module's
+        own parameters -- a learner's fast weights.  Differentiable once w.r.t. the parameters (mi_learner_backward)."""
+        theta = self.flat_parameters() if theta is None else theta
+        return _LearnerForward.apply(self.engine(), self._images(x), theta)
+
+    def get_base_representation(self, x, theta=None):
+        """reference vision_models.py:57-58,112-113: `self.base(x)`, NCHW [N, hidden, h, w]."""
+        return self.get_rep_layer(x, self.layers, theta)
+
+    def get_rep_layer(self, x, layer, theta=None):
+        """reference vision_models.py:60-63,115-118: layer == -1 -> `self.linear(x.view(-1, 25 * hidden))` on a given base
+        representation; otherwise the output of the first `layer` ConvBlocks (0 = x itself)."""
+        theta = (self.flat_parameters() if theta is None else theta).detach()
+        if layer == -1:
+            f = x.reshape(-1, 25 * self.hidden_size).float().contiguous()     # raises like the reference's view for Omniglot
+            nl = self.linear.weight.numel() + self.linear.bias.numel()
+            wl = theta[-nl:-self.linear.bias.numel()].reshape(self.linear.weight.shape)
+            return self.engine().head_logits(f, wl, theta[-self.linear.bias.numel():])
+        if layer == 0:
+            return x
+        if not 1 <= layer <= self.layers:
+            raise ValueError(f'layer must be -1 or in 0..{self.layers}')
+        return self.engine().learner_forward(theta, self._images(x).unsqueeze(0), rep_layer=layer, want_logits=False)[1][0]
+
+
+class _LearnerForward(torch.autograd.Function):
+    """logits = net(x; theta) through mi_learner_forward; backward = mi_learner_backward (re-runs the forward, keeps nothing
+    but x and theta).  Once differentiable: a second-order meta-gradient through step-wise calls raises -- use fast_adapt /
+    meta_batch_adapt, which fuse the K inner steps with the second-order backward."""
+
+    @staticmethod
+    def forward(ctx, engine, x, theta):
+        if x.requires_grad:
+            raise RuntimeError('gradients with respect to the input images are not provided by the HIP engine')
+        theta_d = theta.detach().contiguous()
+        ctx.engine = engine
+        ctx.save_for_backward(x, theta_d)
+        return engine.learner_forward(theta_d, x.unsqueeze(0))[0][0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dlogits):
+        x, theta = ctx.saved_tensors
+        return None, None, ctx.engine.learner_backward(theta, x.unsqueeze(0), dlogits.unsqueeze(0))[0]
 
 
 class MiniImagenetCNN(_EngineModel):

@@ -600,7 +600,7 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
     return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
   const size_t TP = (size_t)T * e->PS;
   LAUNCH(e, st, OP_MISC, 0, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
-  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
   for (int k = 0; k < K; ++k) {
     ActSet& A = so ? pl.sup[k] : pl.sup[0];
     float* th = pl.theta + (size_t)k * TP;
@@ -705,7 +705,7 @@ extern "C" int mi_meta_batch_anil(mi_engine* e, void* stream, const float* theta
   const size_t TP = (size_t)T * e->PS, fsz = (size_t)T * n * e->feat, pw = (size_t)T * n * e->d.ways;
   LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, data, (size_t)T * 2 * n, e->d.in_channels, e->d.in_h, e->d.in_w, ap.x));
   LAUNCH(e, st, OP_MISC, 0, launch_split_labels(st, labels, T, 2 * n, ap.ys, ap.yq));
-  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, e->perm_dev, (int)e->P, (int)e->PS, T, ap.theta));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, ap.theta));
   int rc = trunk_forward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta);     // features(data) on all rows
   if (rc) return rc;
   LAUNCH(e, st, OP_MISC, 4, launch_split_rows(st, ap.act.p[nl - 1], T, 2 * n, e->feat, ap.fs, ap.fq));
@@ -760,7 +760,7 @@ extern "C" int mi_forward_logits(mi_engine* e, void* stream, const float* theta,
   if (pl.bytes > workspace_bytes)
     return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
   LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xq));
-  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
   HIPCHK(e, hipMemsetAsync(pl.yq, 0, (size_t)tasks * n * sizeof(int32_t), st));
   return pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, n, tasks, pl.theta, pl.lam, pl.tmp_loss, pl.tmp_acc, logits_out, false);
 }
@@ -770,6 +770,79 @@ extern "C" int mi_forward_workspace_bytes(const mi_engine* e, int tasks, int n, 
   Plan pl;
   make_plan(e, nullptr, tasks, n, n, 0, 0, pl);
   *bytes = pl.bytes;
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Step-wise learner (reference: `learner(x)`, `learner.adapt(loss)`, `get_rep`, `get_rep_i` on a learn2learn clone --
+// misc_scripts/cl_vision.py:56-66, misc_scripts/rc_vision.py:66-86, core_functions/maml.py:15-19).  The fast weights live
+// with the caller (theta [theta_tasks][P], reference order); forward and backward are two stateless calls, the backward
+// re-runs the forward into the workspace instead of keeping activations alive between calls.
+static int learner_args(mi_engine* e, const float* theta, int theta_tasks, const float* x, int tasks, int n, void* workspace,
+                        size_t workspace_bytes, Plan& pl) {
+  if (!e) return fail(nullptr, MI_ERR_ARG, "null engine");
+  if (!theta || !x || !workspace || tasks < 1 || n < 1) return fail(e, MI_ERR_ARG, "bad learner arguments");
+  if (theta_tasks != 1 && theta_tasks != tasks) return fail(e, MI_ERR_ARG, "theta_tasks must be 1 (shared) or == tasks");
+  make_plan(e, workspace, tasks, n, n, 0, 0, pl);
+  if (pl.bytes > workspace_bytes)
+    return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
+  return MI_OK;
+}
+
+extern "C" int mi_learner_forward(mi_engine* e, void* stream, const float* theta, int theta_tasks, const float* x, int tasks,
+                                  int n, float* logits_out, int rep_layer, float* rep_out, void* workspace,
+                                  size_t workspace_bytes) {
+  Plan pl;
+  int rc = learner_args(e, theta, theta_tasks, x, tasks, n, workspace, workspace_bytes, pl);
+  if (rc) return rc;
+  const int nl = (int)e->L.size();
+  if (rep_out && (rep_layer < 1 || rep_layer > nl)) return fail(e, MI_ERR_ARG, "rep_layer must be in 1..layers");
+  if (!logits_out && !rep_out) return fail(e, MI_ERR_ARG, "nothing to compute: logits_out and rep_out are both NULL");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xq));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, theta_tasks == 1 ? 0 : e->P, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
+  HIPCHK(e, hipMemsetAsync(pl.yq, 0, (size_t)tasks * n * sizeof(int32_t), st));
+  rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, n, tasks, pl.theta, pl.lam, pl.tmp_loss, pl.tmp_acc, logits_out, false);
+  if (rc) return rc;
+  if (rep_out) {
+    const Layer& L = e->L[rep_layer - 1];
+    LAUNCH(e, st, OP_MISC, 0, launch_nhwc_to_nchw(st, pl.qry.p[rep_layer - 1], (size_t)tasks * n, L.co, L.hp, L.wp, rep_out));
+  }
+  return MI_OK;
+}
+
+extern "C" int mi_learner_backward(mi_engine* e, void* stream, const float* theta, int theta_tasks, const float* x,
+                                   const float* dlogits, int tasks, int n, float* grad_out, void* workspace,
+                                   size_t workspace_bytes) {
+  Plan pl;
+  int rc = learner_args(e, theta, theta_tasks, x, tasks, n, workspace, workspace_bytes, pl);
+  if (rc) return rc;
+  if (!dlogits || !grad_out) return fail(e, MI_ERR_ARG, "null dlogits / grad_out");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nl = (int)e->L.size();
+  ActSet& A = pl.qry;
+  LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xq));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, theta_tasks == 1 ? 0 : e->P, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
+  rc = trunk_forward(e, st, pl, A, pl.xq, n, tasks, pl.theta);
+  if (rc) return rc;
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, tasks * n, e->head_hw, e->head_c));
+  HIPCHK(e, hipMemsetAsync(pl.lam, 0, (size_t)tasks * e->PS * sizeof(float), st));
+  HeadArgs ha{};
+  ha.f = A.f;
+  ha.wl = pl.theta + e->off_wl; ha.bl = pl.theta + e->off_bl; ha.pstride = e->PS;
+  ha.dl = const_cast<float*>(dlogits);
+  ha.dwl = pl.lam + e->off_wl; ha.dbl = pl.lam + e->off_bl; ha.gstride = e->PS;
+  ha.df = A.df;
+  ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+  LAUNCH(e, st, OP_HEAD, 0, launch_head_grads(st, ha, tasks));
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], tasks * n, e->head_hw, e->head_c));
+  rc = trunk_backward(e, st, pl, A, pl.xq, n, tasks, pl.theta, pl.lam);
+  if (rc) return rc;
+  if (theta_tasks == 1) {
+    LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, tasks, grad_out));
+  } else {
+    LAUNCH(e, st, OP_MISC, 3, launch_scatter_tasks(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, tasks, grad_out));
+  }
   return MI_OK;
 }
 

@@ -170,6 +170,13 @@ hipError_t launch_head_tangent(hipStream_t st, const HeadArgs& a, int tasks) {
   hipLaunchKernelGGL(head_grads_kernel<true>, dim3(tasks, ceil_div(a.feat, 256)), dim3(256), sm, st, a);
   return hipGetLastError();
 }
+// Backward of the linear head from caller-supplied dlogits (a.dl): dWl, dbl, df.  Used by the step-wise learner whose loss
+// is computed outside the engine (rc_vision.py:68-70 scales it, cl_vision.py:58-59 does not).
+hipError_t launch_head_grads(hipStream_t st, const HeadArgs& a, int tasks) {
+  const size_t sm = (size_t)(a.n * a.ways) * sizeof(float);
+  hipLaunchKernelGGL(head_grads_kernel<false>, dim3(tasks, ceil_div(a.feat, 256)), dim3(256), sm, st, a);
+  return hipGetLastError();
+}
 hipError_t launch_spatial_mean(hipStream_t st, const float* p, float* f, int rows, int hw, int c) {
   const size_t n = (size_t)rows * c;
   hipLaunchKernelGGL(spatial_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, f, rows, hw, c);

@@ -104,6 +104,7 @@ struct HeadArgs {
 };
 hipError_t launch_head_fwd_bwd(hipStream_t st, const HeadArgs& a, int tasks, int with_grad);
 hipError_t launch_head_tangent(hipStream_t st, const HeadArgs& a, int tasks);
+hipError_t launch_head_grads(hipStream_t st, const HeadArgs& a, int tasks);   // backward only, a.dl supplied by the caller
 hipError_t launch_spatial_mean(hipStream_t st, const float* p, float* f, int rows, int hw, int c);
 hipError_t launch_spatial_mean_bwd(hipStream_t st, const float* df, float* dp, int rows, int hw, int c);
 
@@ -114,7 +115,10 @@ hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, size_t images, 
 hipError_t launch_split_rows(hipStream_t st, const float* src, int tasks, int n2, int f, float* even, float* odd);
 hipError_t launch_interleave_rows(hipStream_t st, const float* even, const float* odd, int tasks, int n, int f, float* dst);
 hipError_t launch_split_labels(hipStream_t st, const int64_t* labels, int tasks, int n2, int32_t* ys, int32_t* yq);
-hipError_t launch_gather_params(hipStream_t st, const float* theta_ref, const int32_t* perm, int p, int pstride, int tasks, float* theta_eng);
+hipError_t launch_gather_params(hipStream_t st, const float* theta_ref, size_t src_stride, const int32_t* perm, int p, int pstride,
+                                int tasks, float* theta_eng);   // src_stride 0 = one shared theta
+hipError_t launch_scatter_tasks(hipStream_t st, const float* g, const int32_t* perm, int p, int pstride, int tasks, float* out_ref);
+hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* src, size_t images, int c, int h, int w, float* dst);
 hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* perm, int p, int pstride, int tasks, float* out_ref);
 hipError_t launch_axpy(hipStream_t st, const float* a, const float* b, float alpha, size_t n, float* out);
 hipError_t launch_adam(hipStream_t st, float* theta, const float* grad, float* m, float* v, size_t n, int step, float lr,

@@ -57,11 +57,28 @@ __global__ void split_labels_kernel(const int64_t* __restrict__ labels, size_t r
 }
 
 // theta_eng[t][i] = theta_ref[perm[i]] for every task (learn2learn clone_module: each task starts from the meta-parameters)
-__global__ void gather_params_kernel(const float* __restrict__ theta_ref, const int32_t* __restrict__ perm, int p, int pstride,
-                                     float* __restrict__ theta_eng) {
+__global__ void gather_params_kernel(const float* __restrict__ theta_ref, size_t src_stride, const int32_t* __restrict__ perm,
+                                     int p, int pstride, float* __restrict__ theta_eng) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pstride) return;
-  theta_eng[(size_t)blockIdx.y * pstride + i] = i < p ? theta_ref[perm[i]] : 0.f;
+  theta_eng[(size_t)blockIdx.y * pstride + i] = i < p ? theta_ref[(size_t)blockIdx.y * src_stride + perm[i]] : 0.f;
+}
+
+// out_ref[t][perm[i]] = g[t][i]: per-task gradients back in the reference's parameter order (step-wise learner.adapt).
+__global__ void scatter_tasks_kernel(const float* __restrict__ g, const int32_t* __restrict__ perm, int p, int pstride,
+                                     float* __restrict__ out_ref) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p) return;
+  out_ref[(size_t)blockIdx.y * p + perm[i]] = g[(size_t)blockIdx.y * pstride + i];
+}
+
+// NHWC -> NCHW for representations handed back to the caller (get_rep / get_rep_i): one thread per pixel.
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, size_t images, int c, int h, int w, float* __restrict__ dst) {
+  const size_t hw = (size_t)h * w;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= images * hw) return;
+  const size_t pix = e % hw, img = e / hw;
+  for (int ch = 0; ch < c; ++ch) dst[(img * c + ch) * hw + pix] = src[e * c + ch];
 }
 
 // out_ref[perm[i]] = sum_t lam[t][i]   (eval_loss.backward() accumulates over tasks, maml_vision.py:112); fixed task order.
@@ -125,10 +142,19 @@ hipError_t launch_split_labels(hipStream_t st, const int64_t* labels, int tasks,
   hipLaunchKernelGGL(split_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, labels, total, ys, yq);
   return hipGetLastError();
 }
-hipError_t launch_gather_params(hipStream_t st, const float* theta_ref, const int32_t* perm, int p, int pstride, int tasks,
-                                float* theta_eng) {
-  hipLaunchKernelGGL(gather_params_kernel, dim3(ceil_div(pstride, 256), tasks), dim3(256), 0, st, theta_ref, perm, p, pstride,
-                     theta_eng);
+hipError_t launch_gather_params(hipStream_t st, const float* theta_ref, size_t src_stride, const int32_t* perm, int p, int pstride,
+                                int tasks, float* theta_eng) {
+  hipLaunchKernelGGL(gather_params_kernel, dim3(ceil_div(pstride, 256), tasks), dim3(256), 0, st, theta_ref, src_stride, perm, p,
+                     pstride, theta_eng);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_tasks(hipStream_t st, const float* g, const int32_t* perm, int p, int pstride, int tasks, float* out_ref) {
+  hipLaunchKernelGGL(scatter_tasks_kernel, dim3(ceil_div(p, 256), tasks), dim3(256), 0, st, g, perm, p, pstride, out_ref);
+  return hipGetLastError();
+}
+hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* src, size_t images, int c, int h, int w, float* dst) {
+  const size_t total = images * h * w;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, images, c, h, w, dst);
   return hipGetLastError();
 }
 hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* perm, int p, int pstride, int tasks,

@@ -41,6 +41,18 @@ class ModelSpec:
         (vision/anil_vision.py:86-94): Mini-ImageNet (64 filters, 3x84x84, pooling) or Omniglot (32 filters, 1x28x28)."""
         return ModelSpec(layers, channels, in_hw, in_hw, hidden, bool(max_pool), ways, False)
 
+    def block_output_shape(self, layer):
+        """(C, H, W) after the first `layer` ConvBlocks (layer in 1..n_layers)."""
+        if not 1 <= layer <= self.n_layers:
+            raise ValueError(f'layer must be in 1..{self.n_layers}')
+        h, w = self.in_h, self.in_w
+        for _ in range(layer):
+            if self.max_pool:
+                h, w = h // 2, w // 2
+            else:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        return self.hidden, h, w
+
     def param_shapes(self):
         """(name, shape) in the reference's parameters() order / state_dict naming."""
         out, ci = [], self.in_channels
@@ -174,6 +186,55 @@ class MetaEngine:
         logits = torch.empty(T, n, self.spec.ways, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.mi_forward_logits(self._h, _stream(), _ptr(theta.contiguous()), _ptr(x.contiguous()), T, n,
                                               _ptr(logits), _ptr(ws), ws.numel()), self._h)
+        return logits
+
+    def _learner_args(self, theta, x):
+        theta = theta.reshape(-1, self.param_count) if theta.dim() == 1 else theta
+        if theta.dim() != 2 or theta.shape[1] != self.param_count or theta.shape[0] not in (1, x.shape[0]):
+            raise ValueError(f'theta must be [P] or [1 | tasks, P] with P={self.param_count}, got {tuple(theta.shape)}')
+        for t in (theta, x):
+            if t.dtype != torch.float32 or not t.is_cuda:
+                raise ValueError('theta / x must be fp32 CUDA tensors')
+        T, n = x.shape[0], x.shape[1]
+        b = C.c_size_t()
+        _lib.check(self.lib.mi_forward_workspace_bytes(self._h, T, n, C.byref(b)), self._h)
+        return theta.contiguous(), x.contiguous(), T, n, self._workspace(b.value)
+
+    def learner_forward(self, theta, x, rep_layer=None, want_logits=True):
+        """`learner(x)` with caller-held fast weights: theta [P] / [1,P] (shared) or [T,P]; x [T, n, C, H, W].
+        Returns (logits [T,n,ways] or None, rep or None) where rep = output of the first `rep_layer` ConvBlocks in NCHW
+        (reference get_rep_layer, vision_models.py:60-63,115-118)."""
+        theta, x, T, n, ws = self._learner_args(theta, x)
+        logits = torch.empty(T, n, self.spec.ways, dtype=torch.float32, device=self.device) if want_logits else None
+        rep = None
+        if rep_layer is not None:
+            c, h, w = self.spec.block_output_shape(rep_layer)
+            rep = torch.empty(T, n, c, h, w, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mi_learner_forward(self._h, _stream(), _ptr(theta), theta.shape[0], _ptr(x), T, n, _ptr(logits),
+                                               int(rep_layer or 0), _ptr(rep), _ptr(ws), ws.numel()), self._h)
+        return logits, rep
+
+    def learner_backward(self, theta, x, dlogits):
+        """Vector-Jacobian product of `learner(x)`: d sum(logits*dlogits)/d theta, [theta_tasks, P] (first derivatives)."""
+        theta, x, T, n, ws = self._learner_args(theta, x)
+        dlogits = dlogits.to(torch.float32).contiguous()
+        if tuple(dlogits.shape) != (T, n, self.spec.ways):
+            raise ValueError(f'dlogits must be {(T, n, self.spec.ways)}, got {tuple(dlogits.shape)}')
+        grad = torch.empty(theta.shape[0], self.param_count, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mi_learner_backward(self._h, _stream(), _ptr(theta), theta.shape[0], _ptr(x), _ptr(dlogits), T, n,
+                                                _ptr(grad), _ptr(ws), ws.numel()), self._h)
+        return grad
+
+    def head_logits(self, f, wl, bl):
+        """`linear(f)` for f [n, F] with explicit weights (reference get_rep_layer(x, -1)); mi_head_fwd_bwd, forward only."""
+        f, wl, bl = f.contiguous(), wl.contiguous().float(), bl.contiguous().float()
+        n, feat, ways = f.shape[0], f.shape[1], wl.shape[0]
+        y = torch.zeros(n, dtype=torch.int32, device=self.device)
+        scr = torch.empty(max(2 * n, n * feat), dtype=torch.float32, device=self.device)
+        la = torch.empty(2, dtype=torch.float32, device=self.device)
+        logits = torch.empty(n, ways, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mi_head_fwd_bwd(_stream(), _ptr(f), _ptr(wl), _ptr(bl), 0, _ptr(y), 1, n, feat, ways, _ptr(la[:1]),
+                                            _ptr(la[1:]), _ptr(logits), None, None, None, None, 0, _ptr(scr)), self._h)
         return logits
 
     def profile(self, on, op=None, layer=0):

@@ -102,6 +102,22 @@ int mi_forward_workspace_bytes(const mi_engine* e, int tasks, int n, size_t* byt
 int mi_forward_logits(mi_engine* e, void* stream, const float* theta, const float* x, int tasks, int n, float* logits_out,
                       void* workspace, size_t workspace_bytes);
 
+/* Step-wise learner: the reference's `learner = maml.clone(); learner(x); learner.adapt(loss); learner.get_rep_i(x, i)`
+ * (misc_scripts/cl_vision.py:56-66, misc_scripts/rc_vision.py:66-86, core_functions/maml.py:15-19,
+ * core_functions/vision_models.py:57-63,112-118) with the fast weights held by the caller.
+ *   theta [theta_tasks, P]  reference parameter order; theta_tasks = 1 (all task batches share theta) or = tasks
+ *   x     [tasks, n, C, H, W] NCHW; BatchNorm in train mode over the n images of each task batch
+ * mi_learner_forward:  logits_out [tasks, n, ways] (or NULL); rep_out (or NULL) = output of the first `rep_layer` ConvBlocks,
+ *   rep_layer in 1..layers, NCHW [tasks, n, hidden, h', w'] (`Sequential(*base.children()[:layer])(x)`; layers = base(x)).
+ * mi_learner_backward: grad_out [theta_tasks, P] = d sum(logits * dlogits) / d theta (summed over task batches when theta
+ *   is shared): the vector-Jacobian product autograd asks of `learner(x)`; conv biases get exact zeros (batch-stat BN).
+ *   First derivatives only: second-order meta-gradients go through mi_meta_batch_maml.
+ * Workspace: mi_forward_workspace_bytes(e, tasks, n). */
+int mi_learner_forward(mi_engine* e, void* stream, const float* theta, int theta_tasks, const float* x, int tasks, int n,
+                       float* logits_out, int rep_layer, float* rep_out, void* workspace, size_t workspace_bytes);
+int mi_learner_backward(mi_engine* e, void* stream, const float* theta, int theta_tasks, const float* x, const float* dlogits,
+                        int tasks, int n, float* grad_out, void* workspace, size_t workspace_bytes);
+
 /* Adam step on the flat meta-parameters with torch.optim.Adam defaults (maml_vision.py:85,139-141):
  * grad is first scaled by grad_scale (= 1/meta_batch_size). step is the 1-based step count after increment. */
 int mi_adam_step(void* stream, float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step,

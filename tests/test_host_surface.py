@@ -72,8 +72,14 @@ def test_maml_wrapper_surface():
     assert maml.clone(first_order=True).first_order is True
     assert learner.hidden_size == 64                       # attribute forwarding to the wrapped module
     assert set(maml.state_dict().keys()) == {'module.' + k for k in model.state_dict().keys()}
-    with pytest.raises(NotImplementedError):
+    fw = learner.fast_weights()                            # flat, parameters() order, graph-connected to the base parameters
+    assert fw.shape == (sum(p.numel() for p in model.parameters()),) and fw.requires_grad
+    assert learner.clone().fast_weights() is fw            # a clone starts from the learner's current weights
+    with pytest.raises(RuntimeError):                      # a loss that does not come from learner(x)
         learner.adapt(torch.tensor(0.0))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):                  # step-wise forward is GPU-only as well
+            learner(torch.zeros(5, 1, 28, 28))
 
 
 def test_loss_must_be_mean_cross_entropy():
