@@ -877,6 +877,15 @@ extern "C" int mi_prepare_batch(void* stream, const float* data, const int64_t* 
   return MI_OK;
 }
 
+extern "C" int mi_sample_tasks(void* stream, const void* dataset, int dataset_is_u8, size_t num_images, int c, int h, int w,
+                               const int64_t* index, const uint8_t* rot, int tasks, int n2, float* data_out) {
+  if (!dataset || !index || !data_out || tasks < 1 || n2 < 1 || num_images < 1) return fail(nullptr, MI_ERR_ARG, "bad sampler arguments");
+  if (((size_t)c * h * w) % 4 != 0) return fail(nullptr, MI_ERR_ARG, "C*H*W must be a multiple of 4");
+  if (rot && h != w) return fail(nullptr, MI_ERR_ARG, "quarter-turn rotations need square images");
+  HIPCHK0(launch_sample_tasks(reinterpret_cast<hipStream_t>(stream), dataset, dataset_is_u8, index, rot, (size_t)tasks * n2, c, h, w, data_out));
+  return MI_OK;
+}
+
 extern "C" int mi_conv3x3_bn_stats(void* stream, const float* x, const float* w9, size_t pstride, int tasks, int n, int h,
                                    int wd, int ci, int co, int stride, float* z, float* mu, float* rstd, void* scratch,
                                    size_t scratch_bytes) {

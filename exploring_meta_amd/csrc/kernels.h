@@ -112,6 +112,8 @@ hipError_t launch_spatial_mean_bwd(hipStream_t st, const float* df, float* dp, i
 hipError_t launch_prepare_batch(hipStream_t st, const float* data, const int64_t* labels, int tasks, int n2, int c, int h,
                                 int w, float* xs, float* xq, int32_t* ys, int32_t* yq);
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, size_t images, int c, int h, int w, float* dst);
+hipError_t launch_sample_tasks(hipStream_t st, const void* dataset, int u8, const int64_t* index, const uint8_t* rot, size_t rows,
+                               int c, int h, int w, float* out);
 hipError_t launch_split_rows(hipStream_t st, const float* src, int tasks, int n2, int f, float* even, float* odd);
 hipError_t launch_interleave_rows(hipStream_t st, const float* even, const float* odd, int tasks, int n, int f, float* dst);
 hipError_t launch_split_labels(hipStream_t st, const int64_t* labels, int tasks, int n2, int32_t* ys, int32_t* yq);

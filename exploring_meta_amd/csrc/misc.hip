@@ -34,6 +34,46 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, size_t images
   for (int ch = 0; ch < c; ++ch) dst[e * c + ch] = src[(img * c + ch) * hw + pix];
 }
 
+// Task sampling from a dataset resident in HBM (replaces learn2learn TaskDataset.sample() + LoadData for a whole meta-batch,
+// utils/data_pre.py:16-112): out[row] = image index[row] of the dataset, optionally rotated by rot[row] quarter turns
+// counter-clockwise (RandomClassRotation, data_pre.py:34,46,58; the host draws one angle per class).  U8 = dataset stored as
+// bytes (Mini-ImageNet's raw 0..255 pixels: 4x less HBM footprint and gather traffic), converted to fp32 exactly.
+template <bool U8>
+__global__ void sample_tasks_kernel(const void* __restrict__ dataset, const int64_t* __restrict__ index,
+                                    const uint8_t* __restrict__ rot, size_t rows, int c, int h, int w, float* __restrict__ out) {
+  const size_t img = (size_t)c * h * w;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per 4 consecutive output floats
+  const size_t per = img / 4;
+  if (e >= rows * per) return;
+  const size_t row = e / per, o4 = (e - row * per) * 4;
+  const size_t src = (size_t)index[row] * img;
+  const int r = rot ? (rot[row] & 3) : 0;
+  float v[4];
+  if (r == 0) {
+    if (U8) {
+      const uchar4 b = *reinterpret_cast<const uchar4*>(static_cast<const uint8_t*>(dataset) + src + o4);
+      v[0] = (float)b.x; v[1] = (float)b.y; v[2] = (float)b.z; v[3] = (float)b.w;
+    } else {
+      const float4 f = *reinterpret_cast<const float4*>(static_cast<const float*>(dataset) + src + o4);
+      v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    }
+  } else {
+    const size_t hw = (size_t)h * w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t o = o4 + k, ch = o / hw, pix = o - ch * hw;
+      const int i = (int)(pix / w), j = (int)(pix - (size_t)i * w);
+      int si, sj;                                   // h == w is checked by the launcher
+      if (r == 1) { si = j; sj = w - 1 - i; }
+      else if (r == 2) { si = h - 1 - i; sj = w - 1 - j; }
+      else { si = h - 1 - j; sj = i; }
+      const size_t so = src + ch * hw + (size_t)si * w + sj;
+      v[k] = U8 ? (float)static_cast<const uint8_t*>(dataset)[so] : static_cast<const float*>(dataset)[so];
+    }
+  }
+  *reinterpret_cast<float4*>(out + row * img + o4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ANIL: prepare_batch's even/odd split applied to feature rows (data_pre.py:122-127 after :118-119) and its transpose.
 __global__ void split_rows_kernel(const float* __restrict__ src, size_t rows2, int f, float* __restrict__ even,
                                   float* __restrict__ odd) {
@@ -124,6 +164,17 @@ hipError_t launch_prepare_batch(hipStream_t st, const float* data, const int64_t
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, size_t images, int c, int h, int w, float* dst) {
   const size_t total = images * h * w;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, images, c, h, w, dst);
+  return hipGetLastError();
+}
+hipError_t launch_sample_tasks(hipStream_t st, const void* dataset, int u8, const int64_t* index, const uint8_t* rot, size_t rows,
+                               int c, int h, int w, float* out) {
+  const size_t img = (size_t)c * h * w;
+  if (img % 4 != 0 || (rot && h != w)) return hipErrorInvalidValue;
+  const size_t total = rows * (img / 4);
+  if (u8)
+    hipLaunchKernelGGL(sample_tasks_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dataset, index, rot, rows, c, h, w, out);
+  else
+    hipLaunchKernelGGL(sample_tasks_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dataset, index, rot, rows, c, h, w, out);
   return hipGetLastError();
 }
 hipError_t launch_split_rows(hipStream_t st, const float* src, int tasks, int n2, int f, float* even, float* odd) {

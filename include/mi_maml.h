@@ -132,6 +132,16 @@ int mi_adam_step(void* stream, float* theta, const float* grad, float* exp_avg, 
 int mi_prepare_batch(void* stream, const float* data, const int64_t* labels, int tasks, int n2, int c, int h, int w,
                      float* xs, float* xq, int32_t* ys, int32_t* yq);
 
+/* Task sampling from a dataset resident in HBM: `tasks.sample()` of learn2learn's TaskDataset with LoadData
+ * (utils/data_pre.py:16-112; call sites vision/maml_vision.py:103,116) for a whole meta-batch, no host pixel traffic.
+ *   dataset [num_images, C, H, W]  fp32, or uint8 when dataset_is_u8 (raw 0..255 pixels, converted exactly)
+ *   index   [tasks, n2] int64      image ids drawn on the host (NWays / KShots(2*shots) / ConsecutiveLabels order), each in
+ *                                  [0, num_images) -- the caller guarantees the range, the kernel does not check it
+ *   rot     [tasks, n2] uint8      quarter turns counter-clockwise per row (RandomClassRotation, data_pre.py:34), or NULL
+ *   data_out [tasks, n2, C, H, W]  exactly the stacked task batches mi_meta_batch_maml / _anil take */
+int mi_sample_tasks(void* stream, const void* dataset, int dataset_is_u8, size_t num_images, int c, int h, int w,
+                    const int64_t* index, const uint8_t* rot, int tasks, int n2, float* data_out);
+
 /* conv3x3 pad 1 (ConvBlock.conv, vision_models.py:177-185, bias dropped: batch-stat BN cancels it) + per-channel
  * sum / sum-of-squares partials; then finalize -> mu, rstd (BatchNorm2d train mode, eps 1e-5, biased variance). */
 int mi_conv3x3_bn_stats(void* stream, const float* x, const float* w9, size_t pstride, int tasks, int n, int h, int wd,

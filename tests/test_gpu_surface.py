@@ -68,7 +68,7 @@ def test_model_forward_matches_reference(golden_small):
     assert np.max(np.abs(y - ref)) < 1e-4 * max(1.0, np.abs(ref).max())
     omni = _load(cf.OmniglotCNN(5), model_params(R.omniglot_spec(5), 7))
     data, _ = synthetic.make_task('omni', 3, 5, 1)
-    y = omni(torch.from_numpy(data).cuda()).cpu().numpy()
+    y = omni(torch.from_numpy(data).cuda()).detach().cpu().numpy()
     ref = golden_small['g2_omni64_f64_out']
     assert np.max(np.abs(y - ref)) < 1e-4 * max(1.0, np.abs(ref).max())
 
