@@ -27,6 +27,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on (fits one GPU)
     'cfg2': dict(name='Mini-ImageNet 5-way 5-shot second-order MAML, 4-conv-32, 5 adapt steps, meta-batch 32 per GPU',
                  dataset='min', ways=5, shots=5, steps=5, lr=0.5, first_order=False, tasks=32),
+    # BASELINE.json configs[2]: ANIL, 64-filter trunk once on all 50 rows, head-only inner loop (anil_vision.py defaults: K=1)
+    'cfg3': dict(name='Mini-ImageNet 5-way 5-shot ANIL (head-only inner loop), 4-conv-64 trunk, 1 adapt step, meta-batch 32 per GPU',
+                 dataset='min', ways=5, shots=5, steps=1, lr=0.5, first_order=False, tasks=32, anil=True),
     'cfg4': dict(name='Mini-ImageNet 5-way 1-shot second-order MAML, 1 adapt step, 32 tasks per GPU',
                  dataset='min', ways=5, shots=1, steps=1, lr=0.5, first_order=False, tasks=32),
     'cfg1': dict(name='Omniglot 5-way 1-shot first-order MAML, meta-batch 4', dataset='omni', ways=5, shots=1, steps=1,
@@ -70,6 +73,15 @@ def cpu_baseline(wl, budget_s=20.0, max_tasks=16):
     w = synthetic.hash_weights(R.param_shapes(spec), 42)
     theta = OrderedDict((k, torch.from_numpy(v).float()) for k, v in w.items())
 
+    anil = None
+    if wl.get('anil'):
+        base = R.convbase_spec(hidden=64, channels=3, max_pool=True)
+        shapes = R.param_shapes(base, prefix_base='0.', with_head=False)
+        tf = OrderedDict((k, torch.from_numpy(v).float()) for k, v in synthetic.hash_weights(shapes, 42).items())
+        th = OrderedDict((k, torch.from_numpy(v).float()) for k, v in
+                         synthetic.hash_weights(OrderedDict([('weight', (wl['ways'], 1600)), ('bias', (wl['ways'],))]), 43).items())
+        anil = (tf, th, base)
+
     def run(task_ids):
         datas, labels = [], []
         for t in task_ids:
@@ -77,7 +89,11 @@ def cpu_baseline(wl, budget_s=20.0, max_tasks=16):
             datas.append(torch.from_numpy(d))
             labels.append(torch.from_numpy(l))
         t0 = time.perf_counter()
-        R.maml_meta_batch(theta, spec, datas, labels, wl['steps'], wl['shots'], wl['ways'], wl['lr'], wl['first_order'])
+        if anil:
+            R.anil_meta_batch(anil[0], anil[1], anil[2], 1600, datas, labels, wl['steps'], wl['shots'], wl['ways'], wl['lr'],
+                              wl['first_order'])
+        else:
+            R.maml_meta_batch(theta, spec, datas, labels, wl['steps'], wl['shots'], wl['ways'], wl['lr'], wl['first_order'])
         return time.perf_counter() - t0
 
     # PyTorch-CPU autograd on 5..25-image batches does not scale to hundreds of threads: pick the fastest intra-op thread
@@ -130,8 +146,12 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     T = wl['tasks']
-    spec = ModelSpec.mini_imagenet(wl['ways']) if wl['dataset'] == 'min' else ModelSpec.omniglot(wl['ways'])
+    if wl.get('anil'):
+        spec = ModelSpec.anil(wl['ways'])
+    else:
+        spec = ModelSpec.mini_imagenet(wl['ways']) if wl['dataset'] == 'min' else ModelSpec.omniglot(wl['ways'])
     eng = MetaEngine(spec)
+    run_batch = eng.meta_batch_anil if wl.get('anil') else eng.meta_batch
     theta = init_theta(spec).cuda()
     task_ids = [rank * T + i for i in range(T)]          # shard by global task id: rank r owns tasks [rT, (r+1)T)
     data, labels = synthetic.make_meta_batch(wl['dataset'], task_ids, wl['ways'], wl['shots'])
@@ -142,7 +162,7 @@ def main():
     from exploring_meta_amd.sharding import MetaTrainer
 
     def compute(th, _task_ids):                 # this rank's shard is already resident in HBM (data, labels)
-        loss, acc, grad, _ = eng.meta_batch(th, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
+        loss, acc, grad, _ = run_batch(th, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
         return loss, acc, grad
 
     def adam_fn(th, grad, scale):               # maml_vision.py:139-141
@@ -192,6 +212,48 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
 
+    # Secondary figure: the reference runs one validation fast_adapt per train task without backward
+    # (maml_vision.py:117-124); here that half is one more fused call with with_grad=0 on T other tasks.
+    vdata, vlabels = synthetic.make_meta_batch(wl['dataset'], [10_000 + t for t in task_ids], wl['ways'], wl['shots'])
+    vdata, vlabels = torch.from_numpy(vdata).cuda(), torch.from_numpy(vlabels).cuda()
+
+    def valid():
+        return run_batch(theta, vdata, vlabels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], with_grad=False)
+
+    valid()
+    nsec = max(2, min(5, args.steps))
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(nsec):
+        step()
+        vloss, vacc, _, _ = valid()
+    fence()
+    dt_tv = (time.perf_counter() - t1) / nsec
+    if dist is not None:
+        tmax = torch.tensor([dt_tv], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_tv = tmax.item()
+    secondary = {'metric': 'iterations/sec (train + validation halves)', 'value': round(1.0 / dt_tv, 3), 'ms_per_iteration': round(dt_tv * 1e3, 3),
+                 'tasks_per_iteration': f'{T * world} train + {T * world} validation', 'steps': nsec,
+                 'valid_acc_mean': round(float(vacc.mean()), 5)}
+
+    # Measured HBM roofline: the build's own streaming-copy kernel, same process, same run (read + write bytes / time).
+    import ctypes as C
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device='cuda').zero_()
+    dst = torch.empty_like(src)
+    cp = lambda: eng.lib.mi_stream_copy(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(src.data_ptr()),
+                                        C.c_void_p(dst.data_ptr()), nbytes)
+    cp()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        cp()
+    e1.record()
+    torch.cuda.synchronize()
+    hbm_copy_gbps = 2.0 * nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+
     roofline = None
     if dom in prof:
         ms, cnt = prof[dom]
@@ -207,7 +269,8 @@ def main():
                         achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
                         frac=round(achieved / FP32_MFMA_PEAK_TF, 4), traffic=traffic, launches=int(cnt),
                         avg_launch_ms=round(ms / cnt, 4), flops_per_launch=flops,
-                        algorithmic_bytes_per_launch=terms * conv_launch_bytes(dom[1], n_img))
+                        algorithmic_bytes_per_launch=terms * conv_launch_bytes(dom[1], n_img),
+                        hbm_stream_copy_measured_GBps=round(hbm_copy_gbps, 1))
 
     if args.breakdown and rank == 0:
         eng.profile(True)
@@ -236,7 +299,7 @@ def main():
                        'shots': wl['shots'], 'adapt_steps': wl['steps'], 'inner_lr': wl['lr'],
                        'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter'},
             'post_adapt': {'query_loss_mean': round(float(out['loss']), 5), 'query_acc_mean': round(float(out['acc']), 5)},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

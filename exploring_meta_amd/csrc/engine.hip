@@ -877,6 +877,12 @@ extern "C" int mi_prepare_batch(void* stream, const float* data, const int64_t* 
   return MI_OK;
 }
 
+extern "C" int mi_stream_copy(void* stream, const void* src, void* dst, size_t bytes) {
+  if (!src || !dst || bytes % 16) return fail(nullptr, MI_ERR_ARG, "mi_stream_copy: null pointer or size not a multiple of 16");
+  HIPCHK0(launch_stream_copy(reinterpret_cast<hipStream_t>(stream), src, dst, bytes));
+  return MI_OK;
+}
+
 extern "C" int mi_sample_tasks(void* stream, const void* dataset, int dataset_is_u8, size_t num_images, int c, int h, int w,
                                const int64_t* index, const uint8_t* rot, int tasks, int n2, float* data_out) {
   if (!dataset || !index || !data_out || tasks < 1 || n2 < 1 || num_images < 1) return fail(nullptr, MI_ERR_ARG, "bad sampler arguments");

@@ -123,5 +123,6 @@ hipError_t launch_scatter_tasks(hipStream_t st, const float* g, const int32_t* p
 hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* src, size_t images, int c, int h, int w, float* dst);
 hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* perm, int p, int pstride, int tasks, float* out_ref);
 hipError_t launch_axpy(hipStream_t st, const float* a, const float* b, float alpha, size_t n, float* out);
+hipError_t launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes);
 hipError_t launch_adam(hipStream_t st, float* theta, const float* grad, float* m, float* v, size_t n, int step, float lr,
                        float b1, float b2, float eps, float gscale);

@@ -138,6 +138,22 @@ __global__ void axpy_kernel(const float* __restrict__ a, const float* __restrict
   if (i < n) out[i] = a[i] - alpha * b[i];
 }
 
+// Streaming copy: the build's own measurement of the HBM roofline (bench.py times it in the same run as the engine kernels;
+// SURVEY.md 8d "measured HBM roofline").  One workgroup per CU, 4 x 16 bytes per lane in flight, non-temporal both ways:
+// the fastest of the grid x unroll x temporal variants measured on MI355X (6.08 TB/s; hipMemcpy D2D 5.18 TB/s).
+__global__ __launch_bounds__(256) void stream_copy_kernel(const floatx4* __restrict__ src, floatx4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    floatx4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 // torch.optim.Adam (defaults, no weight decay / amsgrad) on the flat meta-parameters; grad scaled by 1/meta_batch first
 // (maml_vision.py:139-141).
 __global__ void adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
@@ -215,6 +231,11 @@ hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* p
 }
 hipError_t launch_axpy(hipStream_t st, const float* a, const float* b, float alpha, size_t n, float* out) {
   hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, alpha, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes) {
+  if (bytes % 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(256), dim3(256), 0, st, static_cast<const floatx4*>(src), static_cast<floatx4*>(dst), bytes / 16);
   return hipGetLastError();
 }
 hipError_t launch_adam(hipStream_t st, float* theta, const float* grad, float* m, float* v, size_t n, int step, float lr,

@@ -132,6 +132,10 @@ int mi_adam_step(void* stream, float* theta, const float* grad, float* exp_avg, 
 int mi_prepare_batch(void* stream, const float* data, const int64_t* labels, int tasks, int n2, int c, int h, int w,
                      float* xs, float* xq, int32_t* ys, int32_t* yq);
 
+/* Device-to-device streaming copy (bytes % 16 == 0): the kernel bench.py uses to measure the achievable HBM bandwidth in the
+ * same run as the engine kernels ("measured HBM roofline"). */
+int mi_stream_copy(void* stream, const void* src, void* dst, size_t bytes);
+
 /* Task sampling from a dataset resident in HBM: `tasks.sample()` of learn2learn's TaskDataset with LoadData
  * (utils/data_pre.py:16-112; call sites vision/maml_vision.py:103,116) for a whole meta-batch, no host pixel traffic.
  *   dataset [num_images, C, H, W]  fp32, or uint8 when dataset_is_u8 (raw 0..255 pixels, converted exactly)

