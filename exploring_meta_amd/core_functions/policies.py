@@ -1,5 +1,5 @@
-"""``DiagNormalPolicy`` with the reference's constructor, parameter names/order and initialisers
-(core_functions/policies.py:30-67); the MLP runs on the GPU through ``mi_policy_forward``."""
+"""``DiagNormalPolicy`` / ``DiagNormalPolicyANIL`` with the reference's constructors, parameter names/order and initialisers
+(core_functions/policies.py:30-67,70-126); the MLP runs on the GPU through ``mi_policy_forward``."""
 import math
 
 import torch
@@ -26,35 +26,43 @@ class DiagNormalPolicy(nn.Module):
         super().__init__()
         if hiddens is None:
             hiddens = [100, 100]
-        if activation != 'relu':
-            raise ValueError('the HIP policy path implements the ReLU policy (the reference default; rl/maml_trpo.py:86 never '
-                             'passes params["activation"])')
-        layers = [linear_init(nn.Linear(input_size, hiddens[0])), nn.ReLU()]
+        if activation == 'relu':                                              # reference policies.py:32-37
+            act = nn.ReLU
+        elif activation == 'tanh':
+            act = nn.Tanh
+        else:
+            raise NotImplementedError
+        layers = [linear_init(nn.Linear(input_size, hiddens[0])), act()]
         for i, o in zip(hiddens[:-1], hiddens[1:]):
-            layers += [linear_init(nn.Linear(i, o)), nn.ReLU()]
+            layers += [linear_init(nn.Linear(i, o)), act()]
         layers.append(linear_init(nn.Linear(hiddens[-1], output_size)))
-        self.mean = nn.Sequential(*layers)
-        self.sigma = nn.Parameter(torch.Tensor(output_size))
+        self.sigma = nn.Parameter(torch.Tensor(output_size))                  # registered first (named_parameters order)
         self.sigma.data.fill_(math.log(1))
-        self.input_size, self.output_size, self.hiddens = input_size, output_size, tuple(hiddens)
+        self.mean = nn.Sequential(*layers)
+        self.input_size, self.output_size, self.hiddens, self.activation = input_size, output_size, tuple(hiddens), activation
+
+    def _engine_params(self):
+        """Parameters in the engine's order: sigma, then (weight, bias) of the three Linear layers."""
+        lin = [m for m in self.mean if isinstance(m, nn.Linear)]
+        return [self.sigma] + [q for m in lin for q in (m.weight, m.bias)]
 
     def engine(self):
         dev = self.sigma.device
         if dev.type != 'cuda':
-            raise RuntimeError('DiagNormalPolicy computes only on the GPU (HIP engine); move it with .to("cuda")')
-        key = (self.input_size, self.output_size, self.hiddens, dev.index)
+            raise RuntimeError(f'{type(self).__name__} computes only on the GPU (HIP engine); move it with .to("cuda")')
+        key = (self.input_size, self.output_size, self.hiddens, self.activation, dev.index)
         if key not in _engines:
-            _engines[key] = PolicyEngine(self.input_size, self.output_size, self.hiddens, dev)
+            _engines[key] = PolicyEngine(self.input_size, self.output_size, self.hiddens, dev, activation=self.activation)
         return _engines[key]
 
     def flat(self):
-        """Flat parameter vector in named_parameters() order (sigma first)."""
-        return torch.cat([p.detach().reshape(-1) for p in self.parameters()]).float().contiguous()
+        """Flat parameter vector in the engine's order (sigma, W1, b1, W2, b2, W3, b3)."""
+        return torch.cat([p.detach().reshape(-1) for p in self._engine_params()]).float().contiguous()
 
     def load_flat(self, theta):
         off = 0
         with torch.no_grad():
-            for p in self.parameters():
+            for p in self._engine_params():
                 p.copy_(theta[off:off + p.numel()].view_as(p))
                 off += p.numel()
 
@@ -72,3 +80,36 @@ class DiagNormalPolicy(nn.Module):
     def forward(self, state):
         """reference policies.py:58-61"""
         return self.density(state).sample()
+
+
+class DiagNormalPolicyANIL(DiagNormalPolicy):
+    """reference policies.py:70-126: tanh body (`self.body`), linear head (`self.head`), `sigma` registered last;
+    `turn_off_body_grads()` puts the body under no_grad for the inner loop (rl.py:381-382), which on this engine is the
+    `head_only` mode of mi_policy_adapt."""
+
+    def __init__(self, input_size, output_size, fc_neurons, hiddens=None):
+        nn.Module.__init__(self)
+        if hiddens is None:
+            hiddens = [100, 100]
+        if len(hiddens) != 2 or fc_neurons != hiddens[-1]:
+            raise ValueError('fc_neurons must equal the width of the last hidden layer (head = Linear(fc_neurons, output_size))')
+        self.fc_neurons = fc_neurons
+        layers = [linear_init(nn.Linear(input_size, hiddens[0])), nn.Tanh()]
+        for i, o in zip(hiddens[:-1], hiddens[1:]):
+            layers += [linear_init(nn.Linear(i, o)), nn.Tanh()]
+        self.body = nn.Sequential(*layers)
+        self.head = linear_init(nn.Linear(fc_neurons, output_size))
+        self.sigma = nn.Parameter(torch.Tensor(output_size))
+        self.sigma.data.fill_(math.log(1))
+        self.features_no_grad = False
+        self.input_size, self.output_size, self.hiddens, self.activation = input_size, output_size, tuple(hiddens), 'tanh'
+
+    def _engine_params(self):
+        lin = [m for m in self.body if isinstance(m, nn.Linear)] + [self.head]
+        return [self.sigma] + [q for m in lin for q in (m.weight, m.bias)]
+
+    def turn_on_body_grads(self):
+        self.features_no_grad = False
+
+    def turn_off_body_grads(self):
+        self.features_no_grad = True

@@ -104,12 +104,14 @@ def trpo_a2c_loss(episodes, learner, baseline, gamma, tau, update_vf=True):
 def trpo_update(episodes, learner, baseline, inner_lr, gamma, tau, anil=False, first_order=False):
     """reference rl.py:361-374: one MAML update of the policy on ``episodes``; returns the adapted policy (a new object; the
     second-order dependence on the original parameters is handled inside meta_optimize_trpo's fused calls)."""
-    if anil:
-        raise NotImplementedError('ANIL-TRPO (tanh body) is not part of this build (SURVEY.md 8f rank 3)')
+    # anil only sets allow_unused (rl.py:371): which parameters move is decided by the policy's own switch -- with
+    # DiagNormalPolicyANIL.turn_off_body_grads() the body's gradients are None and maml_update leaves it unchanged.
+    head_only = bool(getattr(learner, 'features_no_grad', False))
     adv = _advantages(episodes, baseline, gamma, tau)
     eng = learner.engine()
     batch = _pad([episodes], [adv], learner.input_size, learner.output_size, learner.sigma.device)
-    theta_new, _ = eng.adapt(learner.flat(), batch['states'], batch['actions'], batch['adv'], batch['count'], inner_lr)
+    theta_new, _ = eng.adapt(learner.flat(), batch['states'], batch['actions'], batch['adv'], batch['count'], inner_lr,
+                             head_only=head_only)
     new = deepcopy(learner)
     new.load_flat(theta_new[0])
     return new
@@ -118,11 +120,15 @@ def trpo_update(episodes, learner, baseline, inner_lr, gamma, tau, anil=False, f
 def fast_adapt_trpo(task, learner, baseline, params, anil=False, first_order=False, render=False):
     """reference rl.py:377-406.  ``task.run(policy, episodes=n)`` returns a replay dict."""
     task_replay = []
+    if anil:                                                   # rl.py:381-382
+        learner.turn_off_body_grads()
     for step in range(params['adapt_steps']):
         support_episodes = task.run(learner, episodes=params['adapt_batch_size'])
         task_replay.append(support_episodes)
         learner = trpo_update(support_episodes, learner, baseline, params['inner_lr'], params['gamma'], params['tau'],
                               anil=anil, first_order=first_order)
+    if anil:                                                   # rl.py:395-396
+        learner.turn_on_body_grads()
     query_episodes = task.run(learner, episodes=params['adapt_batch_size'])
     task_replay.append(query_episodes)
     valid_loss = trpo_a2c_loss(query_episodes, learner, baseline, params['gamma'], params['tau'], update_vf=False)
@@ -195,12 +201,15 @@ def meta_surrogate_loss(iter_replays, iter_policies, policy, baseline, params, a
 
 
 def conjugate_gradient(Ax, b, num_iterations=10, tol=1e-10, eps=1e-8):
-    """cherry.algorithms.trpo.conjugate_gradient (reference rl.py:418)."""
+    """cherry.algorithms.trpo.conjugate_gradient (reference rl.py:418).  The recurrences (dot products, axpys on 10,604
+    elements) are carried in fp64 on the device; every A p is one fp32 Fisher-vector product through the engine."""
+    dt = b.dtype
+    b = b.double()
     x = torch.zeros_like(b)
     r, p = b.clone(), b.clone()
     r_dot_old = torch.dot(r, r)
     for _ in range(num_iterations):
-        Ap = Ax(p)
+        Ap = Ax(p.to(dt)).double()
         alpha = r_dot_old / (torch.dot(p, Ap) + eps)
         x += alpha * p
         r -= alpha * Ap
@@ -209,12 +218,20 @@ def conjugate_gradient(Ax, b, num_iterations=10, tol=1e-10, eps=1e-8):
         r_dot_old = r_dot_new
         if r_dot_new.item() < tol:
             break
-    return x
+    return x.to(dt)
 
 
 def meta_optimize_trpo(params, policy, baseline, iter_replays, iter_policies, anil=False):
     """reference rl.py:409-438: CG step direction from the Fisher-vector product of the mean KL, then backtracking line
     search on (surrogate loss, KL); updates ``policy`` in place.  Returns diagnostics."""
+    if anil:
+        # The reference's surrogate replays the inner step with ALL parameters (clone_module(policy) has its body grads on,
+        # rl.py:447-453) while the stored old policies were adapted head-only (rl.py:381-382): at the current parameters the
+        # new policies differ from the old ones, KL's gradient is not zero, and the Hessian-vector product of the mean KL
+        # picks up third derivatives of the inner loss.  mi_trpo_fvp implements the case new == old (MAML-TRPO); the ANIL
+        # surrogate VALUE and gradient are available through meta_surrogate_loss / _SurrogateContext.evaluate.
+        raise NotImplementedError('meta_optimize_trpo(anil=True): the KL Hessian-vector product away from new == old is not '
+                                  'implemented (needs third-order terms); see the comment above')
     ctx = _SurrogateContext(iter_replays, iter_policies, policy, baseline, params)
     theta = policy.flat()
     old_loss, old_kl, grad = ctx.evaluate(theta, want_grad=True)

@@ -27,10 +27,19 @@ struct DenseArgs {
   size_t wstride[2];
   const float* bias;     // [O] (term 0 only), may be null
   size_t bstride;
-  const float* mask;     // optional [T][B][O]: output multiplied by (mask > 0)
+  const float* mask;     // optional [T][B][O]: stored activations h; output multiplied by phi'(z) written in terms of h
+  const float* hd;       // tanh tangent-backward only: tangent activations  [T][B][.]
+  const float* dpre;     // tanh tangent-backward only: primal cotangent w.r.t. h (before the phi' factor)
   float* y;              // [T][B][O]
-  int B, I, O, nterms, relu;
+  float* ypre;           // optional: the value before the phi' factor (primal backward of a tanh layer keeps it for the HVP)
+  int B, I, O, nterms;
+  int act;               // forward: activation applied to the output (ACT_*); mask users: which phi' to form from h
 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+// phi'(z) from the stored activation h = phi(z): ReLU -> [h > 0], tanh -> 1 - h^2
+__device__ __forceinline__ float act_gate(float s, float h, int act) {
+  return act == ACT_TANH ? s * (1.f - h * h) : (h > 0.f ? s : 0.f);
+}
 
 __global__ void dense_fwd_kernel(DenseArgs a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,8 +53,9 @@ __global__ void dense_fwd_kernel(DenseArgs a) {
     for (int i = 0; i < a.I; ++i) s = fmaf(x[i], w[i], s);
   }
   const size_t oi = ((size_t)t * a.B + b) * a.O + o;
-  if (a.mask) s = a.mask[oi] > 0.f ? s : 0.f;
-  if (a.relu) s = fmaxf(s, 0.f);
+  if (a.mask) s = act_gate(s, a.mask[oi], a.act);        // tangent forward: hdot = phi'(z) zdot
+  else if (a.act == ACT_RELU) s = fmaxf(s, 0.f);
+  else if (a.act == ACT_TANH) s = tanhf(s);
   a.y[oi] = s;
 }
 
@@ -62,7 +72,13 @@ __global__ void dense_bwd_x_kernel(DenseArgs a) {   // here x[k] = dy_k [T][B][O
     for (int o = 0; o < a.O; ++o) s = fmaf(dy[o], w[(size_t)o * a.I], s);
   }
   const size_t oi = ((size_t)t * a.B + b) * a.I + i;
-  if (a.mask) s = a.mask[oi] > 0.f ? s : 0.f;
+  if (a.ypre) a.ypre[oi] = s;
+  if (a.mask) {
+    const float h = a.mask[oi];
+    s = act_gate(s, h, a.act);
+    // R{dz} = phi' R{dh} + phi'' zdot dh, and for tanh phi'' zdot = -2 h hdot
+    if (a.hd) s = fmaf(-2.f * h * a.hd[oi], a.dpre[oi], s);
+  }
   a.y[oi] = s;
 }
 
@@ -233,6 +249,7 @@ struct mi_policy {
   mi_policy_desc d;
   int device;
   int S, A, H1, H2;
+  int act;   // ACT_RELU / ACT_TANH between the dense layers (policies.py:32-37,76)
   size_t o_sigma, o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, P;
   std::string err;
 };
@@ -254,9 +271,10 @@ extern "C" int mi_policy_create(const mi_policy_desc* d, int device, mi_policy**
   if (!d || !out) return pfail(nullptr, MI_ERR_ARG, "null argument");
   if (d->state_size < 1 || d->action_size < 1 || d->action_size > 6 || d->hidden1 < 1 || d->hidden2 < 1)
     return pfail(nullptr, MI_ERR_ARG, "unsupported policy sizes (action_size must be 1..6)");
-  if (d->activation != 0) return pfail(nullptr, MI_ERR_ARG, "only the ReLU policy (DiagNormalPolicy default) is implemented");
+  if (d->activation != 0 && d->activation != 1) return pfail(nullptr, MI_ERR_ARG, "activation must be 0 (ReLU) or 1 (tanh)");
   mi_policy* p = new mi_policy();
   p->d = *d; p->device = device;
+  p->act = d->activation == 1 ? ACT_TANH : ACT_RELU;
   p->S = d->state_size; p->A = d->action_size; p->H1 = d->hidden1; p->H2 = d->hidden2;
   size_t o = 0;
   p->o_sigma = o; o += p->A;
@@ -285,18 +303,20 @@ struct PBump {
 
 static hipError_t dense_fwd(hipStream_t st, int T, int B, int I, int O, const float* x0, const float* w0, size_t ws0,
                             const float* x1, const float* w1, size_t ws1, const float* bias, size_t bs, const float* mask,
-                            int relu, float* y) {
+                            int act, float* y) {
   DenseArgs a{};
   a.x[0] = x0; a.w[0] = w0; a.wstride[0] = ws0; a.x[1] = x1; a.w[1] = w1; a.wstride[1] = ws1;
-  a.bias = bias; a.bstride = bs; a.mask = mask; a.y = y; a.B = B; a.I = I; a.O = O; a.nterms = x1 ? 2 : 1; a.relu = relu;
+  a.bias = bias; a.bstride = bs; a.mask = mask; a.y = y; a.B = B; a.I = I; a.O = O; a.nterms = x1 ? 2 : 1; a.act = act;
   hipLaunchKernelGGL(dense_fwd_kernel, dim3(ceil_div(B * O, 256), T), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 static hipError_t dense_bwd_x(hipStream_t st, int T, int B, int I, int O, const float* dy0, const float* w0, size_t ws0,
-                              const float* dy1, const float* w1, size_t ws1, const float* mask, float* dx) {
+                              const float* dy1, const float* w1, size_t ws1, const float* mask, int act, float* dx,
+                              float* dx_pre = nullptr, const float* hd = nullptr, const float* dpre = nullptr) {
   DenseArgs a{};
   a.x[0] = dy0; a.w[0] = w0; a.wstride[0] = ws0; a.x[1] = dy1; a.w[1] = w1; a.wstride[1] = ws1;
-  a.mask = mask; a.y = dx; a.B = B; a.I = I; a.O = O; a.nterms = dy1 ? 2 : 1;
+  a.mask = mask; a.act = act; a.y = dx; a.ypre = dx_pre; a.hd = hd; a.dpre = dpre;
+  a.B = B; a.I = I; a.O = O; a.nterms = dy1 ? 2 : 1;
   hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(ceil_div(B * I, 256), T), dim3(256), 0, st, a);
   return hipGetLastError();
 }
@@ -311,19 +331,23 @@ static hipError_t dense_bwd_w(hipStream_t st, int T, int B, int I, int O, const 
 
 // MLP forward on [T][B][S]; theta with per-task stride ts (0 = shared)
 static int mlp_forward(mi_policy* p, hipStream_t st, int T, int B, const float* x, const float* th, size_t ts, Acts& a) {
-  PCHK(p, dense_fwd(st, T, B, p->S, p->H1, x, th + p->o_w1, ts, nullptr, nullptr, 0, th + p->o_b1, ts, nullptr, 1, a.h1));
-  PCHK(p, dense_fwd(st, T, B, p->H1, p->H2, a.h1, th + p->o_w2, ts, nullptr, nullptr, 0, th + p->o_b2, ts, nullptr, 1, a.h2));
-  PCHK(p, dense_fwd(st, T, B, p->H2, p->A, a.h2, th + p->o_w3, ts, nullptr, nullptr, 0, th + p->o_b3, ts, nullptr, 0, a.mu));
+  PCHK(p, dense_fwd(st, T, B, p->S, p->H1, x, th + p->o_w1, ts, nullptr, nullptr, 0, th + p->o_b1, ts, nullptr, p->act, a.h1));
+  PCHK(p, dense_fwd(st, T, B, p->H1, p->H2, a.h1, th + p->o_w2, ts, nullptr, nullptr, 0, th + p->o_b2, ts, nullptr, p->act, a.h2));
+  PCHK(p, dense_fwd(st, T, B, p->H2, p->A, a.h2, th + p->o_w3, ts, nullptr, nullptr, 0, th + p->o_b3, ts, nullptr, ACT_NONE, a.mu));
   return MI_OK;
 }
-// MLP backward from dmu: grads into g [T][P] (sigma slot untouched); scratch d2 [T][B][H2], d1 [T][B][H1]; keeps da2/da1 there
+// MLP backward from dmu: grads into g [T][P] (sigma slot untouched); scratch d2 [T][B][H2], d1 [T][B][H1] keep dz2 / dz1;
+// pre2 / pre1 (optional) keep the cotangents w.r.t. h2 / h1 before the phi' factor (a tanh HVP needs them).
+// head_only: only W3 / b3 get gradients (ANIL inner loop with the body under no_grad, rl.py:381-382, policies.py:100-106).
 static int mlp_backward(mi_policy* p, hipStream_t st, int T, int B, const float* x, const float* th, size_t ts, const Acts& a,
-                        const float* dmu, float* d2, float* d1, float* g) {
+                        const float* dmu, float* d2, float* d1, float* g, float* pre2 = nullptr, float* pre1 = nullptr,
+                        bool head_only = false) {
   const size_t P = p->P;
   PCHK(p, dense_bwd_w(st, T, B, p->H2, p->A, dmu, a.h2, nullptr, nullptr, g + p->o_w3, g + p->o_b3, P));
-  PCHK(p, dense_bwd_x(st, T, B, p->H2, p->A, dmu, th + p->o_w3, ts, nullptr, nullptr, 0, a.h2, d2));
+  if (head_only) return MI_OK;
+  PCHK(p, dense_bwd_x(st, T, B, p->H2, p->A, dmu, th + p->o_w3, ts, nullptr, nullptr, 0, a.h2, p->act, d2, pre2));
   PCHK(p, dense_bwd_w(st, T, B, p->H1, p->H2, d2, a.h1, nullptr, nullptr, g + p->o_w2, g + p->o_b2, P));
-  PCHK(p, dense_bwd_x(st, T, B, p->H1, p->H2, d2, th + p->o_w2, ts, nullptr, nullptr, 0, a.h1, d1));
+  PCHK(p, dense_bwd_x(st, T, B, p->H1, p->H2, d2, th + p->o_w2, ts, nullptr, nullptr, 0, a.h1, p->act, d1, pre1));
   PCHK(p, dense_bwd_w(st, T, B, p->S, p->H1, d1, x, nullptr, nullptr, g + p->o_w1, g + p->o_b1, P));
   return MI_OK;
 }
@@ -331,20 +355,24 @@ static int mlp_backward(mi_policy* p, hipStream_t st, int T, int B, const float*
 static int mlp_tangent_forward(mi_policy* p, hipStream_t st, int T, int B, const float* x, const float* th, size_t ts,
                                const Acts& a, const float* v, Acts& ad) {
   const size_t P = p->P;
-  PCHK(p, dense_fwd(st, T, B, p->S, p->H1, x, v + p->o_w1, P, nullptr, nullptr, 0, v + p->o_b1, P, a.h1, 0, ad.h1));
-  PCHK(p, dense_fwd(st, T, B, p->H1, p->H2, a.h1, v + p->o_w2, P, ad.h1, th + p->o_w2, ts, v + p->o_b2, P, a.h2, 0, ad.h2));
-  PCHK(p, dense_fwd(st, T, B, p->H2, p->A, a.h2, v + p->o_w3, P, ad.h2, th + p->o_w3, ts, v + p->o_b3, P, nullptr, 0, ad.mu));
+  PCHK(p, dense_fwd(st, T, B, p->S, p->H1, x, v + p->o_w1, P, nullptr, nullptr, 0, v + p->o_b1, P, a.h1, p->act, ad.h1));
+  PCHK(p, dense_fwd(st, T, B, p->H1, p->H2, a.h1, v + p->o_w2, P, ad.h1, th + p->o_w2, ts, v + p->o_b2, P, a.h2, p->act, ad.h2));
+  PCHK(p, dense_fwd(st, T, B, p->H2, p->A, a.h2, v + p->o_w3, P, ad.h2, th + p->o_w3, ts, v + p->o_b3, P, nullptr, ACT_NONE, ad.mu));
   return MI_OK;
 }
 // tangent backward: R{grads} into hv [T][P]; needs primal cotangents dmu, da2 (d2), da1 (d1), tangent acts ad, R{dmu} = rdmu.
 static int mlp_tangent_backward(mi_policy* p, hipStream_t st, int T, int B, const float* x, const float* th, size_t ts,
                                 const Acts& a, const Acts& ad, const float* v, const float* dmu, const float* d2,
-                                const float* d1, const float* rdmu, float* r2, float* r1, float* hv) {
+                                const float* d1, const float* pre2, const float* pre1, const float* rdmu, float* r2, float* r1,
+                                float* hv) {
   const size_t P = p->P;
+  const bool th2 = p->act == ACT_TANH;      // the curvature of tanh adds  -2 h hdot dh  to R{dz}
   PCHK(p, dense_bwd_w(st, T, B, p->H2, p->A, rdmu, a.h2, dmu, ad.h2, hv + p->o_w3, hv + p->o_b3, P));
-  PCHK(p, dense_bwd_x(st, T, B, p->H2, p->A, rdmu, th + p->o_w3, ts, dmu, v + p->o_w3, P, a.h2, r2));
+  PCHK(p, dense_bwd_x(st, T, B, p->H2, p->A, rdmu, th + p->o_w3, ts, dmu, v + p->o_w3, P, a.h2, p->act, r2, nullptr,
+                      th2 ? ad.h2 : nullptr, th2 ? pre2 : nullptr));
   PCHK(p, dense_bwd_w(st, T, B, p->H1, p->H2, r2, a.h1, d2, ad.h1, hv + p->o_w2, hv + p->o_b2, P));
-  PCHK(p, dense_bwd_x(st, T, B, p->H1, p->H2, r2, th + p->o_w2, ts, d2, v + p->o_w2, P, a.h1, r1));
+  PCHK(p, dense_bwd_x(st, T, B, p->H1, p->H2, r2, th + p->o_w2, ts, d2, v + p->o_w2, P, a.h1, p->act, r1, nullptr,
+                      th2 ? ad.h1 : nullptr, th2 ? pre1 : nullptr));
   PCHK(p, dense_bwd_w(st, T, B, p->S, p->H1, r1, x, nullptr, nullptr, hv + p->o_w1, hv + p->o_b1, P));
   return MI_OK;
 }
@@ -358,6 +386,7 @@ static hipError_t gauss(hipStream_t st, int T, GaussArgs& a) {
 struct TrpoPlan {
   Acts sa, qa, ta;                      // support acts at theta, query acts at theta', tangent acts (scratch)
   float *s_dmu, *s_d2, *s_d1, *s_coef;  // support primal cotangents
+  float *s_pre2, *s_pre1;               // ... before the phi' factor (tanh HVP)
   float *q_dmu, *q_d2, *q_d1, *q_coef;
   float *rdmu, *r2, *r1;                // tangent scratch
   float *g, *thetap, *q, *hv, *u, *w, *tmpP;   // [T][P]
@@ -371,6 +400,7 @@ static void trpo_plan(const mi_policy* p, void* ws, int T, int B, TrpoPlan& pl) 
   auto acts = [&](Acts& a) { a.h1 = b.f(TB * p->H1); a.h2 = b.f(TB * p->H2); a.mu = b.f(TB * p->A); };
   acts(pl.sa); acts(pl.qa); acts(pl.ta);
   pl.s_dmu = b.f(TB * p->A); pl.s_d2 = b.f(TB * p->H2); pl.s_d1 = b.f(TB * p->H1); pl.s_coef = b.f(TB);
+  pl.s_pre2 = b.f(TB * p->H2); pl.s_pre1 = b.f(TB * p->H1);
   pl.q_dmu = b.f(TB * p->A); pl.q_d2 = b.f(TB * p->H2); pl.q_d1 = b.f(TB * p->H1); pl.q_coef = b.f(TB);
   pl.rdmu = b.f(TB * p->A); pl.r2 = b.f(TB * p->H2); pl.r1 = b.f(TB * p->H1);
   pl.g = b.f(TP); pl.thetap = b.f(TP); pl.q = b.f(TP); pl.hv = b.f(TP); pl.u = b.f(TP); pl.w = b.f(TP); pl.tmpP = b.f(TP);
@@ -407,13 +437,14 @@ static int support_hvp(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B,
   ga.act = s_actions; ga.count = s_count; ga.coef = pl.s_coef; ga.dmu = pl.rdmu; ga.drho = hv + p->o_sigma; ga.gstride = p->P;
   ga.B = B; ga.A = p->A; ga.mode = G_TANGENT;
   PCHK(p, gauss(st, T, ga));
-  return mlp_tangent_backward(p, st, T, B, s_states, theta, 0, pl.sa, pl.ta, v, pl.s_dmu, pl.s_d2, pl.s_d1, pl.rdmu, pl.r2, pl.r1, hv);
+  return mlp_tangent_backward(p, st, T, B, s_states, theta, 0, pl.sa, pl.ta, v, pl.s_dmu, pl.s_d2, pl.s_d1, pl.s_pre2, pl.s_pre1, pl.rdmu,
+                              pl.r2, pl.r1, hv);
 }
 
 // trpo_update (rl.py:361-374) for a meta-batch: theta_out[t] = theta[t] - lr * grad_t(-mean(logp * adv)).  loss_out [T].
 extern "C" int mi_policy_adapt(mi_policy* p, void* stream, const float* theta, size_t tstride, const float* states,
                                const float* actions, const float* adv, const int32_t* count, int tasks, int batch, float lr,
-                               float* theta_out, float* loss_out, void* workspace, size_t workspace_bytes) {
+                               int head_only, float* theta_out, float* loss_out, void* workspace, size_t workspace_bytes) {
   if (!p || !theta || !states || !actions || !adv || !theta_out || !workspace) return pfail(p, MI_ERR_ARG, "null argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   TrpoPlan pl;
@@ -427,7 +458,7 @@ extern "C" int mi_policy_adapt(mi_policy* p, void* stream, const float* theta, s
   ga.coef = pl.s_coef; ga.dmu = pl.s_dmu; ga.drho = pl.g + p->o_sigma; ga.gstride = p->P; ga.loss = loss_out ? loss_out : pl.loss_t;
   ga.B = batch; ga.A = p->A; ga.mode = G_A2C;
   PCHK(p, gauss(st, tasks, ga));
-  rc = mlp_backward(p, st, tasks, batch, states, theta, tstride, pl.sa, pl.s_dmu, pl.s_d2, pl.s_d1, pl.g);
+  rc = mlp_backward(p, st, tasks, batch, states, theta, tstride, pl.sa, pl.s_dmu, pl.s_d2, pl.s_d1, pl.g, nullptr, nullptr, head_only != 0);
   if (rc) return rc;
   hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)p->P, 256), tasks), dim3(256), 0, st, theta, tstride, pl.g, lr,
                      (int)p->P, theta_out);
@@ -460,7 +491,7 @@ extern "C" int mi_trpo_surrogate(mi_policy* p, void* stream, const float* theta,
   ga.coef = pl.s_coef; ga.dmu = pl.s_dmu; ga.drho = pl.g + p->o_sigma; ga.gstride = P; ga.loss = pl.loss_t;
   ga.B = B; ga.A = p->A; ga.mode = G_A2C;
   PCHK(p, gauss(st, T, ga));
-  rc = mlp_backward(p, st, T, B, s_states, theta, 0, pl.sa, pl.s_dmu, pl.s_d2, pl.s_d1, pl.g);
+  rc = mlp_backward(p, st, T, B, s_states, theta, 0, pl.sa, pl.s_dmu, pl.s_d2, pl.s_d1, pl.g, pl.s_pre2, pl.s_pre1);
   if (rc) return rc;
   hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, theta, (size_t)0, pl.g, inner_lr, (int)P,
                      pl.thetap);

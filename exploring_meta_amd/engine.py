@@ -272,15 +272,17 @@ def flatten_parameters(module):
 class PolicyEngine:
     """ctypes wrapper of the MAML-TRPO policy path (mi_policy_* / mi_trpo_*), batched over tasks."""
 
-    def __init__(self, state_size, action_size, hiddens=(100, 100), device=None):
+    def __init__(self, state_size, action_size, hiddens=(100, 100), device=None, activation='relu'):
         self.lib = _lib.load()
+        if activation not in ('relu', 'tanh'):
+            raise NotImplementedError(f'activation {activation!r}: the reference offers relu and tanh (policies.py:32-37)')
         if not torch.cuda.is_available():
             raise _lib.MiError('PolicyEngine needs a GPU: there is no CPU implementation of the policy path in this package.')
         if len(hiddens) != 2:
             raise ValueError('the HIP policy path implements the reference default: two hidden layers (policies.py:33-34)')
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.S, self.A, self.H = state_size, action_size, tuple(hiddens)
-        desc = _lib.MiPolicyDesc(state_size, action_size, hiddens[0], hiddens[1], 0)
+        desc = _lib.MiPolicyDesc(state_size, action_size, hiddens[0], hiddens[1], int(activation == 'tanh'))
         self._h = C.c_void_p()
         rc = self.lib.mi_policy_create(C.byref(desc), self.device.index or 0, C.byref(self._h))
         if rc:
@@ -317,15 +319,15 @@ class PolicyEngine:
                                                _ptr(loc), _ptr(ws), ws.numel()))
         return loc
 
-    def adapt(self, theta, states, actions, adv, count, lr):
-        """trpo_update for T tasks: returns (theta_out [T, P], loss [T])."""
+    def adapt(self, theta, states, actions, adv, count, lr, head_only=False):
+        """trpo_update for T tasks: returns (theta_out [T, P], loss [T]).  head_only: ANIL inner loop (body under no_grad)."""
         T, B = states.shape[0], states.shape[1]
         ws = self._workspace(T, B)
         out = torch.empty(T, self.param_count, device=self.device)
         loss = torch.empty(T, device=self.device)
         stride = 0 if theta.dim() == 1 else self.param_count
         self._check(self.lib.mi_policy_adapt(self._h, _stream(), _ptr(theta.contiguous()), stride, _ptr(states), _ptr(actions),
-                                             _ptr(adv), _ptr(count), T, B, float(lr), _ptr(out), _ptr(loss), _ptr(ws), ws.numel()))
+                                             _ptr(adv), _ptr(count), T, B, float(lr), int(head_only), _ptr(out), _ptr(loss), _ptr(ws), ws.numel()))
         return out, loss
 
     def surrogate(self, theta, sup, qry, old_loc, old_scale, inner_lr, want_grad):

@@ -183,7 +183,8 @@ int mi_profile_collect(mi_engine* e, double* total_ms, int64_t* count, int n_kin
 typedef struct mi_policy mi_policy;
 typedef struct {
   int32_t state_size, action_size, hidden1, hidden2;
-  int32_t activation; /* 0 = ReLU (DiagNormalPolicy default, policies.py:32-37) */
+  int32_t activation; /* 0 = ReLU (DiagNormalPolicy default), 1 = tanh (activation='tanh', policies.py:32-37; the
+                         DiagNormalPolicyANIL body, policies.py:76) */
 } mi_policy_desc;
 
 int mi_policy_create(const mi_policy_desc* desc, int device, mi_policy** out);
@@ -195,10 +196,12 @@ int mi_trpo_workspace_bytes(const mi_policy* p, int tasks, int batch, size_t* by
 /* density(state).loc (policies.py:49-52) for acting; theta shared (tstride 0) or one vector per task (tstride = P). */
 int mi_policy_forward(mi_policy* p, void* stream, const float* theta, size_t tstride, const float* states, int tasks, int batch,
                       float* loc_out, void* workspace, size_t workspace_bytes);
-/* trpo_update (rl.py:361-374): theta_out[t] = theta[t] - lr * grad_t( a2c.policy_loss = -mean(log_prob * advantages) ). */
+/* trpo_update (rl.py:361-374): theta_out[t] = theta[t] - lr * grad_t( a2c.policy_loss = -mean(log_prob * advantages) ).
+ * head_only != 0: the hidden layers run under no_grad (DiagNormalPolicyANIL.turn_off_body_grads, policies.py:100-106,
+ * rl.py:381-382), so only sigma and the last Linear are updated (learn2learn maml_update skips None gradients). */
 int mi_policy_adapt(mi_policy* p, void* stream, const float* theta, size_t tstride, const float* states, const float* actions,
-                    const float* adv, const int32_t* count, int tasks, int batch, float lr, float* theta_out, float* loss_out,
-                    void* workspace, size_t workspace_bytes);
+                    const float* adv, const int32_t* count, int tasks, int batch, float lr, int head_only, float* theta_out,
+                    float* loss_out, void* workspace, size_t workspace_bytes);
 /* meta_surrogate_loss (rl.py:441-473) with one second-order inner step per task: mean surrogate loss, mean KL(new||old),
  * and (grad_out != NULL) the gradient w.r.t. theta (rl.py:413-416).  old_loc [tasks,batch,A], old_scale [tasks,A] are the
  * stored adapted policies' densities on the query states.  Leaves the context mi_trpo_fvp needs in `workspace`. */

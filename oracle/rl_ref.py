@@ -30,6 +30,34 @@ def policy_param_shapes(input_size=2, output_size=2, hiddens=(100, 100)):
     return shapes
 
 
+def anil_policy_param_shapes(input_size=2, output_size=2, fc_neurons=100, hiddens=(100, 100)):
+    """DiagNormalPolicyANIL (policies.py:70-95) named_parameters() order: the module's own `sigma` first, then body.*, head.*."""
+    shapes = OrderedDict()
+    shapes['sigma'] = (output_size,)
+    sizes = [input_size] + list(hiddens)
+    for i in range(len(sizes) - 1):
+        shapes[f'body.{2 * i}.weight'] = (sizes[i + 1], sizes[i])
+        shapes[f'body.{2 * i}.bias'] = (sizes[i + 1],)
+    shapes['head.weight'] = (output_size, fc_neurons)
+    shapes['head.bias'] = (output_size,)
+    return shapes
+
+
+def anil_as_policy_params(p):
+    """body.{i}.* / head.* -> mean.{i}.* / mean.{last}.*: the ANIL policy is the same MLP with tanh between the layers
+    (forward_pass = head(body(state)), policies.py:100-106); use with activation=torch.tanh."""
+    n_body = sum(1 for k in p if k.startswith('body.') and k.endswith('.weight'))
+    out = OrderedDict()
+    for k, v in p.items():
+        if k.startswith('body.'):
+            out['mean.' + k[len('body.'):]] = v
+        elif k.startswith('head.'):
+            out[f'mean.{2 * n_body}.' + k[len('head.'):]] = v
+        else:
+            out[k] = v
+    return out
+
+
 def policy_loc_scale(p, state, activation=torch.relu):
     """density (policies.py:49-52): loc = MLP(state), scale = exp(clamp(sigma, min=log(EPSILON)))."""
     h = state
@@ -184,7 +212,7 @@ class Particles2D:
         return self.state.copy(), reward, done, self.goal
 
 
-def collect_episodes(env, p, episodes, max_path_length, generator, dtype=torch.float64):
+def collect_episodes(env, p, episodes, max_path_length, generator, dtype=torch.float64, activation=torch.relu):
     """Stand-in for core_functions/runner.py (cherry Runner fork, out of scope): ``episodes`` full episodes of at most
     ``max_path_length`` steps, actions sampled from the policy (policies.py:58-61).  Returns a dict of [N,*] tensors."""
     S, A, Rw, D, NS = [], [], [], [], []
@@ -193,7 +221,7 @@ def collect_episodes(env, p, episodes, max_path_length, generator, dtype=torch.f
             s = env.reset()
             for t in range(max_path_length):
                 st = torch.as_tensor(s, dtype=dtype).view(1, -1)
-                loc, scale = policy_loc_scale(p, st)
+                loc, scale = policy_loc_scale(p, st, activation)
                 a = (loc + scale * torch.randn(loc.shape, generator=generator, dtype=dtype))[0]
                 ns, r, done, _ = env.step(a.numpy().astype(np.float32))
                 last = done or t == max_path_length - 1
@@ -218,44 +246,51 @@ def compute_advantages(baseline, tau, gamma, ep, update_vf=True):
     return generalized_advantage(gamma, tau, ep['rewards'], ep['dones'], bootstraps, torch.zeros(1, dtype=values.dtype))
 
 
-def trpo_a2c_loss(ep, p, baseline, gamma, tau, update_vf=True):
+def trpo_a2c_loss(ep, p, baseline, gamma, tau, update_vf=True, activation=torch.relu):
     """rl.py:346-358"""
-    log_probs = policy_log_prob(p, ep['states'], ep['actions'])
+    log_probs = policy_log_prob(p, ep['states'], ep['actions'], activation)
     adv = normalize(compute_advantages(baseline, tau, gamma, ep, update_vf)).detach()
     return a2c_policy_loss(log_probs, adv)
 
 
-def trpo_update(ep, p, baseline, inner_lr, gamma, tau, first_order=False):
-    """rl.py:361-374: grad (create_graph = second order) + learn2learn maml_update (p <- p - lr g)."""
+def trpo_update(ep, p, baseline, inner_lr, gamma, tau, first_order=False, activation=torch.relu, head_only=False):
+    """rl.py:361-374: grad (create_graph = second order) + learn2learn maml_update (p <- p - lr g).
+    head_only restates DiagNormalPolicyANIL with `features_no_grad` (policies.py:100-106): the hidden layers are evaluated
+    under no_grad, their gradients are None (allow_unused=anil, rl.py:371) and maml_update leaves them unchanged -- pinned by
+    the g5_anil fixtures (gradient with the body switched off)."""
     so = not first_order
-    loss = trpo_a2c_loss(ep, p, baseline, gamma, tau)
+    loss = trpo_a2c_loss(ep, p, baseline, gamma, tau, activation=activation)
     grads = torch.autograd.grad(loss, list(p.values()), retain_graph=so, create_graph=so)
-    return OrderedDict((k, v - inner_lr * g) for (k, v), g in zip(p.items(), grads))
+    last = max(int(k.split('.')[1]) for k in p if k.startswith('mean.'))
+    keep = lambda k: (not head_only) or k == 'sigma' or k.startswith(f'mean.{last}.')
+    return OrderedDict((k, v - inner_lr * g if keep(k) else v) for (k, v), g in zip(p.items(), grads))
 
 
-def fast_adapt_trpo(env, p, baseline, params, generator, first_order=False):
-    """rl.py:377-406 (rollouts through collect_episodes)."""
+def fast_adapt_trpo(env, p, baseline, params, generator, first_order=False, activation=torch.relu, anil=False):
+    """rl.py:377-406 (rollouts through collect_episodes); anil: the inner updates run with the body grads off (:381-382)."""
     replay = []
     for _ in range(params['adapt_steps']):
-        ep = collect_episodes(env, p, params['adapt_batch_size'], params['max_path_length'], generator)
+        ep = collect_episodes(env, p, params['adapt_batch_size'], params['max_path_length'], generator, activation=activation)
         replay.append(ep)
-        p = trpo_update(ep, p, baseline, params['inner_lr'], params['gamma'], params['tau'], first_order=first_order)
-    q = collect_episodes(env, p, params['adapt_batch_size'], params['max_path_length'], generator)
+        p = trpo_update(ep, p, baseline, params['inner_lr'], params['gamma'], params['tau'], first_order=first_order,
+                        activation=activation, head_only=anil)
+    q = collect_episodes(env, p, params['adapt_batch_size'], params['max_path_length'], generator, activation=activation)
     replay.append(q)
-    valid_loss = trpo_a2c_loss(q, p, baseline, params['gamma'], params['tau'], update_vf=False)
+    valid_loss = trpo_a2c_loss(q, p, baseline, params['gamma'], params['tau'], update_vf=False, activation=activation)
     return p, valid_loss, replay, q['rewards'].sum().item() / params['adapt_batch_size']
 
 
-def meta_surrogate_loss(iter_replays, iter_policies, p, baseline, params):
+def meta_surrogate_loss(iter_replays, iter_policies, p, baseline, params, activation=torch.relu):
     """rl.py:441-473"""
     mean_loss, mean_kl = 0.0, 0.0
     for task_replays, old in zip(iter_replays, iter_policies):
         new = OrderedDict((k, v.clone()) for k, v in p.items())               # clone_module
         for ep in task_replays[:-1]:
-            new = trpo_update(ep, new, baseline, params['inner_lr'], params['gamma'], params['tau'], first_order=False)
+            new = trpo_update(ep, new, baseline, params['inner_lr'], params['gamma'], params['tau'], first_order=False,
+                              activation=activation)
         v = task_replays[-1]
-        old_loc, old_scale = policy_loc_scale(old, v['states'])
-        new_loc, new_scale = policy_loc_scale(new, v['states'])
+        old_loc, old_scale = policy_loc_scale(old, v['states'], activation)
+        new_loc, new_scale = policy_loc_scale(new, v['states'], activation)
         mean_kl = mean_kl + normal_kl(new_loc, new_scale, old_loc, old_scale).mean()
         adv = normalize(compute_advantages(baseline, params['tau'], params['gamma'], v)).detach()
         old_lp = normal_log_prob(old_loc, old_scale, v['actions']).mean(dim=1, keepdim=True).detach()
@@ -264,9 +299,9 @@ def meta_surrogate_loss(iter_replays, iter_policies, p, baseline, params):
     return mean_loss / len(iter_replays), mean_kl / len(iter_replays)
 
 
-def meta_optimize_trpo(params, p, baseline, iter_replays, iter_policies):
+def meta_optimize_trpo(params, p, baseline, iter_replays, iter_policies, activation=torch.relu):
     """rl.py:409-438.  ``p``: OrderedDict of leaf tensors (requires_grad); updated in place.  Returns diagnostics."""
-    old_loss, old_kl = meta_surrogate_loss(iter_replays, iter_policies, p, baseline, params)
+    old_loss, old_kl = meta_surrogate_loss(iter_replays, iter_policies, p, baseline, params, activation)
     plist = list(p.values())
     grad = torch.autograd.grad(old_loss, plist, retain_graph=True)
     grad = torch.cat([g.detach().reshape(-1) for g in grad])
@@ -284,7 +319,7 @@ def meta_optimize_trpo(params, p, baseline, iter_replays, iter_policies):
             n = v.numel()
             cand[k] = (v.detach() - stepsize * step[off:off + n].view_as(v)).requires_grad_(True)
             off += n
-        new_loss, kl = meta_surrogate_loss(iter_replays, iter_policies, cand, baseline, params)
+        new_loss, kl = meta_surrogate_loss(iter_replays, iter_policies, cand, baseline, params, activation)
         if new_loss < old_loss and kl < params['max_kl']:
             with torch.no_grad():
                 for k in p:

@@ -31,6 +31,31 @@ def test_policy_log_prob_and_grad_match_reference(golden_small):
     assert np.allclose(torch.cat([x.reshape(-1) for x in g]).numpy(), golden_small['g5_policy_f64_grad'], rtol=1e-9, atol=1e-12)
 
 
+def test_anil_policy_matches_reference(golden_small):
+    """DiagNormalPolicyANIL (tanh body) from the reference: log-prob, and the gradient with the body grads on / off
+    (policies.py:97-106) -- the `head_only` semantics of the oracle's trpo_update."""
+    raw = hash_params(RL.anil_policy_param_shapes(), 23)
+    p = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in RL.anil_as_policy_params(raw).items())
+    assert list(p.keys()) == list(RL.policy_param_shapes().keys())
+    st, ac = torch.from_numpy(golden_small['g5_states']), torch.from_numpy(golden_small['g5_actions'])
+    lp = RL.policy_log_prob(p, st, ac, activation=torch.tanh)
+    for off in (0, 1):
+        assert np.allclose(lp.detach().numpy(), golden_small[f'g5_anil_f64_bodyoff{off}_logp'], rtol=1e-11, atol=1e-13)
+    g = torch.autograd.grad(lp.sum(), list(p.values()))
+    flat = torch.cat([x.reshape(-1) for x in g]).numpy()
+    assert np.allclose(flat, golden_small['g5_anil_f64_bodyoff0_grad'], rtol=1e-9, atol=1e-12)
+    head = np.concatenate([np.ones(v.numel()) if (k == 'sigma' or k.startswith('mean.4.')) else np.zeros(v.numel()) for k, v in p.items()])
+    assert np.allclose(flat * head, golden_small['g5_anil_f64_bodyoff1_grad'], rtol=1e-9, atol=1e-12)
+    # head_only update = that masked gradient
+    ep = dict(states=st, actions=ac, rewards=torch.from_numpy(golden_small['g5_actions'][:, :1]), dones=torch.zeros(64, 1, dtype=torch.float64),
+              next_states=st)
+    ep['dones'][-1] = 1.0
+    new = RL.trpo_update(ep, p, RL.LinearValue(2, 2), 0.1, 0.99, 1.0, first_order=True, activation=torch.tanh, head_only=True)
+    for k in p:
+        moved = not torch.equal(new[k], p[k])
+        assert moved == (k == 'sigma' or k.startswith('mean.4.')), k
+
+
 def test_discount_and_gae():
     r = torch.tensor([[1.0], [1.0], [1.0], [2.0]], dtype=torch.float64)
     d = torch.tensor([[0.0], [1.0], [0.0], [1.0]], dtype=torch.float64)
