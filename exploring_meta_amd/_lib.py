@@ -63,6 +63,10 @@ _SIGS = {
                                C.c_float, C.c_float, C.c_float, C.c_float]),
     'mi_prepare_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mi_input_gram_scratch_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'mi_input_gram': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mi_gram_bn_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mi_stream_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'mi_sample_tasks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p]),

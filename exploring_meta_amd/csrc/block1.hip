@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
   const float* dp_t = a.dp ? a.dp + (size_t)task * p_task : nullptr;
   const float* dpd_t = a.dpd ? a.dpd + (size_t)task * p_task : nullptr;
   float* out_t = a.out ? a.out + (size_t)task * p_task : nullptr;
+  float* zho_t = a.zh_out ? a.zh_out + (size_t)task * p_task : nullptr;
   const int nwin = a.n * HP * WP;
 
   double s0 = 0.0, s1 = 0.0;     // the two per-channel sums of the reduction modes
@@ -186,9 +187,11 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
       const bool on = umax > 0.f;
       if (MODE == B1_FWD) {
         if (wvalid) out_t[poff] = on ? umax : 0.f;
+        if (zho_t && wvalid) zho_t[poff] = zh_at;          // lets the BN-backward reductions run at pooled resolution
       } else if (MODE == B1_TFWD) {
         const float ud = gmd * zh_at + gm * zhd_at + btd;
         if (wvalid) out_t[poff] = on ? ud : 0.f;
+        if (zho_t && wvalid) zho_t[poff] = zhd_at;
       } else {
         const bool ld = wvalid && on;
         const float d = *(ld ? dp_t + poff : mi_zero_word);

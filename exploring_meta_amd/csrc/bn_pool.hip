@@ -402,6 +402,74 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// dgamma / dbeta (and their tangents) of a fused block 1 from pooled-resolution tensors.  The fused forward kernels store
+// zhat (TFWD: its tangent) at every window's argmax; the cotangent dp reaches z only there and only if the maximum passed
+// the ReLU (p > 0), so   dgamma = sum [p>0] dp zhat,  dbeta = sum [p>0] dp,
+//                        R{dgamma} = sum [p>0] (dpd zhat + dp zhatd),  R{dbeta} = sum [p>0] dpd
+// -- the sums block1_kernel<BWD_REDUCE / TBWD_REDUCE> forms after recomputing conv1, here as one streaming pass.
+template <bool TAN>
+__global__ __launch_bounds__(256) void pooled_reduce_kernel(PoolRedArgs a) {
+  __shared__ double red[256 * 8];
+  const int task = blockIdx.y, quads = a.c >> 2, wpb = 256 / quads;
+  const int q = threadIdx.x % quads, rl = threadIdx.x / quads;
+  const size_t base = (size_t)task * a.rows * a.c + 4 * q;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (rl < wpb)
+    for (int row = blockIdx.x * wpb + rl; row < a.rows; row += gridDim.x * wpb) {
+      const size_t off = base + (size_t)row * a.c;
+      float p[4], d[4], zh[4], dd[4], zhd[4];
+      load4(a.p + off, p); load4(a.dp + off, d); load4(a.zh + off, zh);
+      if (TAN) { load4(a.dpd + off, dd); load4(a.zhd + off, zhd); }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool on = p[c] > 0.f;
+        const float dv = on ? d[c] : 0.f;
+        if (!TAN) {
+          s0[c] += (double)dv * (double)zh[c];
+          s1[c] += (double)dv;
+        } else {
+          const float ddv = on ? dd[c] : 0.f;
+          s0[c] += (double)ddv * (double)zh[c] + (double)dv * (double)zhd[c];
+          s1[c] += (double)ddv;
+        }
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    red[threadIdx.x * 8 + c] = s0[c];
+    red[threadIdx.x * 8 + 4 + c] = s1[c];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.c) {
+    const int qq = threadIdx.x >> 2, comp = threadIdx.x & 3;
+    double t0 = 0.0, t1 = 0.0;
+    for (int w = 0; w < wpb; ++w) {
+      t0 += red[(w * quads + qq) * 8 + comp];
+      t1 += red[(w * quads + qq) * 8 + 4 + comp];
+    }
+    double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * a.c;
+    pb[threadIdx.x] = t0;
+    pb[a.c + threadIdx.x] = t1;
+  }
+}
+
+int pooled_reduce_blocks(int rows, int c, int tasks) {
+  const int wpb = 256 / (c / 4);
+  int blocks = ceil_div(rows, wpb);
+  const int cap = ceil_div(2048, tasks);
+  if (blocks > cap) blocks = cap;
+  return blocks < 1 ? 1 : blocks;
+}
+hipError_t launch_pooled_reduce(hipStream_t st, const PoolRedArgs& a, int tasks, int tangent, int* nblk) {
+  if (a.c % 4 || a.c > 256 || 256 % (a.c / 4)) return hipErrorInvalidValue;
+  const int blocks = pooled_reduce_blocks(a.rows, a.c, tasks);
+  if (tangent) hipLaunchKernelGGL(pooled_reduce_kernel<true>, dim3(blocks, tasks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(pooled_reduce_kernel<false>, dim3(blocks, tasks), dim3(256), 0, st, a);
+  *nblk = blocks;
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 int bn_blocks_per_task(int n, int ho, int wo, int c, int pool, int tasks) {
   const int nwin = pool ? n * ((ho + 1) / 2) * ((wo + 1) / 2) : n * ho * wo;
   const int wpb = 256 / (c / 4);

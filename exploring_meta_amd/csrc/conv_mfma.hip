@@ -96,6 +96,10 @@ __device__ __forceinline__ float buf_ld(mi_rsrc r, unsigned off) {
 // MODE 1: dgrad     out[i] = sum_tap in[(i + 1 - d)/S] * W[tap]^T        weights [9][CO_op][CI_op] (the forward layout)
 // waves per workgroup: the 2-term variants stage 2 x 36 KB of weights, so 8 waves share one copy (2 workgroups = 4 waves/SIMD)
 template <int CI, int NTERMS> struct ConvWaves { static constexpr int value = (NTERMS == 2 && CI == 32) ? 8 : 4; };
+// Measured (rocprofv3 SQ counters + hipOccupancy): the 2-term EPI_TSTATS variant takes 178 VGPRs, so one 8-wave workgroup is
+// resident per CU (1.8 waves/SIMD) while the 2-term dgrad (108 VGPRs, two workgroups, 2.9 waves/SIMD) reaches the same 74 % MFMA
+// busy fraction: occupancy is not the limiter.  Forcing <= 128 VGPRs (__launch_bounds__(512, 4)) spills 17 dwords into the
+// main loop and is 13 % slower.
 
 template <int CI, int NTERMS, int EPI, int MODE, int STRIDE>
 __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_mfma_kernel(ConvArgs a) {

@@ -33,6 +33,8 @@ struct mi_engine {
   size_t PS;  // per-task stride of parameter-shaped buffers (P padded so every task's vectors stay 16-B aligned)
   int32_t* perm_dev;
   bool fuse1 = false;   // block 1 runs through the conv-recompute kernels of block1.hip
+  bool gram1 = true;    // ... with the statistics of repeated passes from the input Gram matrix (gram.hip) and the BN-backward
+                        // reductions from zhat stored at the pooling argmax, instead of further conv-recompute passes
   std::string err;
   // optional per-launch HIP-event profiling (bench.py's roofline leg): kind = op*8 + layer
   int prof_on = 0, prof_filter = -1;
@@ -43,11 +45,11 @@ struct mi_engine {
 
 enum ProfOp { OP_CONV_FWD = 0, OP_BN_FINALIZE, OP_BN_FWD, OP_HEAD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_WGRAD, OP_WGRAD_REDUCE,
               OP_DGRAD, OP_TAN_CONV, OP_BN_TAN_FWD, OP_HEAD_TAN, OP_BN_TAN_BWD_REDUCE, OP_BN_TAN_BWD_APPLY, OP_TAN_WGRAD,
-              OP_TAN_DGRAD, OP_MISC, OP_COUNT };
+              OP_TAN_DGRAD, OP_MISC, OP_GRAM, OP_GRAM_STATS, OP_COUNT };
 static const char* kOpNames[OP_COUNT] = {"conv_fwd_stats", "bn_finalize", "bn_relu_pool_fwd", "head_fwd_bwd", "bn_bwd_reduce",
                                          "bn_bwd_apply", "wgrad", "wgrad_reduce", "dgrad", "tangent_conv_fwd", "bn_tangent_fwd",
                                          "head_tangent", "bn_tangent_bwd_reduce", "bn_tangent_bwd_apply", "tangent_wgrad",
-                                         "tangent_dgrad", "misc"};
+                                         "tangent_dgrad", "misc", "input_gram", "gram_stats"};
 
 static bool prof_begin(mi_engine* e, hipStream_t st, int kind) {
   if (!e || !e->prof_on || (e->prof_filter >= 0 && e->prof_filter != kind)) return false;
@@ -169,6 +171,7 @@ extern "C" void mi_engine_destroy(mi_engine* e) {
 extern "C" int mi_engine_set_fused_block1(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->fuse1 = on && block1_supported(e->L[0].ci, e->L[0].stride, e->L[0].pool, e->L[0].ho, e->L[0].wo, e->L[0].co);
+  e->gram1 = on != 2;      // 2 = fused kernels, statistics by conv-recompute passes (no Gram matrix)
   return MI_OK;
 }
 
@@ -192,10 +195,12 @@ struct Bump {
 
 struct ActSet {
   float *z[8], *p[8], *dz[8], *dp[8], *mu[8], *rstd[8];
+  float* zhm;     // fused block 1 with backward: zhat at every pooling window's argmax (same shape as p[0]), else nullptr
   float *f, *df, *prob, *dl;
 };
 struct TanSet {
   float *zd[8], *pd[8], *m1[8], *m2[8];
+  float* zhdm;    // fused block 1: tangent of zhat at the argmax
   float *rdz, *dpd[2], *fd, *rdf;
 };
 struct Plan {
@@ -207,6 +212,7 @@ struct Plan {
   TanSet tan;
   double* bnpart;
   float* wgpart;
+  double *gram_part, *gram_s;   // input Gram matrix of the support images (block 1 statistics), or nullptr
   float *tmp_loss, *tmp_acc;
   float* hscr;   // head scratch: R{dl} [T][n][ways], row loss [T][n], row hit [T][n]
   size_t bytes;
@@ -214,6 +220,7 @@ struct Plan {
 
 static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bool with_bwd) {
   const int nl = (int)e->L.size();
+  A.zhm = nullptr;
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
     const size_t zs = (size_t)T * n * L.ho * L.wo * L.co, ps = (size_t)T * n * L.hp * L.wp * L.co;
@@ -222,6 +229,7 @@ static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bo
     A.p[l] = b.take<float>(ps);
     A.dz[l] = (with_bwd && !fused) ? b.take<float>(zs) : nullptr;
     A.dp[l] = with_bwd ? b.take<float>(ps) : nullptr;
+    if (fused && with_bwd && e->gram1) A.zhm = b.take<float>(ps);
     A.mu[l] = b.take<float>((size_t)T * L.co);
     A.rstd[l] = b.take<float>((size_t)T * L.co);
   }
@@ -276,12 +284,18 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   }
   pl.bnpart = b.take<double>(bnp);
   pl.wgpart = b.take<float>(wgp);
+  pl.gram_part = pl.gram_s = nullptr;
+  if (e->fuse1 && e->gram1 && (K >= 2 || (K >= 1 && second_order))) {   // the support set is swept at least twice
+    pl.gram_part = b.take<double>(gram_partial_doubles(T, ns, e->L[0].h, e->L[0].ci));
+    pl.gram_s = b.take<double>(gram_doubles(T, e->L[0].ci));
+  }
   if (second_order && K > 0) {
     TanSet& X = pl.tan;
     for (int l = 0; l < nl; ++l) {
       const Layer& L = e->L[l];
       X.zd[l] = (l == 0 && e->fuse1) ? nullptr : b.take<float>((size_t)T * ns * L.ho * L.wo * L.co);
       X.pd[l] = b.take<float>((size_t)T * ns * L.hp * L.wp * L.co);
+      if (l == 0) X.zhdm = e->fuse1 ? b.take<float>((size_t)T * ns * L.hp * L.wp * L.co) : nullptr;
       X.m1[l] = b.take<float>((size_t)T * L.co);
       X.m2[l] = b.take<float>((size_t)T * L.co);
     }
@@ -338,7 +352,8 @@ static B1Args b1_args(const mi_engine* e, Plan& pl, ActSet& A, const float* x0, 
 }
 
 // Trunk forward: ConvBlocks on n images per task (conv + BN-stat epilogue, finalize, BN+ReLU+pool).
-static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta) {
+static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
+                         const double* gram = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   for (int l = 0; l < nl; ++l) {
@@ -346,9 +361,14 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
     if (l == 0 && e->fuse1) {
       B1Args ba = b1_args(e, pl, A, x0, n, theta);
       int blk = 0;
-      LAUNCH(e, st, OP_CONV_FWD, 0, launch_block1(st, ba, T, L.ci, B1_STATS, &blk));
-      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / ((double)n * L.ho * L.wo), FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co));
+      if (gram) {   // mean / variance of conv1's output as quadratic forms of this step's weights (gram.hip)
+        LAUNCH(e, st, OP_GRAM_STATS, 0, launch_gram_stats(st, gram, T, L.ci, L.co, theta + L.off_w, P, nullptr, 0, 1.0 / ((double)n * L.ho * L.wo), 0, A.mu[0], A.rstd[0], nullptr, nullptr));
+      } else {
+        LAUNCH(e, st, OP_CONV_FWD, 0, launch_block1(st, ba, T, L.ci, B1_STATS, &blk));
+        LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / ((double)n * L.ho * L.wo), FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co));
+      }
       ba.out = A.p[0];
+      ba.zh_out = A.zhm;
       LAUNCH(e, st, OP_BN_FWD, 0, launch_block1(st, ba, T, L.ci, B1_FWD, nullptr));
       continue;
     }
@@ -385,7 +405,12 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       B1Args b1 = b1_args(e, pl, A, x0, n, theta);
       b1.dp = A.dp[0];
       int blk = 0;
-      LAUNCH(e, st, OP_BN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_BWD_REDUCE, &blk));
+      if (A.zhm) {   // dgamma / dbeta from pooled-resolution tensors (no conv recompute)
+        PoolRedArgs pr{A.p[0], A.zhm, nullptr, A.dp[0], nullptr, pl.bnpart, n * L.hp * L.wp, L.co};
+        LAUNCH(e, st, OP_BN_BWD_REDUCE, 0, launch_pooled_reduce(st, pr, T, 0, &blk));
+      } else {
+        LAUNCH(e, st, OP_BN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_BWD_REDUCE, &blk));
+      }
       LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
       b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
       LAUNCH(e, st, OP_WGRAD, 0, launch_block1(st, b1, T, L.ci, B1_BWD_WGRAD, &blk));
@@ -452,9 +477,10 @@ static int head_pass(mi_engine* e, hipStream_t st, float* hscr, const float* f, 
 
 // One forward (+ backward) pass of the whole net on n images per task.
 static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, const int32_t* y, int n, int T,
-                        const float* theta, float* g, float* loss, float* acc, float* logits, bool with_grad) {
+                        const float* theta, float* g, float* loss, float* acc, float* logits, bool with_grad,
+                        const double* gram = nullptr) {
   const int nl = (int)e->L.size();
-  int rc = trunk_forward(e, st, pl, A, x0, n, T, theta);
+  int rc = trunk_forward(e, st, pl, A, x0, n, T, theta, gram);
   if (rc) return rc;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
   if (with_grad) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * e->PS * sizeof(float), st));
@@ -466,7 +492,7 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
 
 // hv = H(theta) v for the saved support pass A (activations) / g (its gradient): forward-over-reverse.
 static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
-                    const float* g, const float* v, float* hv) {
+                    const float* g, const float* v, float* hv, const double* gram = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   TanSet& X = pl.tan;
@@ -478,11 +504,16 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       B1Args b1 = b1_args(e, pl, A, x0, n, theta);
       b1.wd = v + L.off_w; b1.vstride = P;
       int blk = 0;
-      LAUNCH(e, st, OP_TAN_CONV, 0, launch_block1(st, b1, T, L.ci, B1_TSTATS, &blk));
-      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[0], L.co, X.m2[0], L.co));
+      if (gram) {
+        LAUNCH(e, st, OP_GRAM_STATS, 0, launch_gram_stats(st, gram, T, L.ci, L.co, theta + L.off_w, P, v + L.off_w, P, 1.0 / (double)mpix, 1, X.m1[0], X.m2[0], A.mu[0], A.rstd[0]));
+      } else {
+        LAUNCH(e, st, OP_TAN_CONV, 0, launch_block1(st, b1, T, L.ci, B1_TSTATS, &blk));
+        LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[0], L.co, X.m2[0], L.co));
+      }
       b1.m1 = X.m1[0]; b1.m2 = X.m2[0];
       b1.gammad = v + L.off_gamma; b1.betad = v + L.off_beta;
       b1.out = X.pd[0];
+      b1.zh_out = A.zhm ? X.zhdm : nullptr;
       LAUNCH(e, st, OP_BN_TAN_FWD, 0, launch_block1(st, b1, T, L.ci, B1_TFWD, nullptr));
       continue;
     }
@@ -535,7 +566,12 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
       b1.dp = A.dp[0]; b1.dpd = X.dpd[cur];
       int blk = 0;
-      LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_REDUCE, &blk));
+      if (A.zhm) {
+        PoolRedArgs pr{A.p[0], A.zhm, X.zhdm, A.dp[0], X.dpd[cur], pl.bnpart, n * L.hp * L.wp, L.co};
+        LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, 0, launch_pooled_reduce(st, pr, T, 1, &blk));
+      } else {
+        LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_REDUCE, &blk));
+      }
       LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
       b1.rdgamma = hv + L.off_gamma; b1.rdbeta = hv + L.off_beta; b1.hstride = P;
       LAUNCH(e, st, OP_TAN_WGRAD, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_WGRAD, &blk));
@@ -601,11 +637,13 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
   const size_t TP = (size_t)T * e->PS;
   LAUNCH(e, st, OP_MISC, 0, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
+  if (pl.gram_s)
+    LAUNCH(e, st, OP_GRAM, 0, launch_input_gram(st, pl.xs, T, ns, e->L[0].h, e->L[0].w, e->L[0].ci, pl.gram_part, pl.gram_s));
   for (int k = 0; k < K; ++k) {
     ActSet& A = so ? pl.sup[k] : pl.sup[0];
     float* th = pl.theta + (size_t)k * TP;
     float* gk = pl.g + (size_t)k * TP;
-    int rc = pass_fwd_bwd(e, st, pl, A, pl.xs, pl.ys, ns, T, th, gk, pl.tmp_loss, pl.tmp_acc, nullptr, true);
+    int rc = pass_fwd_bwd(e, st, pl, A, pl.xs, pl.ys, ns, T, th, gk, pl.tmp_loss, pl.tmp_acc, nullptr, true, pl.gram_s);
     if (rc) return rc;
     LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, th, gk, inner_lr, TP, th + TP));
   }
@@ -615,7 +653,7 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
   if (!with_grad) return MI_OK;
   if (so) {
     for (int k = K - 1; k >= 0; --k) {
-      rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, T, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv);
+      rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, T, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv, pl.gram_s);
       if (rc) return rc;
       LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, pl.lam, pl.hv, inner_lr, TP, pl.lam));
     }
@@ -874,6 +912,26 @@ extern "C" int mi_prepare_batch(void* stream, const float* data, const int64_t* 
                                 float* xs, float* xq, int32_t* ys, int32_t* yq) {
   if (n2 % 2) return fail(nullptr, MI_ERR_ARG, "task batch must hold 2*shots*ways rows");
   HIPCHK0(launch_prepare_batch(reinterpret_cast<hipStream_t>(stream), data, labels, tasks, n2, c, h, w, xs, xq, ys, yq));
+  return MI_OK;
+}
+
+// Input Gram matrix of block 1 and BatchNorm statistics of conv1 from it (gram.hip); unit-test entry points.
+extern "C" size_t mi_input_gram_scratch_bytes(int tasks, int n, int h, int ci) {
+  return gram_partial_doubles(tasks, n, h, ci) * sizeof(double);
+}
+extern "C" int mi_input_gram(void* stream, const float* x, int tasks, int n, int h, int w, int ci, void* scratch,
+                             size_t scratch_bytes, double* g_out) {
+  if (!x || !scratch || !g_out || (ci != 1 && ci != 3)) return fail(nullptr, MI_ERR_ARG, "mi_input_gram: bad arguments (ci must be 1 or 3)");
+  if (scratch_bytes < mi_input_gram_scratch_bytes(tasks, n, h, ci)) return fail(nullptr, MI_ERR_WORKSPACE, "mi_input_gram: scratch too small");
+  HIPCHK0(launch_input_gram(reinterpret_cast<hipStream_t>(stream), x, tasks, n, h, w, ci, static_cast<double*>(scratch), g_out));
+  return MI_OK;
+}
+extern "C" int mi_gram_bn_stats(void* stream, const double* g, int tasks, int ci, int co, const float* w9, size_t pstride,
+                                const float* w9d, size_t vstride, int pixels, float* out0, float* out1, const float* mu,
+                                const float* rstd) {
+  if (!g || !w9 || !out0 || !out1 || (w9d && (!mu || !rstd))) return fail(nullptr, MI_ERR_ARG, "mi_gram_bn_stats: bad arguments");
+  HIPCHK0(launch_gram_stats(reinterpret_cast<hipStream_t>(stream), g, tasks, ci, co, w9, pstride, w9d, vstride, 1.0 / (double)pixels,
+                            w9d ? 1 : 0, out0, out1, mu, rstd));
   return MI_OK;
 }
 

@@ -45,6 +45,20 @@ struct BnArgs {
 
 enum { FIN_STATS = 0, FIN_TSTATS = 1, FIN_SUMS = 2 };
 
+// BatchNorm-backward reductions of a fused block 1 from pooled-resolution tensors (bn_pool.hip): the forward kernels leave
+// zhat (and its tangent) at every window's argmax next to the pooled output, so dgamma/dbeta need no conv recompute.
+struct PoolRedArgs {
+  const float* p;       // [T][rows][c] pooled output (p > 0 <=> the window's maximum passed the ReLU)
+  const float* zh;      // zhat at the argmax
+  const float* zhd;     // tangent of zhat at the argmax (tangent mode)
+  const float* dp;      // cotangent of p
+  const float* dpd;     // tangent of that cotangent (tangent mode)
+  double* partial;      // [T][nblk][2][c]
+  int rows, c;
+};
+int pooled_reduce_blocks(int rows, int c, int tasks);
+hipError_t launch_pooled_reduce(hipStream_t st, const PoolRedArgs& a, int tasks, int tangent, int* nblk);
+
 // conv_mfma.hip
 hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int epi, int mode, int* blocks_per_task);
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out);
@@ -75,6 +89,7 @@ struct B1Args {
   const float *rdgamma, *rdbeta; size_t hstride;
   const float* dp; const float* dpd;      // [T][n][H/2][W/2][Co]
   float* out;                // p or pd
+  float* zh_out;             // optional: zhat (FWD) / its tangent (TFWD) at each window's argmax, same shape as out
   double* partial;           // [T][blocks][2][Co]
   float* wpartial;           // [T][blocks][9*Ci0][Co]
   int n, hh, ww, co;         // images per task, conv output height / width (= input, stride 1), filters
@@ -85,6 +100,15 @@ enum { B1_STATS = 0, B1_FWD = 1, B1_BWD_REDUCE = 2, B1_BWD_WGRAD = 3, B1_TSTATS 
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co);
 int block1_blocks_per_task(int n, int h, int w, int co, int tasks);
 hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task);
+
+// gram.hip: input Gram matrix of block 1 (BatchNorm statistics of conv1 as quadratic forms of the weights)
+int gram_blocks_per_task(int n, int h);
+size_t gram_partial_doubles(int tasks, int n, int h, int ci);
+size_t gram_doubles(int tasks, int ci);
+hipError_t launch_input_gram(hipStream_t st, const float* x, int tasks, int n, int h, int w, int ci, double* partial, double* g);
+hipError_t launch_gram_stats(hipStream_t st, const double* g, int tasks, int ci, int co, const float* w, size_t wstride,
+                             const float* wd, size_t vstride, double inv_m, int tangent, float* out0, float* out1,
+                             const float* mu, const float* rstd);
 
 // head.hip
 struct HeadArgs {

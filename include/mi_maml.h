@@ -50,7 +50,9 @@ const char* mi_last_error(const mi_engine* e);
 const char* mi_version(void);
 
 /* Ablation/test switch: 0 = block 1 through the generic (z-storing) kernels, 1 = fused conv-recompute kernels (default when
- * the geometry allows: Ci in {1,3}, stride-1 conv + pooling, even H/W). */
+ * the geometry allows: Ci in {1,3}, stride-1 conv + pooling, even H/W) with the BatchNorm statistics of repeated support
+ * passes taken from the input Gram matrix (mi_input_gram) and the BatchNorm-backward reductions from zhat kept at the pooling
+ * argmax, 2 = fused kernels only: every statistic / reduction by a conv-recompute pass. */
 int mi_engine_set_fused_block1(mi_engine* e, int on);
 
 /* Debug/test aid: byte offsets of {theta, g, xs, sup[0].p[0], sup[0].dp[0], sup[0].mu[0], sup[0].rstd[0], sup[0].p[1],
@@ -131,6 +133,19 @@ int mi_adam_step(void* stream, float* theta, const float* grad, float* exp_avg, 
 /* utils/data_pre.py:115-129 prepare_batch: even rows -> support, odd rows -> query, NCHW -> NHWC, labels -> int32. */
 int mi_prepare_batch(void* stream, const float* data, const int64_t* labels, int tasks, int n2, int c, int h, int w,
                      float* xs, float* xq, int32_t* ys, int32_t* yq);
+
+/* Block-1 statistics without running conv1 (gram.hip): conv1's output is linear in its weights, so BatchNorm's per-channel
+ * sums are quadratic forms of G = P^T P, P = the zero-padded 3x3xCi patches of the images (+ a constant-one column).
+ *   mi_input_gram: x [tasks,n,H,W,ci] NHWC (ci = 1 or 3) -> g_out [tasks, NG, NG] fp64, NG = 32 (ci=3) / 16 (ci=1);
+ *     entry (a, b) for a,b < 9ci = sum over pixels of patch_a * patch_b (a = tap*ci + c), row/column 9ci = the patch sums.
+ *   mi_gram_bn_stats: w9d == NULL -> out0 = mean, out1 = 1/sqrt(biased var + eps) of conv3x3(x, w9) over `pixels` = n*H*W
+ *     positions (what mi_conv3x3_bn_stats finalises); w9d != NULL -> out0 = mean(zd), out1 = mean(zhat * zd) for the tangent
+ *     zd = conv3x3(x, w9d), zhat = (z - mu) * rstd (the statistics of the tangent BatchNorm). */
+size_t mi_input_gram_scratch_bytes(int tasks, int n, int h, int ci);
+int mi_input_gram(void* stream, const float* x, int tasks, int n, int h, int w, int ci, void* scratch, size_t scratch_bytes,
+                  double* g_out);
+int mi_gram_bn_stats(void* stream, const double* g, int tasks, int ci, int co, const float* w9, size_t pstride, const float* w9d,
+                     size_t vstride, int pixels, float* out0, float* out1, const float* mu, const float* rstd);
 
 /* Device-to-device streaming copy (bytes % 16 == 0): the kernel bench.py uses to measure the achievable HBM bandwidth in the
  * same run as the engine kernels ("measured HBM roofline"). */

@@ -143,24 +143,28 @@ def test_adam_matches_torch():
 
 
 def test_fused_block1_matches_generic_kernels():
-    """The conv-recompute kernels of block 1 (block1.hip, all 8 modes) against the generic conv / BN / wgrad kernels on the same
-    inputs: second-order K=2 exercises stats, forward, backward-reduce, backward+wgrad and their four tangent versions."""
+    """Block 1 three ways on the same inputs: 1 = conv-recompute kernels with Gram-matrix statistics and pooled-resolution
+    BN-backward reductions (gram.hip, pooled_reduce_kernel), 2 = conv-recompute kernels for everything (block1.hip, all 8 modes),
+    0 = the generic conv / BN / wgrad kernels.  Second-order K=2 exercises stats, forward, backward-reduce, backward+wgrad and
+    their four tangent versions."""
     spec, mspec = _spec('min', 5)
     theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
     data, labels = synthetic.make_meta_batch('min', [0, 1, 2], 5, 1)
     d, l = torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda()
     outs = []
-    for fused in (1, 0):
+    for fused in (1, 2, 0):
         eng = MetaEngine(mspec)
         eng.set_fused_block1(fused)
         loss, acc, grad, logits = eng.meta_batch(theta, d, l, 1, 2, 0.1, first_order=False, return_logits=True)
         torch.cuda.synchronize()
         outs.append((loss.cpu().numpy(), acc.cpu().numpy(), grad.cpu().numpy(), logits.cpu().numpy()))
-    e = rel_err(outs[0][2], outs[1][2])
-    report('fused_block1_vs_generic', grad_rel=e, loss_fused=[float(x) for x in outs[0][0]], loss_generic=[float(x) for x in outs[1][0]])
-    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-5) and np.array_equal(outs[0][1], outs[1][1])
-    assert np.allclose(outs[0][3], outs[1][3], rtol=1e-4, atol=1e-4)
-    assert e < 1e-4
+    e, e2 = rel_err(outs[0][2], outs[2][2]), rel_err(outs[1][2], outs[2][2])
+    report('fused_block1_vs_generic', grad_rel=e, grad_rel_recompute_only=e2, loss_fused=[float(x) for x in outs[0][0]],
+           loss_generic=[float(x) for x in outs[2][0]])
+    for o in outs[:2]:
+        assert np.allclose(o[0], outs[2][0], rtol=1e-5) and np.array_equal(o[1], outs[2][1])
+        assert np.allclose(o[3], outs[2][3], rtol=1e-4, atol=1e-4)
+    assert e < 1e-4 and e2 < 1e-4
 
 
 @pytest.mark.parametrize('dataset,ways,shots,K,fo,tasks', [

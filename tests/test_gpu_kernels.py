@@ -200,3 +200,57 @@ def test_head_fwd_bwd(lib, T, n, feat, ways):
         assert acc[t].item() == ar.item()
     report(f'head[{T},{n},{feat},{ways}]', **errs)
     assert errs['loss'] < 2e-6 and errs['logits'] < 5e-6 and errs['dwl'] < 5e-6 and errs['dbl'] < 5e-6 and errs['df'] < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------- block-1 statistics from the input Gram matrix
+def _patches(x, ci):
+    """x [n,H,W,ci] -> P [n*H*W, 9*ci] zero-padded 3x3 patches, entry a = tap*ci + c (the weight-row order)."""
+    n, H, W, _ = x.shape
+    xp = np.zeros((n, H + 2, W + 2, ci), np.float64)
+    xp[:, 1:-1, 1:-1] = x
+    cols = [xp[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)]
+    return np.concatenate(cols, axis=-1).reshape(n * H * W, 9 * ci)
+
+
+@pytest.mark.parametrize('name,T,n,h,w,ci,co,lo,hi', [('min', 2, 3, 84, 84, 3, 32, 0.0, 255.0), ('omni_like', 3, 5, 28, 28, 1, 64, 0.0, 1.0),
+                                                       ('odd_w', 1, 2, 10, 14, 3, 32, -1.0, 1.0), ('tiny', 2, 1, 4, 6, 1, 32, 0.0, 2.0)])
+def test_input_gram_and_stats(lib, name, T, n, h, w, ci, co, lo, hi):
+    x = _rand(21, (T, n, h, w, ci), lo, hi).astype(np.float32)
+    # weights with a large DC component: |mean z| >> std z, the case where E[z^2] - mean^2 cancels (block1.hip comment)
+    w9 = (_rand(22, (T, 9, ci, co), -0.05, 0.05) + 0.3).astype(np.float32)
+    w9d = _rand(23, (T, 9, ci, co), -1.0, 1.0).astype(np.float32)
+    ng = 32 if ci == 3 else 16
+    kp = 9 * ci
+    xd = dev(x)
+    sb = lib.mi_input_gram_scratch_bytes(T, n, h, ci)
+    scratch = torch.empty(sb, dtype=torch.uint8, device='cuda')
+    g = torch.full((T, ng, ng), float('nan'), dtype=torch.float64, device='cuda')
+    _lib.check(lib.mi_input_gram(stream(), ptr(xd), T, n, h, w, ci, ptr(scratch), sb, ptr(g)))
+    pstride = kp * co + 5
+    wbuf, vbuf = np.zeros((T, pstride), np.float32), np.zeros((T, pstride), np.float32)
+    wbuf[:, :kp * co], vbuf[:, :kp * co] = w9.reshape(T, -1), w9d.reshape(T, -1)
+    wd_, vd_ = dev(wbuf), dev(vbuf)
+    mu, rstd, m1, m2 = (torch.empty(T, co, device='cuda') for _ in range(4))
+    M = n * h * w
+    _lib.check(lib.mi_gram_bn_stats(stream(), ptr(g), T, ci, co, ptr(wd_), pstride, None, 0, M, ptr(mu), ptr(rstd), None, None))
+    _lib.check(lib.mi_gram_bn_stats(stream(), ptr(g), T, ci, co, ptr(wd_), pstride, ptr(vd_), pstride, M, ptr(m1), ptr(m2), ptr(mu), ptr(rstd)))
+    torch.cuda.synchronize()
+    gh = g.cpu().numpy()
+    worst = {}
+    for t in range(T):
+        P = _patches(x[t].astype(np.float64), ci)
+        Pe = np.concatenate([P, np.ones((M, 1))], axis=1)
+        G = Pe.T @ Pe
+        assert np.allclose(gh[t, :kp + 1, :kp + 1], G, rtol=1e-12, atol=1e-9 * np.abs(G).max())
+        assert np.all(gh[t, kp + 1:, :] == 0.0) and np.all(gh[t, :, kp + 1:] == 0.0)
+        z = P @ w9[t].reshape(kp, co).astype(np.float64)
+        zd = P @ w9d[t].reshape(kp, co).astype(np.float64)
+        mean, var = z.mean(0), z.var(0)
+        r = 1.0 / np.sqrt(var + 1e-5)
+        mu_t, r_t = mu[t].cpu().numpy().astype(np.float64), rstd[t].cpu().numpy().astype(np.float64)
+        zh = (z - mu_t) * r_t
+        for k, (got, want, scale) in {'mu': (mu_t, mean, np.sqrt(var)), 'rstd': (r_t, r, r), 'm1': (m1[t].cpu().numpy(), zd.mean(0), zd.std(0)),
+                                      'm2': (m2[t].cpu().numpy(), (zh * zd).mean(0), zd.std(0))}.items():
+            worst[k] = max(worst.get(k, 0.0), float(np.max(np.abs(got - want) / scale)))
+    report(f'gram_stats[{name}]', **worst)
+    assert worst['mu'] < 1e-6 and worst['rstd'] < 1e-6 and worst['m1'] < 1e-6 and worst['m2'] < 1e-6
