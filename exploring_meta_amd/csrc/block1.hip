@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
   const float* dpd_t = a.dpd ? a.dpd + (size_t)task * p_task : nullptr;
   float* out_t = a.out ? a.out + (size_t)task * p_task : nullptr;
   float* zho_t = a.zh_out ? a.zh_out + (size_t)task * p_task : nullptr;
+  uint8_t* ago_t = (MODE == B1_FWD && a.arg_out) ? a.arg_out + (size_t)task * p_task : nullptr;
   const int nwin = a.n * HP * WP;
 
   double s0 = 0.0, s1 = 0.0;     // the two per-channel sums of the reduction modes
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
       if (MODE == B1_FWD) {
         if (wvalid) out_t[poff] = on ? umax : 0.f;
         if (zho_t && wvalid) zho_t[poff] = zh_at;          // lets the BN-backward reductions run at pooled resolution
+        if (ago_t && wvalid) ago_t[poff] = (uint8_t)(on ? arg : 4);   // ... and the weight gradient find du without conv1
       } else if (MODE == B1_TFWD) {
         const float ud = gmd * zh_at + gm * zhd_at + btd;
         if (wvalid) out_t[poff] = on ? ud : 0.f;

@@ -196,6 +196,7 @@ struct Bump {
 struct ActSet {
   float *z[8], *p[8], *dz[8], *dp[8], *mu[8], *rstd[8];
   float* zhm;     // fused block 1 with backward: zhat at every pooling window's argmax (same shape as p[0]), else nullptr
+  uint8_t* arg0;  // ... and the argmax position itself (4 = did not pass the ReLU)
   float *f, *df, *prob, *dl;
 };
 struct TanSet {
@@ -221,6 +222,7 @@ struct Plan {
 static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bool with_bwd) {
   const int nl = (int)e->L.size();
   A.zhm = nullptr;
+  A.arg0 = nullptr;
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
     const size_t zs = (size_t)T * n * L.ho * L.wo * L.co, ps = (size_t)T * n * L.hp * L.wp * L.co;
@@ -229,7 +231,7 @@ static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bo
     A.p[l] = b.take<float>(ps);
     A.dz[l] = (with_bwd && !fused) ? b.take<float>(zs) : nullptr;
     A.dp[l] = with_bwd ? b.take<float>(ps) : nullptr;
-    if (fused && with_bwd && e->gram1) A.zhm = b.take<float>(ps);
+    if (fused && with_bwd && e->gram1) { A.zhm = b.take<float>(ps); A.arg0 = b.take<uint8_t>(ps); }
     A.mu[l] = b.take<float>((size_t)T * L.co);
     A.rstd[l] = b.take<float>((size_t)T * L.co);
   }
@@ -276,7 +278,12 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
     const size_t need = (size_t)T * blk * 2 * L.co;
     if (need > bnp) bnp = need;
     size_t w = wgrad_partial_floats(gg, T);
-    if (l == 0 && e->fuse1) w = (size_t)T * block1_blocks_per_task(nmax, L.ho, L.wo, L.co, T) * 9 * L.ci * L.co;
+    if (l == 0 && e->fuse1) {
+      int bpt = block1_blocks_per_task(nmax, L.ho, L.wo, L.co, T);
+      const int sb = sparse_wgrad_blocks_per_task(nmax, L.ho, L.wo, L.co, T);
+      if (sb > bpt) bpt = sb;
+      w = (size_t)T * bpt * 9 * L.ci * L.co;
+    }
     if (w > wgp) wgp = w;
     const size_t zs = (l == 0 && e->fuse1) ? 0 : (size_t)T * nmax * L.ho * L.wo * L.co, ps = (size_t)T * nmax * L.hp * L.wp * L.co;
     if (zs > zmax) zmax = zs;
@@ -369,6 +376,7 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
       }
       ba.out = A.p[0];
       ba.zh_out = A.zhm;
+      ba.arg_out = A.arg0;
       LAUNCH(e, st, OP_BN_FWD, 0, launch_block1(st, ba, T, L.ci, B1_FWD, nullptr));
       continue;
     }
@@ -395,7 +403,7 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
 
 // Trunk backward from A.dp[last] (gradient w.r.t. the last block's output): writes gamma/beta/conv-weight gradients into g.
 static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
-                          float* g) {
+                          float* g, const double* gram = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;
   for (int l = nl - 1; l >= 0; --l) {
@@ -413,6 +421,18 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       }
       LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
       b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
+      if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci)) {   // sparse part on the matrix pipe, dense parts from the Gram matrix: no conv recompute
+        SparseWgArgs sw{};
+        sw.x = x0; sw.arg = A.arg0; sw.dp = A.dp[0]; sw.wpartial = pl.wgpart; sw.n = n; sw.hh = L.ho; sw.ww = L.wo; sw.co = L.co;
+        LAUNCH(e, st, OP_WGRAD, 0, launch_sparse_wgrad(st, sw, T, L.ci, 0, &blk));
+        GramWgArgs gw{};
+        gw.g = gram; gw.spartial = pl.wgpart; gw.nblk = blk; gw.w = theta + L.off_w; gw.wstride = P;
+        gw.mu = A.mu[0]; gw.rstd = A.rstd[0]; gw.gamma = theta + L.off_gamma; gw.pstride = P;
+        gw.dgamma = g + L.off_gamma; gw.dbeta = g + L.off_beta; gw.gstride = P;
+        gw.out = g + L.off_w; gw.ostride = P; gw.ci = L.ci; gw.co = L.co; gw.inv_m = 1.0 / (double)mpix;
+        LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_gram_wgrad(st, gw, T, 0));
+        continue;
+      }
       LAUNCH(e, st, OP_WGRAD, 0, launch_block1(st, b1, T, L.ci, B1_BWD_WGRAD, &blk));
       LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_wgrad_reduce(st, pl.wgpart, blk, 9 * L.ci * L.co, T, g + L.off_w, P));
       continue;
@@ -487,7 +507,7 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
   rc = head_pass(e, st, pl.hscr, A.f, y, n, T, theta, g, loss, acc, logits, A.prob, A.dl, A.df, with_grad);
   if (rc || !with_grad) return rc;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], T * n, e->head_hw, e->head_c));
-  return trunk_backward(e, st, pl, A, x0, n, T, theta, g);
+  return trunk_backward(e, st, pl, A, x0, n, T, theta, g, gram);
 }
 
 // hv = H(theta) v for the saved support pass A (activations) / g (its gradient): forward-over-reverse.
@@ -574,6 +594,22 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       }
       LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
       b1.rdgamma = hv + L.off_gamma; b1.rdbeta = hv + L.off_beta; b1.hstride = P;
+      if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci)) {
+        SparseWgArgs sw{};
+        sw.x = x0; sw.arg = A.arg0; sw.dp = A.dp[0]; sw.dpd = X.dpd[cur]; sw.rstd = A.rstd[0]; sw.m2 = X.m2[0];
+        sw.gamma = theta + L.off_gamma; sw.pstride = P; sw.gammad = v + L.off_gamma; sw.vstride = P;
+        sw.wpartial = pl.wgpart; sw.n = n; sw.hh = L.ho; sw.ww = L.wo; sw.co = L.co;
+        LAUNCH(e, st, OP_TAN_WGRAD, 0, launch_sparse_wgrad(st, sw, T, L.ci, 1, &blk));
+        GramWgArgs gw{};
+        gw.g = gram; gw.spartial = pl.wgpart; gw.nblk = blk; gw.w = theta + L.off_w; gw.wstride = P; gw.wd = v + L.off_w; gw.vstride = P;
+        gw.mu = A.mu[0]; gw.rstd = A.rstd[0]; gw.m1 = X.m1[0]; gw.m2 = X.m2[0];
+        gw.gamma = theta + L.off_gamma; gw.pstride = P; gw.gammad = v + L.off_gamma;
+        gw.dgamma = g + L.off_gamma; gw.dbeta = g + L.off_beta; gw.gstride = P;
+        gw.rdgamma = hv + L.off_gamma; gw.rdbeta = hv + L.off_beta; gw.hstride = P;
+        gw.out = hv + L.off_w; gw.ostride = P; gw.ci = L.ci; gw.co = L.co; gw.inv_m = 1.0 / (double)mpix;
+        LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_gram_wgrad(st, gw, T, 1));
+        continue;
+      }
       LAUNCH(e, st, OP_TAN_WGRAD, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_WGRAD, &blk));
       LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_wgrad_reduce(st, pl.wgpart, blk, 9 * L.ci * L.co, T, hv + L.off_w, P));
       continue;

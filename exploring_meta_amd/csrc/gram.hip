@@ -165,6 +165,235 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Sparse part of the block-1 weight gradient.  The cotangent du of BN+ReLU+max-pool reaches the conv output at ONE position per
+// pooling window and channel (the argmax, if it passed the ReLU); block1_kernel<FWD> left that position in `arg`.
+//   S[k][co] = sum over windows of patch_k(pixel of window at position arg[co]) * cot[window][co]
+// as four masked MFMA accumulations (one per position q): A operand = patch entries of the window's q-th pixel (lane = entry k,
+// two windows per K step), B operand = cot where arg == q else 0.  cot = dp (primal) or c1 dp + gr dpd (tangent, the sparse
+// part of R{dz}).  No BatchNorm arithmetic, no conv: 64 MFMAs per 32 windows against 124 in block1_kernel<*_WGRAD>.
+template <int CI0, bool TAN>
+__global__ __launch_bounds__(256) void sparse_wgrad_kernel(SparseWgArgs a) {
+  constexpr int K = 9 * CI0;
+  // LDS: per wave the 4 input rows a pooled row touches, [4][RP] with a zero halo pixel left and right; the pitch is padded to
+  // 12 (mod 32) floats so the three tap rows land on disjoint banks.  The cross-wave reduction at the end re-uses the buffer.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y, ct = blockIdx.z, cbase = ct * 32, ch = cbase + j;
+  const int H = a.hh, W = a.ww, HP = H >> 1, WP = W >> 1, CO = a.co;
+  const int RP = a.row_pitch, ROWF = W * CI0;
+  float* rows = lds + wave * 4 * RP;
+  const float* x_t = a.x + (size_t)task * a.n * H * W * CI0;
+  const size_t p_task = (size_t)a.n * HP * WP * CO;
+  const uint8_t* arg_t = a.arg + (size_t)task * p_task;
+  const float* dp_t = a.dp + (size_t)task * p_task;
+  const float* dpd_t = TAN ? a.dpd + (size_t)task * p_task : nullptr;
+  // A-operand role of this lane: patch entry k = j (tap, channel); lanes j >= K feed zeros (they read a halo zero)
+  const bool kval = j < K;
+  const int tap = kval ? j / CI0 : 0, kc = kval ? j % CI0 : 0;
+  const int kdy = tap / 3 - 1, kdx = tap % 3 - 1;
+  // LDS offset of pixel (qy = 0, qx = 0) of window 0 for this lane's tap: row (kdy + 1), column (kdx + 1) pixels incl. the halo
+  const int aoff = kval ? (kdy + 1) * RP + (kdx + 1) * CI0 + kc : 0;
+  // B-operand role: output channel ch
+  float sA = 1.f, sB = 0.f;
+  if (TAN) {
+    const float rs = a.rstd[(size_t)task * CO + ch], gm = a.gamma[(size_t)task * a.pstride + ch];
+    sA = a.gammad[(size_t)task * a.vstride + ch] * rs + gm * (-rs * rs * a.m2[(size_t)task * CO + ch]);   // c1
+    sB = gm * rs;                                                                                             // gr
+  }
+  floatx16 acc, acc2;          // two accumulation chains: consecutive MFMAs never wait for each other's result
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+  for (int e = lane; e < 4 * RP; e += 64) rows[e] = 0.f;      // halos (and padding) stay zero for the whole kernel
+
+  // one tile = one pooled row (img, wy): WP windows, ceil(WP / 2) K steps of two windows
+  const int nsteps = (WP + 1) >> 1;
+  const int tile_base = blockIdx.x * 4 * a.tiles_per_wave;
+  const int tile_end = min(tile_base + 4 * a.tiles_per_wave, a.ntiles);
+  // Latency is hidden by the wave itself: the next tile's input rows travel in registers while this tile computes, and the B
+  // operands (arg, dp, dpd) are fetched one chunk of CH K-steps ahead.
+  constexpr int CH = 8, RL = 4;                       // RL * 64 >= W * CI0 (checked by the launcher)
+  float rbuf[4][RL];
+  auto fetch_rows = [&](int tile) {
+    const int img = tile / HP, wy = tile - img * HP;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = 2 * wy - 1 + r;
+      const bool rv = (unsigned)y < (unsigned)H;
+      const float* src = x_t + (size_t)(img * H + (rv ? y : 0)) * ROWF;
+#pragma unroll
+      for (int i = 0; i < RL; ++i) {
+        const int e = lane + 64 * i;
+        rbuf[r][i] = *((rv && e < ROWF) ? src + e : mi_zero_word);
+      }
+    }
+  };
+  auto fetch_b = [&](size_t prow, int s0, float* cot, int* ag) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int wx = 2 * (s0 + i) + h;
+      const bool wv = wx < WP;
+      const size_t po = (prow + (wv ? wx : 0)) * CO + ch;
+      ag[i] = wv ? (int)arg_t[po] : 4;
+      float c = dp_t[po];
+      if (TAN) c = sA * c + sB * dpd_t[po];
+      cot[i] = c;
+    }
+  };
+  // flat stream of (tile, chunk) work items so the B prefetch also runs across tile boundaries
+  int tile = tile_base + wave, s0 = 0;
+  float cotA[CH];
+  int agA[CH];
+  if (tile < tile_end) {
+    fetch_rows(tile);
+    fetch_b((size_t)tile * WP, 0, cotA, agA);
+  }
+  while (tile < tile_end) {
+    if (s0 == 0) {
+      // this tile's rows: registers -> LDS (row r <-> input row 2wy - 1 + r, zeros outside the image)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+          const int e = lane + 64 * i;
+          if (e < ROWF) rows[r * RP + CI0 + e] = rbuf[r][i];
+        }
+      if (tile + 4 < tile_end) fetch_rows(tile + 4);
+    }
+    int ntile = tile, ns0 = s0 + CH;
+    if (ns0 >= nsteps) { ns0 = 0; ntile += 4; }
+    float cotB[CH];
+    int agB[CH];
+    if (ntile < tile_end) fetch_b((size_t)ntile * WP, ns0, cotB, agB);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (s0 + i < nsteps) {
+        const int wx = 2 * (s0 + i) + h;
+        const float* ap = rows + aoff + 2 * (wx < WP ? wx : 0) * CI0;      // pixel (2wy, 2wx) + tap; LDS ops of a wave are in order
+        const float a0 = ap[0], a1 = ap[CI0], a2 = ap[RP], a3 = ap[RP + CI0];
+        const int ag = agA[i];
+        const float cot = cotA[i];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ag == 0 ? cot : 0.f, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ag == 1 ? cot : 0.f, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, ag == 2 ? cot : 0.f, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, ag == 3 ? cot : 0.f, acc2, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { cotA[i] = cotB[i]; agA[i] = agB[i]; }
+    tile = ntile; s0 = ns0;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+  // 4 waves -> one partial per workgroup (same layout as block1_kernel<*_WGRAD>'s partials)
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lds[wave * 1024 + r * 64 + lane] = acc[r];
+  __syncthreads();
+  float* pt = a.wpartial + ((size_t)task * gridDim.x + blockIdx.x) * K * CO;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int e = tid + 256 * qq;
+    const float v = lds[e] + lds[1024 + e] + lds[2048 + e] + lds[3072 + e];
+    const int r = e >> 6, l = e & 63;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    if (row < K) pt[(size_t)row * CO + cbase + col] = v;
+  }
+}
+
+// Dense parts and assembly, one workgroup per task (fp64).  With s = patch sums, GW = G w, Z = sum patch x zhat = r (GW - mu s):
+//   primal :  dW    = gr (S - dbm s - dgm Z)
+//   tangent:  R{dW} = S - (c1 dbm + gr rbm) s - (c1 dgm + gr rgm) Z - gr dgm Zd,   Zd = sum patch x zhatd = r (G wd - m1 s - m2 Z)
+// (dbm = dbeta/M, dgm = dgamma/M, rbm / rgm their tangents; S already carries c1 / gr in tangent mode.)
+__global__ __launch_bounds__(64) void gram_wgrad_kernel(GramWgArgs a, int ng, int kp, int tangent) {
+  // one small workgroup per (task, patch entry k): thread = output channel
+  const int task = blockIdx.x, k = blockIdx.y, co = a.co;
+  const double* grow = a.g + (size_t)task * ng * ng + (size_t)k * ng;      // G[k][.]; G[k][kp] = s[k]
+  for (int c = threadIdx.x; c < co; c += 64) {
+    const int e = k * co + c;
+    double S = 0.0;
+    const float* sp = a.spartial + (size_t)task * a.nblk * kp * co + e;
+#pragma unroll 8
+    for (int b = 0; b < a.nblk; ++b) S += (double)sp[(size_t)b * kp * co];     // fixed order; unrolled so the loads overlap
+    const float* wc = a.w + (size_t)task * a.wstride + c;
+    const float* vc = tangent ? a.wd + (size_t)task * a.vstride + c : wc;
+    double gw = 0.0, gwd = 0.0;
+#pragma unroll 9
+    for (int b = 0; b < kp; ++b) {
+      gw = fma(grow[b], (double)wc[(size_t)b * co], gw);
+      if (tangent) gwd = fma(grow[b], (double)vc[(size_t)b * co], gwd);
+    }
+    const double sk = grow[kp];
+    const double mu = (double)a.mu[(size_t)task * co + c], rs = (double)a.rstd[(size_t)task * co + c];
+    const double gm = (double)a.gamma[(size_t)task * a.pstride + c];
+    const double gr = gm * rs;
+    const double dgm = (double)a.dgamma[(size_t)task * a.gstride + c] * a.inv_m, dbm = (double)a.dbeta[(size_t)task * a.gstride + c] * a.inv_m;
+    const double Z = rs * (gw - mu * sk);
+    double out;
+    if (!tangent) {
+      out = gr * (S - dbm * sk - dgm * Z);
+    } else {
+      const double m1 = (double)a.m1[(size_t)task * co + c], m2 = (double)a.m2[(size_t)task * co + c];
+      const double gmd = (double)a.gammad[(size_t)task * a.vstride + c];
+      const double c1 = gmd * rs + gm * (-rs * rs * m2);
+      const double rgm = (double)a.rdgamma[(size_t)task * a.hstride + c] * a.inv_m, rbm = (double)a.rdbeta[(size_t)task * a.hstride + c] * a.inv_m;
+      const double Zd = rs * (gwd - m1 * sk - m2 * Z);
+      out = S - (c1 * dbm + gr * rbm) * sk - (c1 * dgm + gr * rgm) * Z - gr * dgm * Zd;
+    }
+    a.out[(size_t)task * a.ostride + e] = (float)out;
+  }
+}
+
+static int sparse_row_pitch(int w, int ci) {
+  int rp = (w + 2) * ci;
+  while (rp % 32 != 12) ++rp;
+  return rp;
+}
+bool sparse_wgrad_supported(int w, int ci) { return w * ci <= 256; }   // one input row = at most 4 floats per lane (RL)
+static void sparse_wgrad_grid(int n, int h, int w, int co, int tasks, int& ntiles, int& tpw, dim3& grid) {
+  ntiles = n * (h / 2);                       // pooled rows
+  const long slots = 1024L * 4;
+  const long total = (long)ntiles * tasks * (co / 32);
+  tpw = (int)((total + slots - 1) / slots);
+  if (tpw < 1) tpw = 1;
+  grid = dim3(ceil_div(ntiles, 4 * tpw), tasks, co / 32);
+}
+int sparse_wgrad_blocks_per_task(int n, int h, int w, int co, int tasks) {
+  int ntiles, tpw;
+  dim3 grid;
+  sparse_wgrad_grid(n, h, w, co, tasks, ntiles, tpw, grid);
+  return (int)grid.x;
+}
+hipError_t launch_sparse_wgrad(hipStream_t st, SparseWgArgs a, int tasks, int ci, int tangent, int* blocks_per_task) {
+  int ntiles, tpw;
+  dim3 grid;
+  sparse_wgrad_grid(a.n, a.hh, a.ww, a.co, tasks, ntiles, tpw, grid);
+  a.ntiles = ntiles;
+  a.tiles_per_wave = tpw;
+  a.row_pitch = sparse_row_pitch(a.ww, ci);
+  if (!sparse_wgrad_supported(a.ww, ci)) return hipErrorInvalidValue;
+  size_t smem = (size_t)a.row_pitch * 16 * sizeof(float);
+  if (smem < 4 * 1024 * sizeof(float)) smem = 4 * 1024 * sizeof(float);
+  if (blocks_per_task) *blocks_per_task = grid.x;
+  if (ci == 3) {
+    if (tangent) hipLaunchKernelGGL((sparse_wgrad_kernel<3, true>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((sparse_wgrad_kernel<3, false>), grid, dim3(256), smem, st, a);
+  } else if (ci == 1) {
+    if (tangent) hipLaunchKernelGGL((sparse_wgrad_kernel<1, true>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((sparse_wgrad_kernel<1, false>), grid, dim3(256), smem, st, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_gram_wgrad(hipStream_t st, const GramWgArgs& a, int tasks, int tangent) {
+  const int ng = a.ci == 3 ? GramDims<3>::NG : GramDims<1>::NG, kp = 9 * a.ci;
+  hipLaunchKernelGGL(gram_wgrad_kernel, dim3(tasks, kp), dim3(64), 0, st, a, ng, kp, tangent);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 static int gram_ng(int ci) { return ci == 3 ? GramDims<3>::NG : GramDims<1>::NG; }
 static const int kGramRowsPerWave = 8;
 

@@ -90,6 +90,7 @@ struct B1Args {
   const float* dp; const float* dpd;      // [T][n][H/2][W/2][Co]
   float* out;                // p or pd
   float* zh_out;             // optional: zhat (FWD) / its tangent (TFWD) at each window's argmax, same shape as out
+  uint8_t* arg_out;          // optional (FWD): argmax position 0..3 of every window, 4 where the maximum did not pass the ReLU
   double* partial;           // [T][blocks][2][Co]
   float* wpartial;           // [T][blocks][9*Ci0][Co]
   int n, hh, ww, co;         // images per task, conv output height / width (= input, stride 1), filters
@@ -100,6 +101,36 @@ enum { B1_STATS = 0, B1_FWD = 1, B1_BWD_REDUCE = 2, B1_BWD_WGRAD = 3, B1_TSTATS 
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co);
 int block1_blocks_per_task(int n, int h, int w, int co, int tasks);
 hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task);
+
+// Block-1 weight gradient without recomputing conv1 (gram.hip): dz = gr (du - mean(du) - zhat mean(du zhat)) splits into a
+// SPARSE part (du lives at one position per pooling window: S = sum patch(argmax) x cot, sparse_wgrad kernel, fp32 MFMA)
+// and DENSE parts that are products of the input Gram matrix with the weights (gram_wgrad kernel, fp64).
+struct SparseWgArgs {
+  const float* x;            // [T][n][H][W][Ci0]
+  const uint8_t* arg;        // [T][rows][Co] from block1 FWD (rows = n*H/2*W/2)
+  const float* dp; const float* dpd;             // cotangent of p and its tangent (tangent mode)
+  const float *mu_unused, *rstd, *m2;            // [T][Co]   (tangent mode: c1 = gammad r - gamma r^2 m2)
+  const float* gamma; size_t pstride;
+  const float* gammad; size_t vstride;
+  float* wpartial;           // [T][blocks][9*Ci0][Co]
+  int n, hh, ww, co;
+  int ntiles, tiles_per_wave, row_pitch;
+};
+bool sparse_wgrad_supported(int w, int ci);
+int sparse_wgrad_blocks_per_task(int n, int h, int w, int co, int tasks);
+hipError_t launch_sparse_wgrad(hipStream_t st, SparseWgArgs a, int tasks, int ci, int tangent, int* blocks_per_task);
+struct GramWgArgs {
+  const double* g;           // [T][NG][NG]
+  const float* spartial; int nblk;               // sparse partials [T][nblk][9*Ci0][Co]
+  const float* w; size_t wstride; const float* wd; size_t vstride;
+  const float *mu, *rstd, *m1, *m2;              // [T][Co]
+  const float* gamma; size_t pstride; const float* gammad;
+  const float *dgamma, *dbeta; size_t gstride;   // primal BN gradients (sums)
+  const float *rdgamma, *rdbeta; size_t hstride; // their tangents (tangent mode)
+  float* out; size_t ostride;                    // dW (primal) or R{dW} (tangent): [T][.. 9*Ci0*Co]
+  int ci, co; double inv_m;
+};
+hipError_t launch_gram_wgrad(hipStream_t st, const GramWgArgs& a, int tasks, int tangent);
 
 // gram.hip: input Gram matrix of block 1 (BatchNorm statistics of conv1 as quadratic forms of the weights)
 int gram_blocks_per_task(int n, int h);
