@@ -5,8 +5,9 @@
 
 Algorithmic bytes of one launch = the tensors the op must read or write once (SURVEY.md section 8(d) accounting: layer input,
 conv output z, pooled output p; parameters are negligible), algorithmic FLOPs = 2*9*Ci*Co per output pixel per GEMM term.
-Block 1 ("layer" 0) runs the fused conv-recompute kernels of block1.hip: their FLOPs count the recomputed convolution, their
-bytes only what reaches HBM (x, and the pooled-resolution cotangents / outputs).
+Block 1 ("layer" 0): forward / tangent-forward are the conv-recompute kernels of block1.hip (FLOPs = the recomputed
+convolution, bytes = what reaches HBM); its statistics come from the Gram matrix (gram_stats: latency), its BN-backward
+reductions stream pooled tensors (HBM), its weight gradients are the sparse MFMA pass of gram.hip (algorithmic wgrad FLOPs).
 """
 import csv
 import sys
@@ -26,11 +27,12 @@ def costs(op, l, images):
     z = H[l] * H[l] * CO * 4
     p = HP[l] * HP[l] * CO * 4
     f = 2 * 9 * CI[l] * CO * H[l] * H[l]
-    if l == 0:      # fused block-1 kernels: z1 / dz1 and their tangents stay in registers
+    if l == 0:      # block 1: conv-recompute kernels (z1 / dz1 stay in registers), Gram-matrix statistics, pooled-resolution reductions
+        a = p // 4  # argmax bytes (one per pooled element)
         t = {
-            'conv_fwd_stats': (f, x), 'bn_relu_pool_fwd': (f, x + p), 'bn_bwd_reduce': (f, x + p), 'wgrad': (2 * f, x + p),
-            'tangent_conv_fwd': (2 * f, x), 'bn_tangent_fwd': (2 * f, x + p), 'bn_tangent_bwd_reduce': (2 * f, x + 2 * p),
-            'tangent_wgrad': (4 * f, x + 2 * p),
+            'conv_fwd_stats': (f, x), 'bn_relu_pool_fwd': (f, x + 2 * p + a), 'bn_bwd_reduce': (0, 3 * p), 'wgrad': (f, x + p + a),
+            'tangent_conv_fwd': (2 * f, x), 'bn_tangent_fwd': (2 * f, x + 2 * p), 'bn_tangent_bwd_reduce': (0, 5 * p),
+            'tangent_wgrad': (2 * f, x + 2 * p + a),
         }
     else:
         t = {
@@ -63,7 +65,10 @@ def main():
         fl, by = c
         tf = fl / (avg * 1e-3) / 1e12
         gb = by / (avg * 1e-3) / 1e9
-        bound = 'mfma' if fl and (fl / by) > PEAK_TFLOPS * 1e12 / (PEAK_GBPS * 1e9) and l > 0 else ('valu/latency' if l == 0 else 'hbm')
+        if l == 0:
+            bound = 'hbm' if not fl else ('mfma (sparse)' if 'wgrad' in op else 'valu/latency')
+        else:
+            bound = 'mfma' if fl and (fl / by) > PEAK_TFLOPS * 1e12 / (PEAK_GBPS * 1e9) else 'hbm'
         tfs = f'{tf:.1f} ({tf / PEAK_TFLOPS * 100:.0f} %)' if fl else '-'
         print(f'| {op} | {l + 1} | {n} | {avg:.4f} | {share * 100:.1f} % | {fl / 1e9:.2f} | {by / 1e6:.1f} | '
               f'{tfs} | {gb:.0f} ({gb / PEAK_GBPS * 100:.0f} %) | {bound} |')
