@@ -745,11 +745,21 @@ static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, An
     const size_t need = (size_t)T * blk * 2 * L.co;
     if (need > bnp) bnp = need;
     size_t w = wgrad_partial_floats(gg, T);
-    if (&L == &e->L[0] && e->fuse1) w = (size_t)T * block1_blocks_per_task(2 * n, L.ho, L.wo, L.co, T) * 9 * L.ci * L.co;
+    if (&L == &e->L[0] && e->fuse1) {
+      int bpt = block1_blocks_per_task(2 * n, L.ho, L.wo, L.co, T);
+      const int sb = sparse_wgrad_blocks_per_task(2 * n, L.ho, L.wo, L.co, T);
+      if (sb > bpt) bpt = sb;
+      w = (size_t)T * bpt * 9 * L.ci * L.co;
+    }
     if (w > wgp) wgp = w;
   }
   ap.scratch.bnpart = b.take<double>(bnp);
   ap.scratch.wgpart = b.take<float>(wgp);
+  ap.scratch.gram_part = ap.scratch.gram_s = nullptr;
+  if (e->fuse1 && e->gram1) {   // statistics + weight gradient of block 1 from the Gram matrix: cheaper than two conv recomputes
+    ap.scratch.gram_part = b.take<double>(gram_partial_doubles(T, 2 * n, e->L[0].h, e->L[0].ci));
+    ap.scratch.gram_s = b.take<double>(gram_doubles(T, e->L[0].ci));
+  }
   ap.bytes = align_up(b.off, 256);
 }
 
@@ -780,7 +790,10 @@ extern "C" int mi_meta_batch_anil(mi_engine* e, void* stream, const float* theta
   LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, data, (size_t)T * 2 * n, e->d.in_channels, e->d.in_h, e->d.in_w, ap.x));
   LAUNCH(e, st, OP_MISC, 0, launch_split_labels(st, labels, T, 2 * n, ap.ys, ap.yq));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, ap.theta));
-  int rc = trunk_forward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta);     // features(data) on all rows
+  const double* gram = (with_grad && workspace) ? ap.scratch.gram_s : nullptr;       // pays off only with a backward pass
+  if (gram)
+    LAUNCH(e, st, OP_GRAM, 0, launch_input_gram(st, ap.x, T, 2 * n, e->L[0].h, e->L[0].w, e->L[0].ci, ap.scratch.gram_part, ap.scratch.gram_s));
+  int rc = trunk_forward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta, gram);     // features(data) on all rows
   if (rc) return rc;
   LAUNCH(e, st, OP_MISC, 4, launch_split_rows(st, ap.act.p[nl - 1], T, 2 * n, e->feat, ap.fs, ap.fq));
   for (int k = 0; k < K; ++k) {                                                    // head-only inner loop
@@ -816,7 +829,7 @@ extern "C" int mi_meta_batch_anil(mi_engine* e, void* stream, const float* theta
     }
   }
   LAUNCH(e, st, OP_MISC, 4, launch_interleave_rows(st, ap.dfs, ap.dfq, T, n, e->feat, ap.act.dp[nl - 1]));
-  rc = trunk_backward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta, ap.lam);  // trunk grads join the head part in lam
+  rc = trunk_backward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta, ap.lam, gram);  // trunk grads join the head part in lam
   if (rc) return rc;
   LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, ap.lam, e->perm_dev, (int)e->P, (int)e->PS, T, meta_grad_out));
   return MI_OK;
