@@ -253,6 +253,115 @@ def meta_optimize_trpo(params, policy, baseline, iter_replays, iter_policies, an
                 new_loss=None if new_loss is None else new_loss[0], kl=None if kl is None else kl[0], fvp=Fvp, context=ctx)
 
 
+# ---------------------------------------------------------------------------------------------- VPG / PPO (reference rl.py:209-337)
+def _unwrap(learner):
+    return getattr(learner, 'module', learner)
+
+
+class _PolicyMetaLoss(torch.autograd.Function):
+    """Validation loss of one task whose gradient w.r.t. the policy parameters came out of the same fused call
+    (mi_policy_meta_batch); `.backward()` accumulates it like the reference's autograd graph through learner.adapt."""
+
+    @staticmethod
+    def forward(ctx, loss, grad, shapes, *params):
+        ctx.shapes = shapes
+        ctx.save_for_backward(grad)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            n = int(torch.Size(shp).numel())
+            outs.append((grad[off:off + n] * gout).reshape(shp))
+            off += n
+        return (None, None, None) + tuple(outs)
+
+
+def _stack(replays, advs, S, A, dev):
+    """Support replays of ONE task -> {states [NB,1,B,S], ...} with a common padded length."""
+    batches = [_pad([e], [a], S, A, dev) for e, a in zip(replays, advs)]
+    B = max(b['states'].shape[1] for b in batches)
+    def padto(t, dim):
+        n = B - t.shape[dim]
+        if n == 0:
+            return t
+        pad = [0, 0] * (t.dim() - 1 - dim) + [0, n]
+        return torch.nn.functional.pad(t, pad)
+    out = {k: torch.stack([padto(b[k], 1) if k != 'count' else b[k] for b in batches]).contiguous() for k in ('states', 'actions', 'adv', 'count')}
+    return out, B
+
+
+def _replay_meta(pol, support, sup_adv, query, q_adv, inner_lr, loss, clip, epochs, anil, first_order, with_grad):
+    """One task through mi_policy_meta_batch: (validation loss [1], adapted theta [P], grad [P] or None)."""
+    S, A, dev = pol.input_size, pol.output_size, pol.sigma.device
+    sup, B1 = _stack(support, sup_adv, S, A, dev) if support else (None, 0)
+    qry = _pad([query], [q_adv], S, A, dev)
+    B = max(B1, qry['states'].shape[1])
+    def fit(d, dim):
+        for k in ('states', 'actions', 'adv'):
+            n = B - d[k].shape[dim]
+            if n:
+                pad = [0, 0] * (d[k].dim() - 1 - dim) + [0, n]
+                d[k] = torch.nn.functional.pad(d[k], pad).contiguous()
+        return d
+    if sup is not None:
+        sup = fit(sup, 2)
+    qry = fit(qry, 1)
+    step_batch = [b for b in range(len(support)) for _ in range(epochs)]
+    lt, th, g = pol.engine().meta_batch(pol.flat(), sup, qry, step_batch, inner_lr, loss=loss, clip=clip, head_only=anil,
+                                        first_order=first_order, with_grad=with_grad)
+    return lt, th[0], g
+
+
+def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order):
+    pol = _unwrap(learner)
+    gamma, tau = params['gamma'], params['tau']
+    epochs = params['ppo_epochs'] if algo == 'ppo' else 1
+    clip = params.get('ppo_clip_ratio', 0.1)
+    kind = 'ppo' if algo == 'ppo' else 'a2c'
+
+    def adv_of(ep):
+        a = compute_advantages(baseline, tau, gamma, ep['rewards'], ep['dones'], ep['states'], ep['next_states'])
+        return normalize(a) if algo == 'ppo' else a                     # vpg_a2c_loss does not normalise (rl.py:217)
+
+    if anil:
+        pol.turn_off_body_grads()
+    support, sup_adv, current = [], [], pol
+    for step in range(params['adapt_steps']):
+        ep = task.run(current, episodes=params['adapt_batch_size'])
+        support.append(ep)
+        sup_adv.append(adv_of(ep))
+        # parameters after the updates so far (the rollouts of the next step / the query need them); value of the loss unused
+        _, theta_k, _ = _replay_meta(pol, support, sup_adv, ep, sup_adv[-1], params['inner_lr'], kind, clip, epochs, anil, first_order, False)
+        current = deepcopy(pol)
+        current.load_flat(theta_k)
+    if anil:
+        pol.turn_on_body_grads()
+    query = task.run(current, episodes=params['adapt_batch_size'])
+    need = torch.is_grad_enabled() and any(q.requires_grad for q in pol.parameters())
+    lt, _, grad = _replay_meta(pol, support, sup_adv, query, adv_of(query), params['inner_lr'], kind, clip, epochs, anil, first_order, need)
+    if need:
+        eparams = pol._engine_params()
+        valid_loss = _PolicyMetaLoss.apply(lt[0], grad, [q.shape for q in eparams], *eparams)
+    else:
+        valid_loss = lt[0]
+    rew = query['rewards'].sum().item() / params['adapt_batch_size']
+    return valid_loss, rew, 0.0
+
+
+def fast_adapt_vpg(task, learner, baseline, params, anil=False, first_order=False, render=False):
+    """reference rl.py:231-255 -> (valid_loss, query reward, success rate); `valid_loss.backward()` accumulates the MAML
+    gradient (second order unless first_order) into the policy's parameters."""
+    return _adapt_and_validate(task, learner, baseline, params, 'vpg', anil, first_order)
+
+
+def fast_adapt_ppo(task, learner, baseline, params, anil=False, render=False):
+    """reference rl.py:267-318: ppo_epochs clipped-surrogate updates per adapt step (second order, as learner.adapt defaults)."""
+    return _adapt_and_validate(task, learner, baseline, params, 'ppo', anil, False)
+
+
 # ---------------------------------------------------------------------------------------------- Particles2D rollouts (host loop, device math)
 class Particles2DRunner:
     """Minimal stand-in for core_functions/runner.py + learn2learn's Particles2D (both out of scope):

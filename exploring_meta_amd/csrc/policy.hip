@@ -557,3 +557,262 @@ extern "C" int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const
   PCHK(p, hipGetLastError());
   return MI_OK;
 }
+
+// =====================================================================================================================
+// MAML inner loop of the policy with a general number of updates and the VPG / PPO losses (reference core_functions/rl.py:
+// vpg_a2c_loss :209-228 (dice=False), fast_adapt_vpg :231-255, fast_adapt_ppo :267-318, single_ppo_update :321-337; drivers
+// rl/maml_ppo.py, rl/anil_ppo.py): per task  theta_{k+1} = theta_k - lr * [head mask] grad L_k(theta_k)  for k < K on replayed
+// support batches, a query loss at theta_K, and -- what `av_loss.backward()` computes through learn2learn's second-order
+// `learner.adapt` -- its gradient w.r.t. theta via the adjoint recursion  lam_k = lam_{k+1} - lr H_k [mask] lam_{k+1},
+// every H_k v as a forward-over-reverse sweep over the saved step-k pass (as in engine.hip for the classifier).
+//
+// Losses as functions of the per-sample mean log-prob lp_i:   A2C  f_i = -A_i lp_i / B                    (a2c.policy_loss)
+//   PPO  f_i = -min(r_i A_i, clamp(r_i, 1-c, 1+c) A_i) / B,  r_i = exp(lp_i - lp_old_i)                    (ppo.policy_loss)
+// f' feeds the backward pass, f'' (0 for A2C, = f' for an active PPO sample) the Hessian-vector product:
+//   R{dL/dx} = f'' (dlp/dtheta . v) dlp/dx + f' R{dlp/dx}.   torch.min splits the gradient of ties evenly between its arguments;
+// inside the clip range both arguments ARE r A, so the sum is again r A -- active = inside the range, or outside with r A the
+// smaller argument.
+struct Gauss2Args {
+  const float* mu; const float* mud;
+  const float* rho; const float* rhod; size_t rstride, vstride;
+  const float* act; const float* adv; const int32_t* count;
+  const float* oldlp;     // [T][B] PPO: log-prob under the parameters the epoch group started from
+  float* lp_out;          // [T][B] (P_LOGP)
+  float* coef;            // [T][B] f'  (written by P_PRIMAL, read by P_TANGENT)
+  float* coef2;           // [T][B] f''
+  float* dmu; float* drho; size_t gstride;
+  float* loss;            // [T]
+  float clip;
+  int B, A, kind, mode, value_ratio_one;
+};
+enum { P_PRIMAL = 0, P_TANGENT = 1, P_LOGP = 2 };
+
+__global__ __launch_bounds__(256) void gauss2_kernel(Gauss2Args a) {
+  __shared__ float red[256];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int B = a.B, A = a.A, cnt = a.count ? a.count[t] : B;
+  const float invB = 1.f / (float)cnt, invD = 1.f / (float)A;
+  float acc[7];   // loss, drho[0..5]
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc[k] = 0.f;
+  for (int b = tid; b < B; b += 256) {
+    const bool valid = b < cnt;
+    const size_t ob = (size_t)t * B + b;
+    float lp = 0.f;
+    for (int d = 0; d < A; ++d) {
+      const float r = fmaxf(a.rho[(size_t)t * a.rstride + d], LOG_EPS), sg = expf(r);
+      const float df = a.act[ob * A + d] - a.mu[ob * A + d];
+      lp += -(df * df) / (2.f * sg * sg) - r - HALF_LOG_2PI;
+    }
+    lp *= invD;
+    if (a.mode == P_LOGP) { a.lp_out[ob] = lp; continue; }
+    if (a.mode == P_PRIMAL) {
+      float c = 0.f, c2 = 0.f;
+      if (valid) {
+        const float ad = a.adv[ob];
+        if (a.kind == MI_PLOSS_A2C) {
+          c = -ad * invB;
+          acc[0] += a.value_ratio_one ? c : c * lp;          // PPO's validation loss: ratio == 1 exactly, value -mean(A)
+        } else {
+          const float ratio = expf(lp - a.oldlp[ob]);
+          const float o1 = ratio * ad, o2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * ad;
+          acc[0] += -fminf(o1, o2) * invB;
+          const bool inside = ratio >= 1.f - a.clip && ratio <= 1.f + a.clip;
+          const bool active = inside || o1 < o2;
+          c = active ? -o1 * invB : 0.f;
+          c2 = c;
+        }
+      }
+      a.coef[ob] = c;
+      a.coef2[ob] = c2;
+      for (int d = 0; d < A; ++d) {
+        const float rp = a.rho[(size_t)t * a.rstride + d];
+        const float r = fmaxf(rp, LOG_EPS), sg = expf(r), iv = 1.f / (sg * sg);
+        const float df = a.act[ob * A + d] - a.mu[ob * A + d];
+        a.dmu[ob * A + d] = c * invD * df * iv;
+        if (rp > LOG_EPS) acc[1 + d] += c * invD * (df * df * iv - 1.f);
+      }
+    } else {   // P_TANGENT
+      const float c = valid ? a.coef[ob] : 0.f, c2 = valid ? a.coef2[ob] : 0.f;
+      float lpd = 0.f;                                       // tangent of lp along (mud, rhod)
+      for (int d = 0; d < A; ++d) {
+        const float rp = a.rho[(size_t)t * a.rstride + d];
+        const bool live = rp > LOG_EPS;
+        const float r = fmaxf(rp, LOG_EPS), sg = expf(r), iv = 1.f / (sg * sg);
+        const float rd = live ? a.rhod[(size_t)t * a.vstride + d] : 0.f;
+        const float df = a.act[ob * A + d] - a.mu[ob * A + d];
+        lpd += invD * (df * iv * a.mud[ob * A + d] + (df * df * iv - 1.f) * rd);
+      }
+      const float cd = c2 * lpd;                             // R{f'}
+      for (int d = 0; d < A; ++d) {
+        const float rp = a.rho[(size_t)t * a.rstride + d];
+        const bool live = rp > LOG_EPS;
+        const float r = fmaxf(rp, LOG_EPS), sg = expf(r), iv = 1.f / (sg * sg);
+        const float rd = live ? a.rhod[(size_t)t * a.vstride + d] : 0.f;
+        const float df = a.act[ob * A + d] - a.mu[ob * A + d];
+        const float md = a.mud[ob * A + d];
+        a.dmu[ob * A + d] = cd * invD * df * iv + c * invD * (-md * iv - 2.f * df * rd * iv);
+        if (live) acc[1 + d] += cd * invD * (df * df * iv - 1.f) + c * invD * (-2.f * df * md * iv - 2.f * df * df * rd * iv);
+      }
+    }
+  }
+  if (a.mode == P_LOGP) return;
+  for (int k = 0; k < 1 + A; ++k) {
+    red[tid] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) red[tid] += red[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (k == 0) { if (a.loss && a.mode == P_PRIMAL) a.loss[t] = red[0]; }
+      else if (a.drho) a.drho[(size_t)t * a.gstride + (k - 1)] = red[0];
+    }
+    __syncthreads();
+  }
+}
+
+// keep only sigma and the last Linear of a [T][P] vector (ANIL: body under no_grad)
+__global__ void head_mask_kernel(float* __restrict__ v, int p, int body_lo, int body_hi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= body_lo && i < body_hi) v[(size_t)blockIdx.y * p + i] = 0.f;
+}
+
+struct StepSet { Acts a; float *dmu, *d2, *d1, *pre2, *pre1, *coef, *coef2; };
+struct MetaPlan {
+  std::vector<StepSet> st;          // per inner update (second order) or one shared set
+  StepSet q;                        // query pass
+  Acts ta;                          // tangent activations (scratch)
+  float *rdmu, *r2, *r1;            // tangent cotangent scratch
+  float *theta, *g, *lam, *hv, *vmask;      // [K+1][T][P], [T][P] ...
+  float* oldlp;                     // [n_batches][T][B]
+  size_t bytes;
+};
+static void meta_plan(const mi_policy* p, void* ws, int T, int B, int K, int nb, bool keep_all, MetaPlan& pl) {
+  PBump b{reinterpret_cast<char*>(ws), 0};
+  const size_t TB = (size_t)T * B, TP = (size_t)T * p->P;
+  auto set = [&](StepSet& s) {
+    s.a.h1 = b.f(TB * p->H1); s.a.h2 = b.f(TB * p->H2); s.a.mu = b.f(TB * p->A);
+    s.dmu = b.f(TB * p->A); s.d2 = b.f(TB * p->H2); s.d1 = b.f(TB * p->H1); s.pre2 = b.f(TB * p->H2); s.pre1 = b.f(TB * p->H1);
+    s.coef = b.f(TB); s.coef2 = b.f(TB);
+  };
+  pl.st.resize(keep_all ? (K > 0 ? K : 1) : 1);
+  for (auto& s : pl.st) set(s);
+  set(pl.q);
+  pl.ta.h1 = b.f(TB * p->H1); pl.ta.h2 = b.f(TB * p->H2); pl.ta.mu = b.f(TB * p->A);
+  pl.rdmu = b.f(TB * p->A); pl.r2 = b.f(TB * p->H2); pl.r1 = b.f(TB * p->H1);
+  pl.theta = b.f(TP * (K + 1)); pl.g = b.f(TP); pl.lam = b.f(TP); pl.hv = b.f(TP); pl.vmask = b.f(TP);
+  pl.oldlp = b.f(TB * (nb > 0 ? nb : 1));
+  pl.bytes = align_up(b.off, 256);
+}
+
+extern "C" int mi_policy_meta_workspace_bytes(const mi_policy* p, int tasks, int batch, int steps, int n_batches, int second_order,
+                                              size_t* bytes) {
+  if (!p || !bytes || tasks < 1 || batch < 1 || steps < 0 || n_batches < 0) return MI_ERR_ARG;
+  MetaPlan pl;
+  meta_plan(p, nullptr, tasks, batch, steps, n_batches, second_order != 0, pl);
+  *bytes = pl.bytes;
+  return MI_OK;
+}
+
+extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* theta, int steps, const int32_t* step_batch,
+                                    const int32_t* step_new_old, int n_batches, const float* s_states, const float* s_actions,
+                                    const float* s_adv, const int32_t* s_count, const float* q_states, const float* q_actions,
+                                    const float* q_adv, const int32_t* q_count, int tasks, int batch, int loss_kind, float clip,
+                                    float inner_lr, int head_only, int second_order, int with_grad, float* loss_out,
+                                    float* theta_out, float* grad_out, void* workspace, size_t workspace_bytes) {
+  if (!p || !theta || !q_states || !q_actions || !q_adv || !loss_out || !workspace) return pfail(p, MI_ERR_ARG, "null argument");
+  if (steps > 0 && (!step_batch || !s_states || !s_actions || !s_adv || n_batches < 1)) return pfail(p, MI_ERR_ARG, "support batches missing");
+  if (loss_kind != MI_PLOSS_A2C && loss_kind != MI_PLOSS_PPO) return pfail(p, MI_ERR_ARG, "loss_kind must be MI_PLOSS_A2C or MI_PLOSS_PPO");
+  if (loss_kind == MI_PLOSS_PPO && steps > 0 && !step_new_old) return pfail(p, MI_ERR_ARG, "PPO needs step_new_old");
+  if (with_grad && !grad_out) return pfail(p, MI_ERR_ARG, "grad_out is NULL but with_grad != 0");
+  for (int k = 0; k < steps; ++k)
+    if (step_batch[k] < 0 || step_batch[k] >= n_batches) return pfail(p, MI_ERR_ARG, "step_batch entry out of range");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int T = tasks, B = batch, K = steps;
+  const size_t P = p->P, TB = (size_t)T * B, TP = (size_t)T * P;
+  const bool so = second_order && with_grad;
+  MetaPlan pl;
+  meta_plan(p, workspace, T, B, K, n_batches, so, pl);
+  if (pl.bytes > workspace_bytes) return pfail(p, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes));
+  const int body_lo = (int)p->o_w1, body_hi = (int)p->o_w3;          // W1, b1, W2, b2
+  auto mask = [&](float* v) {
+    if (head_only) hipLaunchKernelGGL(head_mask_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, v, (int)P, body_lo, body_hi);
+  };
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, theta, (size_t)0, pl.g, 0.f, (int)P, pl.theta);
+  PCHK(p, hipGetLastError());
+  auto primal = [&](StepSet& s, const float* th, const float* states, const float* actions, const float* adv, const int32_t* count,
+                    int kind, const float* oldlp, int value_ratio_one, float* g, float* loss) -> int {
+    int rc = mlp_forward(p, st, T, B, states, th, P, s.a);
+    if (rc) return rc;
+    PCHK(p, hipMemsetAsync(g, 0, TP * sizeof(float), st));
+    Gauss2Args ga{};
+    ga.mu = s.a.mu; ga.rho = th + p->o_sigma; ga.rstride = P; ga.act = actions; ga.adv = adv; ga.count = count; ga.oldlp = oldlp;
+    ga.coef = s.coef; ga.coef2 = s.coef2; ga.dmu = s.dmu; ga.drho = g + p->o_sigma; ga.gstride = P; ga.loss = loss; ga.clip = clip;
+    ga.B = B; ga.A = p->A; ga.kind = kind; ga.mode = P_PRIMAL; ga.value_ratio_one = value_ratio_one;
+    hipLaunchKernelGGL(gauss2_kernel, dim3(T), dim3(256), 0, st, ga);
+    PCHK(p, hipGetLastError());
+    return mlp_backward(p, st, T, B, states, th, P, s.a, s.dmu, s.d2, s.d1, g, s.pre2, s.pre1, false);
+  };
+  // ---- inner updates
+  for (int k = 0; k < K; ++k) {
+    StepSet& s = so ? pl.st[k] : pl.st[0];
+    float* th = pl.theta + (size_t)k * TP;
+    const int bi = step_batch[k];
+    const float* xs = s_states + (size_t)bi * TB * p->S;
+    const float* as = s_actions + (size_t)bi * TB * p->A;
+    const float* ad = s_adv + (size_t)bi * TB;
+    const int32_t* cn = s_count ? s_count + (size_t)bi * T : nullptr;
+    float* olp = pl.oldlp + (size_t)bi * TB;
+    if (loss_kind == MI_PLOSS_PPO && step_new_old[k]) {       // old_log_probs = learner.log_prob(...) under no_grad (rl.py:282-283)
+      int rc = mlp_forward(p, st, T, B, xs, th, P, s.a);
+      if (rc) return rc;
+      Gauss2Args gl{};
+      gl.mu = s.a.mu; gl.rho = th + p->o_sigma; gl.rstride = P; gl.act = as; gl.count = cn; gl.lp_out = olp; gl.B = B; gl.A = p->A; gl.mode = P_LOGP;
+      hipLaunchKernelGGL(gauss2_kernel, dim3(T), dim3(256), 0, st, gl);
+      PCHK(p, hipGetLastError());
+    }
+    int rc = primal(s, th, xs, as, ad, cn, loss_kind, olp, 0, pl.g, pl.hv /* scratch for the step loss */);
+    if (rc) return rc;
+    mask(pl.g);
+    hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, th, P, pl.g, inner_lr, (int)P, th + TP);
+    PCHK(p, hipGetLastError());
+  }
+  float* thK = pl.theta + (size_t)K * TP;
+  if (theta_out) PCHK(p, hipMemcpyAsync(theta_out, thK, TP * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // ---- query loss: VPG = a2c loss; PPO = ppo loss against the adapted policy itself (ratio == 1: value -mean(A), gradient of A2C form)
+  int rc = primal(pl.q, thK, q_states, q_actions, q_adv, q_count, MI_PLOSS_A2C, nullptr, loss_kind == MI_PLOSS_PPO ? 1 : 0, pl.lam, loss_out);
+  if (rc) return rc;
+  if (!with_grad) return MI_OK;
+  // ---- adjoint recursion through the updates
+  if (so) {
+    for (int k = K - 1; k >= 0; --k) {
+      StepSet& s = pl.st[k];
+      const float* th = pl.theta + (size_t)k * TP;
+      const int bi = step_batch[k];
+      const float* xs = s_states + (size_t)bi * TB * p->S;
+      const float* as = s_actions + (size_t)bi * TB * p->A;
+      const int32_t* cn = s_count ? s_count + (size_t)bi * T : nullptr;
+      // v = [mask] lam ; hv = H_k v
+      PCHK(p, hipMemcpyAsync(pl.vmask, pl.lam, TP * sizeof(float), hipMemcpyDeviceToDevice, st));
+      mask(pl.vmask);
+      PCHK(p, hipMemsetAsync(pl.hv, 0, TP * sizeof(float), st));
+      rc = mlp_tangent_forward(p, st, T, B, xs, th, P, s.a, pl.vmask, pl.ta);
+      if (rc) return rc;
+      Gauss2Args gt{};
+      gt.mu = s.a.mu; gt.mud = pl.ta.mu; gt.rho = th + p->o_sigma; gt.rstride = P; gt.rhod = pl.vmask + p->o_sigma; gt.vstride = P;
+      gt.act = as; gt.count = cn; gt.coef = s.coef; gt.coef2 = s.coef2; gt.dmu = pl.rdmu; gt.drho = pl.hv + p->o_sigma; gt.gstride = P;
+      gt.B = B; gt.A = p->A; gt.mode = P_TANGENT;
+      hipLaunchKernelGGL(gauss2_kernel, dim3(T), dim3(256), 0, st, gt);
+      PCHK(p, hipGetLastError());
+      rc = mlp_tangent_backward(p, st, T, B, xs, th, P, s.a, pl.ta, pl.vmask, s.dmu, s.d2, s.d1, s.pre2, s.pre1, pl.rdmu, pl.r2, pl.r1, pl.hv);
+      if (rc) return rc;
+      mask(pl.hv);      // the body sat under no_grad during the update: no path from theta_{k+1} back into it
+      hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.lam, P, pl.hv, inner_lr, (int)P, pl.lam);
+      PCHK(p, hipGetLastError());
+    }
+  }
+  hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, pl.lam, T, (int)P, 1.f, (const float*)nullptr, 0.f, grad_out);
+  PCHK(p, hipGetLastError());
+  return MI_OK;
+}

@@ -343,6 +343,37 @@ class PolicyEngine:
                                                float(inner_lr), _ptr(loss), _ptr(kl), _ptr(grad), _ptr(ws), ws.numel()))
         return loss, kl, grad
 
+    def meta_batch(self, theta, sup, qry, step_batch, inner_lr, loss='a2c', clip=0.1, step_new_old=None, head_only=False,
+                   first_order=False, with_grad=True):
+        """K = len(step_batch) MAML updates of the policy on replayed support batches + validation loss + meta-gradient for all
+        tasks (mi_policy_meta_batch: fast_adapt_vpg / fast_adapt_ppo, reference rl.py:231-255,267-318).
+        sup: dict states [NB,T,B,S], actions [NB,T,B,A], adv [NB,T,B], count [NB,T] int32 (NB support batches); qry: the same
+        without the NB axis.  Returns (loss [T], theta_adapted [T,P], grad [P] summed over tasks or None)."""
+        import numpy as np
+        K = len(step_batch)
+        T, B = qry['states'].shape[0], qry['states'].shape[1]
+        NB = sup['states'].shape[0] if K else 0
+        kind = {'a2c': 0, 'ppo': 1}[loss]
+        sb = (C.c_int32 * max(K, 1))(*[int(x) for x in step_batch])
+        if step_new_old is None:
+            step_new_old = [1 if (k == 0 or step_batch[k] != step_batch[k - 1]) else 0 for k in range(K)]
+        sn = (C.c_int32 * max(K, 1))(*[int(x) for x in step_new_old])
+        so = (not first_order) and with_grad
+        b = C.c_size_t()
+        self._check(self.lib.mi_policy_meta_workspace_bytes(self._h, T, B, K, NB, int(so), C.byref(b)))
+        if self._ws is None or self._ws.numel() < b.value:
+            self._ws = torch.empty(b.value, dtype=torch.uint8, device=self.device)
+        loss_t = torch.empty(T, device=self.device)
+        theta_out = torch.empty(T, self.param_count, device=self.device)
+        grad = torch.empty(self.param_count, device=self.device) if with_grad else None
+        g = lambda d, k: _ptr(d[k].contiguous()) if d is not None and K else C.c_void_p(0)
+        self._check(self.lib.mi_policy_meta_batch(
+            self._h, _stream(), _ptr(theta.contiguous()), K, sb, sn, NB, g(sup, 'states'), g(sup, 'actions'), g(sup, 'adv'),
+            g(sup, 'count'), _ptr(qry['states'].contiguous()), _ptr(qry['actions'].contiguous()), _ptr(qry['adv'].contiguous()),
+            _ptr(qry['count'].contiguous()), T, B, kind, float(clip), float(inner_lr), int(head_only), int(not first_order),
+            int(with_grad), _ptr(loss_t), _ptr(theta_out), _ptr(grad), _ptr(self._ws), self._ws.numel()))
+        return loss_t, theta_out, grad
+
     def fvp(self, theta, sup, qry, inner_lr, damping, v):
         """Fisher-vector product at the theta of the preceding ``surrogate`` call (same batches)."""
         T, B = sup['states'].shape[0], sup['states'].shape[1]

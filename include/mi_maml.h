@@ -231,6 +231,28 @@ int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const float* s_s
                 const int32_t* s_count, const float* q_states, const int32_t* q_count, int tasks, int batch, float inner_lr,
                 float damping, const float* v, float* out, void* workspace, size_t workspace_bytes);
 
+/* MAML inner loop of the policy with K updates and the VPG / PPO losses, all tasks per call (core_functions/rl.py:
+ * fast_adapt_vpg :231-255 with vpg_a2c_loss :209-228 (dice=False), fast_adapt_ppo :267-318; drivers rl/maml_ppo.py, anil_ppo.py).
+ *   theta_{k+1} = theta_k - inner_lr * grad L_k(theta_k), k < steps; update k replays support batch step_batch[k] (host array):
+ *     VPG: one batch per adapt step; PPO: ppo_epochs consecutive updates share a batch, step_new_old[k] = 1 on the first of them
+ *     (old_log_probs are taken at theta_k under no_grad, rl.py:282-283).
+ *   support batches [n_batches, tasks, batch, ...] padded like the TRPO replays; count [n_batches, tasks] (NULL = all valid).
+ *   loss_out[t] = the validation loss of task t at theta_steps: VPG a2c.policy_loss, PPO ppo.policy_loss against the adapted
+ *     policy itself (ratio 1).  theta_out [tasks, P] (or NULL) = adapted parameters.
+ *   with_grad: grad_out [P] = SUM over tasks of d loss_out[t] / d theta -- what `av_loss.backward()` leaves in .grad after the
+ *     caller's 1/meta_batch_size; second_order = learn2learn's default adapt (0: first-order MAML).
+ *   head_only: updates touch only sigma and the last Linear (ANIL, body under no_grad). */
+#define MI_PLOSS_A2C 0
+#define MI_PLOSS_PPO 1
+int mi_policy_meta_workspace_bytes(const mi_policy* p, int tasks, int batch, int steps, int n_batches, int second_order,
+                                   size_t* bytes);
+int mi_policy_meta_batch(mi_policy* p, void* stream, const float* theta, int steps, const int32_t* step_batch,
+                         const int32_t* step_new_old, int n_batches, const float* s_states, const float* s_actions,
+                         const float* s_adv, const int32_t* s_count, const float* q_states, const float* q_actions,
+                         const float* q_adv, const int32_t* q_count, int tasks, int batch, int loss_kind, float clip,
+                         float inner_lr, int head_only, int second_order, int with_grad, float* loss_out, float* theta_out,
+                         float* grad_out, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

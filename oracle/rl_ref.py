@@ -149,6 +149,14 @@ def trpo_policy_loss(new_log_probs, old_log_probs, advantages):
     return -torch.mean(torch.exp(new_log_probs - old_log_probs) * advantages)
 
 
+def ppo_policy_loss(new_log_probs, old_log_probs, advantages, clip=0.1):
+    """cherry.algorithms.ppo.policy_loss (rl.py:290,312,333): -mean(min(r A, clamp(r, 1-clip, 1+clip) A)), r = exp(new - old)."""
+    ratios = torch.exp(new_log_probs - old_log_probs)
+    obj = ratios * advantages
+    obj_clip = ratios.clamp(1.0 - clip, 1.0 + clip) * advantages
+    return -torch.min(obj, obj_clip).mean()
+
+
 def conjugate_gradient(Ax, b, num_iterations=10, tol=1e-10, eps=1e-8):
     """cherry.algorithms.trpo.conjugate_gradient (rl.py:418)."""
     x = torch.zeros_like(b)
@@ -328,3 +336,52 @@ def meta_optimize_trpo(params, p, baseline, iter_replays, iter_policies, activat
             break
     return dict(grad=grad, step=step, old_loss=old_loss, accepted=accepted, new_loss=new_loss, kl=kl,
                 fvp=lambda v: Fvp(v))
+
+
+# ----------------------------------------------------------------------------------------------- rl.py VPG / PPO part (replayed)
+def maml_adapt_policy(loss, p, lr, first_order, head_only=False):
+    """learn2learn MAML.adapt (rl.py:241,292,335): g = grad(loss, params, create_graph = second order, allow_unused = anil);
+    p <- p - lr g for the parameters that received a gradient (with the ANIL body under no_grad: sigma and the last Linear)."""
+    so = not first_order
+    last = max(int(k.split('.')[1]) for k in p if k.startswith('mean.'))
+    keep = [k for k in p if (not head_only) or k == 'sigma' or k.startswith(f'mean.{last}.')]
+    grads = torch.autograd.grad(loss, [p[k] for k in keep], retain_graph=so, create_graph=so)
+    new = OrderedDict(p)
+    for k, g in zip(keep, grads):
+        new[k] = p[k] - lr * g
+    return new
+
+
+def _body_detached(p, head_only):
+    """DiagNormalPolicyANIL.forward_pass with features_no_grad (policies.py:100-106): the hidden layers see no gradient."""
+    if not head_only:
+        return p
+    last = max(int(k.split('.')[1]) for k in p if k.startswith('mean.'))
+    return OrderedDict((k, v if (k == 'sigma' or k.startswith(f'mean.{last}.')) else v.detach()) for k, v in p.items())
+
+
+def replay_vpg(p, support, query, params, baseline, first_order=False, activation=torch.relu, anil=False):
+    """fast_adapt_vpg (rl.py:231-255) on given replays: one a2c update per support replay, validation loss = vpg_a2c_loss."""
+    for ep in support:
+        adv = compute_advantages(baseline, params['tau'], params['gamma'], ep).detach()
+        lp = policy_log_prob(_body_detached(p, anil), ep['states'], ep['actions'], activation)
+        p = maml_adapt_policy(a2c_policy_loss(lp, adv), p, params['inner_lr'], first_order, head_only=anil)
+    adv = compute_advantages(baseline, params['tau'], params['gamma'], query).detach()
+    return a2c_policy_loss(policy_log_prob(p, query['states'], query['actions'], activation), adv), p
+
+
+def replay_ppo(p, support, query, params, baseline, activation=torch.relu, anil=False):
+    """fast_adapt_ppo (rl.py:267-318) on given replays: ppo_epochs clipped-surrogate updates per support replay (second order:
+    the reference calls learner.adapt without first_order), validation loss = ppo loss against the adapted policy itself."""
+    for ep in support:
+        adv = normalize(compute_advantages(baseline, params['tau'], params['gamma'], ep)).detach()
+        with torch.no_grad():
+            old = policy_log_prob(p, ep['states'], ep['actions'], activation)
+        for _ in range(params['ppo_epochs']):
+            new = policy_log_prob(_body_detached(p, anil), ep['states'], ep['actions'], activation)
+            p = maml_adapt_policy(ppo_policy_loss(new, old, adv, params['ppo_clip_ratio']), p, params['inner_lr'], False, head_only=anil)
+    adv = normalize(compute_advantages(baseline, params['tau'], params['gamma'], query)).detach()
+    with torch.no_grad():
+        old = policy_log_prob(p, query['states'], query['actions'], activation)
+    new = policy_log_prob(p, query['states'], query['actions'], activation)
+    return ppo_policy_loss(new, old, adv, params['ppo_clip_ratio']), p

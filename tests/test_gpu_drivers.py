@@ -31,3 +31,32 @@ def test_anil_vision_driver_trains():
     before = torch.nn.Linear(128, 5).weight                       # the head and the trunk both moved away from their init
     assert all(torch.isfinite(q).all() for q in list(features.parameters()) + list(head.parameters()))
     assert head.module.weight.shape == before.shape
+
+
+@pytest.mark.parametrize('anil', [False, True])
+def test_maml_ppo_driver_runs(anil):
+    from exploring_meta_amd.rl import maml_ppo
+    p = dict(maml_ppo.params, meta_batch_size=3, adapt_batch_size=4, max_path_length=15, num_iterations=2, adapt_steps=2)
+    logs = []
+    policy = maml_ppo.run(p, anil=anil, log=logs.append)
+    assert len(logs) == 2 and all(torch.isfinite(q).all() for q in policy.parameters())
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in policy.parameters())
+
+
+def test_fast_adapt_vpg_accumulates_meta_gradient():
+    from exploring_meta_amd import core_functions as cf
+    pol = cf.MAML(cf.DiagNormalPolicy(2, 2).cuda(), lr=0.05)
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    P = dict(inner_lr=0.05, gamma=0.99, tau=1.0, adapt_steps=2, adapt_batch_size=4)
+    total = 0.0
+    for goal in ([0.2, -0.1], [-0.3, 0.4]):
+        task = cf.Particles2DRunner(goal, 12, gen)
+        loss, rew, _ = cf.fast_adapt_vpg(task, pol.clone(), cf.LinearValue(2, 2), P)
+        total = total + loss
+        assert rew < 0
+    (total / 2).backward()
+    g = torch.cat([q.grad.reshape(-1) for q in pol.parameters()])
+    assert torch.isfinite(g).all() and g.abs().sum() > 0
+    with torch.no_grad():                                   # evaluation: no graph, plain tensor
+        loss, _, _ = cf.fast_adapt_vpg(cf.Particles2DRunner([0.1, 0.1], 12, gen), pol.clone(), cf.LinearValue(2, 2), P)
+    assert not loss.requires_grad

@@ -232,3 +232,91 @@ def test_tanh_meta_optimize_trpo_matches_oracle():
     # Fisher-vector product agrees with fp64 to 2e-7 (test above; measured here: 1.3e-2 / 8.6e-4 with fp64 CG recurrences).
     # Bar: 2x the reference's own fp32 deviation.
     assert es < 2e-2 and et < 1.3e-3
+
+
+# ---------------------------------------------------------------------------------------------- VPG / PPO inner loops (rl.py:209-337)
+def _stack_batches(eps_per_task_per_batch, advs, dev='cuda'):
+    """eps[nb][t] replay dicts + advantages -> {states [NB,T,B,S], actions, adv [NB,T,B], count [NB,T]} padded to a common B."""
+    NB, T = len(eps_per_task_per_batch), len(eps_per_task_per_batch[0])
+    B = max(int(e['states'].shape[0]) for row in eps_per_task_per_batch for e in row)
+    st, ac = torch.zeros(NB, T, B, 2), torch.zeros(NB, T, B, 2)
+    ad, cnt = torch.zeros(NB, T, B), torch.zeros(NB, T, dtype=torch.int32)
+    for b in range(NB):
+        for t in range(T):
+            e, a = eps_per_task_per_batch[b][t], advs[b][t]
+            n = int(e['states'].shape[0])
+            st[b, t, :n], ac[b, t, :n], ad[b, t, :n], cnt[b, t] = e['states'].float(), e['actions'].float(), a.reshape(-1).float(), n
+    return dict(states=st.to(dev), actions=ac.to(dev), adv=ad.to(dev), count=cnt.to(dev)), B
+
+
+@pytest.mark.parametrize('algo,act,anil,first_order,lr', [('vpg', 'relu', False, False, 0.05), ('vpg', 'tanh', True, False, 0.05),
+                                                            ('vpg', 'relu', False, True, 0.05), ('ppo', 'relu', False, False, 0.05),
+                                                            ('ppo', 'tanh', False, False, 0.05), ('ppo', 'tanh', True, False, 0.05),
+                                                            ('ppo', 'relu', False, False, 2.0)])   # large steps: the clip is active
+def test_policy_meta_batch_vpg_ppo(algo, act, anil, first_order, lr):
+    """mi_policy_meta_batch against the autograd restatement of fast_adapt_vpg / fast_adapt_ppo on the same replays: validation
+    loss, adapted parameters and the (second-order) meta-gradient `av_loss.backward()` leaves behind (rl/maml_ppo.py:129)."""
+    T, adapt_steps = 3, 2
+    P = dict(tau=1.0, gamma=0.99, inner_lr=lr, ppo_epochs=3, ppo_clip_ratio=0.1 if lr < 1 else 0.02)
+    activation = torch.relu if act == 'relu' else torch.tanh
+    theta = _theta64()
+    env = RL.Particles2D(seed=3)
+    gen = torch.Generator().manual_seed(4)
+    sup, qry = [[None] * T for _ in range(adapt_steps)], [None] * T
+    for t, task in enumerate(env.sample_tasks(T)):
+        env.set_task(task)
+        for b in range(adapt_steps):
+            sup[b][t] = RL.collect_episodes(env, theta, 5, 12 + 3 * b, gen, activation=activation)
+        qry[t] = RL.collect_episodes(env, theta, 5, 15, gen, activation=activation)
+    # oracle: per-task loss, adapted parameters, gradient; advantages from the (deterministic) baseline fits it performs
+    leaves = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+    losses, thetas, gsum = [], [], torch.zeros(sum(v.numel() for v in theta.values()), dtype=torch.float64)
+    for t in range(T):
+        s_t = [sup[b][t] for b in range(adapt_steps)]
+        if algo == 'vpg':
+            loss, pk = RL.replay_vpg(leaves, s_t, qry[t], P, RL.LinearValue(2, 2), first_order=first_order, activation=activation, anil=anil)
+        else:
+            loss, pk = RL.replay_ppo(leaves, s_t, qry[t], P, RL.LinearValue(2, 2), activation=activation, anil=anil)
+        g = torch.autograd.grad(loss, list(leaves.values()))
+        gsum += torch.cat([x.reshape(-1) for x in g])
+        losses.append(float(loss))
+        thetas.append(torch.cat([v.detach().reshape(-1) for v in pk.values()]))
+    # the same advantages for the engine
+    def adv_of(ep):
+        a = RL.compute_advantages(RL.LinearValue(2, 2), P['tau'], P['gamma'], ep)
+        return (RL.normalize(a) if algo == 'ppo' else a).detach()
+    sup_b, B1 = _stack_batches(sup, [[adv_of(e) for e in row] for row in sup])
+    qry_b, B2 = _stack_batches([qry], [[adv_of(e) for e in qry]])
+    B = max(B1, B2)
+    def padB(d):
+        out = {}
+        for k, v in d.items():
+            if k == 'count':
+                out[k] = v
+            else:
+                shp = list(v.shape); ax = 2
+                padn = B - shp[ax]
+                out[k] = torch.nn.functional.pad(v, ((0, 0, 0, padn) if v.dim() == 4 else (0, padn))).contiguous()
+        return out
+    sup_b, qry_b = padB(sup_b), {k: v[0] for k, v in padB(qry_b).items()}
+    pol = (_policy_tanh if act == 'tanh' else _policy)(theta)
+    eng = pol.engine()
+    epochs = P['ppo_epochs'] if algo == 'ppo' else 1
+    step_batch = [b for b in range(adapt_steps) for _ in range(epochs)]
+    loss, th_out, grad = eng.meta_batch(pol.flat(), sup_b, qry_b, step_batch, P['inner_lr'], loss='ppo' if algo == 'ppo' else 'a2c',
+                                        clip=P['ppo_clip_ratio'], head_only=anil, first_order=first_order)
+    torch.cuda.synchronize()
+    e_th = max(rel_err(th_out[t].cpu().numpy() - pol.flat().cpu().numpy(),
+                       thetas[t].numpy() - torch.cat([v.reshape(-1) for v in theta.values()]).numpy()) for t in range(T))
+    e_g = rel_err(grad.cpu().numpy(), gsum.numpy())
+    e_l = max(abs(float(loss[t]) - losses[t]) for t in range(T))
+    report(f'policy_meta[{algo},{act},anil={anil},fo={first_order},lr={lr}]', loss_abs=e_l, theta_step_rel=e_th, grad_rel=e_g)
+    assert e_l < 2e-6 * max(1.0, max(abs(x) for x in losses))
+    assert e_th < 1e-4 and e_g < 2e-4
+    if anil:                                                             # the body did not move during adaptation
+        body = slice(2, 2 + 100 * 2 + 100 + 100 * 100 + 100)
+        assert torch.equal(th_out[:, body], pol.flat()[body].expand(T, -1))
+    # evaluation-only call: same loss, no gradient
+    l2, _, g2 = eng.meta_batch(pol.flat(), sup_b, qry_b, step_batch, P['inner_lr'], loss='ppo' if algo == 'ppo' else 'a2c',
+                               clip=P['ppo_clip_ratio'], head_only=anil, first_order=first_order, with_grad=False)
+    assert g2 is None and torch.allclose(l2, loss, rtol=1e-6, atol=1e-8)
