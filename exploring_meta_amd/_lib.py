@@ -100,6 +100,11 @@ _SIGS = {
     'mi_policy_meta_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 +
                              [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_size_t]),
+    'mi_trpo_steps_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    'mi_trpo_surrogate_steps': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10 +
+                                [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'mi_trpo_fvp_steps': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 +
+                          [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'mi_profile_enable': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     'mi_profile_kinds': (C.c_int, []),
     'mi_profile_op_name': (C.c_char_p, [C.c_int]),

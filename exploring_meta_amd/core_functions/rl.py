@@ -141,16 +141,20 @@ class _SurrogateContext:
     the replays only -- the reference re-fits the baseline to the same data on every call, rl.py:99,465)."""
 
     def __init__(self, iter_replays, iter_policies, policy, baseline, params):
-        if any(len(r) != 2 for r in iter_replays):
-            raise NotImplementedError('the fused second-order TRPO path implements adapt_steps == 1 (the reference default)')
         S, A, dev = policy.input_size, policy.output_size, policy.sigma.device
-        sup = [r[0] for r in iter_replays]
-        qry = [r[1] for r in iter_replays]
-        sadv = [_advantages(e, baseline, params['gamma'], params['tau']) for e in sup]
-        qadv = [_advantages(e, baseline, params['gamma'], params['tau']) for e in qry]
-        self.sup, self.qry = _pad(sup, sadv, S, A, dev), _pad(qry, qadv, S, A, dev)
-        B = max(self.sup['states'].shape[1], self.qry['states'].shape[1])
-        for d in (self.sup, self.qry):                           # one common padded length
+        K = len(iter_replays[0]) - 1
+        if K < 1 or any(len(r) != K + 1 for r in iter_replays):
+            raise ValueError('every task needs the same number (>= 1) of support replays plus one query replay')
+        self.steps = K
+        adv = lambda e: _advantages(e, baseline, params['gamma'], params['tau'])
+        sups = []
+        for k in range(K):                                       # the reference walks task by task, replay by replay (rl.py:444-465);
+            eps = [r[k] for r in iter_replays]                   # the baseline is re-fitted per replay, so the order is immaterial
+            sups.append(_pad(eps, [adv(e) for e in eps], S, A, dev))
+        qry_eps = [r[-1] for r in iter_replays]
+        self.qry = _pad(qry_eps, [adv(e) for e in qry_eps], S, A, dev)
+        B = max([d['states'].shape[1] for d in sups] + [self.qry['states'].shape[1]])
+        for d in sups + [self.qry]:                              # one common padded length
             if d['states'].shape[1] < B:
                 pad = B - d['states'].shape[1]
                 d['states'] = torch.nn.functional.pad(d['states'], (0, 0, 0, pad))
@@ -158,6 +162,10 @@ class _SurrogateContext:
                 d['adv'] = torch.nn.functional.pad(d['adv'], (0, pad))
             for k in ('states', 'actions', 'adv'):
                 d[k] = d[k].contiguous()
+        if K == 1:
+            self.sup = sups[0]
+        else:
+            self.sup = {k: torch.stack([d[k] for d in sups]).contiguous() for k in ('states', 'actions', 'adv', 'count')}
         self.engine = policy.engine()
         thetas = torch.stack([p.flat() for p in iter_policies])
         self.old_loc = self.engine.forward(thetas, self.qry['states'])
@@ -170,7 +178,7 @@ class _SurrogateContext:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return tensors
-        n_local = float(self.sup['states'].shape[0])
+        n_local = float(self.qry['states'].shape[0])
         flat = torch.cat([t.reshape(-1) for t in tensors] + [torch.ones(1, device=tensors[0].device)]) * n_local
         dist.all_reduce(flat)
         flat = flat / flat[-1]
@@ -181,7 +189,8 @@ class _SurrogateContext:
         return tuple(out)
 
     def evaluate(self, theta, want_grad=False):
-        loss, kl, grad = self.engine.surrogate(theta, self.sup, self.qry, self.old_loc, self.old_scale, self.inner_lr, want_grad)
+        fn = self.engine.surrogate if self.steps == 1 else self.engine.surrogate_steps
+        loss, kl, grad = fn(theta, self.sup, self.qry, self.old_loc, self.old_scale, self.inner_lr, want_grad)
         if grad is None:
             loss, kl = self._allmean(loss, kl)
         else:
@@ -190,7 +199,9 @@ class _SurrogateContext:
 
     def fvp(self, theta, v, damping=1e-5):
         # the damping term is linear in v, so averaging the per-rank results keeps it exact
-        return self._allmean(self.engine.fvp(theta, self.sup, self.qry, self.inner_lr, damping, v))[0]
+        if self.steps == 1:
+            return self._allmean(self.engine.fvp(theta, self.sup, self.qry, self.inner_lr, damping, v))[0]
+        return self._allmean(self.engine.fvp_steps(self.sup, self.qry, self.inner_lr, damping, v))[0]
 
 
 def meta_surrogate_loss(iter_replays, iter_policies, policy, baseline, params, anil=False):

@@ -816,3 +816,150 @@ extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* the
   PCHK(p, hipGetLastError());
   return MI_OK;
 }
+
+// =====================================================================================================================
+// MAML-TRPO with any number of inner updates (params['adapt_steps'] > 1): meta_surrogate_loss replays `steps` second-order
+// trpo_update calls, one per support replay (rl.py:447-453), before the surrogate / KL on the query replay.  With
+// J = d theta_K / d theta = prod_k (I - lr H_k(theta_k)):
+//   grad mean_t S_t = mean_t J_t^T grad S_t(theta_K)                 (adjoint recursion, as in mi_policy_meta_batch)
+//   Fvp(v)          = mean_t J_t^T F_t J_t v + damping v              (tangent recursion forward, Fisher at the query, adjoint back;
+//                                                                     exact where the adapted policy equals the stored old one)
+static int hvp_step(mi_policy* p, hipStream_t st, MetaPlan& pl, StepSet& s, int T, int B, const float* th, const float* xs,
+                    const float* as, const int32_t* cn, const float* v, float* hv) {
+  const size_t P = p->P;
+  PCHK(p, hipMemsetAsync(hv, 0, (size_t)T * P * sizeof(float), st));
+  int rc = mlp_tangent_forward(p, st, T, B, xs, th, P, s.a, v, pl.ta);
+  if (rc) return rc;
+  Gauss2Args gt{};
+  gt.mu = s.a.mu; gt.mud = pl.ta.mu; gt.rho = th + p->o_sigma; gt.rstride = P; gt.rhod = v + p->o_sigma; gt.vstride = P;
+  gt.act = as; gt.count = cn; gt.coef = s.coef; gt.coef2 = s.coef2; gt.dmu = pl.rdmu; gt.drho = hv + p->o_sigma; gt.gstride = P;
+  gt.B = B; gt.A = p->A; gt.mode = P_TANGENT;
+  hipLaunchKernelGGL(gauss2_kernel, dim3(T), dim3(256), 0, st, gt);
+  PCHK(p, hipGetLastError());
+  return mlp_tangent_backward(p, st, T, B, xs, th, P, s.a, pl.ta, v, s.dmu, s.d2, s.d1, s.pre2, s.pre1, pl.rdmu, pl.r2, pl.r1, hv);
+}
+
+extern "C" int mi_trpo_steps_workspace_bytes(const mi_policy* p, int tasks, int batch, int steps, size_t* bytes) {
+  if (!p || !bytes || tasks < 1 || batch < 1 || steps < 1) return MI_ERR_ARG;
+  MetaPlan pl;
+  meta_plan(p, nullptr, tasks, batch, steps, 1, true, pl);
+  *bytes = pl.bytes + align_up((size_t)2 * tasks * sizeof(float), 256);
+  return MI_OK;
+}
+
+extern "C" int mi_trpo_surrogate_steps(mi_policy* p, void* stream, const float* theta, int steps, const float* s_states,
+                                       const float* s_actions, const float* s_adv, const int32_t* s_count, const float* q_states,
+                                       const float* q_actions, const float* q_adv, const int32_t* q_count, const float* old_loc,
+                                       const float* old_scale, int tasks, int batch, float inner_lr, float* loss_out,
+                                       float* kl_out, float* grad_out, void* workspace, size_t workspace_bytes) {
+  if (!p || !theta || !s_states || !s_actions || !s_adv || !q_states || !q_actions || !q_adv || !old_loc || !old_scale || !loss_out ||
+      !kl_out || !workspace || steps < 1)
+    return pfail(p, MI_ERR_ARG, "null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int T = tasks, B = batch, K = steps;
+  const size_t P = p->P, TB = (size_t)T * B, TP = (size_t)T * P;
+  MetaPlan pl;
+  meta_plan(p, workspace, T, B, K, 1, true, pl);
+  size_t need = 0;
+  mi_trpo_steps_workspace_bytes(p, T, B, K, &need);
+  if (need > workspace_bytes) return pfail(p, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  float* loss_t = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.bytes);
+  float* kl_t = loss_t + T;
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, theta, (size_t)0, pl.g, 0.f, (int)P, pl.theta);
+  PCHK(p, hipGetLastError());
+  for (int k = 0; k < K; ++k) {                                   // trpo_update on support replay k (a2c loss, normalised advantages)
+    StepSet& s = pl.st[k];
+    float* th = pl.theta + (size_t)k * TP;
+    const float* xs = s_states + (size_t)k * TB * p->S;
+    const float* as = s_actions + (size_t)k * TB * p->A;
+    int rc = mlp_forward(p, st, T, B, xs, th, P, s.a);
+    if (rc) return rc;
+    PCHK(p, hipMemsetAsync(pl.g, 0, TP * sizeof(float), st));
+    Gauss2Args ga{};
+    ga.mu = s.a.mu; ga.rho = th + p->o_sigma; ga.rstride = P; ga.act = as; ga.adv = s_adv + (size_t)k * TB;
+    ga.count = s_count ? s_count + (size_t)k * T : nullptr; ga.coef = s.coef; ga.coef2 = s.coef2; ga.dmu = s.dmu;
+    ga.drho = pl.g + p->o_sigma; ga.gstride = P; ga.loss = pl.hv; ga.B = B; ga.A = p->A; ga.kind = MI_PLOSS_A2C; ga.mode = P_PRIMAL;
+    hipLaunchKernelGGL(gauss2_kernel, dim3(T), dim3(256), 0, st, ga);
+    PCHK(p, hipGetLastError());
+    rc = mlp_backward(p, st, T, B, xs, th, P, s.a, s.dmu, s.d2, s.d1, pl.g, s.pre2, s.pre1, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, th, P, pl.g, inner_lr, (int)P, th + TP);
+    PCHK(p, hipGetLastError());
+  }
+  float* thK = pl.theta + (size_t)K * TP;
+  int rc = mlp_forward(p, st, T, B, q_states, thK, P, pl.q.a);
+  if (rc) return rc;
+  PCHK(p, hipMemsetAsync(pl.lam, 0, TP * sizeof(float), st));
+  GaussArgs gq{};
+  gq.mu = pl.q.a.mu; gq.rho = thK + p->o_sigma; gq.rstride = P; gq.act = q_actions; gq.adv = q_adv; gq.count = q_count;
+  gq.old_loc = old_loc; gq.old_scale = old_scale; gq.coef = pl.q.coef; gq.dmu = pl.q.dmu; gq.drho = pl.lam + p->o_sigma;
+  gq.gstride = P; gq.loss = loss_t; gq.kl = kl_t; gq.B = B; gq.A = p->A; gq.mode = G_SURROGATE;
+  PCHK(p, gauss(st, T, gq));
+  hipLaunchKernelGGL(mean_tasks_kernel, dim3(1), dim3(64), 0, st, loss_t, T, 1, 1.f / (float)T, (const float*)nullptr, 0.f, loss_out);
+  hipLaunchKernelGGL(mean_tasks_kernel, dim3(1), dim3(64), 0, st, kl_t, T, 1, 1.f / (float)T, (const float*)nullptr, 0.f, kl_out);
+  PCHK(p, hipGetLastError());
+  if (!grad_out) return MI_OK;
+  rc = mlp_backward(p, st, T, B, q_states, thK, P, pl.q.a, pl.q.dmu, pl.q.d2, pl.q.d1, pl.lam);
+  if (rc) return rc;
+  for (int k = K - 1; k >= 0; --k) {
+    const float* th = pl.theta + (size_t)k * TP;
+    rc = hvp_step(p, st, pl, pl.st[k], T, B, th, s_states + (size_t)k * TB * p->S, s_actions + (size_t)k * TB * p->A,
+                  s_count ? s_count + (size_t)k * T : nullptr, pl.lam, pl.hv);
+    if (rc) return rc;
+    hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.lam, P, pl.hv, inner_lr, (int)P, pl.lam);
+    PCHK(p, hipGetLastError());
+  }
+  hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, pl.lam, T, (int)P, 1.f / (float)T,
+                     (const float*)nullptr, 0.f, grad_out);
+  PCHK(p, hipGetLastError());
+  return MI_OK;
+}
+
+extern "C" int mi_trpo_fvp_steps(mi_policy* p, void* stream, int steps, const float* s_states, const float* s_actions,
+                                 const int32_t* s_count, const float* q_states, const int32_t* q_count, int tasks, int batch,
+                                 float inner_lr, float damping, const float* v, float* out, void* workspace, size_t workspace_bytes) {
+  if (!p || !s_states || !s_actions || !q_states || !v || !out || !workspace || steps < 1) return pfail(p, MI_ERR_ARG, "null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int T = tasks, B = batch, K = steps;
+  const size_t P = p->P, TB = (size_t)T * B, TP = (size_t)T * P;
+  MetaPlan pl;
+  meta_plan(p, workspace, T, B, K, 1, true, pl);
+  if (pl.bytes > workspace_bytes) return pfail(p, MI_ERR_WORKSPACE, "workspace too small");
+  auto sup = [&](int k, const float*& xs, const float*& as, const int32_t*& cn) {
+    xs = s_states + (size_t)k * TB * p->S; as = s_actions + (size_t)k * TB * p->A; cn = s_count ? s_count + (size_t)k * T : nullptr;
+  };
+  // u = J v : u <- u - lr H_k u, k = 0 .. K-1   (pl.vmask holds u)
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, v, (size_t)0, pl.g, 0.f, (int)P, pl.vmask);
+  PCHK(p, hipGetLastError());
+  for (int k = 0; k < K; ++k) {
+    const float *xs, *as; const int32_t* cn;
+    sup(k, xs, as, cn);
+    int rc = hvp_step(p, st, pl, pl.st[k], T, B, pl.theta + (size_t)k * TP, xs, as, cn, pl.vmask, pl.hv);
+    if (rc) return rc;
+    hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.vmask, P, pl.hv, inner_lr, (int)P, pl.vmask);
+    PCHK(p, hipGetLastError());
+  }
+  // w = F u at the query (Gaussian Fisher at new == old)
+  float* thK = pl.theta + (size_t)K * TP;
+  int rc = mlp_tangent_forward(p, st, T, B, q_states, thK, P, pl.q.a, pl.vmask, pl.ta);
+  if (rc) return rc;
+  PCHK(p, hipMemsetAsync(pl.lam, 0, TP * sizeof(float), st));
+  GaussArgs gf{};
+  gf.mu = pl.q.a.mu; gf.mud = pl.ta.mu; gf.rho = thK + p->o_sigma; gf.rstride = P; gf.rhod = pl.vmask + p->o_sigma; gf.vstride = P;
+  gf.count = q_count; gf.dmu = pl.rdmu; gf.drho = pl.lam + p->o_sigma; gf.gstride = P; gf.B = B; gf.A = p->A; gf.mode = G_FISHER;
+  PCHK(p, gauss(st, T, gf));
+  rc = mlp_backward(p, st, T, B, q_states, thK, P, pl.q.a, pl.rdmu, pl.r2, pl.r1, pl.lam);
+  if (rc) return rc;
+  // out = mean_t J^T w + damping v
+  for (int k = K - 1; k >= 0; --k) {
+    const float *xs, *as; const int32_t* cn;
+    sup(k, xs, as, cn);
+    rc = hvp_step(p, st, pl, pl.st[k], T, B, pl.theta + (size_t)k * TP, xs, as, cn, pl.lam, pl.hv);
+    if (rc) return rc;
+    hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.lam, P, pl.hv, inner_lr, (int)P, pl.lam);
+    PCHK(p, hipGetLastError());
+  }
+  hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, pl.lam, T, (int)P, 1.f / (float)T, v, damping, out);
+  PCHK(p, hipGetLastError());
+  return MI_OK;
+}

@@ -343,6 +343,35 @@ class PolicyEngine:
                                                float(inner_lr), _ptr(loss), _ptr(kl), _ptr(grad), _ptr(ws), ws.numel()))
         return loss, kl, grad
 
+    def _steps_ws(self, T, B, K):
+        b = C.c_size_t()
+        self._check(self.lib.mi_trpo_steps_workspace_bytes(self._h, T, B, K, C.byref(b)))
+        if self._ws is None or self._ws.numel() < b.value:
+            self._ws = torch.empty(b.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def surrogate_steps(self, theta, sup, qry, old_loc, old_scale, inner_lr, want_grad):
+        """meta_surrogate_loss with K = sup['states'].shape[0] inner updates (sup arrays carry a leading [K] axis)."""
+        K, T, B = sup['states'].shape[0], sup['states'].shape[1], sup['states'].shape[2]
+        ws = self._steps_ws(T, B, K)
+        loss = torch.empty(1, device=self.device)
+        kl = torch.empty(1, device=self.device)
+        grad = torch.empty(self.param_count, device=self.device) if want_grad else None
+        self._check(self.lib.mi_trpo_surrogate_steps(
+            self._h, _stream(), _ptr(theta), K, _ptr(sup['states']), _ptr(sup['actions']), _ptr(sup['adv']), _ptr(sup['count']),
+            _ptr(qry['states']), _ptr(qry['actions']), _ptr(qry['adv']), _ptr(qry['count']), _ptr(old_loc), _ptr(old_scale), T, B,
+            float(inner_lr), _ptr(loss), _ptr(kl), _ptr(grad), _ptr(ws), ws.numel()))
+        return loss, kl, grad
+
+    def fvp_steps(self, sup, qry, inner_lr, damping, v):
+        K, T, B = sup['states'].shape[0], sup['states'].shape[1], sup['states'].shape[2]
+        ws = self._steps_ws(T, B, K)
+        out = torch.empty(self.param_count, device=self.device)
+        self._check(self.lib.mi_trpo_fvp_steps(self._h, _stream(), K, _ptr(sup['states']), _ptr(sup['actions']), _ptr(sup['count']),
+                                               _ptr(qry['states']), _ptr(qry['count']), T, B, float(inner_lr), float(damping),
+                                               _ptr(v.contiguous()), _ptr(out), _ptr(ws), ws.numel()))
+        return out
+
     def meta_batch(self, theta, sup, qry, step_batch, inner_lr, loss='a2c', clip=0.1, step_new_old=None, head_only=False,
                    first_order=False, with_grad=True):
         """K = len(step_batch) MAML updates of the policy on replayed support batches + validation loss + meta-gradient for all

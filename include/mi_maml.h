@@ -253,6 +253,20 @@ int mi_policy_meta_batch(mi_policy* p, void* stream, const float* theta, int ste
                          float inner_lr, int head_only, int second_order, int with_grad, float* loss_out, float* theta_out,
                          float* grad_out, void* workspace, size_t workspace_bytes);
 
+/* MAML-TRPO with `steps` >= 1 inner updates (params['adapt_steps'], one support replay per update, rl.py:447-453): the
+ * generalisation of mi_trpo_surrogate / mi_trpo_fvp.  Support arrays carry a leading [steps] axis:
+ * s_states [steps,tasks,batch,S], s_actions [steps,tasks,batch,A], s_adv [steps,tasks,batch], s_count [steps,tasks].
+ * mi_trpo_fvp_steps must follow mi_trpo_surrogate_steps on the same workspace and replays (it re-uses the saved passes). */
+int mi_trpo_steps_workspace_bytes(const mi_policy* p, int tasks, int batch, int steps, size_t* bytes);
+int mi_trpo_surrogate_steps(mi_policy* p, void* stream, const float* theta, int steps, const float* s_states,
+                            const float* s_actions, const float* s_adv, const int32_t* s_count, const float* q_states,
+                            const float* q_actions, const float* q_adv, const int32_t* q_count, const float* old_loc,
+                            const float* old_scale, int tasks, int batch, float inner_lr, float* loss_out, float* kl_out,
+                            float* grad_out, void* workspace, size_t workspace_bytes);
+int mi_trpo_fvp_steps(mi_policy* p, void* stream, int steps, const float* s_states, const float* s_actions, const int32_t* s_count,
+                      const float* q_states, const int32_t* q_count, int tasks, int batch, float inner_lr, float damping,
+                      const float* v, float* out, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif
