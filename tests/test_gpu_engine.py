@@ -221,3 +221,26 @@ def test_two_second_order_steps_on_plateau_free_inputs():
         gerr.append(rel_err(grad.cpu().numpy(), R.flatten_params(g64).double().numpy()))
     report('plateau_free_K2_so', loss_rel=lerr, grad_rel=gerr)
     assert max(lerr) < 1e-4 and np.median(gerr) < 1e-4 and max(gerr) < 2e-3
+
+
+def test_fused_block1_single_channel_inputs():
+    """The Ci = 1 instances of the block-1 kernels (conv recompute, Gram statistics, sparse weight gradient): a pooling trunk on
+    1x28x28 inputs (ConvBase(hidden=32, channels=1, max_pool=True), a configuration the reference's ConvBase allows) three ways."""
+    mspec = ModelSpec(4, 1, 28, 28, 32, True, 5, False)
+    eng0 = MetaEngine(mspec)
+    n = eng0.param_count
+    theta = torch.from_numpy(synthetic.hash_uniform(3, (n,)) * 0.4 - 0.2).float().cuda()
+    data, labels = synthetic.make_meta_batch('omni', [0, 1, 2, 3], 5, 2)
+    d, l = torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda()
+    outs = []
+    for mode in (1, 2, 0):
+        eng = MetaEngine(mspec)
+        eng.set_fused_block1(mode)
+        loss, acc, grad, _ = eng.meta_batch(theta, d, l, 2, 2, 0.05, first_order=False)
+        torch.cuda.synchronize()
+        outs.append((loss.cpu().numpy(), acc.cpu().numpy(), grad.cpu().numpy()))
+    e1, e2 = rel_err(outs[0][2], outs[2][2]), rel_err(outs[1][2], outs[2][2])
+    report('fused_block1_ci1', grad_rel_gram=e1, grad_rel_recompute=e2)
+    for o in outs[:2]:
+        assert np.allclose(o[0], outs[2][0], rtol=1e-5) and np.array_equal(o[1], outs[2][1])
+    assert e1 < 1e-4 and e2 < 1e-4
