@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
   // K index layout: lane half 0 feeds taps 0..4, half 1 taps 5..8 (+ one zero tap): KH = 5*CI0 MFMAs per tile; every tap's
   // CI0 channels are contiguous in NHWC, so a lane needs 5 address computations (one 4*CI0-byte load each) per tile.
   constexpr int K = 9 * CI0, NTH = 5, KH = NTH * CI0, KP = 2 * KH;
-  constexpr bool TAN = MODE >= B1_TSTATS;
+  constexpr bool TAN = MODE >= B1_TSTATS && MODE != B1_TFWD_ARG;
+  constexpr bool ARG = MODE == B1_TFWD_ARG;       // the single conv runs with the DIRECTION's weights: z holds zd
   constexpr bool WG = MODE == B1_BWD_WGRAD || MODE == B1_TBWD_WGRAD;
   constexpr bool RED = MODE == B1_STATS || MODE == B1_BWD_REDUCE || MODE == B1_TSTATS || MODE == B1_TBWD_REDUCE;
   // LDS: [0, 2*KP*32) conv weights (theta, direction); then one 30x33 transpose pad per wave for the weight-gradient A operand;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
 
   // ---- weights -> LDS: [k][32] (and the tangent direction's weights behind them)
   {
-    const float* w0 = a.w + (size_t)task * a.wstride;
+    const float* w0 = ARG ? a.wd + (size_t)task * a.vstride : a.w + (size_t)task * a.wstride;
     const float* w1 = TAN ? a.wd + (size_t)task * a.vstride : nullptr;
     for (int idx = tid; idx < KP * 32; idx += 256) {
       const int k = idx >> 5, nl = idx & 31;          // LDS row k = h*KH + t*CI0 + c  <->  weight row (5h + t)*CI0 + c
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
     gm = a.gamma[(size_t)task * a.pstride + ch];
     bt = a.beta[(size_t)task * a.pstride + ch];
   }
-  if (MODE == B1_TFWD || MODE == B1_TBWD_REDUCE || MODE == B1_TBWD_WGRAD) {
+  if (MODE == B1_TFWD || MODE == B1_TBWD_REDUCE || MODE == B1_TBWD_WGRAD || ARG) {
     m1 = a.m1[(size_t)task * CO + ch];
     m2 = a.m2[(size_t)task * CO + ch];
     gmd = a.gammad[(size_t)task * a.vstride + ch];
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
   float* out_t = a.out ? a.out + (size_t)task * p_task : nullptr;
   float* zho_t = a.zh_out ? a.zh_out + (size_t)task * p_task : nullptr;
   uint8_t* ago_t = (MODE == B1_FWD && a.arg_out) ? a.arg_out + (size_t)task * p_task : nullptr;
+  const uint8_t* agi_t = ARG ? a.arg_in + (size_t)task * p_task : nullptr;
+  const float* zhi_t = ARG ? a.zh_in + (size_t)task * p_task : nullptr;
   const int nwin = a.n * HP * WP;
 
   double s0 = 0.0, s1 = 0.0;     // the two per-channel sums of the reduction modes
@@ -155,6 +158,22 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
       const int widx = wbase + 2 * g + h;
       const bool wvalid = widx < nwin;
       const size_t poff = (size_t)widx * CO + ch;
+      if (ARG) {
+        // zd at the stored argmax, zhat from the forward pass: pd = [on] (gammad zh + gamma zhd + betad), zhd = r (zd - m1 - zh m2)
+        const int ag = wvalid ? (int)agi_t[poff] : 4;
+        const float zh_s = *(wvalid ? zhi_t + poff : mi_zero_word);
+        float zd_at = z[4 * g];
+        zd_at = ag == 1 ? z[4 * g + 1] : zd_at;
+        zd_at = ag == 2 ? z[4 * g + 2] : zd_at;
+        zd_at = ag == 3 ? z[4 * g + 3] : zd_at;
+        const float zhd_s = rs * (zd_at - m1 - zh_s * m2);
+        const bool on_s = ag < 4;
+        if (wvalid) {
+          out_t[poff] = on_s ? gmd * zh_s + gm * zhd_s + btd : 0.f;
+          if (zho_t) zho_t[poff] = on_s ? zhd_s : 0.f;
+        }
+        continue;
+      }
       float zh[4], u[4], zhd[4];
       float umax = 0.f, zh_at = 0.f, zhd_at = 0.f;
       int arg = 0;
@@ -318,6 +337,7 @@ hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, 
     case B1_TFWD: B1_LAUNCH(CI0, B1_TFWD); break;       \
     case B1_TBWD_REDUCE: B1_LAUNCH(CI0, B1_TBWD_REDUCE); break; \
     case B1_TBWD_WGRAD: B1_LAUNCH(CI0, B1_TBWD_WGRAD); break;   \
+    case B1_TFWD_ARG: B1_LAUNCH(CI0, B1_TFWD_ARG); break;       \
     default: return hipErrorInvalidValue;               \
   }
   if (ci == 3) { B1_MODES(3) }

@@ -534,7 +534,12 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       b1.gammad = v + L.off_gamma; b1.betad = v + L.off_beta;
       b1.out = X.pd[0];
       b1.zh_out = A.zhm ? X.zhdm : nullptr;
-      LAUNCH(e, st, OP_BN_TAN_FWD, 0, launch_block1(st, b1, T, L.ci, B1_TFWD, nullptr));
+      if (A.zhm && A.arg0) {   // the forward pass kept zhat and the argmax: one conv with the direction's weights suffices
+        b1.arg_in = A.arg0; b1.zh_in = A.zhm;
+        LAUNCH(e, st, OP_BN_TAN_FWD, 0, launch_block1(st, b1, T, L.ci, B1_TFWD_ARG, nullptr));
+      } else {
+        LAUNCH(e, st, OP_BN_TAN_FWD, 0, launch_block1(st, b1, T, L.ci, B1_TFWD, nullptr));
+      }
       continue;
     }
     ConvArgs ca{};

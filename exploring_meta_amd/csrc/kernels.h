@@ -91,13 +91,15 @@ struct B1Args {
   float* out;                // p or pd
   float* zh_out;             // optional: zhat (FWD) / its tangent (TFWD) at each window's argmax, same shape as out
   uint8_t* arg_out;          // optional (FWD): argmax position 0..3 of every window, 4 where the maximum did not pass the ReLU
+  const uint8_t* arg_in; const float* zh_in;   // TFWD_ARG: the two tensors FWD stored (no primal conv recompute)
   double* partial;           // [T][blocks][2][Co]
   float* wpartial;           // [T][blocks][9*Ci0][Co]
   int n, hh, ww, co;         // images per task, conv output height / width (= input, stride 1), filters
   float inv_m;
   int ntiles, tiles_per_wave;
 };
-enum { B1_STATS = 0, B1_FWD = 1, B1_BWD_REDUCE = 2, B1_BWD_WGRAD = 3, B1_TSTATS = 4, B1_TFWD = 5, B1_TBWD_REDUCE = 6, B1_TBWD_WGRAD = 7 };
+enum { B1_STATS = 0, B1_FWD = 1, B1_BWD_REDUCE = 2, B1_BWD_WGRAD = 3, B1_TSTATS = 4, B1_TFWD = 5, B1_TBWD_REDUCE = 6, B1_TBWD_WGRAD = 7,
+       B1_TFWD_ARG = 8 };   // tangent forward from the stored argmax / zhat: one conv (with the direction's weights) instead of two
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co);
 int block1_blocks_per_task(int n, int h, int w, int co, int tasks);
 hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task);
