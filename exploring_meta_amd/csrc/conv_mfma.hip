@@ -112,20 +112,31 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
   const int H = a.g.h, W = a.g.w, HO = a.g.ho, WO = a.g.wo, CO = a.g.co;
   const int cbase = ct * 32;
 
-  // ---- stage this task's weights: lds[((term*9+tap)*CI + k)*32 + nl]   (unrolled: several loads in flight per thread)
-#pragma unroll 6
-  for (int idx = tid; idx < NTERMS * 9 * CI * 32; idx += NT) {
-    const int nl = idx & 31;
-    const int k = (idx >> 5) % CI;
-    const int tt = idx / (CI * 32);  // term*9 + tap
-    const int term = tt / 9, tap = tt - term * 9;
-    const float* wsrc = a.wt[term] + (size_t)task * a.wstride;
-    float v;
-    if (MODE == 0)
-      v = wsrc[((size_t)tap * CI + k) * CO + cbase + nl];
-    else
-      v = wsrc[((size_t)tap * CO + cbase + nl) * CI + k];
-    lds[idx] = v;
+  // ---- stage this task's weights: lds[((term*9+tap)*CI + k)*32 + nl], 16 bytes per load.  Forward: a weight row's 32 filters
+  // are contiguous in [tap][ci][co], so a quad of nl is one float4 copy.  dgrad: the quad runs along k (contiguous in the forward
+  // layout [tap][co][ci]) and is scattered into four LDS rows.
+  constexpr int NQ = NTERMS * 9 * CI * 32 / 4;
+#pragma unroll 3
+  for (int qd = tid; qd < NQ; qd += NT) {
+    if (MODE == 0) {
+      const int nl4 = (qd & 7) * 4;
+      const int row = qd >> 3;                 // (term*9 + tap)*CI + k
+      const int k = row % CI, tt = row / CI;
+      const int term = tt / 9, tap = tt - term * 9;
+      const float* wsrc = a.wt[term] + (size_t)task * a.wstride;
+      const floatx4 v = *reinterpret_cast<const floatx4*>(wsrc + ((size_t)tap * CI + k) * CO + cbase + nl4);
+      *reinterpret_cast<floatx4*>(lds + row * 32 + nl4) = v;
+    } else {
+      constexpr int KQ = CI / 4;               // quads along k
+      const int k4 = (qd % KQ) * 4;
+      const int rest = qd / KQ;                // (term*9 + tap)*32 + nl
+      const int nl = rest & 31, tt = rest >> 5;
+      const int term = tt / 9, tap = tt - term * 9;
+      const float* wsrc = a.wt[term] + (size_t)task * a.wstride;
+      const floatx4 v = *reinterpret_cast<const floatx4*>(wsrc + ((size_t)tap * CO + cbase + nl) * CI + k4);
+      float* dst = lds + ((size_t)tt * CI + k4) * 32 + nl;
+      dst[0] = v[0]; dst[32] = v[1]; dst[64] = v[2]; dst[96] = v[3];
+    }
   }
   __syncthreads();
 
