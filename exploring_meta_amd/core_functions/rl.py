@@ -359,6 +359,12 @@ def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order
     else:
         valid_loss = lt[0]
     rew = query['rewards'].sum().item() / params['adapt_batch_size']
+    # learn2learn's learner.adapt updates the learner in place; here the base module is shared by every clone, so the adapted
+    # parameters are handed over on the side (evaluate() below acts with them)
+    try:
+        learner._adapted_policy = current
+    except Exception:
+        pass
     return valid_loss, rew, 0.0
 
 
@@ -371,6 +377,46 @@ def fast_adapt_vpg(task, learner, baseline, params, anil=False, first_order=Fals
 def fast_adapt_ppo(task, learner, baseline, params, anil=False, render=False):
     """reference rl.py:267-318: ppo_epochs clipped-surrogate updates per adapt step (second order, as learner.adapt defaults)."""
     return _adapt_and_validate(task, learner, baseline, params, 'ppo', anil, False)
+
+
+def evaluate(algo, goals, policy, baseline, params, anil=False, render=False, generator=None):
+    """reference rl.py:142-196 for Particles2D: adapt a copy of the policy to every evaluation task with `algo` in
+    {'vpg', 'ppo', 'trpo'}, then roll out `adapt_batch_size` query episodes with the adapted policy.
+    `goals`: the evaluation tasks (the reference draws env.sample_tasks(params['n_tasks'])).
+    Returns (tasks_rewards, mean reward, mean success rate)."""
+    tasks_rewards, tasks_success = [], []
+    for goal in goals:
+        learner = deepcopy(policy)
+        task = Particles2DRunner(goal, params['max_path_length'], generator, _unwrap(policy).sigma.device)
+        with torch.no_grad():
+            if algo == 'vpg':
+                fast_adapt_vpg(task, learner, baseline, params, anil=anil)
+                adapted = learner._adapted_policy
+            elif algo == 'ppo':
+                fast_adapt_ppo(task, learner, baseline, params)
+                adapted = learner._adapted_policy
+            else:
+                adapted, _, _, _, _ = fast_adapt_trpo(task, _unwrap(learner), baseline, params, anil=anil)
+        query = task.run(adapted, episodes=params['adapt_batch_size'])
+        tasks_rewards.append(query['rewards'].sum().item() / params['adapt_batch_size'])
+        tasks_success.append(0.0)                             # Particles2D reports no success signal (extra_info only for Meta-World)
+    n = params.get('n_tasks', len(tasks_rewards))
+    return tasks_rewards, sum(tasks_rewards) / n, sum(tasks_success) / n
+
+
+def evaluate_vpg(goals, policy, baseline, eval_params, anil=False, render=False, generator=None):
+    """reference rl.py:258-259"""
+    return evaluate('vpg', goals, policy, baseline, eval_params, anil, render, generator)
+
+
+def evaluate_ppo(goals, policy, baseline, eval_params, anil=False, render=False, generator=None):
+    """reference rl.py:340-341"""
+    return evaluate('ppo', goals, policy, baseline, eval_params, anil, render, generator)
+
+
+def evaluate_trpo(goals, policy, baseline, eval_params, anil=False, render=False, generator=None):
+    """reference rl.py:476-477"""
+    return evaluate('trpo', goals, policy, baseline, eval_params, anil, render, generator)
 
 
 # ---------------------------------------------------------------------------------------------- Particles2D rollouts (host loop, device math)

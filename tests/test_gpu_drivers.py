@@ -60,3 +60,20 @@ def test_fast_adapt_vpg_accumulates_meta_gradient():
     with torch.no_grad():                                   # evaluation: no graph, plain tensor
         loss, _, _ = cf.fast_adapt_vpg(cf.Particles2DRunner([0.1, 0.1], 12, gen), pol.clone(), cf.LinearValue(2, 2), P)
     assert not loss.requires_grad
+
+
+@pytest.mark.parametrize('algo', ['vpg', 'ppo', 'trpo'])
+def test_evaluate_rl(algo):
+    """reference rl.py:142-196 / evaluate_vpg / evaluate_ppo / evaluate_trpo on Particles2D goals: adaptation must not touch the
+    meta-policy, rewards are per-episode sums of negative distances."""
+    from exploring_meta_amd import core_functions as cf
+    torch.manual_seed(0)
+    pol = cf.DiagNormalPolicy(2, 2, activation='tanh').cuda()
+    before = pol.flat().clone()
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    P = dict(inner_lr=0.05, gamma=0.99, tau=1.0, adapt_steps=2, adapt_batch_size=4, max_path_length=12, ppo_epochs=2, ppo_clip_ratio=0.1, n_tasks=3)
+    fn = dict(vpg=cf.evaluate_vpg, ppo=cf.evaluate_ppo, trpo=cf.evaluate_trpo)[algo]
+    policy = cf.MAML(pol, lr=P['inner_lr']) if algo != 'trpo' else pol
+    rewards, mean_rew, mean_suc = fn([[0.3, 0.1], [-0.2, 0.4], [0.0, -0.5]], policy, cf.LinearValue(2, 2), P, generator=gen)
+    assert len(rewards) == 3 and all(r < 0 for r in rewards) and mean_rew == pytest.approx(sum(rewards) / 3) and mean_suc == 0.0
+    assert torch.equal(pol.flat(), before)
