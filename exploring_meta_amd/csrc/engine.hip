@@ -35,6 +35,11 @@ struct mi_engine {
   bool fuse1 = false;   // block 1 runs through the conv-recompute kernels of block1.hip
   bool gram1 = true;    // ... with the statistics of repeated passes from the input Gram matrix (gram.hip) and the BN-backward
                         // reductions from zhat stored at the pooling argmax, instead of further conv-recompute passes
+  // Weight gradients of blocks >= 2 run on a side stream: they depend only on dz_l and the block input, nothing downstream of
+  // them until the parameter update, and they are matrix-bound while the BatchNorm kernels of the next block are HBM-bound.
+  bool overlap = true;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   // optional per-launch HIP-event profiling (bench.py's roofline leg): kind = op*8 + layer
   int prof_on = 0, prof_filter = -1;
@@ -162,6 +167,8 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
 extern "C" void mi_engine_destroy(mi_engine* e) {
   if (!e) return;
   if (e->perm_dev) (void)hipFree(e->perm_dev);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   for (auto ev : e->ev0) (void)hipEventDestroy(ev);
   for (auto ev : e->ev1) (void)hipEventDestroy(ev);
   delete e;
@@ -172,6 +179,37 @@ extern "C" int mi_engine_set_fused_block1(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->fuse1 = on && block1_supported(e->L[0].ci, e->L[0].stride, e->L[0].pool, e->L[0].ho, e->L[0].wo, e->L[0].co);
   e->gram1 = on != 2;      // 2 = fused kernels, statistics by conv-recompute passes (no Gram matrix)
+  return MI_OK;
+}
+
+// 0 = every kernel on the caller's stream; 1 (default) = weight gradients of blocks >= 2 on an engine-owned side stream,
+// forked after dz_l is written and joined before the call returns control of the gradients to the caller's stream.
+extern "C" int mi_engine_set_overlap(mi_engine* e, int on) {
+  if (!e) return MI_ERR_ARG;
+  e->overlap = on != 0;
+  return MI_OK;
+}
+
+// side-stream helpers: fork = side waits for everything issued on `st` so far; join = `st` waits for everything issued on side
+static hipStream_t side_fork(mi_engine* e, hipStream_t st) {
+  if (!e->overlap) return st;
+  if (!e->side) {
+    // one side stream per device for the life of the process, shared by every engine on it (an engine is driven by one host
+    // thread and fork / join order every use): creating a stream costs ~0.4 s on this stack, engines are created freely
+    static hipStream_t g_side[64] = {};
+    const int d = (e->device >= 0 && e->device < 64) ? e->device : 0;
+    if (!g_side[d] && hipStreamCreateWithFlags(&g_side[d], hipStreamNonBlocking) != hipSuccess) { g_side[d] = nullptr; return st; }
+    e->side = g_side[d];
+    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { e->overlap = false; return st; }
+  }
+  if (hipEventRecord(e->ev_fork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_fork, 0) != hipSuccess) return st;
+  return e->side;
+}
+static int side_join(mi_engine* e, hipStream_t st, bool used) {
+  if (!used) return MI_OK;
+  if (hipEventRecord(e->ev_join, e->side) != hipSuccess || hipStreamWaitEvent(st, e->ev_join, 0) != hipSuccess)
+    return fail(e, MI_ERR_HIP, "side-stream join failed");
   return MI_OK;
 }
 
@@ -202,7 +240,8 @@ struct ActSet {
 struct TanSet {
   float *zd[8], *pd[8], *m1[8], *m2[8];
   float* zhdm;    // fused block 1: tangent of zhat at the argmax
-  float *rdz, *dpd[2], *fd, *rdf;
+  float* rdz[8];   // R{dz} per block (kept per block: the side-stream weight gradient of block l reads it while block l-1 is written)
+  float *dpd[2], *fd, *rdf;
 };
 struct Plan {
   float *theta, *g, *lam, *hv;
@@ -213,6 +252,7 @@ struct Plan {
   TanSet tan;
   double* bnpart;
   float* wgpart;
+  float* wgpart_side;   // partials of the weight gradients that run on the side stream
   double *gram_part, *gram_s;   // input Gram matrix of the support images (block 1 statistics), or nullptr
   float *tmp_loss, *tmp_acc;
   float* hscr;   // head scratch: R{dl} [T][n][ways], row loss [T][n], row hit [T][n]
@@ -291,6 +331,7 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   }
   pl.bnpart = b.take<double>(bnp);
   pl.wgpart = b.take<float>(wgp);
+  pl.wgpart_side = b.take<float>(wgp);
   pl.gram_part = pl.gram_s = nullptr;
   if (e->fuse1 && e->gram1 && (K >= 2 || (K >= 1 && second_order))) {   // the support set is swept at least twice
     pl.gram_part = b.take<double>(gram_partial_doubles(T, ns, e->L[0].h, e->L[0].ci));
@@ -306,7 +347,10 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
       X.m1[l] = b.take<float>((size_t)T * L.co);
       X.m2[l] = b.take<float>((size_t)T * L.co);
     }
-    X.rdz = b.take<float>(zmax);
+    for (int l = 0; l < nl; ++l) {
+      const Layer& L = e->L[l];
+      X.rdz[l] = (l == 0 && e->fuse1) ? nullptr : b.take<float>((size_t)T * ns * L.ho * L.wo * L.co);
+    }
     X.dpd[0] = b.take<float>(pmax);
     X.dpd[1] = b.take<float>(pmax);
     if (e->d.head_mean_pool) {
@@ -406,6 +450,7 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
                           float* g, const double* gram = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;
+  bool forked = false;
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
@@ -453,12 +498,14 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = A.dz[l];
-    wa.partial = pl.wgpart;
+    hipStream_t ws = l > 0 ? side_fork(e, st) : st;
+    if (ws != st) forked = true;
+    wa.partial = ws != st ? pl.wgpart_side : pl.wgpart;
     wa.g = geom(L, n);
     wa.mpix = mpix;
     int nch = 0;
-    LAUNCH(e, st, OP_WGRAD, l, launch_wgrad3x3(st, wa, T, 1, &nch));
-    LAUNCH(e, st, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(st, pl.wgpart, nch, 9 * L.ci * L.co, T, g + L.off_w, P));
+    LAUNCH(e, ws, OP_WGRAD, l, launch_wgrad3x3(ws, wa, T, 1, &nch));
+    LAUNCH(e, ws, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(ws, wa.partial, nch, 9 * L.ci * L.co, T, g + L.off_w, P));
     if (l > 0) {
       ConvArgs ca{};
       ca.in[0] = A.dz[l];
@@ -470,7 +517,7 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_NONE, 1, nullptr));
     }
   }
-  return MI_OK;
+  return side_join(e, st, forked);
 }
 
 static void head_scratch(const mi_engine* e, HeadArgs& ha, float* hscr, int T, int n) {
@@ -569,6 +616,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     fd = X.fd;
   }
   int cur = 0;
+  bool forked = false;
   HeadArgs ha{};
   ha.f = A.f; ha.fd = fd;
   ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
@@ -632,21 +680,23 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, l, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
     LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
     ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
-    ba.out = X.rdz;
+    ba.out = X.rdz[l];
     LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
-    wa.dz[0] = X.rdz;
+    wa.dz[0] = X.rdz[l];
     if (l > 0) { wa.x[1] = X.pd[l - 1]; wa.dz[1] = A.dz[l]; }
-    wa.partial = pl.wgpart;
+    hipStream_t ws = l > 0 ? side_fork(e, st) : st;
+    if (ws != st) forked = true;
+    wa.partial = ws != st ? pl.wgpart_side : pl.wgpart;
     wa.g = geom(L, n);
     wa.mpix = mpix;
     int nch = 0;
-    LAUNCH(e, st, OP_TAN_WGRAD, l, launch_wgrad3x3(st, wa, T, l > 0 ? 2 : 1, &nch));
-    LAUNCH(e, st, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(st, pl.wgpart, nch, 9 * L.ci * L.co, T, hv + L.off_w, P));
+    LAUNCH(e, ws, OP_TAN_WGRAD, l, launch_wgrad3x3(ws, wa, T, l > 0 ? 2 : 1, &nch));
+    LAUNCH(e, ws, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(ws, wa.partial, nch, 9 * L.ci * L.co, T, hv + L.off_w, P));
     if (l > 0) {
       ConvArgs ca{};
-      ca.in[0] = X.rdz; ca.wt[0] = theta + L.off_w;
+      ca.in[0] = X.rdz[l]; ca.wt[0] = theta + L.off_w;
       ca.in[1] = A.dz[l]; ca.wt[1] = v + L.off_w;
       ca.wstride = P;
       ca.out = X.dpd[cur ^ 1];
@@ -656,7 +706,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       cur ^= 1;
     }
   }
-  return MI_OK;
+  return side_join(e, st, forked);
 }
 
 extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
@@ -760,6 +810,7 @@ static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, An
   }
   ap.scratch.bnpart = b.take<double>(bnp);
   ap.scratch.wgpart = b.take<float>(wgp);
+  ap.scratch.wgpart_side = b.take<float>(wgp);
   ap.scratch.gram_part = ap.scratch.gram_s = nullptr;
   if (e->fuse1 && e->gram1) {   // statistics + weight gradient of block 1 from the Gram matrix: cheaper than two conv recomputes
     ap.scratch.gram_part = b.take<double>(gram_partial_doubles(T, 2 * n, e->L[0].h, e->L[0].ci));

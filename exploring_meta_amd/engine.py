@@ -109,6 +109,10 @@ class MetaEngine:
         """Ablation/test switch for the conv-recompute kernels of block 1."""
         _lib.check(self.lib.mi_engine_set_fused_block1(self._h, int(on)), self._h)
 
+    def set_overlap(self, on):
+        """Side-stream execution of the weight gradients of blocks >= 2 (default on); results do not depend on it."""
+        _lib.check(self.lib.mi_engine_set_overlap(self._h, int(on)), self._h)
+
     def workspace_bytes(self, tasks, shots, adapt_steps, second_order):
         b = C.c_size_t()
         _lib.check(self.lib.mi_workspace_bytes(self._h, tasks, self.spec.ways, shots, adapt_steps, int(second_order),

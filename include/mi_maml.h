@@ -55,6 +55,12 @@ const char* mi_version(void);
  * argmax, 2 = fused kernels only: every statistic / reduction by a conv-recompute pass. */
 int mi_engine_set_fused_block1(mi_engine* e, int on);
 
+/* 1 (default): the weight gradients of blocks >= 2 run on an engine-owned side stream, forked from the caller's stream once
+ * dz of the block is written and joined before the pass's gradients are used (they are matrix-bound, the BatchNorm kernels
+ * that follow on the main stream are HBM-bound).  0: every kernel on the caller's stream.  Results are identical either way
+ * (per-launch times from mi_profile_* are only additive with 0). */
+int mi_engine_set_overlap(mi_engine* e, int on);
+
 /* Debug/test aid: byte offsets of {theta, g, xs, sup[0].p[0], sup[0].dp[0], sup[0].mu[0], sup[0].rstd[0], sup[0].p[1],
  * qry.p[0], total} inside the workspace of a mi_meta_batch_maml call with these sizes (out: 10 entries). */
 int mi_debug_plan_offsets(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, int second_order, size_t* out);
