@@ -14,6 +14,11 @@ import os
 import sys
 import time
 
+# The engine forks weight gradients onto a side stream and RCCL brings its own: with the HIP default of 4 hardware queues the
+# streams of one process collide on a queue and the overlap turns into a 5 % loss (measured: 26.5 vs 25.2 ms per step under
+# torch.distributed); 8 queues keep every stream on its own.  Must be set before the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 
