@@ -38,8 +38,7 @@ struct mi_engine {
   // Weight gradients of blocks >= 2 run on a side stream: they depend only on dz_l and the block input, nothing downstream of
   // them until the parameter update, and they are matrix-bound while the BatchNorm kernels of the next block are HBM-bound.
   bool overlap = true;
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  struct SideCtx { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; } sc[1];
   std::string err;
   // optional per-launch HIP-event profiling (bench.py's roofline leg): kind = op*8 + layer
   int prof_on = 0, prof_filter = -1;
@@ -167,8 +166,10 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
 extern "C" void mi_engine_destroy(mi_engine* e) {
   if (!e) return;
   if (e->perm_dev) (void)hipFree(e->perm_dev);
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  for (auto& c : e->sc) {
+    if (c.fork) (void)hipEventDestroy(c.fork);
+    if (c.join) (void)hipEventDestroy(c.join);
+  }
   for (auto ev : e->ev0) (void)hipEventDestroy(ev);
   for (auto ev : e->ev1) (void)hipEventDestroy(ev);
   delete e;
@@ -190,25 +191,31 @@ extern "C" int mi_engine_set_overlap(mi_engine* e, int on) {
   return MI_OK;
 }
 
-// side-stream helpers: fork = side waits for everything issued on `st` so far; join = `st` waits for everything issued on side
-static hipStream_t side_fork(mi_engine* e, hipStream_t st) {
-  if (!e->overlap) return st;
-  if (!e->side) {
-    // one side stream per device for the life of the process, shared by every engine on it (an engine is driven by one host
-    // thread and fork / join order every use): creating a stream costs ~0.4 s on this stack, engines are created freely
-    static hipStream_t g_side[64] = {};
-    const int d = (e->device >= 0 && e->device < 64) ? e->device : 0;
-    if (!g_side[d] && hipStreamCreateWithFlags(&g_side[d], hipStreamNonBlocking) != hipSuccess) { g_side[d] = nullptr; return st; }
-    e->side = g_side[d];
-    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { e->overlap = false; return st; }
-  }
-  if (hipEventRecord(e->ev_fork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_fork, 0) != hipSuccess) return st;
-  return e->side;
+// Engine-owned streams: one pool per device for the life of the process, shared by every engine on it (an engine is driven by
+// one host thread and fork / join order every use; creating a stream is slow on this stack while engines are created freely).
+static hipStream_t pool_stream(const mi_engine* e, int which) {
+  static hipStream_t g_pool[64][1] = {};
+  const int d = (e->device >= 0 && e->device < 64) ? e->device : 0;
+  if (!g_pool[d][which] && hipStreamCreateWithFlags(&g_pool[d][which], hipStreamNonBlocking) != hipSuccess) g_pool[d][which] = nullptr;
+  return g_pool[d][which];
 }
-static int side_join(mi_engine* e, hipStream_t st, bool used) {
+static bool make_event(hipEvent_t* ev) { return *ev || hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; }
+
+// fork = the side stream waits for everything issued on `st` so far; join = `st` waits for everything issued on the side stream
+static hipStream_t side_fork(mi_engine* e, hipStream_t st, int half) {
+  if (!e->overlap) return st;
+  mi_engine::SideCtx& c = e->sc[half];
+  if (!c.side) {
+    c.side = pool_stream(e, 0);
+    if (!c.side || !make_event(&c.fork) || !make_event(&c.join)) { e->overlap = false; return st; }
+  }
+  if (hipEventRecord(c.fork, st) != hipSuccess || hipStreamWaitEvent(c.side, c.fork, 0) != hipSuccess) return st;
+  return c.side;
+}
+static int side_join(mi_engine* e, hipStream_t st, int half, bool used) {
   if (!used) return MI_OK;
-  if (hipEventRecord(e->ev_join, e->side) != hipSuccess || hipStreamWaitEvent(st, e->ev_join, 0) != hipSuccess)
+  mi_engine::SideCtx& c = e->sc[half];
+  if (hipEventRecord(c.join, c.side) != hipSuccess || hipStreamWaitEvent(st, c.join, 0) != hipSuccess)
     return fail(e, MI_ERR_HIP, "side-stream join failed");
   return MI_OK;
 }
@@ -254,6 +261,7 @@ struct Plan {
   float* wgpart;
   float* wgpart_side;   // partials of the weight gradients that run on the side stream
   double *gram_part, *gram_s;   // input Gram matrix of the support images (block 1 statistics), or nullptr
+  int half = 0;                 // stream context (engine SideCtx) this plan's side work uses
   float *tmp_loss, *tmp_acc;
   float* hscr;   // head scratch: R{dl} [T][n][ways], row loss [T][n], row hit [T][n]
   size_t bytes;
@@ -498,7 +506,7 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = A.dz[l];
-    hipStream_t ws = l > 0 ? side_fork(e, st) : st;
+    hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
     if (ws != st) forked = true;
     wa.partial = ws != st ? pl.wgpart_side : pl.wgpart;
     wa.g = geom(L, n);
@@ -517,7 +525,7 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_NONE, 1, nullptr));
     }
   }
-  return side_join(e, st, forked);
+  return side_join(e, st, pl.half, forked);
 }
 
 static void head_scratch(const mi_engine* e, HeadArgs& ha, float* hscr, int T, int n) {
@@ -686,7 +694,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = X.rdz[l];
     if (l > 0) { wa.x[1] = X.pd[l - 1]; wa.dz[1] = A.dz[l]; }
-    hipStream_t ws = l > 0 ? side_fork(e, st) : st;
+    hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
     if (ws != st) forked = true;
     wa.partial = ws != st ? pl.wgpart_side : pl.wgpart;
     wa.g = geom(L, n);
@@ -706,7 +714,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       cur ^= 1;
     }
   }
-  return side_join(e, st, forked);
+  return side_join(e, st, pl.half, forked);
 }
 
 extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
