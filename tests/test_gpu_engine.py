@@ -244,3 +244,27 @@ def test_fused_block1_single_channel_inputs():
     for o in outs[:2]:
         assert np.allclose(o[0], outs[2][0], rtol=1e-5) and np.array_equal(o[1], outs[2][1])
     assert e1 < 1e-4 and e2 < 1e-4
+
+
+def test_fused_block1_odd_pooled_width_rectangular_inputs():
+    """Block-1 kernels on 3x36x42 inputs: pooled width 21 is odd (the sparse weight gradient's last K step covers one window),
+    H != W; Gram path vs conv-recompute path vs generic kernels."""
+    mspec = ModelSpec(4, 3, 36, 42, 32, True, 5, False)
+    n = MetaEngine(mspec).param_count
+    theta = torch.from_numpy(synthetic.hash_uniform(8, (n,)) * 0.3 - 0.15).float().cuda()
+    T, ways, shots = 3, 5, 1
+    data = torch.from_numpy(synthetic.hash_uniform(9, (T, 2 * ways * shots, 3, 36, 42)) * 255.0).float().cuda()
+    labels = torch.from_numpy(np.stack([synthetic.task_labels(ways, shots)] * T)).cuda()
+    outs = []
+    for mode in (1, 2, 0):
+        eng = MetaEngine(mspec)
+        eng.set_fused_block1(mode)
+        loss, acc, grad, _ = eng.meta_batch(theta, data, labels, shots, 2, 0.02, first_order=False)
+        torch.cuda.synchronize()
+        outs.append((loss.cpu().numpy(), acc.cpu().numpy(), grad.cpu().numpy()))
+    e1, e2 = rel_err(outs[0][2], outs[2][2]), rel_err(outs[1][2], outs[2][2])
+    report('fused_block1_36x42', grad_rel_gram=e1, grad_rel_recompute=e2, loss=[float(x) for x in outs[0][0]])
+    assert np.isfinite(outs[0][2]).all() and np.abs(outs[0][2]).sum() > 0
+    for o in outs[:2]:
+        assert np.allclose(o[0], outs[2][0], rtol=2e-5)
+    assert e1 < 1e-4 and e2 < 1e-4
