@@ -341,7 +341,7 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   pl.wgpart = b.take<float>(wgp);
   pl.wgpart_side = b.take<float>(wgp);
   pl.gram_part = pl.gram_s = nullptr;
-  if (e->fuse1 && e->gram1 && (K >= 2 || (K >= 1 && second_order))) {   // the support set is swept at least twice
+  if (e->fuse1 && e->gram1 && gram_supported(e->L[0].w, e->L[0].ci) && (K >= 2 || (K >= 1 && second_order))) {   // the support set is swept at least twice
     pl.gram_part = b.take<double>(gram_partial_doubles(T, ns, e->L[0].h, e->L[0].ci));
     pl.gram_s = b.take<double>(gram_doubles(T, e->L[0].ci));
   }
@@ -820,7 +820,7 @@ static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, An
   ap.scratch.wgpart = b.take<float>(wgp);
   ap.scratch.wgpart_side = b.take<float>(wgp);
   ap.scratch.gram_part = ap.scratch.gram_s = nullptr;
-  if (e->fuse1 && e->gram1) {   // statistics + weight gradient of block 1 from the Gram matrix: cheaper than two conv recomputes
+  if (e->fuse1 && e->gram1 && gram_supported(e->L[0].w, e->L[0].ci)) {   // statistics + weight gradient of block 1 from the Gram matrix
     ap.scratch.gram_part = b.take<double>(gram_partial_doubles(T, 2 * n, e->L[0].h, e->L[0].ci));
     ap.scratch.gram_s = b.take<double>(gram_doubles(T, e->L[0].ci));
   }

@@ -26,65 +26,67 @@ template <int CI0> struct GramDims {
 // interleave over the four 16-lane groups, unlike the f32 tiles).
 template <int CI0>
 __global__ __launch_bounds__(256) void input_gram_kernel(const float* __restrict__ x, int n, int H, int W, int rows_per_wave,
-                                                         double* __restrict__ partial) {
+                                                         int row_pitch, double* __restrict__ partial) {
   using D = GramDims<CI0>;
   constexpr int NT = D::NT, KP = D::KP;
-  __shared__ double red[4 * NT * NT * 256];
+  // LDS: per wave the three input rows an output row touches, as fp64, [3][RPD] with a zero halo pixel on the left and zero
+  // padding on the right (so steps that run past the row read zeros); the cross-wave reduction re-uses the buffer from 0.
+  extern __shared__ __attribute__((aligned(16))) double ldsd[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kpix = lane >> 4;
   const int task = blockIdx.y;
+  const int RPD = row_pitch, ROWF = W * CI0;
+  double* rows = ldsd + (size_t)wave * 3 * RPD;
   const float* x_t = x + (size_t)task * n * H * W * CI0;
-  // this lane's patch entries: (dy, dx, c) or the constant / padding
-  int dy[NT], dx[NT], cc[NT], kind[NT];     // kind 0 = pixel value, 1 = constant one, 2 = zero padding
+  // this lane's patch entries: LDS offset of (row dy+1, column dx+1 pixels incl. the halo, channel c); the constant-one entry
+  // and the padding entries read the left halo (zero) and are patched / left at zero
+  int off[NT];
+  bool one[NT], pad[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int a = 16 * t + i;
-    kind[t] = a < KP ? 0 : (a == KP ? 1 : 2);
-    const int tap = a < KP ? a / CI0 : 0;
-    dy[t] = tap / 3 - 1; dx[t] = tap % 3 - 1; cc[t] = a < KP ? a % CI0 : 0;
+    one[t] = a == KP;
+    pad[t] = a > KP;
+    const int tap = a < KP ? a / CI0 : 0, c = a < KP ? a % CI0 : 0;
+    off[t] = a < KP ? (tap / 3) * RPD + (tap % 3) * CI0 + c + kpix * CI0 : 0;
   }
   doublex4 acc[NT][NT];
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = doublex4{0.0, 0.0, 0.0, 0.0};
+  for (int e = lane; e < 3 * RPD; e += 64) rows[e] = 0.0;     // halos and padding stay zero
 
   const int nrows = n * H;
   const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
   for (int row = row0; row < row0 + rows_per_wave && row < nrows; ++row) {
     const int img = row / H, y = row - img * H;
-    const float* rowp[NT];
-    bool rok[NT];
+    // stage input rows y-1, y, y+1 (coalesced), converted to fp64 once; rows outside the image are zeros
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      rok[t] = kind[t] == 0 && (unsigned)(y + dy[t]) < (unsigned)H;
-      rowp[t] = x_t + ((size_t)(img * H + y + dy[t]) * W + dx[t]) * CI0 + cc[t];
+    for (int r = 0; r < 3; ++r) {
+      const int yy = y - 1 + r;
+      const bool rv = (unsigned)yy < (unsigned)H;
+      const float* src = x_t + (size_t)(img * H + (rv ? yy : 0)) * ROWF;
+      for (int e = lane; e < ROWF; e += 64) rows[r * RPD + CI0 + e] = rv ? (double)src[e] : 0.0;
     }
-    // patch values of one 4-pixel step; the next step's loads are issued before this step's MFMAs
-    auto load_step = [&](int x0, double* v) {
-      const int xx = x0 + kpix;
-      const bool pv = xx < W;
+    for (int x0 = 0; x0 < W; x0 += 4) {
+      const bool pv = x0 + kpix < W;
+      double v[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const bool inb = pv && rok[t] && (unsigned)(xx + dx[t]) < (unsigned)W;
-        const float f = *(inb ? rowp[t] + (size_t)xx * CI0 : mi_zero_word);
-        v[t] = kind[t] == 1 ? (pv ? 1.0 : 0.0) : (double)f;
+        const double d = rows[off[t] + x0 * CI0];              // LDS operations of one wave execute in order: no barrier
+        v[t] = (pv && !pad[t]) ? (one[t] ? 1.0 : d) : 0.0;      // pixels past the row end / padding entries contribute nothing
       }
-    };
-    double v[NT], vn[NT];
-    load_step(0, v);
-    for (int x0 = 0; x0 < W; x0 += 4) {
-      if (x0 + 4 < W) load_step(x0 + 4, vn);
       // G is symmetric: tiles below the diagonal are filled in by gram_reduce_kernel
 #pragma unroll
       for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int tj = ti; tj < NT; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti], v[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) v[t] = vn[t];
     }
   }
   // 4 waves -> one partial per workgroup, fixed order
+  __syncthreads();
+  double* red = ldsd;
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -401,15 +403,23 @@ int gram_blocks_per_task(int n, int h) { return ceil_div(n * h, 4 * kGramRowsPer
 size_t gram_partial_doubles(int tasks, int n, int h, int ci) {
   return (size_t)tasks * gram_blocks_per_task(n, h) * gram_ng(ci) * gram_ng(ci);
 }
+bool gram_supported(int w, int ci) { return (size_t)4 * 3 * (w + 6) * ci * sizeof(double) <= 64 * 1024; }
 size_t gram_doubles(int tasks, int ci) { return (size_t)tasks * gram_ng(ci) * gram_ng(ci); }
 
 // x [T][n][H][W][ci] -> g [T][NG][NG] (row/column 9*ci = the constant-one entry: G[a][9ci] = s[a], G[9ci][9ci] = pixel count)
 hipError_t launch_input_gram(hipStream_t st, const float* x, int tasks, int n, int h, int w, int ci, double* partial, double* g) {
   const int nblk = gram_blocks_per_task(n, h), ng = gram_ng(ci);
+  // row pitch in doubles: halo pixel + row + halo pixel + 4 pixels of zero padding for the last 4-pixel step
+  const int rpd = (w + 2 + 4) * ci;
+  const int nt = ng / 16;
+  size_t smem = (size_t)4 * 3 * rpd * sizeof(double);
+  const size_t red = (size_t)4 * nt * nt * 256 * sizeof(double);
+  if (smem < red) smem = red;
+  if (smem > 64 * 1024) return hipErrorInvalidValue;      // W up to ~670 (ci 1) / ~220 (ci 3)
   if (ci == 3)
-    hipLaunchKernelGGL(input_gram_kernel<3>, dim3(nblk, tasks), dim3(256), 0, st, x, n, h, w, kGramRowsPerWave, partial);
+    hipLaunchKernelGGL(input_gram_kernel<3>, dim3(nblk, tasks), dim3(256), smem, st, x, n, h, w, kGramRowsPerWave, rpd, partial);
   else if (ci == 1)
-    hipLaunchKernelGGL(input_gram_kernel<1>, dim3(nblk, tasks), dim3(256), 0, st, x, n, h, w, kGramRowsPerWave, partial);
+    hipLaunchKernelGGL(input_gram_kernel<1>, dim3(nblk, tasks), dim3(256), smem, st, x, n, h, w, kGramRowsPerWave, rpd, partial);
   else
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(ceil_div(ng * ng, 256), tasks), dim3(256), 0, st, partial, nblk, ng, g);

@@ -138,6 +138,7 @@ hipError_t launch_gram_wgrad(hipStream_t st, const GramWgArgs& a, int tasks, int
 int gram_blocks_per_task(int n, int h);
 size_t gram_partial_doubles(int tasks, int n, int h, int ci);
 size_t gram_doubles(int tasks, int ci);
+bool gram_supported(int w, int ci);     // the kernel stages three fp64 input rows per wave in LDS
 hipError_t launch_input_gram(hipStream_t st, const float* x, int tasks, int n, int h, int w, int ci, double* partial, double* g);
 hipError_t launch_gram_stats(hipStream_t st, const double* g, int tasks, int ci, int co, const float* w, size_t wstride,
                              const float* wd, size_t vstride, double inv_m, int tangent, float* out0, float* out1,
