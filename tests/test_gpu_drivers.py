@@ -77,3 +77,25 @@ def test_evaluate_rl(algo):
     rewards, mean_rew, mean_suc = fn([[0.3, 0.1], [-0.2, 0.4], [0.0, -0.5]], policy, cf.LinearValue(2, 2), P, generator=gen)
     assert len(rewards) == 3 and all(r < 0 for r in rewards) and mean_rew == pytest.approx(sum(rewards) / 3) and mean_suc == 0.0
     assert torch.equal(pol.flat(), before)
+
+
+def test_cl_and_rc_experiments_run():
+    """misc_scripts counterparts on the step-wise learner: shapes, ranges, and that adaptation changes later layers' reps."""
+    import numpy as np
+    from exploring_meta_amd import core_functions as cf
+    from exploring_meta_amd.misc_scripts import cl_vision, rc_vision
+    from exploring_meta_amd.vision.maml_vision import SyntheticTasks
+    torch.manual_seed(0)
+    model = cf.OmniglotCNN(5).cuda()
+    maml = cf.MAML(model, lr=0.1)
+    loss = torch.nn.CrossEntropyLoss(reduction='mean')
+    dev = torch.device('cuda')
+    acc = cl_vision.run_cl_exp(maml, loss, SyntheticTasks('omni', 5, 1, 0), dev, 5, 1, dict(adapt_steps=2, inner_lr=0.1, n_tasks=3))
+    assert acc.shape == (3, 3) and (acc >= 0).all() and (acc <= 1).all()
+    accs, reps = rc_vision.run_rep_exp(maml, loss, SyntheticTasks('omni', 5, 1, 50), dev, 5, 1,
+                                       dict(adapt_steps=1, inner_lr=0.1, n_tasks=2, layers=[0, 1, 4]))
+    assert accs.shape == (2, 2) and set(reps) == {0, 1, 4} and len(reps[4]) == 2
+    a0, i0 = reps[0][0]
+    assert np.array_equal(a0, i0)                                  # layer 0 = the input itself
+    a4, i4 = reps[4][-1]
+    assert a4.shape == i4.shape == (64 * 2 * 2, 5) and not np.allclose(a4, i4)
