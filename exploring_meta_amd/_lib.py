@@ -22,6 +22,24 @@ class MiPolicyDesc(C.Structure):
                 ('activation', C.c_int32)]
 
 
+class MiBnTangentArgs(C.Structure):
+    _fields_ = [('z', C.c_void_p), ('zd', C.c_void_p), ('mu', C.c_void_p), ('rstd', C.c_void_p), ('m1', C.c_void_p),
+                ('m2', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('pstride', C.c_size_t),
+                ('gammad', C.c_void_p), ('betad', C.c_void_p), ('vstride', C.c_size_t), ('dgamma', C.c_void_p),
+                ('dbeta', C.c_void_p), ('gstride', C.c_size_t), ('dp', C.c_void_p), ('dpd', C.c_void_p),
+                ('tasks', C.c_int32), ('n', C.c_int32), ('ho', C.c_int32), ('wo', C.c_int32), ('c', C.c_int32),
+                ('pool', C.c_int32)]
+
+
+class MiBlock1Args(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('wd', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('pstride', C.c_size_t), ('gammad', C.c_void_p), ('betad', C.c_void_p), ('vstride', C.c_size_t),
+                ('mu', C.c_void_p), ('rstd', C.c_void_p), ('m1', C.c_void_p), ('m2', C.c_void_p), ('dgamma', C.c_void_p),
+                ('dbeta', C.c_void_p), ('gstride', C.c_size_t), ('rdgamma', C.c_void_p), ('rdbeta', C.c_void_p),
+                ('hstride', C.c_size_t), ('dp', C.c_void_p), ('dpd', C.c_void_p), ('arg_in', C.c_void_p), ('zh_in', C.c_void_p),
+                ('tasks', C.c_int32), ('n', C.c_int32), ('h', C.c_int32), ('w_', C.c_int32), ('ci', C.c_int32), ('co', C.c_int32)]
+
+
 class MiError(RuntimeError):
     pass
 
@@ -84,6 +102,19 @@ _SIGS = {
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     'mi_kernel_scratch_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'mi_conv3x3_tangent': (C.c_int, [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p] * 4 + [C.c_size_t]),
+    'mi_conv3x3_bwd2': (C.c_int, [C.c_void_p] * 7 + [C.c_size_t] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    'mi_bn_tangent_fwd': (C.c_int, [C.c_void_p, C.POINTER(MiBnTangentArgs), C.c_void_p]),
+    'mi_bn_tangent_bwd': (C.c_int, [C.c_void_p, C.POINTER(MiBnTangentArgs), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_void_p, C.c_size_t]),
+    'mi_block1_scratch_bytes': (C.c_size_t, [C.c_int] * 6),
+    'mi_block1_run': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(MiBlock1Args), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    'mi_pooled_reduce': (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    'mi_block1_wgrad_gram': (C.c_int, [C.c_void_p, C.POINTER(MiBlock1Args), C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_size_t]),
+    'mi_debug_conv_tiles_per_wave': (C.c_int, [C.c_int] * 5),
+    'mi_debug_set_trace': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'mi_policy_create': (C.c_int, [C.POINTER(MiPolicyDesc), C.c_int, C.POINTER(C.c_void_p)]),
     'mi_policy_destroy': (None, [C.c_void_p]),
     'mi_policy_last_error': (C.c_char_p, [C.c_void_p]),

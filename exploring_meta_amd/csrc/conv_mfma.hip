@@ -535,6 +535,13 @@ static inline void conv_grid(int mpix, int tasks, int cot, int nw, int& ntiles, 
   grid = dim3(ceil_div(ntiles, nw * tpw), tasks, cot);
 }
 
+int conv_tiles_per_wave(int mpix, int tasks, int cot) {
+  int ntiles, tpw;
+  dim3 grid;
+  conv_grid(mpix, tasks, cot, 4, ntiles, tpw, grid);
+  return tpw;
+}
+
 int conv_max_blocks_per_task(const ConvGeom& g) {  // tiles_per_wave == 1 is the finest split any launch uses
   return ceil_div(ceil_div(g.n * g.ho * g.wo, 32), 4);
 }

@@ -40,6 +40,9 @@ struct mi_engine {
   bool overlap = true;
   struct SideCtx { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; } sc[1];
   std::string err;
+  // debug trace (mi_debug_set_trace): per-step theta_k / g_k / lam fed to the k-th Hessian-vector product / H lam, reference order
+  float* trace = nullptr;
+  size_t trace_floats = 0;
   // optional per-launch HIP-event profiling (bench.py's roofline leg): kind = op*8 + layer
   int prof_on = 0, prof_filter = -1;
   std::vector<hipEvent_t> ev0, ev1;
@@ -219,6 +222,18 @@ static int side_join(mi_engine* e, hipStream_t st, int half, bool used) {
     return fail(e, MI_ERR_HIP, "side-stream join failed");
   return MI_OK;
 }
+
+// Debug/test aid: while set, every second-order mi_meta_batch_maml call with with_grad != 0 also writes, per task and in the
+// reference's parameter order, theta_k (k = 0..K), g_k = grad L_support(theta_k), the vector lam_{k+1} fed to the k-th
+// Hessian-vector product and H_support(theta_k) lam_{k+1} into `buf`:  [K+1][T][P] | [K][T][P] | [K][T][P] | [K][T][P] floats.
+extern "C" int mi_debug_set_trace(mi_engine* e, float* buf, size_t floats) {
+  if (!e) return MI_ERR_ARG;
+  e->trace = buf;
+  e->trace_floats = buf ? floats : 0;
+  return MI_OK;
+}
+
+int mi_internal_fail(int code, const char* msg) { return fail(nullptr, code, msg); }
 
 extern "C" int mi_param_count(const mi_engine* e, size_t* n) {
   if (!e || !n) return MI_ERR_ARG;
@@ -750,12 +765,24 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
   int rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, nq, T, thK, pl.lam, loss_out, acc_out, logits_out, with_grad != 0);
   if (rc) return rc;
   if (!with_grad) return MI_OK;
+  // debug trace layout (floats): theta [K+1][T][P] | g [K][T][P] | lam_in [K][T][P] | hv [K][T][P], reference parameter order
+  const size_t TPr = (size_t)T * e->P;
+  const bool tr = e->trace && e->trace_floats >= (size_t)(4 * K + 1) * TPr;
+  if (e->trace && !tr) return fail(e, MI_ERR_WORKSPACE, "debug trace buffer too small: need " + std::to_string((size_t)(4 * K + 1) * TPr) + " floats");
   if (so) {
     for (int k = K - 1; k >= 0; --k) {
+      if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(2 * K + 1 + k) * TPr));
       rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, T, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv, pl.gram_s);
       if (rc) return rc;
+      if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(3 * K + 1 + k) * TPr));
       LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, pl.lam, pl.hv, inner_lr, TP, pl.lam));
     }
+  }
+  if (tr) {
+    for (int k = 0; k <= K; ++k)
+      HIPCHK(e, launch_scatter_tasks(st, pl.theta + (size_t)k * TP, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)k * TPr));
+    for (int k = 0; k < K; ++k)
+      HIPCHK(e, launch_scatter_tasks(st, pl.g + (size_t)k * TP, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(K + 1 + k) * TPr));
   }
   LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, meta_grad_out));
   return MI_OK;

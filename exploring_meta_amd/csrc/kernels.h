@@ -65,6 +65,7 @@ hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, i
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* partial, int nchunks, int nelem, int tasks, float* out, size_t ostride);
 size_t wgrad_partial_floats(const ConvGeom& g, int tasks);
 int conv_max_blocks_per_task(const ConvGeom& g);
+int conv_tiles_per_wave(int mpix, int tasks, int cot);
 
 // bn_pool.hip
 int bn_blocks_per_task(int n, int ho, int wo, int c, int pool, int tasks);

@@ -120,3 +120,48 @@ def hash_weights(shapes, seed):
             v = u - 0.5
         out[name] = v.astype(np.float64)
     return out
+
+
+def ref_init_weights(shapes, seed):
+    """The reference's initialisers drawn from the hash generator (vision_models.py:175,204-207,48-49): xavier-uniform conv /
+    linear weights, ZERO conv / linear / BatchNorm biases, BatchNorm gamma ~ U(0,1); a 2-d weight named ``linear.weight`` whose
+    fan-in is below 100 (OmniglotCNN's Linear(64, ways)) is N(0,1) as in vision_models.py:48."""
+    out = {}
+    for i, (name, shape) in enumerate(shapes.items()):
+        shape = tuple(shape)
+        u = hash_uniform(seed, shape, stream=100 + i)
+        if name.endswith('normalize.weight'):
+            v = u
+        elif name.endswith('bias'):
+            v = np.zeros(shape)
+        elif len(shape) == 4:
+            bound = np.sqrt(6.0 / ((shape[1] + shape[0]) * shape[2] * shape[3]))
+            v = (2.0 * u - 1.0) * bound
+        elif len(shape) == 2 and name == 'linear.weight' and shape[1] < 100:
+            v = hash_normalish(seed, shape, stream=100 + i)
+        elif len(shape) == 2:
+            v = (2.0 * u - 1.0) * np.sqrt(6.0 / (shape[0] + shape[1]))
+        else:
+            v = u - 0.5
+        out[name] = v.astype(np.float64)
+    return out
+
+
+def uniform_task(dataset, task_id, ways, shots, seed=42):
+    """Plateau-free task: i.i.d. uniform pixels (0..255 for Mini-ImageNet shapes, 0..1 for Omniglot shapes), the layout of
+    ``make_task``.  No two pixels are equal, so max-pool / ReLU decisions have no exact ties: the well-conditioned inputs the
+    tight parity bars are stated on (SURVEY.md 8c calibrated the one-step tolerances on random inputs)."""
+    n = 2 * shots * ways
+    s = seed + 7000003 * int(task_id)
+    if dataset in ('min', 'mini_imagenet'):
+        data = hash_uniform(s, (n, 3, 84, 84), stream=7) * 255.0
+    elif dataset in ('omni', 'omniglot'):
+        data = hash_uniform(s, (n, 1, 28, 28), stream=7)
+    else:
+        raise ValueError(f'Dataset not supported: {dataset}')
+    return data.astype(np.float32), task_labels(ways, shots)
+
+
+def make_uniform_meta_batch(dataset, task_ids, ways, shots, seed=42):
+    ds, ls = zip(*(uniform_task(dataset, t, ways, shots, seed) for t in task_ids))
+    return np.stack(ds), np.stack(ls)

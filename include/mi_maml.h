@@ -188,6 +188,78 @@ int mi_head_fwd_bwd(void* stream, const float* f, const float* wl, const float* 
 size_t mi_kernel_scratch_bytes(int tasks, int n, int h, int w, int c);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Tangent (R-operator) and fused block-1 kernels: unit-test entry points (tests/test_gpu_tangent_kernels.py).  They are the
+ * kernels behind the second-order path -- the double-backward of ConvBlock.forward (vision_models.py:188-193) that the
+ * reference gets from autograd with create_graph=True (learn2learn MAML.adapt, call site core_functions/vision.py:13). */
+
+/* zd = conv3x3(x0, w0) [+ conv3x3(x1, w1) when x1 != NULL]  with the tangent-BatchNorm statistics
+ *   m1 = mean(zd), m2 = mean(zhat * zd), zhat = (z - mu) * rstd          (all [tasks, co]). */
+int mi_conv3x3_tangent(void* stream, const float* x0, const float* w0, const float* x1, const float* w1, size_t pstride,
+                       const float* z, const float* mu, const float* rstd, int tasks, int n, int h, int wd, int ci, int co,
+                       int stride, float* zd, float* m1, float* m2, void* scratch, size_t scratch_bytes);
+/* Two-term conv backward of the tangent pass:  dw9 = wgrad(x0, dz0) + wgrad(x1, dz1);  dx (may be NULL) = dgrad(dz0, w0) +
+ * dgrad(dz1, w1). */
+int mi_conv3x3_bwd2(void* stream, const float* x0, const float* dz0, const float* x1, const float* dz1, const float* w0,
+                    const float* w1, size_t pstride, int tasks, int n, int h, int wd, int ci, int co, int stride, float* dx,
+                    float* dw9, size_t gstride, void* scratch, size_t scratch_bytes);
+
+/* Tangent of BN + ReLU + MaxPool (formulas: oracle/kernels_ref.py header).  Per-task vectors advance by their stride. */
+typedef struct {
+  const float *z, *zd;                  /* conv output and its tangent [tasks, n, ho, wo, c] */
+  const float *mu, *rstd, *m1, *m2;     /* [tasks, c] */
+  const float *gamma, *beta; size_t pstride;      /* parameters */
+  const float *gammad, *betad; size_t vstride;    /* tangent direction */
+  const float *dgamma, *dbeta; size_t gstride;    /* primal BatchNorm gradients (backward only) */
+  const float *dp, *dpd;                /* cotangent of the block output and its tangent [tasks, n, hp, wp, c] (backward only) */
+  int32_t tasks, n, ho, wo, c, pool;
+} mi_bn_tangent_args;
+int mi_bn_tangent_fwd(void* stream, const mi_bn_tangent_args* a, float* pd);
+int mi_bn_tangent_bwd(void* stream, const mi_bn_tangent_args* a, float* rdgamma, float* rdbeta, size_t hstride, float* rdz,
+                      void* scratch, size_t scratch_bytes);
+
+/* Fused first ConvBlock (conv recomputed inside every kernel; Ci in {1,3}, stride 1, pooling, even H/W >= 16). */
+#define MI_B1_STATS 0        /* -> out0 = mean, out1 = rstd of conv1's output */
+#define MI_B1_FWD 1          /* -> p_out (+ zh_out = zhat at each window's argmax, arg_out = argmax position, 4 = ReLU off) */
+#define MI_B1_BWD_REDUCE 2   /* -> out0 = dgamma, out1 = dbeta */
+#define MI_B1_BWD_WGRAD 3    /* -> out0 = dW [tasks][ostride] */
+#define MI_B1_TSTATS 4       /* -> out0 = m1, out1 = m2 */
+#define MI_B1_TFWD 5         /* -> p_out = tangent of the block output (+ zh_out = tangent of zhat at the argmax) */
+#define MI_B1_TBWD_REDUCE 6  /* -> out0 = R{dgamma}, out1 = R{dbeta} */
+#define MI_B1_TBWD_WGRAD 7   /* -> out0 = R{dW} */
+#define MI_B1_TFWD_ARG 8     /* as TFWD, from the stored argmax / zhat (arg_in, zh_in) with one conv instead of two */
+typedef struct {
+  const float* x;                       /* [tasks, n, h, w, ci] NHWC */
+  const float *w, *wd;                  /* conv weights [9*ci, co] of theta / of the tangent direction */
+  const float *gamma, *beta; size_t pstride;      /* stride of w / gamma / beta */
+  const float *gammad, *betad; size_t vstride;    /* stride of wd / gammad / betad */
+  const float *mu, *rstd, *m1, *m2;     /* [tasks, co] */
+  const float *dgamma, *dbeta; size_t gstride;
+  const float *rdgamma, *rdbeta; size_t hstride;
+  const float *dp, *dpd;                /* [tasks, n, h/2, w/2, co] */
+  const uint8_t* arg_in; const float* zh_in;      /* outputs of MI_B1_FWD (TFWD_ARG, mi_block1_wgrad_gram) */
+  int32_t tasks, n, h, w_, ci, co;
+} mi_block1_args;
+size_t mi_block1_scratch_bytes(int tasks, int n, int h, int w, int ci, int co);
+int mi_block1_run(void* stream, int mode, const mi_block1_args* a, float* p_out, float* zh_out, uint8_t* arg_out, float* out0,
+                  float* out1, size_t ostride, void* scratch, size_t scratch_bytes);
+/* dgamma / dbeta of a fused block 1 (zhd, dpd != NULL: their tangents) from pooled-resolution tensors [tasks, rows, c]. */
+int mi_pooled_reduce(void* stream, const float* p, const float* zh, const float* zhd, const float* dp, const float* dpd,
+                     int tasks, int rows, int c, float* out0, float* out1, size_t ostride, void* scratch, size_t scratch_bytes);
+/* Block-1 weight gradient (tangent != 0: its tangent) without conv1: sparse MFMA pass over the pooling argmax + dense parts
+ * from the input Gram matrix g of mi_input_gram. */
+int mi_block1_wgrad_gram(void* stream, const mi_block1_args* a, const double* g, int tangent, float* dw, size_t ostride,
+                         void* scratch, size_t scratch_bytes);
+
+/* Debug/test aids.  mi_debug_conv_tiles_per_wave: the tiles-per-wave split the conv kernels use for this problem (lets a test
+ * assert it exercises the multi-tile loop).  mi_debug_set_trace: while buf != NULL every mi_meta_batch_maml call with
+ * with_grad != 0 also writes, per task and in the reference's parameter order,
+ *   theta_k [K+1][tasks][P] | g_k = grad L_support(theta_k) [K][tasks][P] | lam_{k+1} (the vector fed to the k-th
+ *   Hessian-vector product) [K][tasks][P] | H_support(theta_k) lam_{k+1} [K][tasks][P]
+ * (the last two only for second-order calls): the per-step state the teacher-forced parity tests check against the oracle. */
+int mi_debug_conv_tiles_per_wave(int tasks, int n, int ho, int wo, int co);
+int mi_debug_set_trace(mi_engine* e, float* buf, size_t floats);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Per-launch profiling with HIP events on the caller's stream (the reference has no profiler hooks, SURVEY.md section 5;
  * bench.py uses this for its roofline figures).  kind = op * 8 + layer; kind_filter < 0 profiles every launch. */
 int mi_profile_enable(mi_engine* e, int on, int kind_filter);

@@ -330,3 +330,27 @@ def maml_task(theta0, xs, ys, xq, yq, desc, steps, alpha, first_order):
             hv = net_hvp(thetas[k], saves[k], lam, desc)
             lam = [l - alpha * h for l, h in zip(lam, hv)]
     return loss, acc, lam, svq['logits']
+
+
+# ------------------------------------------------------------------------------------------ fused block-1 bookkeeping
+def pool_argmax(z, mu, r, gamma, beta):
+    """What the fused block-1 forward kernel keeps per pooling window and channel: the (first-max) argmax position 0..3 of
+    u = gamma*zhat + beta, 4 where the maximum did not pass the ReLU, and zhat at that position.  -> arg [N,hp,wp,C] int64,
+    zh_at [N,hp,wp,C]."""
+    zh = (z - mu) * r
+    u = gamma * zh + beta
+    hp, wp = z.shape[1] // 2, z.shape[2] // 2
+    uw, zw = _windows(u, hp, wp), _windows(zh, hp, wp)
+    arg = uw.argmax(dim=3, keepdim=True)
+    on = uw.gather(3, arg)[:, :, :, 0] > 0
+    zh_at = zw.gather(3, arg)[:, :, :, 0]
+    arg = torch.where(on, arg[:, :, :, 0], torch.full_like(arg[:, :, :, 0], 4))
+    return arg, zh_at
+
+
+def at_argmax(t, arg):
+    """Value of the full-resolution tensor t [N,H,W,C] at every window's stored argmax (0 where arg == 4)."""
+    hp, wp = arg.shape[1], arg.shape[2]
+    tw = _windows(t, hp, wp)
+    v = tw.gather(3, arg.clamp(max=3).unsqueeze(3))[:, :, :, 0]
+    return torch.where(arg < 4, v, torch.zeros_like(v))

@@ -1,0 +1,447 @@
+"""Per-kernel parity of the TANGENT (R-operator) kernels and of the fused block-1 kernels: every kernel behind the second-order
+path, called through its C-ABI test entry (include/mi_maml.h, "Tangent ... unit-test entry points") against the fp64
+restatement in oracle/kernels_ref.py on the same seeded inputs.  Includes cases at the sizes bench.py times (32 tasks x 25
+images): the conv kernels then run their multi-tile loop (tiles_per_wave = 11; the cap of 32 is reached with 96 tasks), which
+the small cases never enter.  fp32 kernels vs fp64 oracle: tolerances stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from exploring_meta_amd import _lib
+from exploring_meta_amd.utils import synthetic
+from oracle import kernels_ref as KR
+from gpu_utils import dev, ptr, stream, rel_err, max_err, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    return _lib.load()
+
+
+def _rand(seed, shape, lo=-1.0, hi=1.0):
+    return (synthetic.hash_uniform(seed, shape) * (hi - lo) + lo).astype(np.float32)
+
+
+def _t64(a):
+    return torch.from_numpy(np.asarray(a)).double()
+
+
+def _scratch(lib, T, n, h, w, c):
+    sb = lib.mi_kernel_scratch_bytes(T, n, h, w, c)
+    return torch.empty(sb, dtype=torch.uint8, device='cuda'), sb
+
+
+def _pack(T, parts, pad=5):
+    """Per-task parameter vector [part0 | part1 | ...] + pad floats; returns (device buffer [T, stride], offsets, stride)."""
+    sizes = [int(np.prod(p.shape[1:])) for p in parts]
+    stride = sum(sizes) + pad
+    buf = np.zeros((T, stride), np.float32)
+    offs, o = [], 0
+    for p, s in zip(parts, sizes):
+        buf[:, o:o + s] = p.reshape(T, -1)
+        offs.append(o)
+        o += s
+    return dev(buf), offs, stride
+
+
+def _at(buf, off):
+    return C.c_void_p(buf.data_ptr() + 4 * off)
+
+
+# ---------------------------------------------------------------------------------------------------- two-term conv kernels
+TAN_CONV_CASES = [
+    # name, T, n, h, w, ci, co, stride, tasks checked against the oracle
+    ('min_l2', 2, 3, 42, 42, 32, 32, 1, None),
+    ('min_l3_odd', 3, 5, 21, 21, 32, 32, 1, None),
+    ('min_l4', 2, 5, 10, 10, 32, 32, 1, None),
+    ('anil_l2', 2, 2, 21, 21, 64, 64, 1, None),
+    ('omni_l2', 2, 5, 14, 14, 64, 64, 2, None),
+    ('bench_l2_T32', 32, 25, 42, 42, 32, 32, 1, [0, 17, 31]),     # cfg2 block 2 as timed: tiles_per_wave 11
+    ('bench_l3_T32', 32, 25, 21, 21, 32, 32, 1, [0, 31]),         # tiles_per_wave 3
+    ('anil_l2_T8', 8, 50, 42, 42, 64, 64, 1, [3]),                # ANIL trunk block 2, 50 images per task
+]
+
+
+def _tan_conv_inputs(T, n, h, w, ci, co, stride, seed):
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    x0 = _rand(seed, (T, n, h, w, ci), 0.0, 2.0)
+    x1 = _rand(seed + 1, (T, n, h, w, ci), -1.0, 1.0)
+    w0 = _rand(seed + 2, (T, 9, ci, co), -0.3, 0.3)
+    w1 = _rand(seed + 3, (T, 9, ci, co), -0.3, 0.3)
+    z = _rand(seed + 4, (T, n, ho, wo, co), -2.0, 3.0)
+    return x0, x1, w0, w1, z, ho, wo
+
+
+@pytest.mark.parametrize('name,T,n,h,w,ci,co,stride,check', TAN_CONV_CASES)
+def test_conv_tangent_two_terms(lib, name, T, n, h, w, ci, co, stride, check):
+    """conv3x3_mfma_kernel<CI, 2, EPI_TSTATS>: zd = conv(x0, w0) + conv(x1, w1), m1 = mean zd, m2 = mean(zhat zd)."""
+    x0, x1, w0, w1, z, ho, wo = _tan_conv_inputs(T, n, h, w, ci, co, stride, 50)
+    zt = torch.from_numpy(z)
+    mu = zt.double().mean(dim=(1, 2, 3)).float()
+    rstd = (1.0 / torch.sqrt(zt.double().var(dim=(1, 2, 3), unbiased=False) + 1e-5)).float()
+    wbuf, (o0, o1), pstride = _pack(T, [w0, w1])
+    x0d, x1d, zd_in, mud, rd = dev(x0), dev(x1), dev(z), dev(mu), dev(rstd)
+    zd = torch.full((T, n, ho, wo, co), float('nan'), device='cuda')
+    m1 = torch.empty(T, co, device='cuda')
+    m2 = torch.empty(T, co, device='cuda')
+    scratch, sb = _scratch(lib, T, n, h, w, co)
+    _lib.check(lib.mi_conv3x3_tangent(stream(), ptr(x0d), _at(wbuf, o0), ptr(x1d), _at(wbuf, o1), pstride, ptr(zd_in), ptr(mud),
+                                      ptr(rd), T, n, h, w, ci, co, stride, ptr(zd), ptr(m1), ptr(m2), ptr(scratch), sb))
+    torch.cuda.synchronize()
+    tpw = lib.mi_debug_conv_tiles_per_wave(T, n, ho, wo, co)
+    if name == 'bench_l2_T32':
+        assert tpw >= 2, 'this case must exercise the multi-tile loop'
+    tasks = range(T) if check is None else check
+    ez, e1, e2 = [], [], []
+    for t in tasks:
+        zdr = KR.conv3x3(_t64(x0[t]), _t64(w0[t]), stride) + KR.conv3x3(_t64(x1[t]), _t64(w1[t]), stride)
+        zh = (_t64(z[t]) - mu[t].double()) * rstd[t].double()
+        ez.append(rel_err(zd[t].cpu().numpy(), zdr.numpy()))
+        sd = float(zdr.std())
+        e1.append(max_err(m1[t].cpu().numpy(), zdr.mean(dim=(0, 1, 2)).numpy()) / sd)
+        e2.append(max_err(m2[t].cpu().numpy(), (zh * zdr).mean(dim=(0, 1, 2)).numpy()) / sd)
+    if check is not None:
+        # every task of the big launch against the same kernel run one task at a time (one tile per wave): the conv output
+        # must be bit-identical (same per-tile arithmetic), the statistics equal up to the fp64 partial-sum order
+        for t in range(T):
+            zd1 = torch.full((1, n, ho, wo, co), float('nan'), device='cuda')
+            a1, a2 = torch.empty(1, co, device='cuda'), torch.empty(1, co, device='cuda')
+            _lib.check(lib.mi_conv3x3_tangent(stream(), ptr(x0d[t]), _at(wbuf[t], o0), ptr(x1d[t]), _at(wbuf[t], o1), pstride,
+                                              ptr(zd_in[t]), ptr(mud[t]), ptr(rd[t]), 1, n, h, w, ci, co, stride, ptr(zd1),
+                                              ptr(a1), ptr(a2), ptr(scratch), sb))
+            assert torch.equal(zd1[0], zd[t]), f'task {t}: batched conv output differs from the single-task launch'
+            assert torch.allclose(a1[0], m1[t], rtol=1e-6, atol=1e-7) and torch.allclose(a2[0], m2[t], rtol=1e-6, atol=1e-7)
+    report(f'conv_tangent2[{name}]', tiles_per_wave=tpw, zd_rel=max(ez), m1_err_over_std=max(e1), m2_err_over_std=max(e2))
+    assert max(ez) < 2e-6 and max(e1) < 2e-6 and max(e2) < 2e-6
+
+
+@pytest.mark.parametrize('name,T,n,h,w,ci,co,stride,check', TAN_CONV_CASES)
+def test_conv_bwd_two_terms(lib, name, T, n, h, w, ci, co, stride, check):
+    """R{dW} = wgrad(x0, dz0) + wgrad(x1, dz1) (wgrad3x3_rows_mfma_kernel, 2 terms) and R{dx} = dgrad(dz0, w0) + dgrad(dz1, w1)
+    (conv3x3_mfma_kernel<CI, 2, EPI_NONE, dgrad>)."""
+    x0, x1, w0, w1, _, ho, wo = _tan_conv_inputs(T, n, h, w, ci, co, stride, 60)
+    dz0 = _rand(65, (T, n, ho, wo, co))
+    dz1 = _rand(66, (T, n, ho, wo, co))
+    wbuf, (o0, o1), pstride = _pack(T, [w0, w1])
+    x0d, x1d, d0, d1 = dev(x0), dev(x1), dev(dz0), dev(dz1)
+    dx = torch.full((T, n, h, w, ci), float('nan'), device='cuda')
+    gstride = 9 * ci * co + 3
+    dw = torch.full((T, gstride), float('nan'), device='cuda')
+    scratch, sb = _scratch(lib, T, n, h, w, co)
+    _lib.check(lib.mi_conv3x3_bwd2(stream(), ptr(x0d), ptr(d0), ptr(x1d), ptr(d1), _at(wbuf, o0), _at(wbuf, o1), pstride, T, n, h, w,
+                                   ci, co, stride, ptr(dx), ptr(dw), gstride, ptr(scratch), sb))
+    torch.cuda.synchronize()
+    tasks = range(T) if check is None else check
+    edx, edw = [], []
+    for t in tasks:
+        dwr = KR.conv3x3_wgrad(_t64(x0[t]), _t64(dz0[t]), stride) + KR.conv3x3_wgrad(_t64(x1[t]), _t64(dz1[t]), stride)
+        dxr = KR.conv3x3_dgrad(_t64(dz0[t]), _t64(w0[t]), (h, w), stride) + KR.conv3x3_dgrad(_t64(dz1[t]), _t64(w1[t]), (h, w), stride)
+        edw.append(rel_err(dw[t, :9 * ci * co].cpu().numpy(), dwr.numpy()))
+        edx.append(rel_err(dx[t].cpu().numpy(), dxr.numpy()))
+    if check is not None:
+        for t in range(T):        # dgrad is per-tile arithmetic: bit-identical to the single-task launch
+            dx1 = torch.full((1, n, h, w, ci), float('nan'), device='cuda')
+            dw1 = torch.full((1, gstride), float('nan'), device='cuda')
+            _lib.check(lib.mi_conv3x3_bwd2(stream(), ptr(x0d[t]), ptr(d0[t]), ptr(x1d[t]), ptr(d1[t]), _at(wbuf[t], o0), _at(wbuf[t], o1),
+                                           pstride, 1, n, h, w, ci, co, stride, ptr(dx1), ptr(dw1), gstride, ptr(scratch), sb))
+            assert torch.equal(dx1[0], dx[t]), f'task {t}: batched dgrad differs from the single-task launch'
+            assert rel_err(dw1[0, :9 * ci * co].cpu().numpy(), dw[t, :9 * ci * co].cpu().numpy()) < 2e-6
+    report(f'conv_bwd2[{name}]', dx_rel=max(edx), dw_rel=max(edw))
+    assert max(edx) < 2e-6 and max(edw) < 5e-6
+
+
+BIG_CONV = [('bench_l2_T32', 32, 25, 42, 42, 32, 32, [0, 31]), ('cap32_T96', 96, 25, 42, 42, 32, 32, [0, 95]),
+            ('bench_l4_T32', 32, 25, 10, 10, 32, 32, [5])]
+
+
+@pytest.mark.parametrize('name,T,n,h,w,ci,co,check', BIG_CONV)
+def test_conv_fwd_bwd_at_bench_sizes(lib, name, T, n, h, w, ci, co, check):
+    """The ONE-term kernels (forward + BatchNorm statistics, dgrad, weight gradient) at the sizes the benchmark times: the
+    multi-tile loop of conv3x3_mfma_kernel<32,1,*> (tiles_per_wave 11 at 32 tasks, capped at 32 with 96 tasks)."""
+    nd = 8                                   # distinct tasks, repeated: the kernels do not know
+    x = _rand(70, (nd, n, h, w, ci), 0.0, 2.0)
+    w9 = _rand(71, (nd, 9, ci, co), -0.3, 0.3)
+    dzv = _rand(72, (nd, n, h, w, co))
+    rep = (T + nd - 1) // nd
+    xd = dev(x).repeat(rep, 1, 1, 1, 1)[:T].contiguous()
+    dzd = dev(dzv).repeat(rep, 1, 1, 1, 1)[:T].contiguous()
+    pstride = 9 * ci * co + 17
+    wb = np.zeros((nd, pstride), np.float32)
+    wb[:, :9 * ci * co] = w9.reshape(nd, -1)
+    wd_ = dev(wb).repeat(rep, 1)[:T].contiguous()
+    z = torch.full((T, n, h, w, co), float('nan'), device='cuda')
+    mu, rstd = torch.empty(T, co, device='cuda'), torch.empty(T, co, device='cuda')
+    scratch, sb = _scratch(lib, T, n, h, w, co)
+    _lib.check(lib.mi_conv3x3_bn_stats(stream(), ptr(xd), ptr(wd_), pstride, T, n, h, w, ci, co, 1, ptr(z), ptr(mu), ptr(rstd),
+                                       ptr(scratch), sb))
+    dx = torch.full((T, n, h, w, ci), float('nan'), device='cuda')
+    dw = torch.full((T, pstride), float('nan'), device='cuda')
+    _lib.check(lib.mi_conv3x3_bwd(stream(), ptr(xd), ptr(dzd), ptr(wd_), pstride, T, n, h, w, ci, co, 1, ptr(dx), ptr(dw), pstride,
+                                  ptr(scratch), sb))
+    torch.cuda.synchronize()
+    tpw = lib.mi_debug_conv_tiles_per_wave(T, n, h, w, co)
+    if name == 'bench_l2_T32':
+        assert tpw == 11
+    if name == 'cap32_T96':
+        assert tpw == 32
+    errs = dict(z=0.0, mu=0.0, rstd=0.0, dx=0.0, dw=0.0)
+    for t in check:
+        k = t % nd
+        zr = KR.conv3x3(_t64(x[k]), _t64(w9[k]))
+        m, r = KR.bn_stats(zr)
+        errs['z'] = max(errs['z'], rel_err(z[t].cpu().numpy(), zr.numpy()))
+        errs['mu'] = max(errs['mu'], max_err(mu[t].cpu().numpy(), m.numpy()) / float(zr.std()))
+        errs['rstd'] = max(errs['rstd'], rel_err(rstd[t].cpu().numpy(), r.numpy()))
+        errs['dx'] = max(errs['dx'], rel_err(dx[t].cpu().numpy(), KR.conv3x3_dgrad(_t64(dzv[k]), _t64(w9[k]), (h, w)).numpy()))
+        errs['dw'] = max(errs['dw'], rel_err(dw[t, :9 * ci * co].cpu().numpy(), KR.conv3x3_wgrad(_t64(x[k]), _t64(dzv[k])).numpy()))
+    # all tasks: identical inputs (t and t + nd) must give bit-identical conv outputs wherever they sit in the launch, and
+    # equal the single-task launch (one tile per wave)
+    for t in range(nd, T):
+        assert torch.equal(z[t], z[t % nd]) and torch.equal(dx[t], dx[t % nd])
+        assert torch.allclose(mu[t], mu[t % nd], rtol=1e-6, atol=1e-7) and torch.allclose(rstd[t], rstd[t % nd], rtol=1e-6)
+    for k in range(nd):
+        z1 = torch.full((1, n, h, w, co), float('nan'), device='cuda')
+        m1_, r1_ = torch.empty(1, co, device='cuda'), torch.empty(1, co, device='cuda')
+        _lib.check(lib.mi_conv3x3_bn_stats(stream(), ptr(xd[k]), ptr(wd_[k]), pstride, 1, n, h, w, ci, co, 1, ptr(z1), ptr(m1_), ptr(r1_),
+                                           ptr(scratch), sb))
+        assert torch.equal(z1[0], z[k])
+        assert torch.allclose(m1_[0], mu[k], rtol=1e-6, atol=1e-7) and torch.allclose(r1_[0], rstd[k], rtol=1e-6)
+    report(f'conv_bench_size[{name}]', tiles_per_wave=tpw, **errs)
+    assert errs['z'] < 2e-6 and errs['mu'] < 2e-6 and errs['rstd'] < 2e-6 and errs['dx'] < 2e-6 and errs['dw'] < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------------- BatchNorm tangent kernels
+BN_TAN_CASES = [('pool_even', 2, 3, 42, 42, 32, 1), ('pool_odd', 2, 4, 21, 21, 32, 1), ('pool_c64', 1, 2, 10, 10, 64, 1),
+                ('nopool', 2, 5, 14, 14, 64, 0), ('nopool_small', 3, 5, 2, 2, 64, 0), ('bench_l2_T32', 32, 25, 42, 42, 32, 1)]
+
+
+@pytest.mark.parametrize('name,T,n,ho,wo,c,pool', BN_TAN_CASES)
+def test_bn_tangent_fwd_bwd(lib, name, T, n, ho, wo, c, pool):
+    """bn_tan_fwd / bn_tan_bwd_reduce / bn_tan_bwd_apply against oracle.kernels_ref.bn_tangent_fwd / bn_tangent_bwd."""
+    hp, wp = (ho // 2, wo // 2) if pool else (ho, wo)
+    z = _rand(80, (T, n, ho, wo, c), -2.0, 3.0)
+    zd = _rand(81, (T, n, ho, wo, c), -1.0, 1.0)
+    gamma, beta = _rand(82, (T, c), 0.1, 1.0), _rand(83, (T, c), -0.3, 0.3)
+    gammad, betad = _rand(84, (T, c)), _rand(85, (T, c))
+    dp, dpd = _rand(86, (T, n, hp, wp, c)), _rand(87, (T, n, hp, wp, c))
+    zt, zdt = torch.from_numpy(z).double(), torch.from_numpy(zd).double()
+    mu = zt.mean(dim=(1, 2, 3))
+    rstd = 1.0 / torch.sqrt(zt.var(dim=(1, 2, 3), unbiased=False) + 1e-5)
+    mu32, r32 = mu.float(), rstd.float()
+    zh = (zt - mu32.double()[:, None, None, None]) * r32.double()[:, None, None, None]
+    m1 = zdt.mean(dim=(1, 2, 3)).float()
+    m2 = (zh * zdt).mean(dim=(1, 2, 3)).float()
+    # primal BatchNorm gradients (inputs of the tangent backward) from the oracle, rounded to fp32
+    check = list(range(T)) if T <= 4 else [0, T - 1]
+    dg = np.zeros((T, c), np.float32)
+    db = np.zeros((T, c), np.float32)
+    for t in check:
+        a, b, _ = KR.bn_bwd(zt[t], mu32[t].double(), r32[t].double(), _t64(gamma[t]), _t64(beta[t]), _t64(dp[t]), bool(pool))
+        dg[t], db[t] = a.numpy(), b.numpy()
+    pbuf, (og, ob), pstride = _pack(T, [gamma, beta])
+    vbuf, (ogd, obd), vstride = _pack(T, [gammad, betad], pad=3)
+    gbuf, (odg, odb), gstride = _pack(T, [dg, db], pad=9)
+    zd_, zdd_, mud, rd, m1d, m2d, dpd_, dpdd_ = dev(z), dev(zd), dev(mu32), dev(r32), dev(m1), dev(m2), dev(dp), dev(dpd)
+    a = _lib.MiBnTangentArgs(z=zd_.data_ptr(), zd=zdd_.data_ptr(), mu=mud.data_ptr(), rstd=rd.data_ptr(), m1=m1d.data_ptr(),
+                             m2=m2d.data_ptr(), gamma=pbuf.data_ptr() + 4 * og, beta=pbuf.data_ptr() + 4 * ob, pstride=pstride,
+                             gammad=vbuf.data_ptr() + 4 * ogd, betad=vbuf.data_ptr() + 4 * obd, vstride=vstride,
+                             dgamma=gbuf.data_ptr() + 4 * odg, dbeta=gbuf.data_ptr() + 4 * odb, gstride=gstride,
+                             dp=dpd_.data_ptr(), dpd=dpdd_.data_ptr(), tasks=T, n=n, ho=ho, wo=wo, c=c, pool=pool)
+    pd = torch.full((T, n, hp, wp, c), float('nan'), device='cuda')
+    _lib.check(lib.mi_bn_tangent_fwd(stream(), C.byref(a), ptr(pd)))
+    hstride = 2 * c + 4
+    hb = torch.zeros(T, hstride, device='cuda')
+    rdz = torch.full((T, n, ho, wo, c), float('nan'), device='cuda')
+    scratch, sb = _scratch(lib, T, n, ho, wo, c)
+    _lib.check(lib.mi_bn_tangent_bwd(stream(), C.byref(a), ptr(hb), C.c_void_p(hb.data_ptr() + 4 * c), hstride, ptr(rdz), ptr(scratch), sb))
+    torch.cuda.synchronize()
+    e = dict(pd=0.0, rdgamma=0.0, rdbeta=0.0, rdz=0.0)
+    for t in check:
+        args = (zt[t], zdt[t], mu32[t].double(), r32[t].double())
+        g, b, gd, bd = _t64(gamma[t]), _t64(beta[t]), _t64(gammad[t]), _t64(betad[t])
+        pdr, _ = KR.bn_tangent_fwd(*args, g, b, gd, bd, bool(pool))
+        # the kernels take m1 / m2 as inputs (fp32): feed the oracle the same rounded values
+        rg, rb, rz = KR.bn_tangent_bwd(*args, m1[t].double(), m2[t].double(), g, b, gd, bd, _t64(dp[t]), _t64(dpd[t]),
+                                       _t64(dg[t]), _t64(db[t]), bool(pool))
+        zhd = r32[t].double() * (zdt[t] - m1[t].double() - zh[t] * m2[t].double())
+        _, _, sel = KR._route(zt[t], mu32[t].double(), r32[t].double(), g, b, bool(pool))
+        ud = (gd * zh[t] + g * zhd + bd) * sel
+        pdr = KR._windows(ud, hp, wp).sum(dim=3) if pool else ud
+        e['pd'] = max(e['pd'], max_err(pd[t].cpu().numpy(), pdr.numpy()))
+        e['rdgamma'] = max(e['rdgamma'], rel_err(hb[t, :c].cpu().numpy(), rg.numpy()))
+        e['rdbeta'] = max(e['rdbeta'], rel_err(hb[t, c:2 * c].cpu().numpy(), rb.numpy()))
+        e['rdz'] = max(e['rdz'], rel_err(rdz[t].cpu().numpy(), rz.numpy()))
+    report(f'bn_tangent[{name}]', **e)
+    assert e['pd'] < 1e-5 and e['rdgamma'] < 5e-6 and e['rdbeta'] < 5e-6 and e['rdz'] < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------------- fused block 1
+B1_CASES = [('min_small', 2, 3, 84, 84, 3, 32, None), ('rect', 2, 2, 36, 42, 3, 32, None), ('ci1', 3, 4, 28, 28, 1, 32, None),
+            ('anil64', 1, 2, 84, 84, 3, 64, None), ('bench_T32', 32, 25, 84, 84, 3, 32, [0, 31])]
+
+
+@pytest.mark.parametrize('name,T,n,h,w,ci,co,check', B1_CASES)
+def test_block1_kernels(lib, name, T, n, h, w, ci, co, check):
+    """Every mode of block1_kernel, pooled_reduce_kernel, input_gram + sparse_wgrad + gram_wgrad against the generic formulas
+    of oracle.kernels_ref (conv3x3 -> bn_stats -> bn_relu_pool / bn_bwd / bn_tangent_* -> conv3x3_wgrad)."""
+    hp, wp = h // 2, w // 2
+    hi = 255.0 if ci == 3 else 1.0
+    x = _rand(90, (T, n, h, w, ci), 0.0, hi)
+    sc = 1.0 / hi
+    w9, w9d = _rand(91, (T, 9 * ci, co), -0.3 * sc, 0.3 * sc), _rand(92, (T, 9 * ci, co), -0.3 * sc, 0.3 * sc)
+    gamma, beta = _rand(93, (T, co), 0.1, 1.0), _rand(94, (T, co), -0.3, 0.3)
+    gammad, betad = _rand(95, (T, co)), _rand(96, (T, co))
+    dp, dpd = _rand(97, (T, n, hp, wp, co)), _rand(98, (T, n, hp, wp, co))
+    pbuf, (og, ob, ow), pstride = _pack(T, [gamma, beta, w9])
+    vbuf, (ogd, obd, owd), vstride = _pack(T, [gammad, betad, w9d], pad=7)
+    xd, dpd_, dpdd_ = dev(x), dev(dp), dev(dpd)
+    sb = lib.mi_block1_scratch_bytes(T, n, h, w, ci, co)
+    scratch = torch.empty(sb, dtype=torch.uint8, device='cuda')
+    f32 = lambda *s: torch.full(s, float('nan'), device='cuda')
+    mu, rstd, m1, m2 = f32(T, co), f32(T, co), f32(T, co), f32(T, co)
+    gstride = 2 * co + 9 * ci * co + 11
+    gb, hb = f32(T, gstride), f32(T, gstride)            # [dgamma | dbeta | dW] and the tangent versions
+    p, zhm, pd, zhdm, pd2, zhdm2 = (f32(T, n, hp, wp, co) for _ in range(6))
+    arg = torch.full((T, n, hp, wp, co), 255, dtype=torch.uint8, device='cuda')
+
+    def args(**kw):
+        a = _lib.MiBlock1Args(x=xd.data_ptr(), w=pbuf.data_ptr() + 4 * ow, wd=vbuf.data_ptr() + 4 * owd,
+                              gamma=pbuf.data_ptr() + 4 * og, beta=pbuf.data_ptr() + 4 * ob, pstride=pstride,
+                              gammad=vbuf.data_ptr() + 4 * ogd, betad=vbuf.data_ptr() + 4 * obd, vstride=vstride,
+                              mu=mu.data_ptr(), rstd=rstd.data_ptr(), m1=m1.data_ptr(), m2=m2.data_ptr(),
+                              dgamma=gb.data_ptr(), dbeta=gb.data_ptr() + 4 * co, gstride=gstride,
+                              rdgamma=hb.data_ptr(), rdbeta=hb.data_ptr() + 4 * co, hstride=gstride,
+                              dp=dpd_.data_ptr(), dpd=dpdd_.data_ptr(), arg_in=arg.data_ptr(), zh_in=zhm.data_ptr(),
+                              tasks=T, n=n, h=h, w_=w, ci=ci, co=co)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    def run(mode, p_out=None, zh_out=None, arg_out=None, out0=None, out1=None, ostride=0):
+        a = args()
+        _lib.check(lib.mi_block1_run(stream(), mode, C.byref(a), ptr(p_out), ptr(zh_out), ptr(arg_out), ptr(out0), ptr(out1), ostride,
+                                     ptr(scratch), sb))
+
+    run(0, out0=mu, out1=rstd, ostride=co)                                        # STATS
+    run(1, p_out=p, zh_out=zhm, arg_out=arg)                                      # FWD
+    run(2, out0=gb, out1=gb[:, co:], ostride=gstride)                             # BWD_REDUCE -> dgamma, dbeta
+    gb_red = gb[:, :2 * co].clone()
+    run(3, out0=gb[:, 2 * co:], ostride=gstride)                                  # BWD_WGRAD -> dW
+    run(4, out0=m1, out1=m2, ostride=co)                                          # TSTATS
+    run(5, p_out=pd, zh_out=zhdm)                                                 # TFWD
+    run(8, p_out=pd2, zh_out=zhdm2)                                               # TFWD_ARG
+    run(6, out0=hb, out1=hb[:, co:], ostride=gstride)                             # TBWD_REDUCE
+    run(7, out0=hb[:, 2 * co:], ostride=gstride)                                  # TBWD_WGRAD
+    # pooled-resolution reductions and the Gram-matrix weight gradient (the path the engine takes by default)
+    pr, prt = f32(T, 2 * co), f32(T, 2 * co)
+    rows = n * hp * wp
+    _lib.check(lib.mi_pooled_reduce(stream(), ptr(p), ptr(zhm), None, ptr(dpd_), None, T, rows, co, ptr(pr), ptr(pr[:, co:]), 2 * co,
+                                    ptr(scratch), sb))
+    _lib.check(lib.mi_pooled_reduce(stream(), ptr(p), ptr(zhm), ptr(zhdm2), ptr(dpd_), ptr(dpdd_), T, rows, co, ptr(prt), ptr(prt[:, co:]),
+                                    2 * co, ptr(scratch), sb))
+    ng = 32 if ci == 3 else 16
+    gs = lib.mi_input_gram_scratch_bytes(T, n, h, ci)
+    gscr = torch.empty(gs, dtype=torch.uint8, device='cuda')
+    G = torch.empty(T, ng, ng, dtype=torch.float64, device='cuda')
+    _lib.check(lib.mi_input_gram(stream(), ptr(xd), T, n, h, w, ci, ptr(gscr), gs, ptr(G)))
+    mug, rg_, m1g, m2g = f32(T, co), f32(T, co), f32(T, co), f32(T, co)
+    _lib.check(lib.mi_gram_bn_stats(stream(), ptr(G), T, ci, co, _at(pbuf, ow), pstride, None, 0, n * h * w, ptr(mug), ptr(rg_), None, None))
+    _lib.check(lib.mi_gram_bn_stats(stream(), ptr(G), T, ci, co, _at(pbuf, ow), pstride, _at(vbuf, owd), vstride, n * h * w, ptr(m1g), ptr(m2g),
+                                    ptr(mu), ptr(rstd)))
+    dwg, rdwg = f32(T, 9 * ci * co), f32(T, 9 * ci * co)
+    a = args()
+    _lib.check(lib.mi_block1_wgrad_gram(stream(), C.byref(a), ptr(G), 0, ptr(dwg), 9 * ci * co, ptr(scratch), sb))
+    _lib.check(lib.mi_block1_wgrad_gram(stream(), C.byref(a), ptr(G), 1, ptr(rdwg), 9 * ci * co, ptr(scratch), sb))
+    torch.cuda.synchronize()
+
+    e = {}
+
+    def upd(k, v):
+        e[k] = max(e.get(k, 0.0), float(v))
+
+    for t in (range(T) if check is None else check):
+        xt = _t64(x[t])
+        W, Wd = _t64(w9[t]).reshape(9, ci, co), _t64(w9d[t]).reshape(9, ci, co)
+        g, b, gd, bd = _t64(gamma[t]), _t64(beta[t]), _t64(gammad[t]), _t64(betad[t])
+        z = KR.conv3x3(xt, W)
+        zd = KR.conv3x3(xt, Wd)
+        mr, rr = KR.bn_stats(z)
+        sd = float(z.std())
+        upd('mu', max_err(mu[t].cpu().numpy(), mr.numpy()) / sd)
+        upd('rstd', rel_err(rstd[t].cpu().numpy(), rr.numpy()))
+        upd('mu_gram', max_err(mug[t].cpu().numpy(), mr.numpy()) / sd)
+        upd('rstd_gram', rel_err(rg_[t].cpu().numpy(), rr.numpy()))
+        # downstream kernels take the fp32 statistics as inputs: the oracle gets the same rounded values
+        m, r = mu[t].double().cpu(), rstd[t].double().cpu()
+        pr_ = KR.bn_relu_pool_fwd(z, m, r, g, b, True)
+        argr, zh_at = KR.pool_argmax(z, m, r, g, b)
+        got_arg = arg[t].cpu().long()
+        # a position whose u ties its window's maximum to the last bit may resolve differently in fp32: count, do not compare there
+        same = got_arg == argr
+        upd('argmax_mismatch_frac', 1.0 - float(same.double().mean()))
+        assert float(same.double().mean()) > 0.9999
+        upd('p', max_err(p[t].cpu().numpy()[same.numpy()], pr_.numpy()[same.numpy()]))
+        on = (argr < 4) & same
+        upd('zh_at', max_err(zhm[t].cpu().numpy()[on.numpy()], zh_at.numpy()[on.numpy()]))
+        dgr, dbr, dz = KR.bn_bwd(z, m, r, g, b, _t64(dp[t]), True)
+        upd('dgamma', rel_err(gb_red[t, :co].cpu().numpy(), dgr.numpy()))
+        upd('dbeta', rel_err(gb_red[t, co:2 * co].cpu().numpy(), dbr.numpy()))
+        upd('dgamma_pooled', rel_err(pr[t, :co].cpu().numpy(), dgr.numpy()))
+        upd('dbeta_pooled', rel_err(pr[t, co:].cpu().numpy(), dbr.numpy()))
+        dg32, db32 = gb_red[t, :co].double().cpu(), gb_red[t, co:2 * co].double().cpu()
+        dz = g * r * (KR._spread(_t64(dp[t]), z.shape, True) * KR._route(z, m, r, g, b, True)[2] - db32 / z[..., 0].numel()
+                      - ((z - m) * r) * dg32 / z[..., 0].numel())
+        dwr = KR.conv3x3_wgrad(xt, dz).reshape(9 * ci, co)
+        upd('dW_recompute', rel_err(gb[t, 2 * co:2 * co + 9 * ci * co].cpu().numpy(), dwr.numpy()))
+        upd('dW_gram', rel_err(dwg[t].cpu().numpy(), dwr.numpy()))
+        # tangent
+        zh = (z - m) * r
+        m1r, m2r = zd.mean(dim=(0, 1, 2)), (zh * zd).mean(dim=(0, 1, 2))
+        sdd = float(zd.std())
+        upd('m1', max_err(m1[t].cpu().numpy(), m1r.numpy()) / sdd)
+        upd('m2', max_err(m2[t].cpu().numpy(), m2r.numpy()) / sdd)
+        upd('m1_gram', max_err(m1g[t].cpu().numpy(), m1r.numpy()) / sdd)
+        upd('m2_gram', max_err(m2g[t].cpu().numpy(), m2r.numpy()) / sdd)
+        a1, a2 = m1[t].double().cpu(), m2[t].double().cpu()
+        zhd = r * (zd - a1 - zh * a2)
+        sel = KR._route(z, m, r, g, b, True)[2]
+        pdr = KR._windows((gd * zh + g * zhd + bd) * sel, hp, wp).sum(dim=3)
+        upd('pd', max_err(pd[t].cpu().numpy()[same.numpy()], pdr.numpy()[same.numpy()]))
+        upd('pd_from_arg', max_err(pd2[t].cpu().numpy()[same.numpy()], pdr.numpy()[same.numpy()]))
+        zhd_at = KR.at_argmax(zhd, argr)
+        upd('zhd_at', max_err(zhdm2[t].cpu().numpy()[on.numpy()], zhd_at.numpy()[on.numpy()]))
+        rgr, rbr, rdz = KR.bn_tangent_bwd(z, zd, m, r, a1, a2, g, b, gd, bd, _t64(dp[t]), _t64(dpd[t]), dg32, db32, True)
+        upd('rdgamma', rel_err(hb[t, :co].cpu().numpy(), rgr.numpy()))
+        upd('rdbeta', rel_err(hb[t, co:2 * co].cpu().numpy(), rbr.numpy()))
+        upd('rdgamma_pooled', rel_err(prt[t, :co].cpu().numpy(), rgr.numpy()))
+        upd('rdbeta_pooled', rel_err(prt[t, co:].cpu().numpy(), rbr.numpy()))
+        rg32, rb32 = hb[t, :co].double().cpu(), hb[t, co:2 * co].double().cpu()
+        _, _, rdz = _rdz_with(KR, z, zd, m, r, a1, a2, g, b, gd, bd, _t64(dp[t]), _t64(dpd[t]), dg32, db32, rg32, rb32)
+        rdwr = KR.conv3x3_wgrad(xt, rdz).reshape(9 * ci, co)
+        upd('RdW_recompute', rel_err(hb[t, 2 * co:2 * co + 9 * ci * co].cpu().numpy(), rdwr.numpy()))
+        upd('RdW_gram', rel_err(rdwg[t].cpu().numpy(), rdwr.numpy()))
+    report(f'block1[{name}]', **e)
+    tight = ['mu', 'rstd', 'mu_gram', 'rstd_gram', 'm1', 'm2', 'm1_gram', 'm2_gram']
+    assert all(e[k] < 2e-6 for k in tight), {k: e[k] for k in tight}
+    assert e['p'] < 1e-5 and e['zh_at'] < 1e-5 and e['pd'] < 2e-5 and e['pd_from_arg'] < 2e-5 and e['zhd_at'] < 2e-5
+    for k in ('dgamma', 'dbeta', 'dgamma_pooled', 'dbeta_pooled', 'rdgamma', 'rdbeta', 'rdgamma_pooled', 'rdbeta_pooled'):
+        assert e[k] < 1e-5, (k, e[k])
+    for k in ('dW_recompute', 'dW_gram', 'RdW_recompute', 'RdW_gram'):
+        assert e[k] < 2e-5, (k, e[k])
+
+
+def _rdz_with(KR, z, zd, mu, r, m1, m2, gamma, beta, gammad, betad, dp, dpd, dgamma, dbeta, rdgamma, rdbeta):
+    """R{dz} exactly as the weight-gradient kernels form it: with the (fp32-rounded) R{dgamma} / R{dbeta} they are GIVEN."""
+    m = z.shape[0] * z.shape[1] * z.shape[2]
+    _, zh, sel = KR._route(z, mu, r, gamma, beta, True)
+    zhd = r * (zd - m1 - zh * m2)
+    rd = -r * r * m2
+    du = KR._spread(dp, z.shape, True) * sel
+    dud = KR._spread(dpd, z.shape, True) * sel
+    e = du - dbeta / m - zh * dgamma / m
+    rdz = (gammad * r + gamma * rd) * e + gamma * r * (dud - rdbeta / m - zhd * dgamma / m - zh * rdgamma / m)
+    return rdgamma, rdbeta, rdz
