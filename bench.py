@@ -61,11 +61,10 @@ def conv_launch_bytes(layer, n_img):
 
 
 def init_theta(spec, seed=42):
+    """The reference's initialisers (xavier-uniform weights, zero biases, BatchNorm gamma ~ U(0,1): vision_models.py:175,204-207)
+    drawn from the build's hash generator."""
     shapes = dict(spec.param_shapes())
-    w = synthetic.hash_weights(shapes, seed)
-    for k in w:                      # reference initialisers: biases / BN beta start at zero (vision_models.py:204-207)
-        if k.endswith('bias'):
-            w[k] = np.zeros_like(w[k])
+    w = synthetic.ref_init_weights(shapes, seed)
     return torch.from_numpy(np.concatenate([w[k].ravel() for k in shapes])).float()
 
 

@@ -28,7 +28,9 @@ class _FusedAnil(torch.autograd.Function):
                                                     with_grad=need_grad)
         ctx.shapes = [p.shape for p in params]
         ctx.save_for_backward(grad if grad is not None else torch.empty(0, device=data.device))
-        ctx.mark_non_differentiable(acc)
+        # Only the SUM carries the meta-gradient (the engine reduces over tasks inside the fused call): the per-task losses are
+        # values, so `losses.mean().backward()` fails loudly instead of stepping on zeros.
+        ctx.mark_non_differentiable(loss, acc)
         return loss.sum(), loss, acc
 
     @staticmethod

@@ -25,7 +25,9 @@ class _FusedFastAdapt(torch.autograd.Function):
         ctx.shapes = [p.shape for p in params]
         ctx.per_task = None
         ctx.save_for_backward(grad if grad is not None else torch.empty(0, device=data.device))
-        ctx.mark_non_differentiable(acc)
+        # Only the SUM carries the meta-gradient (the engine reduces over tasks inside the fused call): the per-task losses are
+        # values, so `losses.mean().backward()` fails loudly instead of stepping on zeros.
+        ctx.mark_non_differentiable(loss, acc)
         return loss.sum(), loss, acc
 
     @staticmethod
@@ -46,7 +48,8 @@ class _FusedFastAdapt(torch.autograd.Function):
 def meta_batch_adapt(learner, data, labels, adaptation_steps, shots, ways, first_order=None):
     """Batched entry: data [T, 2*shots*ways, C, H, W], labels [T, 2*shots*ways] on the GPU.
     Returns (loss_sum, loss[T], acc[T]); ``loss_sum.backward()`` accumulates the SUM over tasks of d valid_loss/d theta
-    into the base parameters' ``.grad`` -- what T iterations of the reference loop body leave there."""
+    into the base parameters' ``.grad`` -- what T iterations of the reference loop body leave there.  ``loss[T]`` and ``acc[T]``
+    are plain values (not differentiable): weight tasks by scaling ``loss_sum``, or call once per group of tasks."""
     model = learner.module if isinstance(learner, MAML) else learner
     fo = learner.first_order if first_order is None and isinstance(learner, MAML) else bool(first_order)
     lr = learner.lr

@@ -156,9 +156,14 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
       perm.push_back((int32_t)(e->off_wl + ref));
     }
   for (size_t k = perm.size(); k < off; ++k) perm.push_back((int32_t)k);
+  // the caller's current device is left as it was (torch tracks it on its own)
+  int prev = -1;
+  (void)hipGetDevice(&prev);
   if (hipSetDevice(device) != hipSuccess) { delete e; return fail(nullptr, MI_ERR_HIP, "hipSetDevice failed"); }
-  if (hipMalloc(&e->perm_dev, perm.size() * sizeof(int32_t)) != hipSuccess ||
-      hipMemcpy(e->perm_dev, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+  const bool ok = hipMalloc(&e->perm_dev, perm.size() * sizeof(int32_t)) == hipSuccess &&
+                  hipMemcpy(e->perm_dev, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+  if (!ok) {
     delete e;
     return fail(nullptr, MI_ERR_HIP, "allocating the parameter permutation table failed");
   }
@@ -199,7 +204,13 @@ extern "C" int mi_engine_set_overlap(mi_engine* e, int on) {
 static hipStream_t pool_stream(const mi_engine* e, int which) {
   static hipStream_t g_pool[64][1] = {};
   const int d = (e->device >= 0 && e->device < 64) ? e->device : 0;
-  if (!g_pool[d][which] && hipStreamCreateWithFlags(&g_pool[d][which], hipStreamNonBlocking) != hipSuccess) g_pool[d][which] = nullptr;
+  if (!g_pool[d][which]) {          // created on the ENGINE's device, whatever device is current in the calling thread
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != e->device) (void)hipSetDevice(e->device);
+    if (hipStreamCreateWithFlags(&g_pool[d][which], hipStreamNonBlocking) != hipSuccess) g_pool[d][which] = nullptr;
+    if (prev >= 0 && prev != e->device) (void)hipSetDevice(prev);
+  }
   return g_pool[d][which];
 }
 static bool make_event(hipEvent_t* ev) { return *ev || hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; }

@@ -75,8 +75,29 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _on_device(fn):
+    """Run an engine method with the engine's own device current (launches go to that device's current stream), whatever
+    device the caller has selected."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
+def _resolve_device(device):
+    if device is None:
+        return torch.device('cuda', torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise _lib.MiError(f'the engine runs on a GPU, got device {device}')
+    return torch.device('cuda', device.index if device.index is not None else torch.cuda.current_device())
 
 
 class MetaEngine:
@@ -88,12 +109,11 @@ class MetaEngine:
             raise _lib.MiError('MetaEngine needs a GPU: the MAML hot path has no CPU implementation in this package '
                                '(the CPU restatement under oracle/ is test infrastructure only).')
         self.spec = spec
-        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = _resolve_device(device)
         desc = _lib.MiModelDesc(spec.n_layers, spec.in_channels, spec.in_h, spec.in_w, spec.hidden, int(spec.max_pool),
                                 spec.ways, int(spec.head_mean_pool))
         self._h = C.c_void_p()
-        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        _lib.check(self.lib.mi_engine_create(C.byref(desc), idx, C.byref(self._h)))
+        _lib.check(self.lib.mi_engine_create(C.byref(desc), self.device.index, C.byref(self._h)))
         n = C.c_size_t()
         _lib.check(self.lib.mi_param_count(self._h, C.byref(n)), self._h)
         self.param_count = n.value
@@ -113,6 +133,20 @@ class MetaEngine:
         """Side-stream execution of the weight gradients of blocks >= 2 (default on); results do not depend on it."""
         _lib.check(self.lib.mi_engine_set_overlap(self._h, int(on)), self._h)
 
+    def set_trace(self, tasks=0, adapt_steps=0):
+        """Debug/test aid (mi_debug_set_trace): allocate a trace buffer for meta_batch calls with these sizes and return it as a
+        dict of views {theta [K+1,T,P], g [K,T,P], lam_in [K,T,P], hv [K,T,P]} (reference parameter order); 0 tasks switches it off."""
+        if not tasks:
+            _lib.check(self.lib.mi_debug_set_trace(self._h, None, 0), self._h)
+            self._trace = None
+            return None
+        K, T, P = adapt_steps, tasks, self.param_count
+        buf = torch.zeros((4 * K + 1) * T * P, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mi_debug_set_trace(self._h, _ptr(buf), buf.numel()), self._h)
+        self._trace = buf
+        v = buf.view(4 * K + 1, T, P)
+        return dict(theta=v[:K + 1], g=v[K + 1:2 * K + 1], lam_in=v[2 * K + 1:3 * K + 1], hv=v[3 * K + 1:])
+
     def workspace_bytes(self, tasks, shots, adapt_steps, second_order):
         b = C.c_size_t()
         _lib.check(self.lib.mi_workspace_bytes(self._h, tasks, self.spec.ways, shots, adapt_steps, int(second_order),
@@ -125,6 +159,7 @@ class MetaEngine:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    @_on_device
     def meta_batch(self, theta, data, labels, shots, adapt_steps, inner_lr, first_order=False, with_grad=True,
                    return_logits=False):
         """theta [P] fp32; data [T, 2*shots*ways, C, H, W] fp32 (the reference's task batches, stacked); labels [T, 2*S*W]
@@ -148,12 +183,13 @@ class MetaEngine:
         acc = torch.empty(T, dtype=torch.float32, device=self.device)
         grad = torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None
         logits = torch.empty(T, shots * s.ways, s.ways, dtype=torch.float32, device=self.device) if return_logits else None
-        rc = self.lib.mi_meta_batch_maml(self._h, _stream(), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
+        rc = self.lib.mi_meta_batch_maml(self._h, _stream(self.device), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
                                          adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
                                          _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
         _lib.check(rc, self._h)
         return loss, acc, grad, logits
 
+    @_on_device
     def meta_batch_anil(self, theta, data, labels, shots, adapt_steps, inner_lr, first_order=False, with_grad=True,
                         return_logits=False):
         """ANIL (reference vision/anil_vision.py:116-122): theta = [features.parameters()..., head.weight, head.bias] flat;
@@ -175,12 +211,13 @@ class MetaEngine:
         acc = torch.empty(T, dtype=torch.float32, device=self.device)
         grad = torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None
         logits = torch.empty(T, shots * s.ways, s.ways, dtype=torch.float32, device=self.device) if return_logits else None
-        rc = self.lib.mi_meta_batch_anil(self._h, _stream(), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
+        rc = self.lib.mi_meta_batch_anil(self._h, _stream(self.device), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
                                          adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
                                          _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
         _lib.check(rc, self._h)
         return loss, acc, grad, logits
 
+    @_on_device
     def forward_logits(self, theta, x):
         """Plain forward (no adaptation): x [T, n, C, H, W] -> logits [T, n, ways]; BatchNorm uses each batch's statistics."""
         T, n = x.shape[0], x.shape[1]
@@ -188,7 +225,7 @@ class MetaEngine:
         _lib.check(self.lib.mi_forward_workspace_bytes(self._h, T, n, C.byref(b)), self._h)
         ws = self._workspace(b.value)
         logits = torch.empty(T, n, self.spec.ways, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.mi_forward_logits(self._h, _stream(), _ptr(theta.contiguous()), _ptr(x.contiguous()), T, n,
+        _lib.check(self.lib.mi_forward_logits(self._h, _stream(self.device), _ptr(theta.contiguous()), _ptr(x.contiguous()), T, n,
                                               _ptr(logits), _ptr(ws), ws.numel()), self._h)
         return logits
 
@@ -204,6 +241,7 @@ class MetaEngine:
         _lib.check(self.lib.mi_forward_workspace_bytes(self._h, T, n, C.byref(b)), self._h)
         return theta.contiguous(), x.contiguous(), T, n, self._workspace(b.value)
 
+    @_on_device
     def learner_forward(self, theta, x, rep_layer=None, want_logits=True):
         """`learner(x)` with caller-held fast weights: theta [P] / [1,P] (shared) or [T,P]; x [T, n, C, H, W].
         Returns (logits [T,n,ways] or None, rep or None) where rep = output of the first `rep_layer` ConvBlocks in NCHW
@@ -214,10 +252,11 @@ class MetaEngine:
         if rep_layer is not None:
             c, h, w = self.spec.block_output_shape(rep_layer)
             rep = torch.empty(T, n, c, h, w, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.mi_learner_forward(self._h, _stream(), _ptr(theta), theta.shape[0], _ptr(x), T, n, _ptr(logits),
+        _lib.check(self.lib.mi_learner_forward(self._h, _stream(self.device), _ptr(theta), theta.shape[0], _ptr(x), T, n, _ptr(logits),
                                                int(rep_layer or 0), _ptr(rep), _ptr(ws), ws.numel()), self._h)
         return logits, rep
 
+    @_on_device
     def learner_backward(self, theta, x, dlogits):
         """Vector-Jacobian product of `learner(x)`: d sum(logits*dlogits)/d theta, [theta_tasks, P] (first derivatives)."""
         theta, x, T, n, ws = self._learner_args(theta, x)
@@ -225,10 +264,11 @@ class MetaEngine:
         if tuple(dlogits.shape) != (T, n, self.spec.ways):
             raise ValueError(f'dlogits must be {(T, n, self.spec.ways)}, got {tuple(dlogits.shape)}')
         grad = torch.empty(theta.shape[0], self.param_count, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.mi_learner_backward(self._h, _stream(), _ptr(theta), theta.shape[0], _ptr(x), _ptr(dlogits), T, n,
+        _lib.check(self.lib.mi_learner_backward(self._h, _stream(self.device), _ptr(theta), theta.shape[0], _ptr(x), _ptr(dlogits), T, n,
                                                 _ptr(grad), _ptr(ws), ws.numel()), self._h)
         return grad
 
+    @_on_device
     def head_logits(self, f, wl, bl):
         """`linear(f)` for f [n, F] with explicit weights (reference get_rep_layer(x, -1)); mi_head_fwd_bwd, forward only."""
         f, wl, bl = f.contiguous(), wl.contiguous().float(), bl.contiguous().float()
@@ -237,7 +277,7 @@ class MetaEngine:
         scr = torch.empty(max(2 * n, n * feat), dtype=torch.float32, device=self.device)
         la = torch.empty(2, dtype=torch.float32, device=self.device)
         logits = torch.empty(n, ways, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.mi_head_fwd_bwd(_stream(), _ptr(f), _ptr(wl), _ptr(bl), 0, _ptr(y), 1, n, feat, ways, _ptr(la[:1]),
+        _lib.check(self.lib.mi_head_fwd_bwd(_stream(self.device), _ptr(f), _ptr(wl), _ptr(bl), 0, _ptr(y), 1, n, feat, ways, _ptr(la[:1]),
                                             _ptr(la[1:]), _ptr(logits), None, None, None, None, 0, _ptr(scr)), self._h)
         return logits
 
@@ -257,6 +297,7 @@ class MetaEngine:
         _lib.check(self.lib.mi_profile_collect(self._h, ms, cnt, n), self._h)
         return {(self.lib.mi_profile_op_name(k // 8).decode(), k % 8): (ms[k], cnt[k]) for k in range(n) if cnt[k]}
 
+    @_on_device
     def adam_step(self, theta, grad, state, lr, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
         """torch.optim.Adam defaults on the flat meta-parameters (vision/maml_vision.py:85,139-141)."""
         if 'm' not in state:
@@ -264,7 +305,7 @@ class MetaEngine:
             state['v'] = torch.zeros_like(theta)
             state['step'] = 0
         state['step'] += 1
-        _lib.check(self.lib.mi_adam_step(_stream(), _ptr(theta), _ptr(grad), _ptr(state['m']), _ptr(state['v']),
+        _lib.check(self.lib.mi_adam_step(_stream(self.device), _ptr(theta), _ptr(grad), _ptr(state['m']), _ptr(state['v']),
                                          theta.numel(), state['step'], lr, betas[0], betas[1], eps, grad_scale))
 
 
@@ -284,11 +325,11 @@ class PolicyEngine:
             raise _lib.MiError('PolicyEngine needs a GPU: there is no CPU implementation of the policy path in this package.')
         if len(hiddens) != 2:
             raise ValueError('the HIP policy path implements the reference default: two hidden layers (policies.py:33-34)')
-        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = _resolve_device(device)
         self.S, self.A, self.H = state_size, action_size, tuple(hiddens)
         desc = _lib.MiPolicyDesc(state_size, action_size, hiddens[0], hiddens[1], int(activation == 'tanh'))
         self._h = C.c_void_p()
-        rc = self.lib.mi_policy_create(C.byref(desc), self.device.index or 0, C.byref(self._h))
+        rc = self.lib.mi_policy_create(C.byref(desc), self.device.index, C.byref(self._h))
         if rc:
             raise _lib.MiError(self.lib.mi_policy_last_error(None).decode())
         n = C.c_size_t()
@@ -313,16 +354,18 @@ class PolicyEngine:
             self._ws = torch.empty(b.value, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    @_on_device
     def forward(self, theta, states):
         """loc of the policy density; theta [P] (shared) or [T, P]; states [T, B, S] -> loc [T, B, A]."""
         T, B = states.shape[0], states.shape[1]
         ws = self._workspace(T, B)
         loc = torch.empty(T, B, self.A, device=self.device)
         stride = 0 if theta.dim() == 1 else self.param_count
-        self._check(self.lib.mi_policy_forward(self._h, _stream(), _ptr(theta.contiguous()), stride, _ptr(states.contiguous()), T, B,
+        self._check(self.lib.mi_policy_forward(self._h, _stream(self.device), _ptr(theta.contiguous()), stride, _ptr(states.contiguous()), T, B,
                                                _ptr(loc), _ptr(ws), ws.numel()))
         return loc
 
+    @_on_device
     def adapt(self, theta, states, actions, adv, count, lr, head_only=False):
         """trpo_update for T tasks: returns (theta_out [T, P], loss [T]).  head_only: ANIL inner loop (body under no_grad)."""
         T, B = states.shape[0], states.shape[1]
@@ -330,10 +373,11 @@ class PolicyEngine:
         out = torch.empty(T, self.param_count, device=self.device)
         loss = torch.empty(T, device=self.device)
         stride = 0 if theta.dim() == 1 else self.param_count
-        self._check(self.lib.mi_policy_adapt(self._h, _stream(), _ptr(theta.contiguous()), stride, _ptr(states), _ptr(actions),
+        self._check(self.lib.mi_policy_adapt(self._h, _stream(self.device), _ptr(theta.contiguous()), stride, _ptr(states), _ptr(actions),
                                              _ptr(adv), _ptr(count), T, B, float(lr), int(head_only), _ptr(out), _ptr(loss), _ptr(ws), ws.numel()))
         return out, loss
 
+    @_on_device
     def surrogate(self, theta, sup, qry, old_loc, old_scale, inner_lr, want_grad):
         """sup/qry: dicts with states [T,B,S], actions [T,B,A], adv [T,B], count [T] int32.  -> (loss, kl, grad or None)."""
         T, B = sup['states'].shape[0], sup['states'].shape[1]
@@ -341,7 +385,7 @@ class PolicyEngine:
         loss = torch.empty(1, device=self.device)
         kl = torch.empty(1, device=self.device)
         grad = torch.empty(self.param_count, device=self.device) if want_grad else None
-        self._check(self.lib.mi_trpo_surrogate(self._h, _stream(), _ptr(theta), _ptr(sup['states']), _ptr(sup['actions']),
+        self._check(self.lib.mi_trpo_surrogate(self._h, _stream(self.device), _ptr(theta), _ptr(sup['states']), _ptr(sup['actions']),
                                                _ptr(sup['adv']), _ptr(sup['count']), _ptr(qry['states']), _ptr(qry['actions']),
                                                _ptr(qry['adv']), _ptr(qry['count']), _ptr(old_loc), _ptr(old_scale), T, B,
                                                float(inner_lr), _ptr(loss), _ptr(kl), _ptr(grad), _ptr(ws), ws.numel()))
@@ -354,6 +398,7 @@ class PolicyEngine:
             self._ws = torch.empty(b.value, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    @_on_device
     def surrogate_steps(self, theta, sup, qry, old_loc, old_scale, inner_lr, want_grad):
         """meta_surrogate_loss with K = sup['states'].shape[0] inner updates (sup arrays carry a leading [K] axis)."""
         K, T, B = sup['states'].shape[0], sup['states'].shape[1], sup['states'].shape[2]
@@ -362,20 +407,22 @@ class PolicyEngine:
         kl = torch.empty(1, device=self.device)
         grad = torch.empty(self.param_count, device=self.device) if want_grad else None
         self._check(self.lib.mi_trpo_surrogate_steps(
-            self._h, _stream(), _ptr(theta), K, _ptr(sup['states']), _ptr(sup['actions']), _ptr(sup['adv']), _ptr(sup['count']),
+            self._h, _stream(self.device), _ptr(theta), K, _ptr(sup['states']), _ptr(sup['actions']), _ptr(sup['adv']), _ptr(sup['count']),
             _ptr(qry['states']), _ptr(qry['actions']), _ptr(qry['adv']), _ptr(qry['count']), _ptr(old_loc), _ptr(old_scale), T, B,
             float(inner_lr), _ptr(loss), _ptr(kl), _ptr(grad), _ptr(ws), ws.numel()))
         return loss, kl, grad
 
+    @_on_device
     def fvp_steps(self, sup, qry, inner_lr, damping, v):
         K, T, B = sup['states'].shape[0], sup['states'].shape[1], sup['states'].shape[2]
         ws = self._steps_ws(T, B, K)
         out = torch.empty(self.param_count, device=self.device)
-        self._check(self.lib.mi_trpo_fvp_steps(self._h, _stream(), K, _ptr(sup['states']), _ptr(sup['actions']), _ptr(sup['count']),
+        self._check(self.lib.mi_trpo_fvp_steps(self._h, _stream(self.device), K, _ptr(sup['states']), _ptr(sup['actions']), _ptr(sup['count']),
                                                _ptr(qry['states']), _ptr(qry['count']), T, B, float(inner_lr), float(damping),
                                                _ptr(v.contiguous()), _ptr(out), _ptr(ws), ws.numel()))
         return out
 
+    @_on_device
     def meta_batch(self, theta, sup, qry, step_batch, inner_lr, loss='a2c', clip=0.1, step_new_old=None, head_only=False,
                    first_order=False, with_grad=True):
         """K = len(step_batch) MAML updates of the policy on replayed support batches + validation loss + meta-gradient for all
@@ -401,18 +448,19 @@ class PolicyEngine:
         grad = torch.empty(self.param_count, device=self.device) if with_grad else None
         g = lambda d, k: _ptr(d[k].contiguous()) if d is not None and K else C.c_void_p(0)
         self._check(self.lib.mi_policy_meta_batch(
-            self._h, _stream(), _ptr(theta.contiguous()), K, sb, sn, NB, g(sup, 'states'), g(sup, 'actions'), g(sup, 'adv'),
+            self._h, _stream(self.device), _ptr(theta.contiguous()), K, sb, sn, NB, g(sup, 'states'), g(sup, 'actions'), g(sup, 'adv'),
             g(sup, 'count'), _ptr(qry['states'].contiguous()), _ptr(qry['actions'].contiguous()), _ptr(qry['adv'].contiguous()),
             _ptr(qry['count'].contiguous()), T, B, kind, float(clip), float(inner_lr), int(head_only), int(not first_order),
             int(with_grad), _ptr(loss_t), _ptr(theta_out), _ptr(grad), _ptr(self._ws), self._ws.numel()))
         return loss_t, theta_out, grad
 
+    @_on_device
     def fvp(self, theta, sup, qry, inner_lr, damping, v):
         """Fisher-vector product at the theta of the preceding ``surrogate`` call (same batches)."""
         T, B = sup['states'].shape[0], sup['states'].shape[1]
         ws = self._workspace(T, B)
         out = torch.empty(self.param_count, device=self.device)
-        self._check(self.lib.mi_trpo_fvp(self._h, _stream(), _ptr(theta), _ptr(sup['states']), _ptr(sup['actions']),
+        self._check(self.lib.mi_trpo_fvp(self._h, _stream(self.device), _ptr(theta), _ptr(sup['states']), _ptr(sup['actions']),
                                          _ptr(sup['count']), _ptr(qry['states']), _ptr(qry['count']), T, B, float(inner_lr),
                                          float(damping), _ptr(v.contiguous()), _ptr(out), _ptr(ws), ws.numel()))
         return out
