@@ -133,10 +133,14 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    ap.add_argument('--tasks', type=int, default=0, help='override the tasks per GPU of the workload (sweeps; not a BASELINE configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', default='', help='write a per-kernel event-time breakdown (one extra untimed step) to this file')
     args = ap.parse_args()
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.tasks:
+        wl['tasks'] = args.tasks
+        wl['name'] += f' [tasks per GPU overridden: {args.tasks}]'
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

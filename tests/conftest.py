@@ -22,3 +22,9 @@ def golden_small():
 def golden_fa():
     import numpy as np
     return np.load(os.path.join(REPO, 'tests', 'golden', 'golden_fast_adapt.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden_refinit():
+    import numpy as np
+    return np.load(os.path.join(REPO, 'tests', 'golden', 'golden_refinit.npz'), allow_pickle=False)

@@ -175,6 +175,51 @@ def g3_fast_adapt(ref, out):
         print('g3', tag, out[f'g3_{tag}_f64_loss'], out[f'g3_{tag}_f32_loss'], flush=True)
 
 
+def load_ref_init_weights(module, seed, dtype):
+    """The reference's own initialiser distributions drawn from the hash generator (synthetic.ref_init_weights)."""
+    shapes = {k: tuple(v.shape) for k, v in module.named_parameters()}
+    w = synthetic.ref_init_weights(shapes, seed)
+    module.to(dtype)
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            p.copy_(torch.from_numpy(w[k]).to(dtype))
+    return module
+
+
+def g7_refinit(ref, out):
+    """One-step configurations at the point SURVEY.md 8c calibrated them on: reference initialisers (xavier-uniform weights, zero
+    biases, gamma ~ U(0,1)) and plateau-free inputs (synthetic.uniform_task) -- the reference's fp32 run is within 1e-5 of its fp64
+    run there, so the HIP path is held to 1e-4 in the meta-gradient against BOTH legs."""
+    cases = [
+        ('cfg4r_min_5w1s_K1_so', 'min32', 'min', 5, 1, 1, 0.5, False, [0, 1, 2]),
+        ('cfg1r_omni_5w1s_K1_fo', 'omni64', 'omni', 5, 1, 1, 0.5, True, [0, 1]),
+    ]
+    for tag, model_name, dataset, ways, shots, K, lr, fo, tasks in cases:
+        ctor = {'min32': lambda: ref['MiniImagenetCNN'](ways), 'omni64': lambda: ref['OmniglotCNN'](ways)}[model_name]
+        for dt, dtag in [(torch.float64, 'f64'), (torch.float32, 'f32')]:
+            torch.manual_seed(0)
+            model = load_ref_init_weights(ctor(), seed=11, dtype=dt)
+            loss_fn = torch.nn.CrossEntropyLoss(reduction='mean')
+            losses, accs, grads = [], [], []
+            for t in tasks:
+                for p in model.parameters():
+                    p.grad = None
+                data, labels = synthetic.uniform_task(dataset, t, ways, shots, seed=42)
+                batch = (torch.from_numpy(data).to(dt), torch.from_numpy(labels))
+                learner = StandInLearner(model, lr, fo)
+                vl, va = ref['fast_adapt'](batch, learner, loss_fn, K, shots, ways, torch.device('cpu'))
+                vl.backward()
+                losses.append(vl.item())
+                accs.append(va.item())
+                grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy().astype(np.float32))
+            out[f'g7_{tag}_{dtag}_loss'] = np.array(losses)
+            out[f'g7_{tag}_{dtag}_acc'] = np.array(accs)
+            out[f'g7_{tag}_{dtag}_grad'] = np.stack(grads)             # PER TASK (not summed), stored as fp32
+        out[f'g7_{tag}_meta'] = np.array([ways, shots, K, int(fo)] + tasks, dtype=np.int64)
+        out[f'g7_{tag}_lr'] = np.array([lr])
+        print('g7', tag, out[f'g7_{tag}_f64_loss'], out[f'g7_{tag}_f32_loss'], flush=True)
+
+
 def g3_anil(ref, out):
     """anil_vision.py:86-94,116-122 with the intended Mini-ImageNet sizes (64 filters, 1600 features)."""
     ways, shots, lr = 5, 5, 0.5
@@ -258,6 +303,12 @@ def g6_state_dict(ref, out):
 def main():
     torch.set_num_threads(8)
     ref = import_reference()
+    if '--only-refinit' in sys.argv:           # added in round 2: leaves the other fixture files untouched
+        extra = {}
+        g7_refinit(ref, extra)
+        np.savez_compressed(os.path.join(HERE, 'golden_refinit.npz'), **extra)
+        print('golden_refinit.npz', os.path.getsize(os.path.join(HERE, 'golden_refinit.npz')) // 1024, 'KiB')
+        return
     small, big = {}, {}
     g1_prepare_batch(ref, small)
     g4_accuracy(ref, small)
@@ -268,6 +319,9 @@ def main():
     g3_fast_adapt(ref, big)
     g3_anil(ref, big)
     np.savez_compressed(os.path.join(HERE, 'golden_fast_adapt.npz'), **big)
+    extra = {}
+    g7_refinit(ref, extra)
+    np.savez_compressed(os.path.join(HERE, 'golden_refinit.npz'), **extra)
     for f in ('golden_small.npz', 'golden_fast_adapt.npz'):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')
 

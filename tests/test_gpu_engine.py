@@ -88,6 +88,35 @@ def test_meta_batch_vs_oracle_and_golden(golden_fa, tag, dataset, ways, shots, K
             assert acc[t] == a64[t]
 
 
+@pytest.mark.parametrize('tag,dataset', [('cfg4r_min_5w1s_K1_so', 'min'), ('cfg1r_omni_5w1s_K1_fo', 'omni')])
+def test_one_step_configs_vs_reference_goldens(golden_refinit, tag, dataset):
+    """BASELINE configs 4 and 1 (one inner step) at the reference's initialisers on plateau-free inputs, against fixtures made by
+    the reference's own fast_adapt (tests/golden/make_golden.py::g7_refinit): per-task meta-gradient within 1e-4 of BOTH the fp64
+    and the fp32 leg (SURVEY.md 8c's calibration for the one-step configurations), loss within 1e-5, accuracy equal."""
+    from collections import OrderedDict
+    meta = golden_refinit[f'g7_{tag}_meta']
+    ways, shots, K, fo = (int(v) for v in meta[:4])
+    tasks = [int(t) for t in meta[4:]]
+    lr = float(golden_refinit[f'g7_{tag}_lr'][0])
+    spec, mspec = _spec(dataset, ways)
+    theta = OrderedDict((k, torch.from_numpy(v)) for k, v in synthetic.ref_init_weights(R.param_shapes(spec), 11).items())
+    th32 = R.flatten_params(theta).float().cuda().contiguous()
+    eng = MetaEngine(mspec)
+    e64, e32, el = [], [], []
+    for i, t in enumerate(tasks):
+        d, l = synthetic.uniform_task(dataset, t, ways, shots)
+        loss, acc, grad, _ = eng.meta_batch(th32, torch.from_numpy(d).cuda().unsqueeze(0).contiguous(),
+                                            torch.from_numpy(l).cuda().unsqueeze(0).contiguous(), shots, K, lr, first_order=bool(fo))
+        torch.cuda.synchronize()
+        g = grad.cpu().numpy()
+        e64.append(rel_err(g, golden_refinit[f'g7_{tag}_f64_grad'][i]))
+        e32.append(rel_err(g, golden_refinit[f'g7_{tag}_f32_grad'][i]))
+        el.append(abs(float(loss[0]) - golden_refinit[f'g7_{tag}_f64_loss'][i]) / abs(golden_refinit[f'g7_{tag}_f64_loss'][i]))
+        assert float(acc[0]) == golden_refinit[f'g7_{tag}_f64_acc'][i]
+    report(f'refinit_golden[{tag}]', grad_rel_vs_fp64=e64, grad_rel_vs_ref_fp32=e32, loss_rel=el)
+    assert max(el) < 1e-5 and max(e64) < 1e-4 and max(e32) < 1e-4
+
+
 def test_eval_only_and_batching_equivalence():
     """with_grad=0 (reference `evaluate`, vision.py:26-42) gives the same loss/acc; a task's result does not depend on
     which other tasks share the launch (batched-T vs one-task-at-a-time)."""

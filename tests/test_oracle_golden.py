@@ -97,3 +97,24 @@ def test_fp32_leg_matches_reference_fp32(golden_fa):
     torch.set_num_threads(8)
     losses, _, _, _ = R.maml_meta_batch(theta, spec, datas, labels, 1, 1, 5, 0.5, False)
     assert np.allclose(losses.numpy(), golden_fa[f'g3_{tag}_f32_loss'], rtol=2e-4)
+
+
+@pytest.mark.parametrize('tag,dataset', [('cfg4r_min_5w1s_K1_so', 'min'), ('cfg1r_omni_5w1s_K1_fo', 'omni')])
+def test_fast_adapt_reference_initialisers(golden_refinit, tag, dataset):
+    """Fixtures of round 2: the reference's fast_adapt on reference-initialiser weights and plateau-free inputs (per-task
+    meta-gradients, fp64 and fp32 legs).  The oracle must reproduce the fp64 leg."""
+    from collections import OrderedDict
+    meta = golden_refinit[f'g7_{tag}_meta']
+    ways, shots, K, fo = (int(v) for v in meta[:4])
+    tasks = [int(t) for t in meta[4:]]
+    lr = float(golden_refinit[f'g7_{tag}_lr'][0])
+    spec = R.omniglot_spec(ways) if dataset == 'omni' else R.mini_imagenet_spec(ways)
+    theta = OrderedDict((k, torch.from_numpy(v)) for k, v in synthetic.ref_init_weights(R.param_shapes(spec), 11).items())
+    for i, t in enumerate(tasks):
+        d, l = synthetic.uniform_task(dataset, t, ways, shots)
+        losses, accs, grad, _ = R.maml_meta_batch(theta, spec, [torch.from_numpy(d).double()], [torch.from_numpy(l)], K, shots, ways, lr, bool(fo))
+        assert np.allclose(losses.numpy(), golden_refinit[f'g7_{tag}_f64_loss'][i], rtol=1e-9)
+        assert accs.numpy()[0] == golden_refinit[f'g7_{tag}_f64_acc'][i]
+        assert rel_err(R.flatten_params(grad).numpy(), golden_refinit[f'g7_{tag}_f64_grad'][i]) < 1e-6      # stored as fp32
+        # the reference's own fp32 leg sits this close to its fp64 leg: the conditioning the 1e-4 GPU bar relies on
+        assert rel_err(golden_refinit[f'g7_{tag}_f32_grad'][i], golden_refinit[f'g7_{tag}_f64_grad'][i]) < 5e-5
