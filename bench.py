@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
-"""Benchmark of the MAML hot path on MI355X: tasks/sec for BASELINE.json's headline configuration.
+"""Benchmark of the MAML hot path on MI355X: tasks/sec for BASELINE.json's configurations (headline: configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2] [--scaling weak|strong]
+                                                  (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one meta-iteration of the train half of the reference loop (vision/maml_vision.py:93-141): every rank
-processes its shard of the meta-batch (K inner steps on support, query forward, second-order outer backward) through
-mi_meta_batch_maml, the flat meta-gradient is all-reduced over RCCL, and the identical Adam step is applied on every rank.
-Inputs (synthetic tasks) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+A "step" is one meta-iteration of the train half of the reference loop (vision/maml_vision.py:93-141): every rank processes its
+shard of the meta-batch (K inner steps on support, query forward, second-order outer backward) through mi_meta_batch_maml, the
+flat meta-gradient is all-reduced over RCCL, and the identical Adam step is applied on every rank.  For cfg5 a step is one
+meta_optimize_trpo on resident replays (rl/maml_trpo.py:130-134).  Inputs (synthetic tasks) are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
+
+--scaling weak (default): every rank runs the workload's tasks-per-GPU (32), global meta-batch 32*N -- BASELINE config 4's
+reading (256 tasks sharded 32/GPU over 8 GPUs).  --scaling strong: the global meta-batch stays at the workload's size (32),
+rank r runs its contiguous share of 32/N tasks.
 """
 import argparse
 import json
@@ -26,6 +32,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from exploring_meta_amd.engine import MetaEngine, ModelSpec  # noqa: E402
+from exploring_meta_amd.sharding import MetaTrainer, shard_range  # noqa: E402
+from exploring_meta_amd.utils import roofline as RF  # noqa: E402
 from exploring_meta_amd.utils import synthetic  # noqa: E402
 
 WORKLOADS = {
@@ -39,25 +47,28 @@ WORKLOADS = {
                  dataset='min', ways=5, shots=1, steps=1, lr=0.5, first_order=False, tasks=32),
     'cfg1': dict(name='Omniglot 5-way 1-shot first-order MAML, meta-batch 4', dataset='omni', ways=5, shots=1, steps=1,
                  lr=0.5, first_order=True, tasks=4),
+    # BASELINE.json configs[4]: rl/maml_trpo.py on Particles2D, 20 tasks x 20 episodes x 100 steps, 1 inner step
+    'cfg5': dict(name='Particles2D MAML-TRPO, 2x100 MLP policy, 20 tasks per meta-batch, 20 episodes x 100 steps per replay, '
+                      '1 inner adapt step', kind='trpo', tasks=20),
 }
+# Synthetic-task hardness used by the benchmark: weaker class prototypes and stronger pixel noise than the generator's defaults,
+# so that the post-adaptation accuracy of cfg2 at the initial parameters sits near 0.74 instead of saturating (measured sweep in
+# profiles/r2/hardness_sweep.txt; the one-step configurations are at chance level at initialisation whatever the inputs -- one
+# step at lr 0.5 from random weights overshoots, loss 12..17 -- so their comparison with the oracle is per task, not a mean).
+HARDNESS = {'min': dict(contrast=0.3, noise=64.0), 'omni': dict(flip=0.04)}
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
-
-# MiniImagenetCNN-32 conv geometry (input hw, ci) per block; co = 32 everywhere
-MIN_LAYERS = [(84, 3), (42, 32), (21, 32), (10, 32)]
-
-
-def conv_launch_flops(layer, n_img):
-    """Algorithmic FLOPs of one conv launch over n_img images (2*9*ci*co per output pixel; SURVEY.md 8d per-image figures)."""
-    hw, ci = MIN_LAYERS[layer]
-    return 2.0 * 9 * ci * 32 * hw * hw * n_img
+HBM_PEAK_GBS = RF.PEAK_GBPS
+FP32_MFMA_PEAK_TF = RF.PEAK_TFLOPS
 
 
-def conv_launch_bytes(layer, n_img):
-    """Algorithmic HBM bytes of one conv+stats launch: read the layer input once, write the conv output once."""
-    hw, ci = MIN_LAYERS[layer]
-    return 4.0 * hw * hw * (ci + 32) * n_img
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def init_theta(spec, seed=42):
@@ -68,106 +79,103 @@ def init_theta(spec, seed=42):
     return torch.from_numpy(np.concatenate([w[k].ravel() for k in shapes])).float()
 
 
-def cpu_baseline(wl, budget_s=20.0, max_tasks=16):
-    """The oracle (CPU restatement of the reference loop, fp32, all host cores) on a bounded sample of the same workload."""
+def make_batch(wl, task_ids):
+    return synthetic.make_meta_batch(wl['dataset'], task_ids, wl['ways'], wl['shots'], **HARDNESS[wl['dataset']])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_vision(wl, spec, theta_flat, budget_s=20.0, max_tasks=16):
+    """The oracle (CPU restatement of the reference loop, fp32) on a bounded sample of the same workload: the first tasks of
+    rank 0's shard from the same initial parameters.  Returns (baseline dict, per-task oracle loss, accuracy)."""
     from collections import OrderedDict
     from oracle import vision_ref as R
-    spec = R.mini_imagenet_spec(wl['ways']) if wl['dataset'] == 'min' else R.omniglot_spec(wl['ways'])
     host_cores = os.cpu_count() or 1
-    w = synthetic.hash_weights(R.param_shapes(spec), 42)
-    theta = OrderedDict((k, torch.from_numpy(v).float()) for k, v in w.items())
-
-    anil = None
+    named, off = OrderedDict(), 0
+    for k, shp in spec.param_shapes():
+        n = int(np.prod(shp))
+        named[k] = theta_flat[off:off + n].reshape(shp).clone()
+        off += n
     if wl.get('anil'):
+        rspec = None
         base = R.convbase_spec(hidden=64, channels=3, max_pool=True)
-        shapes = R.param_shapes(base, prefix_base='0.', with_head=False)
-        tf = OrderedDict((k, torch.from_numpy(v).float()) for k, v in synthetic.hash_weights(shapes, 42).items())
-        th = OrderedDict((k, torch.from_numpy(v).float()) for k, v in
-                         synthetic.hash_weights(OrderedDict([('weight', (wl['ways'], 1600)), ('bias', (wl['ways'],))]), 43).items())
-        anil = (tf, th, base)
+        tf = OrderedDict(('0.' + k[len('base.'):], v) for k, v in named.items() if k.startswith('base.'))
+        th = OrderedDict([('weight', named['linear.weight']), ('bias', named['linear.bias'])])
+    else:
+        rspec = R.mini_imagenet_spec(wl['ways']) if wl['dataset'] == 'min' else R.omniglot_spec(wl['ways'])
 
-    def run(task_ids):
+    def run(task_ids, steps=None, fo=None):
         datas, labels = [], []
         for t in task_ids:
-            d, l = synthetic.make_task(wl['dataset'], t, wl['ways'], wl['shots'])
+            d, l = synthetic.make_task(wl['dataset'], t, wl['ways'], wl['shots'], **HARDNESS[wl['dataset']])
             datas.append(torch.from_numpy(d))
             labels.append(torch.from_numpy(l))
+        K = wl['steps'] if steps is None else steps
+        f = wl['first_order'] if fo is None else fo
         t0 = time.perf_counter()
-        if anil:
-            R.anil_meta_batch(anil[0], anil[1], anil[2], 1600, datas, labels, wl['steps'], wl['shots'], wl['ways'], wl['lr'],
-                              wl['first_order'])
+        if wl.get('anil'):
+            out = R.anil_meta_batch(tf, th, base, 1600, datas, labels, K, wl['shots'], wl['ways'], wl['lr'], f)
         else:
-            R.maml_meta_batch(theta, spec, datas, labels, wl['steps'], wl['shots'], wl['ways'], wl['lr'], wl['first_order'])
-        return time.perf_counter() - t0
+            out = R.maml_meta_batch(named, rspec, datas, labels, K, wl['shots'], wl['ways'], wl['lr'], f)
+        return time.perf_counter() - t0, out[0], out[1]
 
     # PyTorch-CPU autograd on 5..25-image batches does not scale to hundreds of threads: pick the fastest intra-op thread
     # count on a small probe (one first-order single-step task) and use that for the baseline.
-    probe = dict(wl, steps=1, first_order=True)
-
     def probe_time(nthreads):
         torch.set_num_threads(nthreads)
-        d, l = synthetic.make_task(probe['dataset'], 0, probe['ways'], probe['shots'])
-        args = (theta, spec, [torch.from_numpy(d)], [torch.from_numpy(l)], 1, probe['shots'], probe['ways'], probe['lr'], True)
-        R.maml_meta_batch(*args)
-        t0 = time.perf_counter()
-        R.maml_meta_batch(*args)
-        return time.perf_counter() - t0
+        run([0], steps=1, fo=True)
+        return run([0], steps=1, fo=True)[0]
 
     cands = sorted({c for c in (4, 8, 16, 32, 64) if c <= host_cores} | {min(host_cores, 8)})
     cores = min(cands, key=probe_time)
     torch.set_num_threads(cores)
     run([0])                                   # warm-up (thread pools, oneDNN primitives)
-    done, elapsed = 0, 0.0
+    done, elapsed, losses, accs = 0, 0.0, [], []
     while done < max_tasks and elapsed < budget_s:
-        elapsed += run([done])
+        dt, l, a = run([done])
+        elapsed += dt
+        losses.append(float(l[0]))
+        accs.append(float(a[0]))
         done += 1
-    return dict(value=done / elapsed, unit='tasks/s', cores=cores, kind='port',
-                sample=f'{done} tasks of the same workload, sequential per-task loop, PyTorch-CPU autograd fp32 '
-                       f'(oracle/vision_ref.py), {cores} intra-op threads (fastest of {cands} on a probe; host has '
-                       f'{host_cores} logical cores)')
+    base_line = dict(value=done / elapsed, unit='tasks/s', cores=cores, kind='port', cpu=cpu_model(), host_logical_cores=host_cores,
+                     sample=f'{done} tasks of the same workload (task ids 0..{done - 1}, same initial parameters), sequential per-task '
+                            f'loop, PyTorch-CPU autograd fp32 (oracle/vision_ref.py), {cores} intra-op threads (fastest of {cands} on a probe)')
+    return base_line, losses, accs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
-    ap.add_argument('--tasks', type=int, default=0, help='override the tasks per GPU of the workload (sweeps; not a BASELINE configuration)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--breakdown', default='', help='write a per-kernel event-time breakdown (one extra untimed step) to this file')
-    args = ap.parse_args()
-    wl = dict(WORKLOADS[args.workload])
-    if args.tasks:
-        wl['tasks'] = args.tasks
-        wl['name'] += f' [tasks per GPU overridden: {args.tasks}]'
+def pick_dominant(spec, prof, n_img):
+    """Among the ops with an algorithmic work count (conv family, BatchNorm streams, fused block-1 kernels) on the MAIN stream, the
+    (op, layer) with the largest HIP-event time in one fully profiled step."""
+    cands = {}
+    for (op, layer), (ms, cnt) in prof.items():
+        if 'wgrad' in op and layer >= 1:
+            continue            # weight gradients of blocks >= 2 run on the engine's side stream concurrently with other work
+        if layer >= spec.n_layers or RF.op_costs(spec, op, layer, n_img) is None:
+            continue
+        cands[(op, layer)] = ms
+    return max(cands, key=cands.get) if cands else None
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run always go through RCCL (also exercised at N=1)
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
-    T = wl['tasks']
+def run_vision(args, wl, rank, world, local, dist):
+    Tw = wl['tasks']
+    if args.scaling == 'strong':
+        lo, hi = shard_range(Tw, rank, world)
+        task_ids, global_T = list(range(lo, hi)), Tw
+        if hi - lo < 1:
+            raise SystemExit(f'--scaling strong: {Tw} tasks cannot be shared by {world} ranks')
+    else:
+        task_ids, global_T = [rank * Tw + i for i in range(Tw)], Tw * world       # rank r owns tasks [r*T, (r+1)*T)
+    T = len(task_ids)
     if wl.get('anil'):
         spec = ModelSpec.anil(wl['ways'])
     else:
         spec = ModelSpec.mini_imagenet(wl['ways']) if wl['dataset'] == 'min' else ModelSpec.omniglot(wl['ways'])
     eng = MetaEngine(spec)
     run_batch = eng.meta_batch_anil if wl.get('anil') else eng.meta_batch
-    theta = init_theta(spec).cuda()
-    task_ids = [rank * T + i for i in range(T)]          # shard by global task id: rank r owns tasks [rT, (r+1)T)
-    data, labels = synthetic.make_meta_batch(wl['dataset'], task_ids, wl['ways'], wl['shots'])
-    data = torch.from_numpy(data).cuda()
-    labels = torch.from_numpy(labels).cuda()
-    adam = {}
-    out = {}
-    from exploring_meta_amd.sharding import MetaTrainer
+    theta0 = init_theta(spec)
+    theta = theta0.cuda()
+    data, labels = make_batch(wl, task_ids)
+    data, labels = torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda()
+    adam, out = {}, {}
 
     def compute(th, _task_ids):                 # this rank's shard is already resident in HBM (data, labels)
         loss, acc, grad, _ = run_batch(th, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
@@ -176,7 +184,7 @@ def main():
     def adam_fn(th, grad, scale):               # maml_vision.py:139-141
         eng.adam_step(th, grad, adam, 0.003, grad_scale=scale)
 
-    trainer = MetaTrainer(compute, adam_fn, T * world)     # one flat all-reduce (RCCL) of the meta-gradient per iteration
+    trainer = MetaTrainer(compute, adam_fn, global_T)      # one flat all-reduce (RCCL) of the meta-gradient per iteration
 
     def step():
         out['loss'], out['acc'], _ = trainer.step(theta)
@@ -187,29 +195,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # post-adaptation loss / accuracy at the INITIAL parameters on the tasks the CPU oracle will also run (untimed)
+    n_cmp = min(T, 16)
+    l0, a0, _, _ = run_batch(theta, data[:n_cmp].contiguous(), labels[:n_cmp].contiguous(), wl['shots'], wl['steps'], wl['lr'],
+                             first_order=wl['first_order'], with_grad=False)
+    eng_loss0, eng_acc0 = l0.cpu().numpy().astype(np.float64), a0.cpu().numpy().astype(np.float64)
+    lall, aall, _, _ = run_batch(theta, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], with_grad=False)
+    init_loss_mean, init_acc_mean = float(lall.mean()), float(aall.mean())
+
     for _ in range(args.warmup):
         step()
 
-    # Dominant kernel = the conv-family (op, block) with the largest share of one meta-iteration's HIP-event time (blocks 2-4:
-    # the kernels with a clean algorithmic FLOP count).  Found on one untimed, fully profiled step; the timed region then
-    # records events around exactly that kernel's launches.
-    n_img = T * wl['ways'] * wl['shots']
-    CONV_OPS = {'conv_fwd_stats': (1, 'conv3x3_mfma_kernel<32,1,EPI_STATS,fwd>'), 'dgrad': (1, 'conv3x3_mfma_kernel<32,1,EPI_NONE,dgrad>'),
-                'wgrad': (1, 'wgrad3x3_rows_mfma_kernel (1 term)'), 'tangent_conv_fwd': (2, 'conv3x3_mfma_kernel<32,2,EPI_TSTATS,fwd>'),
-                'tangent_dgrad': (2, 'conv3x3_mfma_kernel<32,2,EPI_NONE,dgrad>'), 'tangent_wgrad': (2, 'wgrad3x3_rows_mfma_kernel (2 terms)')}
-    dom = None
-    if args.workload == 'cfg2':
-        eng.set_overlap(False)                  # additive per-kernel times for the selection step
-        eng.profile(True)
-        step()
-        torch.cuda.synchronize()
-        first = eng.profile_collect()
-        eng.profile(False)
-        eng.set_overlap(True)
-        # the weight-gradient kernels run on the engine's side stream concurrently with other work: their in-run durations are
-        # not standalone figures, so the roofline kernel is chosen among the main-stream convs
-        cands = {k: v for k, v in first.items() if k[0] in CONV_OPS and k[1] >= 1 and 'wgrad' not in k[0]}
-        dom = max(cands, key=lambda k: cands[k][0])
+    # Dominant kernel: found on one untimed, fully profiled step with everything on one stream (additive per-kernel times); the
+    # timed region then records HIP events around exactly that kernel's launches, on the stream they are launched on.
+    n_img = T * wl['ways'] * wl['shots'] * (2 if wl.get('anil') else 1)
+    eng.set_overlap(False)
+    eng.profile(True)
+    step()
+    torch.cuda.synchronize()
+    first = eng.profile_collect()
+    eng.profile(False)
+    eng.set_overlap(True)
+    dom = pick_dominant(spec, first, n_img)
+    if dom:
         eng.profile(True, *dom)
     fence()
     t0 = time.perf_counter()
@@ -226,7 +234,7 @@ def main():
 
     # Secondary figure: the reference runs one validation fast_adapt per train task without backward
     # (maml_vision.py:117-124); here that half is one more fused call with with_grad=0 on T other tasks.
-    vdata, vlabels = synthetic.make_meta_batch(wl['dataset'], [10_000 + t for t in task_ids], wl['ways'], wl['shots'])
+    vdata, vlabels = make_batch(wl, [10_000 + t for t in task_ids])
     vdata, vlabels = torch.from_numpy(vdata).cuda(), torch.from_numpy(vlabels).cuda()
 
     def valid():
@@ -246,42 +254,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_tv = tmax.item()
     secondary = {'metric': 'iterations/sec (train + validation halves)', 'value': round(1.0 / dt_tv, 3), 'ms_per_iteration': round(dt_tv * 1e3, 3),
-                 'tasks_per_iteration': f'{T * world} train + {T * world} validation', 'steps': nsec,
+                 'tasks_per_iteration': f'{global_T} train + {global_T} validation', 'steps': nsec,
                  'valid_acc_mean': round(float(vacc.mean()), 5)}
 
-    # Measured HBM roofline: the build's own streaming-copy kernel, same process, same run (read + write bytes / time).
-    import ctypes as C
-    nbytes = 1 << 30
-    src = torch.empty(nbytes, dtype=torch.uint8, device='cuda').zero_()
-    dst = torch.empty_like(src)
-    cp = lambda: eng.lib.mi_stream_copy(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(src.data_ptr()),
-                                        C.c_void_p(dst.data_ptr()), nbytes)
-    cp()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        cp()
-    e1.record()
-    torch.cuda.synchronize()
-    hbm_copy_gbps = 2.0 * nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del src, dst
+    hbm_copy_gbps = measure_stream_copy(eng)
 
     roofline = None
     if dom in prof:
         ms, cnt = prof[dom]
-        terms, kname = CONV_OPS[dom[0]]
-        hw = MIN_LAYERS[dom[1]][0]
-        flops = terms * conv_launch_flops(dom[1], n_img)
-        achieved = flops / (ms / cnt * 1e-3) / 1e12
+        flops, nbytes = RF.op_costs(spec, dom[0], dom[1], n_img)
+        bound = RF.bound_of(flops, nbytes)
+        h, w, ci, co, ho, wo, _, _ = RF.layer_geometry(spec)[dom[1]]
+        sec = ms / cnt * 1e-3
+        if bound == 'mfma':
+            achieved, peak, unit = flops / sec / 1e12, FP32_MFMA_PEAK_TF, 'TFLOP/s'
+        else:
+            achieved, peak, unit = nbytes / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'pmc_traffic.json')       # HBM bytes/launch from rocprofv3 --pmc passes (profiles/README.md)
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f'{dom[0]},{dom[1]}')
-        roofline = dict(kernel=f'{kname}, block {dom[1] + 1} ({hw}x{hw}, 32->32 filters)', op=dom[0], bound='mfma',
-                        achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
-                        frac=round(achieved / FP32_MFMA_PEAK_TF, 4), traffic=traffic, launches=int(cnt),
-                        avg_launch_ms=round(ms / cnt, 4), flops_per_launch=flops,
-                        algorithmic_bytes_per_launch=terms * conv_launch_bytes(dom[1], n_img),
+            traffic = json.load(open(tpath)).get(f'{args.workload},{dom[0]},{dom[1]}')
+        roofline = dict(kernel=f'{RF.kernel_name(spec, dom[0], dom[1])}, block {dom[1] + 1} ({h}x{w}, {ci}->{co} filters)', op=dom[0],
+                        bound=bound, achieved=round(achieved, 2), peak=peak, unit=unit, frac=round(achieved / peak, 4), traffic=traffic,
+                        launches=int(cnt), avg_launch_ms=round(ms / cnt, 4), flops_per_launch=flops,
+                        algorithmic_bytes_per_launch=nbytes, images_per_launch=n_img,
                         hbm_stream_copy_measured_GBps=round(hbm_copy_gbps, 1))
 
     if args.breakdown:                          # every rank runs the extra step (it contains the all-reduce); rank 0 writes
@@ -293,29 +289,226 @@ def main():
         eng.profile(False)
         eng.set_overlap(True)
         tot = sum(v[0] for v in full.values())
-    if args.breakdown and rank == 0:
-        with open(args.breakdown, 'w') as f:
-            f.write(f'# per-kernel HIP-event time of ONE meta-iteration, workload {args.workload} (T={T} tasks), total {tot:.3f} ms\n')
-            f.write('op,layer,launches,total_ms,avg_ms,share\n')
-            for (op, layer), (ms, cnt) in sorted(full.items(), key=lambda kv: -kv[1][0]):
-                f.write(f'{op},{layer},{cnt},{ms:.4f},{ms / cnt:.4f},{ms / tot:.4f}\n')
+        if rank == 0:
+            with open(args.breakdown, 'w') as f:
+                f.write(f'# per-kernel HIP-event time of ONE meta-iteration, workload {args.workload} (T={T} tasks), total {tot:.3f} ms\n')
+                f.write('op,layer,launches,total_ms,avg_ms,share\n')
+                for (op, layer), (ms, cnt) in sorted(full.items(), key=lambda kv: -kv[1][0]):
+                    f.write(f'{op},{layer},{cnt},{ms:.4f},{ms / cnt:.4f},{ms / tot:.4f}\n')
+
+    cpu, post = None, {'query_loss_mean_all_tasks_at_init': round(init_loss_mean, 5), 'query_acc_mean_all_tasks_at_init': round(init_acc_mean, 5),
+                       'query_loss_mean_last_step': round(float(out['loss']), 5), 'query_acc_mean_last_step': round(float(out['acc']), 5)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, ol, oa = cpu_baseline_vision(wl, spec, theta0)
+        n = len(ol)
+        ol, oa = np.asarray(ol), np.asarray(oa)
+        note = 'engine vs the CPU oracle (fp32) on the same tasks from the same initial parameters'
+        if wl['steps'] > 1:
+            note += '; with 5 inner steps at lr 0.5 two fp32 runs diverge per task (chaotic inner loop, DESIGN.md section 7)'
+        post.update({'compared_tasks': n, 'engine_loss_mean': round(float(eng_loss0[:n].mean()), 5), 'oracle_loss_mean': round(float(ol.mean()), 5),
+                     'engine_acc_mean': round(float(eng_acc0[:n].mean()), 5), 'oracle_acc_mean': round(float(oa.mean()), 5),
+                     'max_abs_loss_diff_per_task': float(np.max(np.abs(eng_loss0[:n] - ol))),
+                     'max_abs_acc_diff_per_task': float(np.max(np.abs(eng_acc0[:n] - oa))), 'note': note})
+
+    if rank != 0:
+        return None
+    value = global_T * args.steps / dt
+    return {
+        'metric': 'tasks/sec', 'value': round(value, 2), 'unit': 'tasks/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': wl['name'], 'tasks_per_gpu': T, 'global_meta_batch': global_T, 'ways': wl['ways'],
+                   'shots': wl['shots'], 'adapt_steps': wl['steps'], 'inner_lr': wl['lr'],
+                   'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter',
+                   'task_hardness': HARDNESS[wl['dataset']]},
+        'post_adapt': post, 'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline,
+        'cpu_baseline': cpu,
+    }
+
+
+def measure_stream_copy(eng_or_lib):
+    """Measured HBM roofline: the build's own streaming-copy kernel, same process, same run (read + write bytes / time)."""
+    import ctypes as C
+    lib = getattr(eng_or_lib, 'lib', eng_or_lib)
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device='cuda').zero_()
+    dst = torch.empty_like(src)
+    cp = lambda: lib.mi_stream_copy(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(src.data_ptr()),
+                                    C.c_void_p(dst.data_ptr()), nbytes)
+    cp()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        cp()
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+TRPO_PARAMS = dict(inner_lr=0.1, max_path_length=100, adapt_steps=1, adapt_batch_size=20, meta_batch_size=20, outer_lr=0.3,
+                   backtrack_factor=0.5, ls_max_steps=15, max_kl=0.01, tau=1.0, gamma=0.99)
+
+
+def run_trpo(args, wl, rank, world, local, dist):
+    """BASELINE config 5: one step = meta_optimize_trpo (rl/maml_trpo.py:130-134; core_functions/rl.py:409-473) over the resident
+    replays of this rank's tasks: host GAE / baseline fits, one surrogate + gradient call, 11 Fisher-vector products inside CG,
+    up to 15 line-search evaluations -- every device call covers all local tasks.  Rollouts (env stepping) are data generation and
+    happen once, before the timed region, through the package's own fast_adapt_trpo."""
+    from copy import deepcopy
+    from exploring_meta_amd import core_functions as cf
+    p = dict(TRPO_PARAMS)
+    Tw = wl['tasks']
+    if args.scaling == 'strong':
+        lo, hi = shard_range(Tw, rank, world)
+        global_T = Tw
+    else:
+        lo, hi, global_T = rank * Tw, (rank + 1) * Tw, Tw * world
+    p['meta_batch_size'] = global_T
+    dev = torch.device('cuda', local)
+    cf.set_device(dev)
+    torch.manual_seed(42)
+    policy = cf.DiagNormalPolicy(2, 2).to(dev)
+    baseline = cf.LinearValue(2, 2)
+    goals = np.random.RandomState(42).uniform(-0.5, 0.5, size=(global_T, 2))
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    replays, olds = [], []
+    for goal in goals[lo:hi]:
+        learner = deepcopy(policy)
+        task = cf.Particles2DRunner(goal, p['max_path_length'], gen, dev)
+        learner, _, rep, _, _ = cf.fast_adapt_trpo(task, learner, baseline, p, first_order=True)
+        replays.append(rep)
+        olds.append(learner)
+    theta0 = policy.flat().clone()
+    out = {}
+
+    def step():
+        policy.load_flat(theta0)                # every step optimises from the same parameters: identical work per step
+        out['r'] = cf.meta_optimize_trpo(p, policy, baseline, replays, olds)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+
+    # Dominant device call: the Fisher-vector product (11 per step).  Timed with events on the stream it is launched on.
+    ctx = out['r']['context']
+    v = torch.randn_like(theta0)
+    ctx.evaluate(theta0, want_grad=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nf = 50
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(nf):
+        ctx.fvp(theta0, v)
+    e1.record()
+    torch.cuda.synchronize()
+    fvp_ms = e0.elapsed_time(e1) / nf
+    B = int(ctx.qry['states'].shape[1])
+    fwd = 2.0 * B * (2 * 100 + 100 * 100 + 100 * 2)                   # one dense forward over a task's padded batch
+    flops = 16.0 * fwd * (hi - lo)                                       # (I - aH) F (I - aH) v: two 6-pass Hessian products + JVP/VJP through the query forward
+    achieved = flops / (fvp_ms * 1e-3) / 1e12
+    roofline = dict(kernel='mi_trpo_fvp (dense_fwd / dense_bwd_x / dense_bwd_w / gauss kernels of policy.hip, one call = about 20 launches)',
+                    op='fisher_vector_product', bound='mfma', achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
+                    frac=round(achieved / FP32_MFMA_PEAK_TF, 5), traffic=None, launches=nf, avg_launch_ms=round(fvp_ms, 4),
+                    flops_per_launch=flops, note='2x100 MLP on 2000-row batches: launch- and latency-bound fp32 VALU arithmetic '
+                    '(an MFMA tile would be mostly padding); the peak quoted is the fp32 vector = fp32 MFMA peak')
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(wl)
+        cpu = cpu_baseline_trpo(p, policy, theta0, replays, olds, out['r'])
+    if rank != 0:
+        return None
+    value = global_T * args.steps / dt
+    r = out['r']
+    return {
+        'metric': 'tasks/sec', 'value': round(value, 2), 'unit': 'tasks/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': wl['name'], 'tasks_per_gpu': hi - lo, 'global_meta_batch': global_T, 'rows_per_replay': B,
+                   'parallelism': f'task-sharded dp{world}, 1 + 11 + <=15 small all-reduces per step',
+                   **{k: p[k] for k in ('inner_lr', 'max_kl', 'adapt_steps')}},
+        'post_adapt': {'surrogate_loss_before': float(r['old_loss']), 'surrogate_loss_after': None if r['new_loss'] is None else float(r['new_loss']),
+                       'kl_after': None if r['kl'] is None else float(r['kl']), 'line_search_step': r['accepted'],
+                       **(cpu.pop('_post') if cpu else {})},
+        'secondary': {'metric': 'meta_optimize_trpo iterations/sec', 'value': round(args.steps / dt, 3)},
+        'roofline': roofline, 'cpu_baseline': cpu,
+    }
 
+
+def cpu_baseline_trpo(p, policy, theta0, replays, olds, gpu_out):
+    """oracle/rl_ref.py::meta_optimize_trpo (fp64 autograd restatement of rl.py:409-473) on the SAME replays and old policies."""
+    from collections import OrderedDict
+    from oracle import rl_ref as RL
+
+    def named(flat):
+        outp, off = OrderedDict(), 0
+        for k, prm in policy.named_parameters():
+            n = prm.numel()
+            outp[k] = flat[off:off + n].reshape(prm.shape).detach().cpu().double().clone()
+            off += n
+        return outp
+
+    cpu_replays = [[{k: v.detach().cpu().double() for k, v in rep.items()} for rep in task] for task in replays]
+    cpu_olds = [named(o.flat()) for o in olds]
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    p64 = OrderedDict((k, v.requires_grad_(True)) for k, v in named(theta0).items())
+    ref = RL.meta_optimize_trpo(p, p64, RL.LinearValue(2, 2), cpu_replays, cpu_olds)
+    dt = time.perf_counter() - t0
+    gstep = gpu_out['step'].double().cpu()
+    rel = float((gstep - ref['step']).norm() / ref['step'].norm())
+    return dict(value=len(replays) / dt, unit='tasks/s', cores=torch.get_num_threads(), kind='port', cpu=cpu_model(),
+                host_logical_cores=os.cpu_count(),
+                sample=f'one meta_optimize_trpo over the same {len(replays)} tasks (same replays, same old policies), '
+                       f'oracle/rl_ref.py fp64 autograd, {torch.get_num_threads()} intra-op threads',
+                _post={'oracle_line_search_step': ref['accepted'], 'step_direction_rel_err_vs_oracle': rel})
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--tasks', type=int, default=0, help='override the tasks per GPU of the workload (sweeps; not a BASELINE configuration)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', default='', help='write a per-kernel event-time breakdown (one extra untimed step) to this file')
+    args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    if args.tasks:
+        wl['tasks'] = args.tasks
+        wl['name'] += f' [tasks per GPU overridden: {args.tasks}]'
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run always go through RCCL (also exercised at N=1)
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    runner = run_trpo if wl.get('kind') == 'trpo' else run_vision
+    line = runner(args, wl, rank, world, local, dist)
     if rank == 0:
-        value = world * T * args.steps / dt
-        line = {
-            'metric': 'tasks/sec', 'value': round(value, 2), 'unit': 'tasks/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': wl['name'], 'tasks_per_gpu': T, 'global_meta_batch': T * world, 'ways': wl['ways'],
-                       'shots': wl['shots'], 'adapt_steps': wl['steps'], 'inner_lr': wl['lr'],
-                       'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter'},
-            'post_adapt': {'query_loss_mean': round(float(out['loss']), 5), 'query_acc_mean': round(float(out['acc']), 5)},
-            'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline, 'cpu_baseline': cpu,
-        }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -25,12 +25,17 @@ def _np(x):
 
 
 def discount(gamma, rewards, dones):
-    """cherry.td.discount: R_t = r_t + gamma (1 - d_t) R_{t+1}."""
-    out = np.zeros_like(rewards)
-    run = 0.0
-    for t in range(rewards.shape[0] - 1, -1, -1):
-        run = rewards[t, 0] + gamma * (1.0 - dones[t, 0]) * run
-        out[t, 0] = run
+    """cherry.td.discount: R_t = r_t + gamma (1 - d_t) R_{t+1}.  Evaluated episode by episode (a `done` cuts the recursion) with
+    one linear-filter call per episode instead of a Python loop over time steps."""
+    from scipy.signal import lfilter
+    r = rewards[:, 0]
+    out = np.empty_like(rewards)
+    ends = np.flatnonzero(dones[:, 0] != 0.0)
+    start = 0
+    for e in list(ends) + ([r.shape[0] - 1] if (ends.size == 0 or ends[-1] != r.shape[0] - 1) else []):
+        seg = r[start:e + 1]
+        out[start:e + 1, 0] = lfilter([1.0], [1.0, -gamma], seg[::-1])[::-1]
+        start = e + 1
     return out
 
 

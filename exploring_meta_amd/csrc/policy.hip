@@ -2,8 +2,8 @@
 // core_functions/policies.py:30-67, ReLU default) log-prob / gradient / Hessian-vector products, the inner `trpo_update`
 // (core_functions/rl.py:361-374), the meta surrogate loss + KL (rl.py:441-473), its gradient and the Fisher-vector product
 // used by conjugate gradient (rl.py:413-418) -- replacing per-task PyTorch autograd graphs (create_graph=True) with
-// batched-over-tasks kernels and forward-over-reverse tangents.  FLOPs are negligible (41.6 MFLOP per
-// batch forward); the kernels are simple, coalesced, one launch per layer for all tasks, deterministic reductions.
+// batched-over-tasks kernels and forward-over-reverse tangents.  The dense products (41.6 MFLOP per 2000-row batch forward,
+// SURVEY.md a13) run on the fp32 matrix pipe, one launch per layer for all tasks, deterministic reductions.
 //
 // Parameter vector (reference named_parameters() order): sigma[A], W1[H1][S], b1[H1], W2[H2][H1], b2[H2], W3[A][H2], b3[A].
 //
@@ -41,45 +41,70 @@ __device__ __forceinline__ float act_gate(float s, float h, int act) {
   return act == ACT_TANH ? s * (1.f - h * h) : (h > 0.f ? s : 0.f);
 }
 
-__global__ void dense_fwd_kernel(DenseArgs a) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+// The three dense products of the MLP for ALL tasks in one launch each, on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32 is
+// bitwise an fmaf chain, so the parity budget of the fp32 path is untouched).  One wave owns a 32 x 32 output tile; lane half
+// h = lane >> 5 takes the upper / lower half of the reduction index, so a lane's A (and, for the forward product, B) operands of
+// consecutive MFMAs are consecutive floats of one row.  Rows / columns / reduction indices past the end read zeros.
+//   forward   y[b][o]  = sum_k x_k[b][:] . w_k[o][:]          M = B, N = O, K = I     (TRANS_W: B operand = w[n][k])
+//   backward  dx[b][i] = sum_k dy_k[b][:] . w_k[:][i]         M = B, N = I, K = O     (B operand = w[k][n])
+// followed by the same elementwise epilogues as before (bias / activation / phi' gate / tanh curvature term).
+template <bool TRANS_W>
+__global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
   const int t = blockIdx.y;
-  if (e >= a.B * a.O) return;
-  const int b = e / a.O, o = e - b * a.O;
-  float s = a.bias ? a.bias[(size_t)t * a.bstride + o] : 0.f;
-  for (int k = 0; k < a.nterms; ++k) {
-    const float* x = a.x[k] + ((size_t)t * a.B + b) * a.I;
-    const float* w = a.w[k] + (size_t)t * a.wstride[k] + (size_t)o * a.I;
-    for (int i = 0; i < a.I; ++i) s = fmaf(x[i], w[i], s);
+  const int N = TRANS_W ? a.O : a.I, Kd = TRANS_W ? a.I : a.O;
+  const int nt = (N + 31) >> 5, mt = (a.B + 31) >> 5;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= mt * nt) return;
+  const int m0 = (tile / nt) * 32, n0 = (tile % nt) * 32;
+  const int Kh = (Kd + 1) >> 1, kbase = h * Kh;
+  const int row = m0 + j, col = n0 + j;
+  const bool rok = row < a.B, cok = col < N;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int term = 0; term < a.nterms; ++term) {
+    const float* xr = a.x[term] + ((size_t)t * a.B + (rok ? row : 0)) * Kd;
+    const float* wt = a.w[term] + (size_t)t * a.wstride[term];
+    constexpr int CH = 10;
+    for (int s0 = 0; s0 < Kh; s0 += CH) {
+      float av[CH], bv[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int k = kbase + s0 + c;
+        const bool kok = (s0 + c < Kh) && (k < Kd);
+        av[c] = (kok && rok) ? xr[k] : 0.f;
+        if (TRANS_W) bv[c] = (kok && cok) ? wt[(size_t)col * Kd + k] : 0.f;
+        else bv[c] = (kok && cok) ? wt[(size_t)k * N + col] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[c], acc, 0, 0, 0);
+    }
   }
-  const size_t oi = ((size_t)t * a.B + b) * a.O + o;
-  if (a.mask) s = act_gate(s, a.mask[oi], a.act);        // tangent forward: hdot = phi'(z) zdot
-  else if (a.act == ACT_RELU) s = fmaxf(s, 0.f);
-  else if (a.act == ACT_TANH) s = tanhf(s);
-  a.y[oi] = s;
-}
-
-// dx[b][i] = sum_k sum_o dy_k[b][o] w_k[o][i], optionally * (mask[b][i] > 0)
-__global__ void dense_bwd_x_kernel(DenseArgs a) {   // here x[k] = dy_k [T][B][O], y = dx [T][B][I]
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
-  if (e >= a.B * a.I) return;
-  const int b = e / a.I, i = e - b * a.I;
-  float s = 0.f;
-  for (int k = 0; k < a.nterms; ++k) {
-    const float* dy = a.x[k] + ((size_t)t * a.B + b) * a.O;
-    const float* w = a.w[k] + (size_t)t * a.wstride[k] + i;
-    for (int o = 0; o < a.O; ++o) s = fmaf(dy[o], w[(size_t)o * a.I], s);
+  if (!cok) return;
+  const float bias = (TRANS_W && a.bias) ? a.bias[(size_t)t * a.bstride + col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (m >= a.B) continue;
+    const size_t oi = ((size_t)t * a.B + m) * N + col;
+    float s = acc[r] + bias;
+    if (TRANS_W) {
+      if (a.mask) s = act_gate(s, a.mask[oi], a.act);        // tangent forward: hdot = phi'(z) zdot
+      else if (a.act == ACT_RELU) s = fmaxf(s, 0.f);
+      else if (a.act == ACT_TANH) s = tanhf(s);
+    } else {
+      if (a.ypre) a.ypre[oi] = s;
+      if (a.mask) {
+        const float hh = a.mask[oi];
+        s = act_gate(s, hh, a.act);
+        // R{dz} = phi' R{dh} + phi'' zdot dh, and for tanh phi'' zdot = -2 h hdot
+        if (a.hd) s = fmaf(-2.f * hh * a.hd[oi], a.dpre[oi], s);
+      }
+    }
+    a.y[oi] = s;
   }
-  const size_t oi = ((size_t)t * a.B + b) * a.I + i;
-  if (a.ypre) a.ypre[oi] = s;
-  if (a.mask) {
-    const float h = a.mask[oi];
-    s = act_gate(s, h, a.act);
-    // R{dz} = phi' R{dh} + phi'' zdot dh, and for tanh phi'' zdot = -2 h hdot
-    if (a.hd) s = fmaf(-2.f * h * a.hd[oi], a.dpre[oi], s);
-  }
-  a.y[oi] = s;
 }
 
 struct DenseWArgs {
@@ -90,28 +115,51 @@ struct DenseWArgs {
   size_t gstride;
   int B, I, O, nterms;
 };
-// dW[o][i] = sum_k sum_b dy_k[b][o] x_k[b][i] ; db[o] = sum_b dy_0[b][o].  One thread per (o,i) (+ O threads for the bias),
-// fixed summation order over b => deterministic.
-__global__ void dense_bwd_w_kernel(DenseWArgs a) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+// dW[o][i] = sum_k sum_b dy_k[b][o] x_k[b][i] ; db[o] = sum_b dy_0[b][o]:  M = O, N = I + 1 (column I = the bias: a column of
+// ones next to x_0), K = B.  One 8-wave workgroup per 32 x 32 tile; wave w takes the row pairs w, w + 8, ... of the batch (both
+// operands are coalesced 128-B rows), the 8 partial tiles are folded through LDS in wave order => deterministic.
+__global__ __launch_bounds__(512) void dense_wgrad_mfma_kernel(DenseWArgs a) {
+  __shared__ float red[8 * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
   const int t = blockIdx.y;
-  const int nw = a.O * a.I;
-  if (e >= nw + a.O) return;
-  if (e < nw) {
-    const int o = e / a.I, i = e - o * a.I;
-    float s = 0.f;
-    for (int k = 0; k < a.nterms; ++k) {
-      const float* dy = a.dy[k] + (size_t)t * a.B * a.O + o;
-      const float* x = a.x[k] + (size_t)t * a.B * a.I + i;
-      for (int b = 0; b < a.B; ++b) s = fmaf(dy[(size_t)b * a.O], x[(size_t)b * a.I], s);
+  const int N = a.I + 1, nt = (N + 31) >> 5;
+  const int m0 = (blockIdx.x / nt) * 32, n0 = (blockIdx.x % nt) * 32;
+  const int orow = m0 + j, col = n0 + j;
+  const bool ook = orow < a.O, xok = col < a.I, one = col == a.I;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int term = 0; term < a.nterms; ++term) {
+    const float* dy = a.dy[term] + (size_t)t * a.B * a.O + (ook ? orow : 0);
+    const float* x = a.x[term] + (size_t)t * a.B * a.I + (xok ? col : 0);
+    const float onev = (one && term == 0) ? 1.f : 0.f;
+    constexpr int CH = 8;
+    for (int p0 = wave * 2 * CH; p0 < a.B; p0 += 8 * 2 * CH) {      // this wave's chunk of CH row pairs
+      float av[CH], bv[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int b = p0 + 2 * c + h;
+        const bool bok = b < a.B;
+        av[c] = (bok && ook) ? dy[(size_t)b * a.O] : 0.f;
+        bv[c] = bok ? (xok ? x[(size_t)b * a.I] : onev) : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[c], acc, 0, 0, 0);
     }
-    a.dw[(size_t)t * a.gstride + e] = s;
-  } else {
-    const int o = e - nw;
-    const float* dy = a.dy[0] + (size_t)t * a.B * a.O + o;
-    float s = 0.f;
-    for (int b = 0; b < a.B; ++b) s += dy[(size_t)b * a.O];
-    a.db[(size_t)t * a.gstride + o] = s;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 1024; e += 512) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w * 1024 + e];
+    const int r = e >> 6, l = e & 63;
+    const int o = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), c = n0 + (l & 31);
+    if (o >= a.O) continue;
+    if (c < a.I) a.dw[(size_t)t * a.gstride + (size_t)o * a.I + c] = v;
+    else if (c == a.I) a.db[(size_t)t * a.gstride + o] = v;
   }
 }
 
@@ -307,7 +355,7 @@ static hipError_t dense_fwd(hipStream_t st, int T, int B, int I, int O, const fl
   DenseArgs a{};
   a.x[0] = x0; a.w[0] = w0; a.wstride[0] = ws0; a.x[1] = x1; a.w[1] = w1; a.wstride[1] = ws1;
   a.bias = bias; a.bstride = bs; a.mask = mask; a.y = y; a.B = B; a.I = I; a.O = O; a.nterms = x1 ? 2 : 1; a.act = act;
-  hipLaunchKernelGGL(dense_fwd_kernel, dim3(ceil_div(B * O, 256), T), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(dense_mfma_kernel<true>, dim3(ceil_div(ceil_div(B, 32) * ceil_div(O, 32), 4), T), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 static hipError_t dense_bwd_x(hipStream_t st, int T, int B, int I, int O, const float* dy0, const float* w0, size_t ws0,
@@ -317,7 +365,7 @@ static hipError_t dense_bwd_x(hipStream_t st, int T, int B, int I, int O, const 
   a.x[0] = dy0; a.w[0] = w0; a.wstride[0] = ws0; a.x[1] = dy1; a.w[1] = w1; a.wstride[1] = ws1;
   a.mask = mask; a.act = act; a.y = dx; a.ypre = dx_pre; a.hd = hd; a.dpre = dpre;
   a.B = B; a.I = I; a.O = O; a.nterms = dy1 ? 2 : 1;
-  hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(ceil_div(B * I, 256), T), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(dense_mfma_kernel<false>, dim3(ceil_div(ceil_div(B, 32) * ceil_div(I, 32), 4), T), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 static hipError_t dense_bwd_w(hipStream_t st, int T, int B, int I, int O, const float* dy0, const float* x0, const float* dy1,
@@ -325,7 +373,7 @@ static hipError_t dense_bwd_w(hipStream_t st, int T, int B, int I, int O, const 
   DenseWArgs a{};
   a.dy[0] = dy0; a.x[0] = x0; a.dy[1] = dy1; a.x[1] = x1; a.dw = dw; a.db = db; a.gstride = gs;
   a.B = B; a.I = I; a.O = O; a.nterms = dy1 ? 2 : 1;
-  hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(ceil_div(O * I + O, 256), T), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(dense_wgrad_mfma_kernel, dim3(ceil_div(O, 32) * ceil_div(I + 1, 32), T), dim3(512), 0, st, a);
   return hipGetLastError();
 }
 

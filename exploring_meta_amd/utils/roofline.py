@@ -1,0 +1,79 @@
+"""Algorithmic work of one engine launch (SURVEY.md 8d accounting), for any ModelSpec: what bench.py's `roofline` object and
+tools/roofline_table.py divide by the measured launch duration.
+
+FLOPs of a conv-shaped op = 2*9*Ci*Co per output pixel per GEMM term; bytes = the tensors the op must read or write once (layer
+input, conv output z, pooled output p; parameters are negligible).  Block 1 of a pooling net with 1 or 3 input channels runs
+fused ("layer" 0): its forward / tangent-forward kernels recompute the convolution (FLOPs) and touch only the input, the pooled
+output, zhat at the argmax and the argmax byte (bytes); its BatchNorm-backward reductions stream pooled tensors; its weight
+gradients are the sparse matrix pass over pooling windows (algorithmic weight-gradient FLOPs)."""
+
+PEAK_TFLOPS = 157.3      # fp32-input MFMA == fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_GBPS = 8000.0       # HBM3E spec (about 6300 GB/s is achievable with a streaming copy)
+
+
+def layer_geometry(spec):
+    """[(h, w, ci, co, ho, wo, hp, wp)] per ConvBlock."""
+    out, h, w, ci = [], spec.in_h, spec.in_w, spec.in_channels
+    for _ in range(spec.n_layers):
+        s = 1 if spec.max_pool else 2
+        ho, wo = (h - 1) // s + 1, (w - 1) // s + 1
+        hp, wp = (ho // 2, wo // 2) if spec.max_pool else (ho, wo)
+        out.append((h, w, ci, spec.hidden, ho, wo, hp, wp))
+        h, w, ci = hp, wp, spec.hidden
+    return out
+
+
+def fused_block1(spec):
+    return spec.max_pool and spec.in_channels in (1, 3) and spec.in_h % 2 == 0 and spec.in_w % 2 == 0 and spec.in_w // 2 >= 8
+
+
+def op_costs(spec, op, layer, images):
+    """(flops, bytes) of one launch of `op` on block `layer` (0-based) over `images` images, or None for latency-class ops."""
+    h, w, ci, co, ho, wo, hp, wp = layer_geometry(spec)[layer]
+    x, z, p = h * w * ci * 4, ho * wo * co * 4, hp * wp * co * 4
+    f = 2 * 9 * ci * co * ho * wo
+    if layer == 0 and fused_block1(spec):
+        a = p // 4
+        t = {'conv_fwd_stats': (f, x), 'bn_relu_pool_fwd': (f, x + 2 * p + a), 'bn_bwd_reduce': (0, 3 * p), 'wgrad': (f, x + p + a),
+             'tangent_conv_fwd': (2 * f, x), 'bn_tangent_fwd': (f, x + 3 * p + a), 'bn_tangent_bwd_reduce': (0, 5 * p),
+             'tangent_wgrad': (2 * f, x + 2 * p + a)}
+    else:
+        t = {'conv_fwd_stats': (f, x + z), 'dgrad': (f, z + x), 'wgrad': (f, x + z),
+             'tangent_conv_fwd': (2 * f, 2 * x + 2 * z), 'tangent_dgrad': (2 * f, 2 * z + x), 'tangent_wgrad': (2 * f, 2 * x + 2 * z),
+             'bn_relu_pool_fwd': (0, z + p), 'bn_bwd_reduce': (0, z + p), 'bn_bwd_apply': (0, 2 * z + p),
+             'bn_tangent_fwd': (0, 2 * z + p), 'bn_tangent_bwd_reduce': (0, 2 * z + 2 * p), 'bn_tangent_bwd_apply': (0, 3 * z + 2 * p)}
+        if layer == 0:          # first block without a tangent input: one GEMM term
+            t['tangent_conv_fwd'] = (f, x + 2 * z)
+            t['tangent_wgrad'] = (f, x + z)
+    if op not in t:
+        return None
+    fl, by = t[op]
+    return fl * images, by * images
+
+
+def bound_of(flops, nbytes):
+    """Which roofline bounds an op with this arithmetic intensity."""
+    if not flops:
+        return 'hbm'
+    return 'mfma' if flops / nbytes > PEAK_TFLOPS * 1e12 / (PEAK_GBPS * 1e9) else 'hbm'
+
+
+KERNEL_NAMES = {
+    'conv_fwd_stats': 'conv3x3_mfma_kernel<{ci},1,EPI_STATS,fwd>', 'dgrad': 'conv3x3_mfma_kernel<{ci},1,EPI_NONE,dgrad>',
+    'wgrad': 'wgrad3x3_rows_mfma_kernel (1 term)', 'tangent_conv_fwd': 'conv3x3_mfma_kernel<{ci},2,EPI_TSTATS,fwd>',
+    'tangent_dgrad': 'conv3x3_mfma_kernel<{ci},2,EPI_NONE,dgrad>', 'tangent_wgrad': 'wgrad3x3_rows_mfma_kernel (2 terms)',
+    'bn_relu_pool_fwd': 'bn_fwd_kernel', 'bn_bwd_reduce': 'bn_bwd_reduce_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel',
+    'bn_tangent_fwd': 'bn_tan_fwd_kernel', 'bn_tangent_bwd_reduce': 'bn_tan_bwd_reduce_kernel',
+    'bn_tangent_bwd_apply': 'bn_tan_bwd_apply_kernel',
+}
+BLOCK1_KERNEL_NAMES = {
+    'bn_relu_pool_fwd': 'block1_kernel<{ci},FWD>', 'bn_tangent_fwd': 'block1_kernel<{ci},TFWD_ARG>', 'wgrad': 'sparse_wgrad_kernel<{ci},false>',
+    'tangent_wgrad': 'sparse_wgrad_kernel<{ci},true>', 'bn_bwd_reduce': 'pooled_reduce_kernel<false>',
+    'bn_tangent_bwd_reduce': 'pooled_reduce_kernel<true>', 'conv_fwd_stats': 'block1_kernel<{ci},STATS>',
+}
+
+
+def kernel_name(spec, op, layer):
+    ci = layer_geometry(spec)[layer][2]
+    names = BLOCK1_KERNEL_NAMES if (layer == 0 and fused_block1(spec)) else KERNEL_NAMES
+    return names.get(op, op).format(ci=ci)

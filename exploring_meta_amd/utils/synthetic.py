@@ -50,45 +50,48 @@ def task_labels(ways, shots):
     return np.repeat(np.arange(ways, dtype=np.int64), 2 * shots)
 
 
-def mini_imagenet_task(task_id, ways=5, shots=5, seed=42, hw=84, channels=3):
-    """Raw 0..255 float images: class prototype (8x8 block-constant) + sigma=32 noise, clipped."""
+def mini_imagenet_task(task_id, ways=5, shots=5, seed=42, hw=84, channels=3, noise=32.0, contrast=1.0):
+    """Raw 0..255 float images: class prototype (8x8 block-constant) + sigma=`noise` pixel noise, clipped.  `contrast` < 1 pulls
+    the prototypes towards mid-grey (harder tasks: the defaults are separable enough for 100 % post-adaptation accuracy)."""
     s = seed + 1000003 * int(task_id)
     nb = (hw + 7) // 8
     proto = hash_uniform(s, (ways, channels, nb, nb), stream=1) * 255.0
     proto = np.repeat(np.repeat(proto, 8, axis=2), 8, axis=3)[:, :, :hw, :hw]
+    if contrast != 1.0:
+        proto = 127.5 + contrast * (proto - 127.5)
     n = 2 * shots * ways
     labels = task_labels(ways, shots)
-    noise = hash_normalish(s, (n, channels, hw, hw), stream=2)
-    data = np.clip(proto[labels] + 32.0 * noise, 0.0, 255.0).astype(np.float32)
+    nz = hash_normalish(s, (n, channels, hw, hw), stream=2)
+    data = np.clip(proto[labels] + noise * nz, 0.0, 255.0).astype(np.float32)
     return data, labels
 
 
-def omniglot_task(task_id, ways=5, shots=1, seed=42, hw=28):
+def omniglot_task(task_id, ways=5, shots=1, seed=42, hw=28, flip=0.04):
     """Binary stroke-like images in {0,1} (reference feeds 1-img, data_pre.py:19-21): 7x7 prototype
-    upsampled x4 with 4% pixel flips."""
+    upsampled x4 with a fraction `flip` (default 4 %) of the pixels flipped."""
     s = seed + 1000003 * int(task_id)
     cells = (hw + 3) // 4
     proto = (hash_uniform(s, (ways, 1, cells, cells), stream=3) < 0.25).astype(np.float64)
     proto = np.repeat(np.repeat(proto, 4, axis=2), 4, axis=3)[:, :, :hw, :hw]
     n = 2 * shots * ways
     labels = task_labels(ways, shots)
-    flip = hash_uniform(s, (n, 1, hw, hw), stream=4) < 0.04
+    flipped = hash_uniform(s, (n, 1, hw, hw), stream=4) < flip
     img = proto[labels]
-    data = np.where(flip, 1.0 - img, img).astype(np.float32)
+    data = np.where(flipped, 1.0 - img, img).astype(np.float32)
     return data, labels
 
 
-def make_task(dataset, task_id, ways, shots, seed=42):
+def make_task(dataset, task_id, ways, shots, seed=42, **hardness):
     if dataset in ('min', 'mini_imagenet'):
-        return mini_imagenet_task(task_id, ways, shots, seed)
+        return mini_imagenet_task(task_id, ways, shots, seed, **{k: v for k, v in hardness.items() if k in ('noise', 'contrast')})
     if dataset in ('omni', 'omniglot'):
-        return omniglot_task(task_id, ways, shots, seed)
+        return omniglot_task(task_id, ways, shots, seed, **{k: v for k, v in hardness.items() if k == 'flip'})
     raise ValueError(f'Dataset not supported: {dataset}')
 
 
-def make_meta_batch(dataset, task_ids, ways, shots, seed=42):
+def make_meta_batch(dataset, task_ids, ways, shots, seed=42, **hardness):
     """Stack tasks: data [T, 2*S*W, C, H, W] float32, labels [T, 2*S*W] int64."""
-    ds, ls = zip(*(make_task(dataset, t, ways, shots, seed) for t in task_ids))
+    ds, ls = zip(*(make_task(dataset, t, ways, shots, seed, **hardness) for t in task_ids))
     return np.stack(ds), np.stack(ls)
 
 

@@ -32,16 +32,20 @@ def _policy(theta):
     return pol.cuda()
 
 
-def _replays():
+# BASELINE config 5 at full size: 20 tasks per meta-batch, 20 episodes x 100 steps per replay (rl/maml_trpo.py:21-33 defaults)
+PARAMS_CFG5 = dict(PARAMS, max_path_length=100, adapt_batch_size=20, meta_batch_size=20)
+
+
+def _replays(params=PARAMS):
     env = RL.Particles2D(seed=1)
     gen = torch.Generator().manual_seed(2)
     theta = _theta64()
     baseline = RL.LinearValue(2, 2)
     replays, olds = [], []
-    for task in env.sample_tasks(PARAMS['meta_batch_size']):
+    for task in env.sample_tasks(params['meta_batch_size']):
         env.set_task(task)
         learner = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
-        adapted, _, rep, _ = RL.fast_adapt_trpo(env, learner, baseline, PARAMS, gen, first_order=True)
+        adapted, _, rep, _ = RL.fast_adapt_trpo(env, learner, baseline, params, gen, first_order=True)
         replays.append(rep)
         olds.append(OrderedDict((k, v.detach()) for k, v in adapted.items()))
     return theta, replays, olds
@@ -108,6 +112,37 @@ def test_meta_optimize_trpo_matches_oracle():
     report('meta_optimize_trpo', step_rel=es, theta_rel=et, accepted=out['accepted'], accepted_ref=ref['accepted'])
     assert out['accepted'] == ref['accepted']
     assert es < 5e-3 and et < 1e-4
+
+
+def test_cfg5_full_size_matches_oracle():
+    """BASELINE config 5 as benchmarked -- 20 tasks x 2000-row replays -- against oracle/rl_ref.py: surrogate loss / KL, its
+    gradient, a Fisher-vector product and the whole meta_optimize_trpo step (same accepted line-search index)."""
+    theta, replays, olds = _replays(PARAMS_CFG5)
+    assert len(replays) == 20 and replays[0][0]['states'].shape[0] == 2000
+    p64 = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+    loss, kl = RL.meta_surrogate_loss(replays, olds, p64, RL.LinearValue(2, 2), PARAMS_CFG5)
+    plist = list(p64.values())
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, plist, retain_graph=True)])
+    v = torch.randn(grad.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    fv = RL.hessian_vector_product(kl, plist)(v)
+    pol = _policy(theta)
+    old_pols = [_policy(o) for o in olds]
+    from exploring_meta_amd.core_functions.rl import _SurrogateContext
+    ctx = _SurrogateContext(replays, old_pols, pol, cf.LinearValue(2, 2), PARAMS_CFG5)
+    l32, k32, g32 = ctx.evaluate(pol.flat(), want_grad=True)
+    f32 = ctx.fvp(pol.flat(), v.float().cuda())
+    torch.cuda.synchronize()
+    eg, ef = rel_err(g32.cpu().numpy(), grad.numpy()), rel_err(f32.cpu().numpy(), fv.detach().numpy())
+    p64b = OrderedDict((k, v_.clone().requires_grad_(True)) for k, v_ in theta.items())
+    ref = RL.meta_optimize_trpo(PARAMS_CFG5, p64b, RL.LinearValue(2, 2), replays, olds)
+    out = cf.meta_optimize_trpo(PARAMS_CFG5, pol, cf.LinearValue(2, 2), replays, old_pols)
+    es = rel_err(out['step'].cpu().numpy(), ref['step'].numpy())
+    et = rel_err(pol.flat().cpu().numpy(), torch.cat([v_.detach().reshape(-1) for v_ in p64b.values()]).numpy())
+    report('cfg5_full_size', loss=float(l32), loss_ref=float(loss.detach()), kl=float(k32), grad_rel=eg, fvp_rel=ef, step_rel=es,
+           theta_rel=et, accepted=out['accepted'], accepted_ref=ref['accepted'])
+    assert abs(float(l32) - float(loss.detach())) < 1e-5 * max(1.0, abs(float(loss.detach()))) and abs(float(k32)) < 1e-6
+    assert eg < 1e-4 and ef < 1e-3
+    assert out['accepted'] == ref['accepted'] and es < 5e-3 and et < 1e-4
 
 
 def test_runner_and_fast_adapt_trpo_shapes():

@@ -12,39 +12,17 @@ reductions stream pooled tensors (HBM), its weight gradients are the sparse MFMA
 import csv
 import sys
 
-PEAK_TFLOPS = 157.3      # fp32-input MFMA == fp32 vector peak, MI355X_MICROARCH.md
-PEAK_GBPS = 8000.0       # HBM3E spec; about 6300 GB/s is achievable with a streaming copy
+import os
 
-H = [84, 42, 21, 10]
-HP = [42, 21, 10, 5]
-CI = [3, 32, 32, 32]
-CO = 32
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from exploring_meta_amd.engine import ModelSpec  # noqa: E402
+from exploring_meta_amd.utils.roofline import PEAK_TFLOPS, PEAK_GBPS, op_costs  # noqa: E402
+
+SPEC = ModelSpec.mini_imagenet(5)
 
 
 def costs(op, l, images):
-    """(flops, bytes) of one launch of `op` on block l over `images` images."""
-    x = H[l] * H[l] * CI[l] * 4
-    z = H[l] * H[l] * CO * 4
-    p = HP[l] * HP[l] * CO * 4
-    f = 2 * 9 * CI[l] * CO * H[l] * H[l]
-    if l == 0:      # block 1: conv-recompute kernels (z1 / dz1 stay in registers), Gram-matrix statistics, pooled-resolution reductions
-        a = p // 4  # argmax bytes (one per pooled element)
-        t = {
-            'conv_fwd_stats': (f, x), 'bn_relu_pool_fwd': (f, x + 2 * p + a), 'bn_bwd_reduce': (0, 3 * p), 'wgrad': (f, x + p + a),
-            'tangent_conv_fwd': (2 * f, x), 'bn_tangent_fwd': (2 * f, x + 2 * p), 'bn_tangent_bwd_reduce': (0, 5 * p),
-            'tangent_wgrad': (2 * f, x + 2 * p + a),
-        }
-    else:
-        t = {
-            'conv_fwd_stats': (f, x + z), 'dgrad': (f, z + x), 'wgrad': (f, x + z),
-            'tangent_conv_fwd': (2 * f, 2 * x + 2 * z), 'tangent_dgrad': (2 * f, 2 * z + x), 'tangent_wgrad': (2 * f, 2 * x + 2 * z),
-            'bn_relu_pool_fwd': (0, z + p), 'bn_bwd_reduce': (0, z + p), 'bn_bwd_apply': (0, 2 * z + p),
-            'bn_tangent_fwd': (0, 2 * z + p), 'bn_tangent_bwd_reduce': (0, 2 * z + 2 * p), 'bn_tangent_bwd_apply': (0, 3 * z + 2 * p),
-        }
-    if op not in t:
-        return None
-    fl, by = t[op]
-    return fl * images, by * images
+    return op_costs(SPEC, op, l, images)
 
 
 def main():
