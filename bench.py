@@ -84,7 +84,7 @@ def make_batch(wl, task_ids):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_vision(wl, spec, theta_flat, budget_s=20.0, max_tasks=16):
+def cpu_baseline_vision(wl, spec, theta_flat, budget_s=20.0, max_tasks=16):      # max_tasks = n_cmp of run_vision
     """The oracle (CPU restatement of the reference loop, fp32) on a bounded sample of the same workload: the first tasks of
     rank 0's shard from the same initial parameters.  Returns (baseline dict, per-task oracle loss, accuracy)."""
     from collections import OrderedDict
@@ -195,11 +195,13 @@ def run_vision(args, wl, rank, world, local, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # post-adaptation loss / accuracy at the INITIAL parameters on the tasks the CPU oracle will also run (untimed)
-    n_cmp = min(T, 16)
-    l0, a0, _, _ = run_batch(theta, data[:n_cmp].contiguous(), labels[:n_cmp].contiguous(), wl['shots'], wl['steps'], wl['lr'],
+    # post-adaptation loss / accuracy at the INITIAL parameters on the tasks the CPU oracle will also run (task ids 0..15; untimed)
+    n_cmp = 16
+    cdata, clabels = make_batch(wl, list(range(n_cmp)))
+    l0, a0, _, _ = run_batch(theta, torch.from_numpy(cdata).cuda(), torch.from_numpy(clabels).cuda(), wl['shots'], wl['steps'], wl['lr'],
                              first_order=wl['first_order'], with_grad=False)
     eng_loss0, eng_acc0 = l0.cpu().numpy().astype(np.float64), a0.cpu().numpy().astype(np.float64)
+    del cdata, clabels
     lall, aall, _, _ = run_batch(theta, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], with_grad=False)
     init_loss_mean, init_acc_mean = float(lall.mean()), float(aall.mean())
 

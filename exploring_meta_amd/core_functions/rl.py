@@ -25,17 +25,25 @@ def _np(x):
 
 
 def discount(gamma, rewards, dones):
-    """cherry.td.discount: R_t = r_t + gamma (1 - d_t) R_{t+1}.  Evaluated episode by episode (a `done` cuts the recursion) with
-    one linear-filter call per episode instead of a Python loop over time steps."""
+    """cherry.td.discount: R_t = r_t + gamma (1 - d_t) R_{t+1}.  A `done` cuts the recursion, so the replay splits into episodes;
+    they are padded with zeros at the END to a common length (zeros behind the last step leave the backward recursion at exactly
+    0) and the whole replay is one linear-filter call along the time axis -- bit-identical to the step-by-step loop."""
     from scipy.signal import lfilter
     r = rewards[:, 0]
-    out = np.empty_like(rewards)
+    n = r.shape[0]
     ends = np.flatnonzero(dones[:, 0] != 0.0)
-    start = 0
-    for e in list(ends) + ([r.shape[0] - 1] if (ends.size == 0 or ends[-1] != r.shape[0] - 1) else []):
-        seg = r[start:e + 1]
-        out[start:e + 1, 0] = lfilter([1.0], [1.0, -gamma], seg[::-1])[::-1]
-        start = e + 1
+    if ends.size == 0 or ends[-1] != n - 1:
+        ends = np.append(ends, n - 1)
+    starts = np.concatenate([[0], ends[:-1] + 1])
+    lens = ends - starts + 1
+    L = int(lens.max())
+    ep = np.repeat(np.arange(lens.size), lens)             # episode of every step
+    pos = np.arange(n) - starts[ep]                        # position inside its episode
+    pad = np.zeros((lens.size, L))
+    pad[ep, pos] = r
+    disc = lfilter([1.0], [1.0, -gamma], pad[:, ::-1], axis=1)[:, ::-1]
+    out = np.empty_like(rewards)
+    out[:, 0] = disc[ep, pos]
     return out
 
 
@@ -84,18 +92,38 @@ def _advantages(ep, baseline, gamma, tau, update_vf=True):
     return normalize(adv)
 
 
+def _host_replays(replay_list):
+    """Replays (dicts of device tensors) -> dicts of float64 numpy arrays with ONE device-to-host copy per field for the whole list
+    (a copy per replay and field costs a stream synchronisation each: 240 of them for 20 tasks x 2 replays)."""
+    keys = ('states', 'actions', 'rewards', 'dones', 'next_states')
+    lens = [int(r['states'].shape[0]) for r in replay_list]
+    out = [dict() for _ in replay_list]
+    for k in keys:
+        parts = [r[k].detach().reshape(r[k].shape[0], -1) if torch.is_tensor(r[k]) else torch.as_tensor(np.asarray(r[k])).reshape(len(r[k]), -1)
+                 for r in replay_list]
+        big = torch.cat([q.to(parts[0].device, torch.float64) for q in parts]).cpu().numpy()
+        off = 0
+        for o, n in zip(out, lens):
+            o[k] = big[off:off + n]
+            off += n
+    return out
+
+
 def _pad(eps_list, advs, S, A, dev):
-    """List of replays (one per task) -> padded device batch {states [T,B,S], actions, adv, count}."""
+    """List of replays (one per task) -> padded device batch {states [T,B,S], actions, adv, count}: assembled on the host, one
+    upload per field."""
     T = len(eps_list)
     B = max(int(e['states'].shape[0]) for e in eps_list)
-    st, ac = torch.zeros(T, B, S), torch.zeros(T, B, A)
-    ad, cnt = torch.zeros(T, B), torch.zeros(T, dtype=torch.int32)
+    st, ac = np.zeros((T, B, S), np.float32), np.zeros((T, B, A), np.float32)
+    ad, cnt = np.zeros((T, B), np.float32), np.zeros(T, np.int32)
     for t, (e, a) in enumerate(zip(eps_list, advs)):
         n = int(e['states'].shape[0])
-        st[t, :n], ac[t, :n] = e['states'].detach().cpu().float(), e['actions'].detach().cpu().float()
-        ad[t, :n] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(-1))
+        st[t, :n] = _np(e['states']).reshape(n, S)
+        ac[t, :n] = _np(e['actions']).reshape(n, A)
+        ad[t, :n] = np.asarray(a, dtype=np.float32).reshape(-1)
         cnt[t] = n
-    return dict(states=st.to(dev), actions=ac.to(dev), adv=ad.to(dev), count=cnt.to(dev))
+    up = lambda x: torch.from_numpy(x).to(dev)
+    return dict(states=up(st), actions=up(ac), adv=up(ad), count=up(cnt))
 
 
 # ---------------------------------------------------------------------------------------------- reference functions
@@ -152,11 +180,13 @@ class _SurrogateContext:
             raise ValueError('every task needs the same number (>= 1) of support replays plus one query replay')
         self.steps = K
         adv = lambda e: _advantages(e, baseline, params['gamma'], params['tau'])
+        nT = len(iter_replays)
+        host = _host_replays([r[k] for k in range(K + 1) for r in iter_replays])     # [k][task], one D2H copy per field
         sups = []
         for k in range(K):                                       # the reference walks task by task, replay by replay (rl.py:444-465);
-            eps = [r[k] for r in iter_replays]                   # the baseline is re-fitted per replay, so the order is immaterial
+            eps = host[k * nT:(k + 1) * nT]                      # the baseline is re-fitted per replay, so the order is immaterial
             sups.append(_pad(eps, [adv(e) for e in eps], S, A, dev))
-        qry_eps = [r[-1] for r in iter_replays]
+        qry_eps = host[K * nT:]
         self.qry = _pad(qry_eps, [adv(e) for e in qry_eps], S, A, dev)
         B = max([d['states'].shape[1] for d in sups] + [self.qry['states'].shape[1]])
         for d in sups + [self.qry]:                              # one common padded length
