@@ -157,8 +157,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
   // consume them; padding lanes read mi_zero_word through an address select (no predicated loads, no post-load selects).
   // sched_barriers pin the order so the compiler neither hoists every load to the top (register blow-up) nor sinks them.
   constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC, DEPTH = 2, RING = DEPTH + 1;
-  // (16-B operands use global loads with an address select: __builtin_amdgcn_raw_buffer_load_b128 is miscompiled by hipcc 7.2
-  //  for gfx950 -- it emits buffer_load_dword and leaves three result registers undefined.)
+  // (16-B operands use global loads with an address select here; the stride-1 kernel below uses raw buffer loads.)
   const float* in_base[NTERMS];
 #pragma unroll
   for (int term = 0; term < NTERMS; ++term) in_base[term] = a.in[term] + (size_t)task * in_task + h * 16;
@@ -221,6 +220,174 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
       __builtin_amdgcn_sched_barrier(0);
     }
     conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, zpre, mu_c, r_c, s, q);
+  }
+  if (EPI != EPI_NONE) {
+    double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
+    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-1 variant of the generic conv (every pooling net: blocks >= 2 forward, dgrad and their two-term tangent versions).
+// Input and output have the same spatial size, so an output pixel's linear index IS the linear index of the input pixel under
+// the kernel centre and tap (ddy, ddx) sits at the constant displacement (ddy*W + ddx)*CI floats: per tile a lane computes ONE
+// byte offset, per K step it adds a wave-uniform displacement and substitutes an out-of-range offset for padding lanes.  All
+// operands come through raw buffer loads (16 B each, immediate offsets for the four quarters of a 64-B half row): the hardware
+// range check returns zeros for padding, so there are no predicated loads, no 64-bit address arithmetic and no integer
+// multiplies in the main loop.  The epilogue stores through a buffer descriptor as well (rows past the end of the task are
+// dropped by the range check) and the statistics need no validity test: a pixel past the end has all-zero operands, hence
+// acc == 0 exactly.  Requires co == CI (hidden -> hidden blocks) and fewer than 2^24 pixels per task.
+typedef unsigned int mi_u32x4 __attribute__((ext_vector_type(4)));
+// NOTE: the loaded vector must be re-typed as a WHOLE (bit_cast to floatx4).  Extracting the four lanes of the integer vector
+// one by one (bit_cast(float, v.x) ...) makes hipcc 7.2 narrow the instruction to buffer_load_dword and leave three of the four
+// values undefined (reproduced in isolation; this is the "miscompiled b128" of round 1).
+__device__ __forceinline__ floatx4 buf_ld16(mi_rsrc r, unsigned off) {
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_st(mi_rsrc r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+// x / d and x % d for x < 2^24 with the reciprocal of d in fp32: the fp32 quotient is off by at most one
+__device__ __forceinline__ void divmod24(unsigned x, unsigned d, float rd, unsigned& q, unsigned& r) {
+  q = (unsigned)((float)x * rd);
+  int rr = (int)x - (int)__umul24(q, d);
+  if (rr < 0) { --q; rr += (int)d; }
+  if (rr >= (int)d) { ++q; rr -= (int)d; }
+  r = (unsigned)rr;
+}
+
+template <int CI, int NTERMS, int EPI, int MODE>
+__global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s1_mfma_kernel(ConvArgs a) {
+  constexpr int NW = ConvWaves<CI, NTERMS>::value, NT = NW * 64, CO = CI;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y, ct = blockIdx.z;
+  const int H = a.g.h, W = a.g.w;
+  const int cbase = ct * 32;
+
+  // ---- stage this task's weights (same layout as the generic kernel): lds[((term*9+tap)*CI + k)*32 + nl]
+  constexpr int NQ = NTERMS * 9 * CI * 32 / 4;
+#pragma unroll 3
+  for (int qd = tid; qd < NQ; qd += NT) {
+    if (MODE == 0) {
+      const int nl4 = (qd & 7) * 4;
+      const int row = qd >> 3;
+      const int k = row % CI, tt = row / CI;
+      const int term = tt / 9, tap = tt - term * 9;
+      const float* wsrc = a.wt[term] + (size_t)task * a.wstride;
+      const floatx4 v = *reinterpret_cast<const floatx4*>(wsrc + ((size_t)tap * CI + k) * CO + cbase + nl4);
+      *reinterpret_cast<floatx4*>(lds + row * 32 + nl4) = v;
+    } else {
+      constexpr int KQ = CI / 4;
+      const int k4 = (qd % KQ) * 4;
+      const int rest = qd / KQ;
+      const int nl = rest & 31, tt = rest >> 5;
+      const int term = tt / 9, tap = tt - term * 9;
+      const float* wsrc = a.wt[term] + (size_t)task * a.wstride;
+      const floatx4 v = *reinterpret_cast<const floatx4*>(wsrc + ((size_t)tap * CO + cbase + nl) * CI + k4);
+      float* dst = lds + ((size_t)tt * CI + k4) * 32 + nl;
+      dst[0] = v[0]; dst[32] = v[1]; dst[64] = v[2]; dst[96] = v[3];
+    }
+  }
+  __syncthreads();
+
+  const int mpix = a.mpix;
+  const unsigned hw = (unsigned)(H * W);
+  const float rhw = 1.0f / (float)hw, rw = 1.0f / (float)W;
+  const size_t t_elems = (size_t)mpix * CI;                 // input and output tensors of one task have the same size (co == CI)
+  const unsigned t_bytes = (unsigned)(t_elems * 4);
+  mi_rsrc rin[NTERMS];
+#pragma unroll
+  for (int term = 0; term < NTERMS; ++term)
+    rin[term] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in[term] + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+  const mi_rsrc rout = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+  mi_rsrc rz = rout;
+  float mu_c = 0.f, r_c = 0.f;
+  if (EPI == EPI_TSTATS) {
+    rz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+    mu_c = a.mu[(size_t)task * CO + cbase + j];
+    r_c = a.rstd[(size_t)task * CO + cbase + j];
+  }
+  double s = 0.0, q = 0.0;
+  // byte displacement of every tap (wave-uniform): forward reads in[o + d - 1], dgrad reads in[i + 1 - d]
+  const int wci = W * CI * 4;
+  const unsigned lane_in = (unsigned)(h * 64);
+  const unsigned lane_out = (unsigned)(((4 * h) * CO + cbase + j) * 4);
+
+  constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC, DEPTH = 2, RING = DEPTH + 1;
+  const int tile_base = blockIdx.x * NW * a.tiles_per_wave;
+  const int tile_end = min(tile_base + NW * a.tiles_per_wave, a.ntiles);
+  for (int tile = tile_base + wave; tile < tile_end; tile += NW) {
+    const unsigned pix = (unsigned)(tile * 32 + j);
+    unsigned nimg, rem, oy, ox;
+    divmod24(pix, hw, rhw, nimg, rem);
+    divmod24(rem, (unsigned)W, rw, oy, ox);
+    const bool valid = pix < (unsigned)mpix;
+    // row / column validity of the three vertical and horizontal displacements (index 0, 1, 2 <-> -1, 0, +1)
+    const bool rowok[3] = {valid && oy >= 1u, valid, valid && oy + 1u < (unsigned)H};
+    const bool colok[3] = {ox >= 1u, true, ox + 1u < (unsigned)W};
+    const unsigned base = pix * (unsigned)(CI * 4) + lane_in;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const unsigned obase = lane_out + (unsigned)tile * (unsigned)(32 * CO * 4);
+    float zpre[16];
+    if (EPI == EPI_TSTATS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned ro = (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
+        zpre[r] = buf_ld(rz, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro);
+      }
+    }
+    floatx4 ring[RING][4];
+    auto issue = [&](int step, floatx4* dst) {
+      const int cc = step % NCC, tt = step / NCC, tap = tt % 9, term = tt / 9;
+      const int ddy = (MODE == 0) ? tap / 3 - 1 : 1 - tap / 3;
+      const int ddx = (MODE == 0) ? tap % 3 - 1 : 1 - tap % 3;
+      const bool ok = rowok[ddy + 1] && colok[ddx + 1];
+      const unsigned off = ok ? base + (unsigned)(ddy * wci + ddx * CI * 4) : MI_OOB;
+      dst[0] = buf_ld16(rin[term], off + cc * 128);
+      dst[1] = buf_ld16(rin[term], off + cc * 128 + 16);
+      dst[2] = buf_ld16(rin[term], off + cc * 128 + 32);
+      dst[3] = buf_ld16(rin[term], off + cc * 128 + 48);
+    };
+#pragma unroll
+    for (int st = 0; st < DEPTH && st < NSTEP; ++st) issue(st, ring[st % RING]);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + DEPTH < NSTEP) issue(step + DEPTH, ring[(step + DEPTH) % RING]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int cc = step % NCC, tt = step / NCC;           // tt = term*9 + tap
+      const floatx4* av = ring[step % RING];
+      const float* bl = lds + ((size_t)(tt * CI + cc * 32 + h * 16)) * 32 + j;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][0], bl[(4 * v + 0) * 32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][1], bl[(4 * v + 1) * 32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][2], bl[(4 * v + 2) * 32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][3], bl[(4 * v + 3) * 32], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue: rows m = (r&3) + 8*(r>>2) + 4h of the tile; rows past the end of the task are dropped by the range check
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned ro = (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
+      const float v = acc[r];
+      buf_st(rout, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro, v);
+      if (EPI == EPI_STATS) {
+        const double dv = (double)v;
+        s += dv;
+        q = fma(dv, dv, q);
+      } else if (EPI == EPI_TSTATS) {
+        const float zh = bn_zh(zpre[r], mu_c, r_c);
+        s += (double)v;
+        q = fma((double)zh, (double)v, q);
+      }
+    }
   }
   if (EPI != EPI_NONE) {
     double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
@@ -559,9 +726,33 @@ static hipError_t launch_conv_t(hipStream_t st, ConvArgs& a, dim3 grid) {
   hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS>::value * 64), lds, st, a);
   return hipGetLastError();
 }
+template <int CI, int NTERMS, int EPI, int MODE>
+static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
+  const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);
+  auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS>::value * 64), lds, st, a);
+  return hipGetLastError();
+}
+
+// the stride-1 kernel needs co == ci, 32-bit byte offsets inside one task's tensor and pixel indices below 2^24
+static bool conv_s1_ok(const ConvArgs& a) {
+  return a.g.stride == 1 && a.g.co == a.g.ci && a.g.h == a.g.ho && a.g.w == a.g.wo && a.mpix < (1 << 24) &&
+         (size_t)a.mpix * a.g.ci * 4 < (size_t)MI_OOB;
+}
 
 template <int CI, int NTERMS, int EPI>
 static hipError_t launch_conv_ms(hipStream_t st, ConvArgs& a, dim3 grid, int mode, int stride) {
+  if (conv_s1_ok(a)) {
+    if (mode == 0) return launch_conv_s1<CI, NTERMS, EPI, 0>(st, a, grid);
+    if (EPI == EPI_NONE && mode == 1) return launch_conv_s1<CI, NTERMS, EPI_NONE, 1>(st, a, grid);
+    return hipErrorInvalidValue;
+  }
   if (mode == 0 && stride == 1) return launch_conv_t<CI, NTERMS, EPI, 0, 1>(st, a, grid);
   if (mode == 0 && stride == 2) return launch_conv_t<CI, NTERMS, EPI, 0, 2>(st, a, grid);
   if (EPI == EPI_NONE) {
