@@ -46,7 +46,13 @@ class MetaTrainer:
         return list(range(first_task_id + a, first_task_id + b))
 
     def step(self, theta, first_task_id=0):
-        loss, acc, grad = self.compute(theta, self.local_tasks(first_task_id))
-        grad, loss_sum, acc_sum = reduce_meta_batch(grad, loss.sum(), acc.sum(), self.group)
+        tasks = self.local_tasks(first_task_id)
+        if tasks:
+            loss, acc, grad = self.compute(theta, tasks)
+            loss_sum, acc_sum = loss.sum(), acc.sum()
+        else:      # meta-batch smaller than the world: this rank owns no task and contributes zeros to the all-reduce
+            grad = torch.zeros_like(theta)
+            loss_sum = acc_sum = torch.zeros((), dtype=theta.dtype, device=theta.device)
+        grad, loss_sum, acc_sum = reduce_meta_batch(grad, loss_sum, acc_sum, self.group)
         self.adam(theta, grad, 1.0 / self.meta_batch_size)            # maml_vision.py:139-141
         return loss_sum / self.meta_batch_size, acc_sum / self.meta_batch_size, grad

@@ -61,7 +61,7 @@ def _run(rank, world, port, out_path, meta_batch):
         step[0] = R.adam_step(th, grad * scale, m, v, step[0])
 
     tr = MetaTrainer(compute, adam, meta_batch)
-    assert len(tr.local_tasks()) == meta_batch // world
+    assert len(tr.local_tasks()) in (meta_batch // world, meta_batch // world + 1)
     outs = []
     for it in range(2):
         loss, acc, grad = tr.step(theta, first_task_id=it * meta_batch)
@@ -76,8 +76,8 @@ def _run(rank, world, port, out_path, meta_batch):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(tmp_path):
-    meta_batch = 4
+@pytest.mark.parametrize('meta_batch', [4, 33, 1])     # even split; ragged 17 + 16; rank 1 owns no task
+def test_two_ranks_match_single_process(tmp_path, meta_batch):
     single = str(tmp_path / 'single.pt')
     _run(0, 1, 0, single, meta_batch)
     port = _free_port()
@@ -86,7 +86,7 @@ def test_two_ranks_match_single_process(tmp_path):
     a, b = torch.load(single), torch.load(multi)
     for (la, aa, ga), (lb, ab, gb) in zip(a['outs'], b['outs']):
         assert la == pytest.approx(lb, rel=1e-12) and aa == pytest.approx(ab, rel=1e-12)
-        assert torch.allclose(ga, gb, rtol=1e-12, atol=1e-15)
+        assert float((ga - gb).norm() / ga.norm()) < 1e-12        # fp64 sums in a different order (per-rank partial sums)
     # Adam normalises by sqrt(v): where the oracle's autograd gradient is pure rounding noise (conv biases under batch-stat
     # BN, ~1e-17) the sign of the step is arbitrary, so parameters are compared where the gradient is above noise.
     g = a['outs'][-1][2].abs()
