@@ -15,15 +15,20 @@ def shard_range(num_tasks, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def reduce_meta_batch(meta_grad, loss_sum, acc_sum, group=None):
-    """Sum (meta_grad, loss_sum, acc_sum) over ranks with a single all-reduce.  Returns the reduced triple.
+def reduce_meta_batch(meta_grad, loss_sum, acc_sum, group=None, extra=()):
+    """Sum (meta_grad, loss_sum, acc_sum, *extra) over ranks with a single all-reduce: the scalars (train loss / accuracy sums and
+    whatever else the caller logs, e.g. the validation sums) ride behind the gradient.  Returns the reduced
+    (meta_grad, loss_sum, acc_sum) -- with ``extra`` a 4-tuple whose last element is the list of reduced extras.
     Single-process (no initialised process group): identity."""
+    extra = list(extra)
     if not (dist.is_available() and dist.is_initialized()):
-        return meta_grad, loss_sum, acc_sum
-    flat = torch.cat([meta_grad.reshape(-1), torch.stack([loss_sum.reshape(()), acc_sum.reshape(())]).to(meta_grad.dtype)])
+        return (meta_grad, loss_sum, acc_sum, extra) if extra else (meta_grad, loss_sum, acc_sum)
+    scalars = [torch.as_tensor(x, device=meta_grad.device).reshape(()).to(meta_grad.dtype) for x in [loss_sum, acc_sum] + extra]
+    flat = torch.cat([meta_grad.reshape(-1), torch.stack(scalars)])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     n = meta_grad.numel()
-    return flat[:n].view_as(meta_grad), flat[n], flat[n + 1]
+    out = (flat[:n].view_as(meta_grad), flat[n], flat[n + 1])
+    return out + ([flat[n + 2 + i] for i in range(len(extra))],) if extra else out
 
 
 class MetaTrainer:

@@ -60,30 +60,43 @@ def run(dataset, p, first_order=False, log=print):
     lo, hi = shard_range(T, rank, world)
     train, valid = SyntheticTasks(dataset, p['ways'], p['shots'], 0), SyntheticTasks(dataset, p['ways'], p['shots'], 10 ** 6)
     metrics = {}
+    zero = torch.zeros((), device=device)
+    save_dir = p.get('save_dir') or ''
+    if save_dir and rank == 0:
+        os.makedirs(os.path.join(save_dir, 'model_checkpoints'), exist_ok=True)
     for it in range(p['num_iterations']):
         opt.zero_grad()
         ids = list(range(it * T + lo, it * T + hi))
-        d, l = train.sample_batch(ids)
-        total, losses, accs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
-        total.backward()                                                     # accumulates the SUM over this rank's tasks
-        with torch.no_grad():
-            d, l = valid.sample_batch([10 ** 6 + i for i in ids])
-            _, vlosses, vaccs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
-        flat = torch.cat([q.grad.reshape(-1) for q in maml.parameters()])
-        flat, lsum, asum = reduce_meta_batch(flat, losses.sum(), accs.sum())
+        if ids:
+            d, l = train.sample_batch(ids)
+            total, losses, accs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
+            total.backward()                                                 # accumulates the SUM over this rank's tasks
+            with torch.no_grad():
+                d, l = valid.sample_batch([10 ** 6 + i for i in ids])
+                _, vlosses, vaccs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
+            sums = [losses.sum(), accs.sum(), vlosses.sum(), vaccs.sum()]
+        else:                                    # meta_batch_size < world size: this rank owns no task, contributes zeros
+            sums = [zero, zero, zero, zero]
+        flat = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in maml.parameters()])
+        flat, lsum, asum, (vlsum, vasum) = reduce_meta_batch(flat, sums[0], sums[1], extra=sums[2:])   # one all-reduce, valid sums included
         off = 0
         for q in maml.parameters():                                          # maml_vision.py:139-140
-            q.grad.copy_(flat[off:off + q.numel()].view_as(q) * (1.0 / T))
+            g = flat[off:off + q.numel()].view_as(q) * (1.0 / T)
+            q.grad = g.clone() if q.grad is None else q.grad.copy_(g)
             off += q.numel()
         opt.step()
         metrics = {'train_loss': (lsum / T).item(), 'train_acc': (asum / T).item(),
-                   'valid_loss': vlosses.mean().item(), 'valid_acc': vaccs.mean().item()}
+                   'valid_loss': (vlsum / T).item(), 'valid_acc': (vasum / T).item()}
         if rank == 0:
             log(f'iter {it}: {metrics}')
+            if save_dir and it % p['save_every'] == 0:                        # maml_vision.py:143-144, utils/experiment.py:85-90
+                torch.save(model.state_dict(), os.path.join(save_dir, 'model_checkpoints', f'model_{it}.pt'))
     test = SyntheticTasks(dataset, p['ways'], p['shots'], 2 * 10 ** 6)
     metrics['test_acc'] = evaluate(p, test, maml, loss, device)
     if world > 1:
         torch.distributed.destroy_process_group()
+    if save_dir and rank == 0:
+        torch.save(model.state_dict(), os.path.join(save_dir, 'model.pt'))       # utils/experiment.py:85-87
     return model, metrics
 
 
@@ -93,7 +106,9 @@ if __name__ == '__main__':
     for k, v in params.items():
         parser.add_argument(f'--{k}', type=type(v), default=v)
     parser.add_argument('--first_order', action='store_true')
+    parser.add_argument('--save_dir', type=str, default='', help='write model_checkpoints/model_<it>.pt every save_every iterations and model.pt at the end (reference state_dict keys)')
     args = parser.parse_args()
     for k in params:
         params[k] = getattr(args, k)
+    params['save_dir'] = args.save_dir
     run(args.dataset, params, first_order=args.first_order)

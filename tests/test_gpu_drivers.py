@@ -14,6 +14,22 @@ def test_maml_vision_driver_trains():
     assert all(torch.isfinite(q).all() for q in model.parameters())
 
 
+def test_maml_vision_driver_writes_reference_checkpoints(tmp_path, golden_small):
+    """--save_dir: model_checkpoints/model_<it>.pt every save_every iterations and model.pt at the end, with the reference's
+    state_dict keys (utils/experiment.py:85-90, maml_vision.py:143-144; keys pinned by golden G6)."""
+    from exploring_meta_amd.vision import maml_vision
+    p = dict(maml_vision.params, ways=5, shots=1, adapt_steps=1, meta_batch_size=2, num_iterations=3, save_every=2,
+             save_dir=str(tmp_path))
+    model, _ = maml_vision.run('omni', p, first_order=True, log=lambda *_: None)
+    import os
+    assert sorted(os.listdir(tmp_path / 'model_checkpoints')) == ['model_0.pt', 'model_2.pt']
+    sd = torch.load(tmp_path / 'model.pt')
+    assert list(sd.keys()) == list(model.state_dict().keys())
+    assert all(torch.equal(sd[k].cpu(), v.cpu()) for k, v in model.state_dict().items())
+    fresh = maml_vision.OmniglotCNN(5)
+    fresh.load_state_dict(sd)                                 # round trip through the reference key layout
+
+
 def test_maml_trpo_driver_runs():
     from exploring_meta_amd.rl import maml_trpo
     p = dict(maml_trpo.params, meta_batch_size=3, adapt_batch_size=4, max_path_length=20, num_iterations=2)

@@ -104,3 +104,21 @@ def test_shard_range_covers_all_tasks():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _reduce_extras(rank, world, port):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from exploring_meta_amd.sharding import reduce_meta_batch
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    g = torch.full((5,), float(rank + 1))
+    out = reduce_meta_batch(g, torch.tensor(1.0 * rank), torch.tensor(2.0), extra=[torch.tensor(3.0), 4.0])
+    assert torch.equal(out[0], torch.full((5,), 3.0)) and float(out[1]) == 1.0 and float(out[2]) == 4.0
+    assert [float(x) for x in out[3]] == [6.0, 8.0]
+    assert len(reduce_meta_batch(g, torch.tensor(1.0), torch.tensor(2.0))) == 3
+    dist.destroy_process_group()
+
+
+def test_validation_sums_ride_the_same_all_reduce():
+    """The drivers append the validation loss / accuracy sums to the gradient's all-reduce (every rank logs the global values)."""
+    mp.spawn(_reduce_extras, args=(2, _free_port()), nprocs=2, join=True)
