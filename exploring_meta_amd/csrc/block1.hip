@@ -267,9 +267,10 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
       double t0 = 0.0, t1 = 0.0;
       for (int w = 0; w < 4; ++w) { t0 += ldsd[(w * 2 + 0) * 32 + lane]; t1 += ldsd[(w * 2 + 1) * 32 + lane]; }
       double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
-      pb[cbase + lane] = t0;
-      pb[CO + cbase + lane] = t1;
+      mi_partial_store(pb + cbase + lane, t0, a.fin);
+      mi_partial_store(pb + CO + cbase + lane, t1, a.fin);
     }
+    mi_finalize_last(a.fin, a.partial + (size_t)task * gridDim.x * 2 * CO, gridDim.x, CO, task, gridDim.x * gridDim.z, ldsd);
   }
   if (WG) {
     __syncthreads();

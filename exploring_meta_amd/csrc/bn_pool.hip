@@ -172,9 +172,10 @@ __device__ __forceinline__ void block_reduce_write(const double* acc0, const dou
       s1 += red[(w * quads + q) * 8 + 4 + comp];
     }
     double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * a.c;
-    pb[threadIdx.x] = s0;
-    pb[a.c + threadIdx.x] = s1;
+    mi_partial_store(pb + threadIdx.x, s0, a.fin);
+    mi_partial_store(pb + a.c + threadIdx.x, s1, a.fin);
   }
+  mi_finalize_last(a.fin, a.partial + (size_t)task * gridDim.x * 2 * a.c, gridDim.x, a.c, task, gridDim.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -360,45 +361,10 @@ __global__ __launch_bounds__(256) void bn_tan_bwd_apply_kernel(BnArgs a) {
 //  FIN_STATS : (sum z, sum z^2)        -> out0 = mean, out1 = 1/sqrt(biased var + eps)
 //  FIN_TSTATS: (sum zd, sum zh zd)     -> out0 = m1,   out1 = m2
 //  FIN_SUMS  : (first, second)         -> out0 = first, out1 = second (e.g. dgamma, dbeta)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int c, double inv_m,
-                                                          int mode, float* __restrict__ out0, size_t stride0,
-                                                          float* __restrict__ out1, size_t stride1) {
-  // one workgroup per task: thread (slice, channel) folds every `slices`-th partial, slices are then folded in order
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int c, FinArgs f) {
+  // one workgroup per task (the stand-alone form of the fold the producers run in their last workgroup, finalize.h)
   __shared__ double red[2 * 256];
-  const int task = blockIdx.x;
-  const int slices = 256 / c, sl = threadIdx.x / c, ch = threadIdx.x - sl * c;
-  const double* p = partial + (size_t)task * nblk * 2 * c;
-  double s = 0.0, q = 0.0;
-  if (sl < slices)
-    for (int b = sl; b < nblk; b += slices) {
-      s += p[(size_t)b * 2 * c + ch];
-      q += p[(size_t)b * 2 * c + c + ch];
-    }
-  red[threadIdx.x] = s;
-  red[256 + threadIdx.x] = q;
-  __syncthreads();
-  if ((int)threadIdx.x >= c) return;
-  s = 0.0; q = 0.0;
-  for (int k = 0; k < slices; ++k) {
-    s += red[k * c + ch];
-    q += red[256 + k * c + ch];
-  }
-  float o0, o1;
-  if (mode == FIN_STATS) {
-    const double mean = s * inv_m;
-    double var = q * inv_m - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    o0 = (float)mean;
-    o1 = (float)(1.0 / sqrt(var + MI_BN_EPS));
-  } else if (mode == FIN_TSTATS) {
-    o0 = (float)(s * inv_m);
-    o1 = (float)(q * inv_m);
-  } else {
-    o0 = (float)s;
-    o1 = (float)q;
-  }
-  out0[(size_t)task * stride0 + ch] = o0;
-  out1[(size_t)task * stride1 + ch] = o1;
+  mi_fold_partials<false>(partial + (size_t)blockIdx.x * nblk * 2 * c, nblk, c, f, blockIdx.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -448,9 +414,10 @@ __global__ __launch_bounds__(256) void pooled_reduce_kernel(PoolRedArgs a) {
       t1 += red[(w * quads + qq) * 8 + 4 + comp];
     }
     double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * a.c;
-    pb[threadIdx.x] = t0;
-    pb[a.c + threadIdx.x] = t1;
+    mi_partial_store(pb + threadIdx.x, t0, a.fin);
+    mi_partial_store(pb + a.c + threadIdx.x, t1, a.fin);
   }
+  mi_finalize_last(a.fin, a.partial + (size_t)task * gridDim.x * 2 * a.c, gridDim.x, a.c, task, gridDim.x, red);
 }
 
 int pooled_reduce_blocks(int rows, int c, int tasks) {
@@ -484,8 +451,8 @@ int bn_blocks_per_task(int n, int ho, int wo, int c, int pool, int tasks) {
 hipError_t launch_bn_finalize(hipStream_t st, const double* partial, int nblk, int tasks, int c, double inv_m, int mode,
                               float* out0, size_t stride0, float* out1, size_t stride1) {
   if (c > 256 || 256 % c != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(tasks), dim3(256), 0, st, partial, nblk, c, inv_m, mode, out0, stride0, out1,
-                     stride1);
+  const FinArgs f{nullptr, out0, out1, stride0, stride1, inv_m, mode};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(tasks), dim3(256), 0, st, partial, nblk, c, f);
   return hipGetLastError();
 }
 

@@ -23,7 +23,8 @@
 
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void stats_block_reduce(double s, double q, double* ldsd, int lane, int wave, int nwaves,
-                                                   double* partial_blk, int co_total, int cbase) {
+                                                   double* partial_task, int co_total, int cbase, const FinArgs& fin, int task) {
+  double* partial_blk = partial_task + (size_t)blockIdx.x * 2 * co_total;
   // lanes l and l^32 hold the same channel
   s += __shfl_xor(s, 32, 64);
   q += __shfl_xor(q, 32, 64);
@@ -39,9 +40,10 @@ __device__ __forceinline__ void stats_block_reduce(double s, double q, double* l
       ts += ldsd[(w * 2 + 0) * 32 + lane];
       tq += ldsd[(w * 2 + 1) * 32 + lane];
     }
-    partial_blk[cbase + lane] = ts;
-    partial_blk[co_total + cbase + lane] = tq;
+    mi_partial_store(partial_blk + cbase + lane, ts, fin);
+    mi_partial_store(partial_blk + co_total + cbase + lane, tq, fin);
   }
+  mi_finalize_last(fin, partial_task, gridDim.x, co_total, task, gridDim.x * gridDim.z, ldsd);
 }
 
 template <int EPI>
@@ -222,8 +224,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
     conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, zpre, mu_c, r_c, s, q);
   }
   if (EPI != EPI_NONE) {
-    double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
-    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase);
+    double* pb = a.partial + (size_t)task * gridDim.x * 2 * CO;
+    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase, a.fin, task);
   }
 }
 
@@ -390,8 +392,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
     }
   }
   if (EPI != EPI_NONE) {
-    double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
-    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase);
+    double* pb = a.partial + (size_t)task * gridDim.x * 2 * CO;
+    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase, a.fin, task);
   }
 }
 
@@ -400,7 +402,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
 template <int CI0, int EPI, int STRIDE>
 __global__ __launch_bounds__(256) void conv3x3_first_mfma_kernel(ConvArgs a) {
   constexpr int K = 9 * CI0, KP = (K + 1) & ~1, KH = KP / 2;
-  constexpr int LDS_FLOATS = KP * 32 > 512 ? KP * 32 : 512;  // weights, later 4 waves x 2 x 32 doubles for the stats
+  constexpr int LDS_FLOATS = KP * 32 > 1028 ? KP * 32 : 1028;  // weights, later 4 waves x 2 x 32 doubles for the stats / 512 doubles + flag of the fused finalize
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -465,8 +467,8 @@ __global__ __launch_bounds__(256) void conv3x3_first_mfma_kernel(ConvArgs a) {
     conv_epilogue<EPI>(acc, tile, lane, mpix, CO, cbase, out_t, zpre, mu_c, r_c, s, q);
   }
   if (EPI != EPI_NONE) {
-    double* pb = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 2 * CO;
-    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, 4, pb, CO, cbase);
+    double* pb = a.partial + (size_t)task * gridDim.x * 2 * CO;
+    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, 4, pb, CO, cbase, a.fin, task);
   }
 }
 
@@ -803,9 +805,11 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
 
 // wgrad launcher: writes dW (tap-major [9][ci][co]) for every task at out + task*ostride.
 int wgrad_chunks(int mpix, int tasks) {
-  // aim for >= ~2048 waves in flight, chunks of at least 256 pixels and at most 2048
+  // aim for >= ~2048 waves in flight with chunks of 32..1024 pixels.  The small end matters for the launch-bound few-image
+  // configurations: Omniglot 5-way 1-shot has 245 output pixels per task in block 2 -- with 256-pixel chunks ONE wave per
+  // (task, ci tile, co tile) walked them serially (0.29 ms, 40 % of the cfg1 meta-iteration).
   int chunk = 1024;
-  while (chunk > 256 && (long)ceil_div(mpix, chunk) * tasks < 2048) chunk >>= 1;
+  while (chunk > 32 && (long)ceil_div(mpix, chunk) * tasks < 2048) chunk >>= 1;
   return chunk;
 }
 

@@ -38,6 +38,11 @@ struct mi_engine {
   // Weight gradients of blocks >= 2 run on a side stream: they depend only on dz_l and the block input, nothing downstream of
   // them until the parameter update, and they are matrix-bound while the BatchNorm kernels of the next block are HBM-bound.
   bool overlap = true;
+  // BatchNorm statistic / reduction partials are folded by the last workgroup of the producing kernel (finalize.h) instead of a
+  // bn_finalize launch; counters: one zero-initialised arrival counter per task, owned by the engine.
+  bool fuse_fin = true;
+  unsigned* counters = nullptr;
+  static constexpr int kMaxCounterTasks = 65536;
   struct SideCtx { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; } sc[1];
   std::string err;
   // debug trace (mi_debug_set_trace): per-step theta_k / g_k / lam fed to the k-th Hessian-vector product / H lam, reference order
@@ -94,6 +99,11 @@ static int fail(mi_engine* e, int code, const std::string& msg) {
     if (_s != hipSuccess)                                                                          \
       return fail(e, MI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s) + " @" + std::to_string(__LINE__)); \
   } while (0)
+
+static FinArgs fin_of(const mi_engine* e, int T, double inv_m, int mode, float* o0, size_t s0, float* o1, size_t s1) {
+  const bool on = e->fuse_fin && e->counters && T <= mi_engine::kMaxCounterTasks;
+  return FinArgs{on ? e->counters : nullptr, o0, o1, s0, s1, inv_m, mode};
+}
 
 static ConvGeom geom(const Layer& l, int n) { return ConvGeom{n, l.h, l.w, l.ho, l.wo, l.ci, l.co, l.stride}; }
 static ConvGeom geom_dgrad(const Layer& l, int n) {  // op input = dz (ho,wo,co), op output = dx (h,w,ci)
@@ -161,11 +171,15 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
   (void)hipGetDevice(&prev);
   if (hipSetDevice(device) != hipSuccess) { delete e; return fail(nullptr, MI_ERR_HIP, "hipSetDevice failed"); }
   const bool ok = hipMalloc(&e->perm_dev, perm.size() * sizeof(int32_t)) == hipSuccess &&
-                  hipMemcpy(e->perm_dev, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+                  hipMemcpy(e->perm_dev, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMalloc(&e->counters, mi_engine::kMaxCounterTasks * sizeof(unsigned)) == hipSuccess &&
+                  hipMemset(e->counters, 0, mi_engine::kMaxCounterTasks * sizeof(unsigned)) == hipSuccess;
   if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
   if (!ok) {
+    if (e->perm_dev) (void)hipFree(e->perm_dev);
+    if (e->counters) (void)hipFree(e->counters);
     delete e;
-    return fail(nullptr, MI_ERR_HIP, "allocating the parameter permutation table failed");
+    return fail(nullptr, MI_ERR_HIP, "allocating the parameter permutation table / arrival counters failed");
   }
   *out = e;
   return MI_OK;
@@ -174,6 +188,7 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
 extern "C" void mi_engine_destroy(mi_engine* e) {
   if (!e) return;
   if (e->perm_dev) (void)hipFree(e->perm_dev);
+  if (e->counters) (void)hipFree(e->counters);
   for (auto& c : e->sc) {
     if (c.fork) (void)hipEventDestroy(c.fork);
     if (c.join) (void)hipEventDestroy(c.join);
@@ -188,6 +203,14 @@ extern "C" int mi_engine_set_fused_block1(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->fuse1 = on && block1_supported(e->L[0].ci, e->L[0].stride, e->L[0].pool, e->L[0].ho, e->L[0].wo, e->L[0].co);
   e->gram1 = on != 2;      // 2 = fused kernels, statistics by conv-recompute passes (no Gram matrix)
+  return MI_OK;
+}
+
+// Ablation / test switch: 1 (default) = BatchNorm partials folded by the last workgroup of the producing kernel, 0 = separate
+// bn_finalize launches.  Results are bit-identical either way (same fold order).
+extern "C" int mi_engine_set_fused_finalize(mi_engine* e, int on) {
+  if (!e) return MI_ERR_ARG;
+  e->fuse_fin = on != 0;
   return MI_OK;
 }
 
@@ -449,8 +472,11 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
       if (gram) {   // mean / variance of conv1's output as quadratic forms of this step's weights (gram.hip)
         LAUNCH(e, st, OP_GRAM_STATS, 0, launch_gram_stats(st, gram, T, L.ci, L.co, theta + L.off_w, P, nullptr, 0, 1.0 / ((double)n * L.ho * L.wo), 0, A.mu[0], A.rstd[0], nullptr, nullptr));
       } else {
+        ba.fin = fin_of(e, T, 1.0 / ((double)n * L.ho * L.wo), FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co);
         LAUNCH(e, st, OP_CONV_FWD, 0, launch_block1(st, ba, T, L.ci, B1_STATS, &blk));
-        LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / ((double)n * L.ho * L.wo), FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co));
+        if (!ba.fin.counter)
+          LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / ((double)n * L.ho * L.wo), FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co));
+        ba.fin = FinArgs{};
       }
       ba.out = A.p[0];
       ba.zh_out = A.zhm;
@@ -467,8 +493,10 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
     ca.g = geom(L, n);
     ca.mpix = n * L.ho * L.wo;
     int blk = 0;
+    ca.fin = fin_of(e, T, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co);
     LAUNCH(e, st, OP_CONV_FWD, l, launch_conv3x3(st, ca, T, 1, EPI_STATS, 0, &blk));
-    LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co));
+    if (!ca.fin.counter)
+      LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co));
     BnArgs ba{};
     ba.z = A.z[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
@@ -492,13 +520,17 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       B1Args b1 = b1_args(e, pl, A, x0, n, theta);
       b1.dp = A.dp[0];
       int blk = 0;
+      const FinArgs fin = fin_of(e, T, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P);
       if (A.zhm) {   // dgamma / dbeta from pooled-resolution tensors (no conv recompute)
-        PoolRedArgs pr{A.p[0], A.zhm, nullptr, A.dp[0], nullptr, pl.bnpart, n * L.hp * L.wp, L.co};
+        PoolRedArgs pr{A.p[0], A.zhm, nullptr, A.dp[0], nullptr, pl.bnpart, n * L.hp * L.wp, L.co, fin};
         LAUNCH(e, st, OP_BN_BWD_REDUCE, 0, launch_pooled_reduce(st, pr, T, 0, &blk));
       } else {
+        b1.fin = fin;
         LAUNCH(e, st, OP_BN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_BWD_REDUCE, &blk));
+        b1.fin = FinArgs{};
       }
-      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
+      if (!fin.counter)
+        LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
       b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
       if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci)) {   // sparse part on the matrix pipe, dense parts from the Gram matrix: no conv recompute
         SparseWgArgs sw{};
@@ -524,8 +556,10 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
+    ba.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P);
     LAUNCH(e, st, OP_BN_BWD_REDUCE, l, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
-    LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
+    if (!ba.fin.counter)
+      LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
     ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
     ba.out = A.dz[l];
     LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
@@ -608,8 +642,11 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       if (gram) {
         LAUNCH(e, st, OP_GRAM_STATS, 0, launch_gram_stats(st, gram, T, L.ci, L.co, theta + L.off_w, P, v + L.off_w, P, 1.0 / (double)mpix, 1, X.m1[0], X.m2[0], A.mu[0], A.rstd[0]));
       } else {
+        b1.fin = fin_of(e, T, 1.0 / (double)mpix, FIN_TSTATS, X.m1[0], L.co, X.m2[0], L.co);
         LAUNCH(e, st, OP_TAN_CONV, 0, launch_block1(st, b1, T, L.ci, B1_TSTATS, &blk));
-        LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[0], L.co, X.m2[0], L.co));
+        if (!b1.fin.counter)
+          LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[0], L.co, X.m2[0], L.co));
+        b1.fin = FinArgs{};
       }
       b1.m1 = X.m1[0]; b1.m2 = X.m2[0];
       b1.gammad = v + L.off_gamma; b1.betad = v + L.off_beta;
@@ -634,8 +671,10 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ca.g = geom(L, n);
     ca.mpix = mpix;
     int blk = 0;
+    ca.fin = fin_of(e, T, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co);
     LAUNCH(e, st, OP_TAN_CONV, l, launch_conv3x3(st, ca, T, l > 0 ? 2 : 1, EPI_TSTATS, 0, &blk));
-    LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co));
+    if (!ca.fin.counter)
+      LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co));
     BnArgs ba{};
     ba.z = A.z[l]; ba.zd = X.zd[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l]; ba.m1 = X.m1[l]; ba.m2 = X.m2[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
@@ -673,13 +712,17 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
       b1.dp = A.dp[0]; b1.dpd = X.dpd[cur];
       int blk = 0;
+      const FinArgs fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P);
       if (A.zhm) {
-        PoolRedArgs pr{A.p[0], A.zhm, X.zhdm, A.dp[0], X.dpd[cur], pl.bnpart, n * L.hp * L.wp, L.co};
+        PoolRedArgs pr{A.p[0], A.zhm, X.zhdm, A.dp[0], X.dpd[cur], pl.bnpart, n * L.hp * L.wp, L.co, fin};
         LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, 0, launch_pooled_reduce(st, pr, T, 1, &blk));
       } else {
+        b1.fin = fin;
         LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_REDUCE, &blk));
+        b1.fin = FinArgs{};
       }
-      LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
+      if (!fin.counter)
+        LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
       b1.rdgamma = hv + L.off_gamma; b1.rdbeta = hv + L.off_beta; b1.hstride = P;
       if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci)) {
         SparseWgArgs sw{};
@@ -711,8 +754,10 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
+    ba.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P);
     LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, l, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
-    LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
+    if (!ba.fin.counter)
+      LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
     ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
     ba.out = X.rdz[l];
     LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
@@ -1054,8 +1099,11 @@ extern "C" int mi_adam_step(void* stream, float* theta, const float* grad, float
 extern "C" size_t mi_kernel_scratch_bytes(int tasks, int n, int h, int w, int c) {
   // generous: covers bn partials and wgrad partials for one layer with <= 64 input channels
   ConvGeom g{n, h, w, h, w, 64, c, 1};
+  ConvGeom g2{n, h, w, (h - 1) / 2 + 1, (w - 1) / 2 + 1, 64, c, 2};      // the stride-2 (Omniglot) weight gradient splits finer
   size_t bn = (size_t)tasks * (size_t)conv_max_blocks_per_task(g) * 2 * c * sizeof(double);
   size_t wg = wgrad_partial_floats(g, tasks) * sizeof(float);
+  const size_t wg2 = wgrad_partial_floats(g2, tasks) * sizeof(float);
+  if (wg2 > wg) wg = wg2;
   return align_up(bn, 256) + align_up(wg, 256) + 4096;
 }
 

@@ -1,6 +1,7 @@
 // Internal launcher interface between the kernel files and the engine (not part of the C ABI).
 #pragma once
 #include "mi_common.h"
+#include "finalize.h"
 
 struct ConvArgs {
   const float* in[2];   // [T][n][h][w][ci] per term
@@ -11,6 +12,7 @@ struct ConvArgs {
   const float* mu;      // EPI_TSTATS: [T][co]
   const float* rstd;    // EPI_TSTATS: [T][co]
   double* partial;      // EPI_*STATS: [T][blocks_per_task][2][co]
+  FinArgs fin;          // EPI_*STATS: fold the partials in the last workgroup of each task (counter != nullptr)
   ConvGeom g;
   int mpix;             // n*ho*wo
   int ntiles, tiles_per_wave;
@@ -39,11 +41,11 @@ struct BnArgs {
   const float* dpd;
   float* out;
   double* partial;      // [T][nblk][2][c]
+  FinArgs fin;          // reduction kernels: fold the partials in the last workgroup of each task (counter != nullptr)
   int n, ho, wo, c;
   float inv_m;
 };
 
-enum { FIN_STATS = 0, FIN_TSTATS = 1, FIN_SUMS = 2 };
 
 // BatchNorm-backward reductions of a fused block 1 from pooled-resolution tensors (bn_pool.hip): the forward kernels leave
 // zhat (and its tangent) at every window's argmax next to the pooled output, so dgamma/dbeta need no conv recompute.
@@ -55,6 +57,7 @@ struct PoolRedArgs {
   const float* dpd;     // tangent of that cotangent (tangent mode)
   double* partial;      // [T][nblk][2][c]
   int rows, c;
+  FinArgs fin;
 };
 int pooled_reduce_blocks(int rows, int c, int tasks);
 hipError_t launch_pooled_reduce(hipStream_t st, const PoolRedArgs& a, int tasks, int tangent, int* nblk);
@@ -94,6 +97,7 @@ struct B1Args {
   uint8_t* arg_out;          // optional (FWD): argmax position 0..3 of every window, 4 where the maximum did not pass the ReLU
   const uint8_t* arg_in; const float* zh_in;   // TFWD_ARG: the two tensors FWD stored (no primal conv recompute)
   double* partial;           // [T][blocks][2][Co]
+  FinArgs fin;               // reduction modes: fold the partials in the last workgroup of each task (counter != nullptr)
   float* wpartial;           // [T][blocks][9*Ci0][Co]
   int n, hh, ww, co;         // images per task, conv output height / width (= input, stride 1), filters
   float inv_m;

@@ -61,6 +61,11 @@ int mi_engine_set_fused_block1(mi_engine* e, int on);
  * (per-launch times from mi_profile_* are only additive with 0). */
 int mi_engine_set_overlap(mi_engine* e, int on);
 
+/* 1 (default): the per-workgroup fp64 partials of every BatchNorm statistic / reduction are folded, in a fixed order, by the
+ * last workgroup of the producing kernel (arrival counter per task); 0: by separate bn_finalize launches.  Bit-identical
+ * results either way; the switch exists for ablation and tests. */
+int mi_engine_set_fused_finalize(mi_engine* e, int on);
+
 /* Debug/test aid: byte offsets of {theta, g, xs, sup[0].p[0], sup[0].dp[0], sup[0].mu[0], sup[0].rstd[0], sup[0].p[1],
  * qry.p[0], total} inside the workspace of a mi_meta_batch_maml call with these sizes (out: 10 entries). */
 int mi_debug_plan_offsets(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, int second_order, size_t* out);

@@ -152,6 +152,33 @@ def test_determinism_and_task_permutation():
     assert rel_err(c[2], 2.0 * d[2]) < 1e-5
 
 
+@pytest.mark.parametrize('dataset,ways,shots,K,tasks,fused1', [
+    ('min', 5, 5, 2, [3, 4, 5], 1),       # cfg2 shape (2 steps): Gram-matrix block 1, pooled reductions, 2-term convs
+    ('min', 5, 1, 1, [0, 1, 2, 3], 2),    # conv-recompute block 1 (block1_kernel STATS / TSTATS / *_REDUCE partials)
+    ('omni', 5, 1, 1, [0, 1], 0),         # Omniglot: stride-2 convs, conv3x3_first statistics, 64 filters (two channel tiles)
+])
+def test_fused_finalize_is_bit_identical(dataset, ways, shots, K, tasks, fused1):
+    """BatchNorm partials folded by the last workgroup of the producing kernel (finalize.h) vs separate bn_finalize launches:
+    the fold order is the same, so every output is bit-identical; the arrival counters are back to zero after each launch
+    (a second fused call reproduces the first)."""
+    spec, mspec = _spec(dataset, ways)
+    theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
+    data, labels = synthetic.make_meta_batch(dataset, tasks, ways, shots)
+    d, l = torch.from_numpy(data).cuda().contiguous(), torch.from_numpy(labels).cuda().contiguous()
+    outs = []
+    for on in (1, 0, 1):
+        eng = MetaEngine(mspec)
+        eng.set_fused_block1(fused1)
+        eng.set_fused_finalize(on)
+        for _ in range(2):
+            loss, acc, grad, logits = eng.meta_batch(theta, d, l, shots, K, 0.4, first_order=False, return_logits=True)
+            torch.cuda.synchronize()
+            outs.append((loss.cpu().numpy(), grad.cpu().numpy(), logits.cpu().numpy()))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+    assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).sum() > 0
+
+
 def test_adam_matches_torch():
     spec, mspec = _spec('omni', 5)
     eng = MetaEngine(mspec)
