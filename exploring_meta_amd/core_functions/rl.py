@@ -232,8 +232,19 @@ class _SurrogateContext:
             loss, kl, grad = self._allmean(loss, kl, grad)
         return loss, kl, grad
 
+    def prepare_general_kl(self, theta):
+        """ANIL-TRPO: the re-adapted policies differ from the stored old ones, the Fisher form does not apply; set up the exact
+        KL Hessian-vector product (mi_trpo_kl_prepare) at the theta of the preceding ``evaluate``."""
+        if self.steps != 1:
+            raise NotImplementedError('the exact KL Hessian-vector product (anil=True) is implemented for adapt_steps == 1, the '
+                                      'reference default (rl/anil_trpo.py)')
+        self.engine.kl_prepare(theta, self.sup, self.qry, self.old_loc, self.old_scale, self.inner_lr)
+        self.general = True
+
     def fvp(self, theta, v, damping=1e-5):
         # the damping term is linear in v, so averaging the per-rank results keeps it exact
+        if getattr(self, 'general', False):
+            return self._allmean(self.engine.fvp_general(theta, self.sup, self.qry, self.old_scale, self.inner_lr, damping, v))[0]
         if self.steps == 1:
             return self._allmean(self.engine.fvp(theta, self.sup, self.qry, self.inner_lr, damping, v))[0]
         return self._allmean(self.engine.fvp_steps(self.sup, self.qry, self.inner_lr, damping, v))[0]
@@ -270,17 +281,15 @@ def conjugate_gradient(Ax, b, num_iterations=10, tol=1e-10, eps=1e-8):
 def meta_optimize_trpo(params, policy, baseline, iter_replays, iter_policies, anil=False):
     """reference rl.py:409-438: CG step direction from the Fisher-vector product of the mean KL, then backtracking line
     search on (surrogate loss, KL); updates ``policy`` in place.  Returns diagnostics."""
-    if anil:
-        # The reference's surrogate replays the inner step with ALL parameters (clone_module(policy) has its body grads on,
-        # rl.py:447-453) while the stored old policies were adapted head-only (rl.py:381-382): at the current parameters the
-        # new policies differ from the old ones, KL's gradient is not zero, and the Hessian-vector product of the mean KL
-        # picks up third derivatives of the inner loss.  mi_trpo_fvp implements the case new == old (MAML-TRPO); the ANIL
-        # surrogate VALUE and gradient are available through meta_surrogate_loss / _SurrogateContext.evaluate.
-        raise NotImplementedError('meta_optimize_trpo(anil=True): the KL Hessian-vector product away from new == old is not '
-                                  'implemented (needs third-order terms); see the comment above')
     ctx = _SurrogateContext(iter_replays, iter_policies, policy, baseline, params)
     theta = policy.flat()
     old_loss, old_kl, grad = ctx.evaluate(theta, want_grad=True)
+    if anil:
+        # The reference's surrogate replays the inner step with ALL parameters (clone_module(policy) has its body grads on,
+        # rl.py:447-453) while the stored old policies were adapted head-only (rl.py:381-382): at the current parameters the new
+        # policies differ from the old ones, KL's gradient is not zero, and trpo.hessian_vector_product(kl) is the exact Hessian
+        # of the mean KL including the third derivative of the inner loss (mi_trpo_fvp_general).
+        ctx.prepare_general_kl(theta)
     Fvp = lambda v: ctx.fvp(theta, v)
     step = conjugate_gradient(Fvp, grad)
     shs = 0.5 * torch.dot(step, Fvp(step))

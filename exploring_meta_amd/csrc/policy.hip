@@ -21,10 +21,11 @@
 #define LOG_EPS (-13.815510557964274f)   // log(1e-6), policies.py:14,51
 #define HALF_LOG_2PI 0.9189385332046727f
 
+#define MI_DENSE_TERMS 4   // products summed into one output (2 for first tangents, up to 4 for second tangents)
 struct DenseArgs {
-  const float* x[2];     // [T][B][I]
-  const float* w[2];     // [O][I] per task (stride wstride[k] floats, 0 = shared)
-  size_t wstride[2];
+  const float* x[MI_DENSE_TERMS];     // [T][B][I]
+  const float* w[MI_DENSE_TERMS];     // [O][I] per task (stride wstride[k] floats, 0 = shared)
+  size_t wstride[MI_DENSE_TERMS];
   const float* bias;     // [O] (term 0 only), may be null
   size_t bstride;
   const float* mask;     // optional [T][B][O]: stored activations h; output multiplied by phi'(z) written in terms of h
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs a) {
 }
 
 struct DenseWArgs {
-  const float* dy[2];    // [T][B][O]
-  const float* x[2];     // [T][B][I]
+  const float* dy[MI_DENSE_TERMS];    // [T][B][O]
+  const float* x[MI_DENSE_TERMS];     // [T][B][I]
   float* dw;             // [T][gstride] at offset: [O][I]
   float* db;             // [T][gstride] at offset: [O]  (from dy[0])
   size_t gstride;
@@ -1008,6 +1009,323 @@ extern "C" int mi_trpo_fvp_steps(mi_policy* p, void* stream, int steps, const fl
     PCHK(p, hipGetLastError());
   }
   hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, pl.lam, T, (int)P, 1.f / (float)T, v, damping, out);
+  PCHK(p, hipGetLastError());
+  return MI_OK;
+}
+
+// =====================================================================================================================
+// Exact Hessian-vector product of the mean KL where the re-adapted policy differs from the stored old one: ANIL-TRPO.
+// The reference's anil_trpo.py adapts the stored old policies with the body under no_grad (core_functions/rl.py:381-382), but
+// meta_surrogate_loss replays the inner step on clone_module(policy) with every parameter (rl.py:447-453): at the current
+// parameters new != old, the KL gradient c_t = grad KL_t(theta'_t) is not zero, and
+//   Hess_theta KL_t(theta'_t(theta)) v = J_t^T [Hess KL_t(theta'_t)] J_t v  -  lr * T_t[v, c_t],      J_t = I - lr H_t(theta),
+// T_t[v, c] = d/d eps ( H_t(theta + eps v) c ): the third derivative of the inner loss contracted with v and c.  Hess KL u is a
+// forward-over-reverse sweep over the query pass with the EXACT output Hessian of KL(new || old) (diag: 1/sigma_old^2 on the
+// mean, 2 (sigma/sigma_old)^2 on log sigma) and a non-zero primal cotangent; T_t[v, c] = R_v{R_c{grad L_t}} is a SECOND-order
+// tangent sweep over the support pass: every quantity carries a c-tangent, a v-tangent and a mixed (cv) tangent,
+//   z_cv = W_c h_v + W_v h_c + W h_cv,     h_cv = phi' z_cv + phi'' z_c z_v,
+//   dz_cv = phi' dh_cv + phi'' (z_v dh_c + z_c dh_v) + (phi''' z_c z_v + phi'' z_cv) dh,
+//   dW_cv = dz_cv^T h + dz_c^T h_v + dz_v^T h_c + dz^T h_cv,     dh_in_cv = dz_cv W + dz_c W_v + dz_v W_c
+// (tanh: phi' = 1 - h^2 =: p, phi'' = -2 h p, phi''' = p (6 h^2 - 2); ReLU: phi'' = phi''' = 0).  The c-tangent sweep depends on
+// the context only and is computed once (mi_trpo_kl_prepare); v-tangent and mixed sweeps run per product.  All dense products
+// go through the same fp32 matrix-pipe kernels as above with up to four summed terms.
+struct EwArgs {
+  const float* h;                         // stored activation of the layer
+  const float *a0, *a1, *a2, *a3, *a4, *a5, *a6;
+  float* out;
+  size_t n;
+  int act, mode;
+};
+enum { EW_ACT_T = 0, EW_ACT_CV = 1, EW_GATE_T = 2, EW_GATE_CV = 3 };
+//  EW_ACT_T   out = p a0                                                      h_t from z_t = a0
+//  EW_ACT_CV  out = p a0 + phi'' a1 a2                                        h_cv from z_cv = a0 (null: 0), z_c = a1, z_v = a2
+//  EW_GATE_T  out = p a0 + phi'' a1 a2                                        dz_t from dh_t = a0, z_t = a1, dh = a2
+//  EW_GATE_CV out = p a0 + phi'' (a1 a2 + a3 a4) + (phi''' a3 a1 + phi'' a5) a6
+//             dz_cv from dh_cv = a0, z_v = a1, dh_c = a2, z_c = a3, dh_v = a4, z_cv = a5 (null: 0), dh = a6
+__global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const float h = a.h[i];
+  float p, p2, p3;
+  if (a.act == ACT_TANH) { p = 1.f - h * h; p2 = -2.f * h * p; p3 = p * (6.f * h * h - 2.f); }
+  else { p = h > 0.f ? 1.f : 0.f; p2 = 0.f; p3 = 0.f; }
+  float o;
+  if (a.mode == EW_ACT_T) o = p * a.a0[i];
+  else if (a.mode == EW_ACT_CV || a.mode == EW_GATE_T) o = (a.a0 ? p * a.a0[i] : 0.f) + p2 * a.a1[i] * a.a2[i];
+  else {
+    const float zv = a.a1[i], zc = a.a3[i];
+    o = p * a.a0[i] + p2 * (zv * a.a2[i] + zc * a.a4[i]) + (p3 * zc * zv + (a.a5 ? p2 * a.a5[i] : 0.f)) * a.a6[i];
+  }
+  a.out[i] = o;
+}
+static hipError_t ew(hipStream_t st, int act, int mode, size_t n, const float* h, float* out, const float* a0, const float* a1 = nullptr,
+                     const float* a2 = nullptr, const float* a3 = nullptr, const float* a4 = nullptr, const float* a5 = nullptr,
+                     const float* a6 = nullptr) {
+  EwArgs a{h, a0, a1, a2, a3, a4, a5, a6, out, n, act, mode};
+  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+struct FTerm { const float* x; const float* w; size_t ws; };
+// y = sum_k x_k w_k^T (+ bias): raw pre-activation, no gate
+static hipError_t dense_fwd_n(hipStream_t st, int T, int B, int I, int O, const FTerm* tm, int n, const float* bias, size_t bs, float* y) {
+  DenseArgs a{};
+  for (int k = 0; k < n; ++k) { a.x[k] = tm[k].x; a.w[k] = tm[k].w; a.wstride[k] = tm[k].ws; }
+  a.bias = bias; a.bstride = bs; a.y = y; a.B = B; a.I = I; a.O = O; a.nterms = n; a.act = ACT_NONE;
+  hipLaunchKernelGGL(dense_mfma_kernel<true>, dim3(ceil_div(ceil_div(B, 32) * ceil_div(O, 32), 4), T), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+// dx = sum_k dy_k w_k: raw cotangent w.r.t. the layer input (before any phi' factor)
+static hipError_t dense_bwd_x_n(hipStream_t st, int T, int B, int I, int O, const FTerm* tm, int n, float* dx) {
+  DenseArgs a{};
+  for (int k = 0; k < n; ++k) { a.x[k] = tm[k].x; a.w[k] = tm[k].w; a.wstride[k] = tm[k].ws; }
+  a.y = dx; a.B = B; a.I = I; a.O = O; a.nterms = n; a.act = ACT_NONE;
+  hipLaunchKernelGGL(dense_mfma_kernel<false>, dim3(ceil_div(ceil_div(B, 32) * ceil_div(I, 32), 4), T), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+struct WTerm { const float* dy; const float* x; };
+static hipError_t dense_bwd_w_n(hipStream_t st, int T, int B, int I, int O, const WTerm* tm, int n, float* dw, float* db, size_t gs) {
+  DenseWArgs a{};
+  for (int k = 0; k < n; ++k) { a.dy[k] = tm[k].dy; a.x[k] = tm[k].x; }
+  a.dw = dw; a.db = db; a.gstride = gs; a.B = B; a.I = I; a.O = O; a.nterms = n;
+  hipLaunchKernelGGL(dense_wgrad_mfma_kernel, dim3(ceil_div(O, 32) * ceil_div(I + 1, 32), T), dim3(512), 0, st, a);
+  return hipGetLastError();
+}
+
+struct GaussKlArgs {
+  const float* mu;        // [T][B][A] policy mean on this pass
+  const float* rho; size_t rstride;        // log-sigma parameter
+  const float* old_loc; const float* old_scale;      // KL modes
+  const float* mud;       // KL_HESS: tangent of mu;  TAN2: mixed tangent mu_cv
+  const float* rhod; size_t vstride;                 // KL_HESS: tangent of rho
+  const float *muc, *muv;                            // TAN2: first tangents of mu
+  const float* rhoc; size_t cstride;                 // TAN2: c-direction of rho
+  const float* rhov; size_t vvstride;                // TAN2: v-direction of rho
+  const float* act; const float* coef;               // TAN2: actions, dL/dlogp per sample
+  const int32_t* count;
+  float* dmu; float* drho; size_t gstride;
+  int B, A, mode;
+};
+enum { KL_GRAD = 0, KL_HESS = 1, G_TAN2 = 2 };
+// One workgroup per task.
+//  KL_GRAD  cotangent of mean KL(new || old):       dmu = (mu - mu_old) / (B D s_old^2),   drho = (vr - 1) / D,  vr = (s / s_old)^2
+//  KL_HESS  its exact output Hessian times (mud, rhod):  dmu = mud / (B D s_old^2),        drho = 2 vr rhod / D
+//  G_TAN2   second tangent of the A2C log-prob cotangents (kappa = coef / D, d = a - mu, iv = exp(-2 rho)):
+//           R_cv{g_mu}  = kappa [ -mu_cv iv + 2 iv (mu_c rho_v + mu_v rho_c) + 4 d iv rho_c rho_v ]
+//           R_cv{g_rho} = kappa [ 2 mu_c mu_v iv - 2 d mu_cv iv + 4 d iv (mu_c rho_v + mu_v rho_c) + 4 d^2 iv rho_c rho_v ]
+__global__ __launch_bounds__(256) void gauss_kl_kernel(GaussKlArgs a) {
+  __shared__ float red[256];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int B = a.B, A = a.A, cnt = a.count ? a.count[t] : B;
+  const float invB = 1.f / (float)cnt, invD = 1.f / (float)A;
+  float acc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[k] = 0.f;
+  for (int b = tid; b < B; b += 256) {
+    const bool valid = b < cnt;
+    const size_t ob = (size_t)t * B + b;
+    for (int d = 0; d < A; ++d) {
+      const float rp = a.rho[(size_t)t * a.rstride + d];
+      const bool live = rp > LOG_EPS;
+      const float r = fmaxf(rp, LOG_EPS);
+      if (a.mode == G_TAN2) {
+        const float iv = expf(-2.f * r);
+        const float kap = valid ? a.coef[ob] * invD : 0.f;
+        const float df = a.act[ob * A + d] - a.mu[ob * A + d];
+        const float mc = a.muc[ob * A + d], mv = a.muv[ob * A + d], mcv = a.mud[ob * A + d];
+        const float rc = live ? a.rhoc[(size_t)t * a.cstride + d] : 0.f, rv = live ? a.rhov[(size_t)t * a.vvstride + d] : 0.f;
+        a.dmu[ob * A + d] = kap * (-mcv * iv + 2.f * iv * (mc * rv + mv * rc) + 4.f * df * iv * rc * rv);
+        if (live) acc[d] += kap * (2.f * mc * mv * iv - 2.f * df * mcv * iv + 4.f * df * iv * (mc * rv + mv * rc) + 4.f * df * df * iv * rc * rv);
+      } else {
+        const float so = a.old_scale[(size_t)t * A + d];
+        const float w = valid ? invB * invD / (so * so) : 0.f;
+        a.dmu[ob * A + d] = a.mode == KL_GRAD ? w * (a.mu[ob * A + d] - a.old_loc[ob * A + d]) : w * a.mud[ob * A + d];
+      }
+    }
+  }
+  for (int k = 0; k < A; ++k) {
+    float v;
+    if (a.mode == G_TAN2) {
+      red[tid] = acc[k];
+      __syncthreads();
+      for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+      }
+      v = red[0];
+      __syncthreads();
+    } else {
+      const float rp = a.rho[(size_t)t * a.rstride + k];
+      const float sg = expf(fmaxf(rp, LOG_EPS)), so = a.old_scale[(size_t)t * A + k], vr = (sg / so) * (sg / so);
+      v = rp > LOG_EPS ? (a.mode == KL_GRAD ? (vr - 1.f) * invD : 2.f * vr * a.rhod[(size_t)t * a.vstride + k] * invD) : 0.f;
+    }
+    if (tid == 0 && a.drho) a.drho[(size_t)t * a.gstride + k] = v;
+  }
+}
+
+struct TanSweep { float *z1, *h1, *z2, *h2, *mu, *rdmu, *dh2, *dz2, *dh1, *dz1; };
+struct GenPlan {
+  float *k_dmu, *k_d2, *k_d1, *k_pre2, *k_pre1;      // KL primal cotangents on the query pass at theta'
+  float* c;                                           // [T][P] grad KL_t(theta'_t)
+  TanSweep sc, sv;                                    // c-tangent (context) and v-tangent (per product) sweeps over the support pass
+  float *hcv1, *zcv2, *hcv2, *mucv, *rdmu_cv, *dh2cv, *dz2cv, *dh1cv, *dz1cv;
+  float *s3, *scr;                                    // [T][P]: third-order term, scratch
+  size_t bytes;
+};
+static void gen_plan(const mi_policy* p, void* ws, int T, int B, TrpoPlan& pl, GenPlan& gp) {
+  trpo_plan(p, ws, T, B, pl);
+  PBump b{reinterpret_cast<char*>(ws), pl.bytes};
+  const size_t TB = (size_t)T * B, TP = (size_t)T * p->P;
+  gp.k_dmu = b.f(TB * p->A); gp.k_d2 = b.f(TB * p->H2); gp.k_d1 = b.f(TB * p->H1); gp.k_pre2 = b.f(TB * p->H2); gp.k_pre1 = b.f(TB * p->H1);
+  gp.c = b.f(TP);
+  auto sweep = [&](TanSweep& s) {
+    s.z1 = b.f(TB * p->H1); s.h1 = b.f(TB * p->H1); s.z2 = b.f(TB * p->H2); s.h2 = b.f(TB * p->H2); s.mu = b.f(TB * p->A);
+    s.rdmu = b.f(TB * p->A); s.dh2 = b.f(TB * p->H2); s.dz2 = b.f(TB * p->H2); s.dh1 = b.f(TB * p->H1); s.dz1 = b.f(TB * p->H1);
+  };
+  sweep(gp.sc); sweep(gp.sv);
+  gp.hcv1 = b.f(TB * p->H1); gp.zcv2 = b.f(TB * p->H2); gp.hcv2 = b.f(TB * p->H2); gp.mucv = b.f(TB * p->A); gp.rdmu_cv = b.f(TB * p->A);
+  gp.dh2cv = b.f(TB * p->H2); gp.dz2cv = b.f(TB * p->H2); gp.dh1cv = b.f(TB * p->H1); gp.dz1cv = b.f(TB * p->H1);
+  gp.s3 = b.f(TP); gp.scr = b.f(TP);
+  gp.bytes = align_up(b.off, 256);
+}
+extern "C" int mi_trpo_general_workspace_bytes(const mi_policy* p, int tasks, int batch, size_t* bytes) {
+  if (!p || !bytes || tasks < 1 || batch < 1) return MI_ERR_ARG;
+  TrpoPlan pl; GenPlan gp;
+  gen_plan(p, nullptr, tasks, batch, pl, gp);
+  *bytes = gp.bytes;
+  return MI_OK;
+}
+
+// First-order tangent sweep over the cached support pass at theta (shared) along direction d (stride ds floats per task, 0 = one
+// direction for all tasks), keeping the pre-activation tangents the mixed sweep needs.
+static int tan_sweep(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B, const float* theta, const float* xs, const float* as,
+                     const int32_t* cn, const float* d, size_t ds, TanSweep& s, float* drho_scratch) {
+  const size_t TB = (size_t)T * B;
+  { FTerm tm[1] = {{xs, d + p->o_w1, ds}};
+    PCHK(p, dense_fwd_n(st, T, B, p->S, p->H1, tm, 1, d + p->o_b1, ds, s.z1)); }
+  PCHK(p, ew(st, p->act, EW_ACT_T, TB * p->H1, pl.sa.h1, s.h1, s.z1));
+  { FTerm tm[2] = {{pl.sa.h1, d + p->o_w2, ds}, {s.h1, theta + p->o_w2, 0}};
+    PCHK(p, dense_fwd_n(st, T, B, p->H1, p->H2, tm, 2, d + p->o_b2, ds, s.z2)); }
+  PCHK(p, ew(st, p->act, EW_ACT_T, TB * p->H2, pl.sa.h2, s.h2, s.z2));
+  { FTerm tm[2] = {{pl.sa.h2, d + p->o_w3, ds}, {s.h2, theta + p->o_w3, 0}};
+    PCHK(p, dense_fwd_n(st, T, B, p->H2, p->A, tm, 2, d + p->o_b3, ds, s.mu)); }
+  GaussArgs ga{};
+  ga.mu = pl.sa.mu; ga.mud = s.mu; ga.rho = theta + p->o_sigma; ga.rstride = 0; ga.rhod = d + p->o_sigma; ga.vstride = ds;
+  ga.act = as; ga.count = cn; ga.coef = pl.s_coef; ga.dmu = s.rdmu; ga.drho = drho_scratch + p->o_sigma; ga.gstride = p->P;
+  ga.B = B; ga.A = p->A; ga.mode = G_TANGENT;
+  PCHK(p, gauss(st, T, ga));
+  { FTerm tm[2] = {{s.rdmu, theta + p->o_w3, 0}, {pl.s_dmu, d + p->o_w3, ds}};
+    PCHK(p, dense_bwd_x_n(st, T, B, p->H2, p->A, tm, 2, s.dh2)); }
+  PCHK(p, ew(st, p->act, EW_GATE_T, TB * p->H2, pl.sa.h2, s.dz2, s.dh2, s.z2, pl.s_pre2));
+  { FTerm tm[2] = {{s.dz2, theta + p->o_w2, 0}, {pl.s_d2, d + p->o_w2, ds}};
+    PCHK(p, dense_bwd_x_n(st, T, B, p->H1, p->H2, tm, 2, s.dh1)); }
+  PCHK(p, ew(st, p->act, EW_GATE_T, TB * p->H1, pl.sa.h1, s.dz1, s.dh1, s.z1, pl.s_pre1));
+  return MI_OK;
+}
+
+// After mi_trpo_surrogate(theta, ...) on the same workspace: the KL cotangent pass on the query replay (c_t = grad KL_t at theta'_t)
+// and the c-tangent sweep over the support pass.  kl_grad_out (optional, [P]) = d mean_t KL_t / d theta = mean_t (I - lr H_t) c_t.
+extern "C" int mi_trpo_kl_prepare(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
+                                  const int32_t* s_count, const float* q_states, const int32_t* q_count, const float* old_loc,
+                                  const float* old_scale, int tasks, int batch, float inner_lr, float* kl_grad_out, void* workspace,
+                                  size_t workspace_bytes) {
+  if (!p || !theta || !s_states || !s_actions || !q_states || !old_loc || !old_scale || !workspace) return pfail(p, MI_ERR_ARG, "null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int T = tasks, B = batch;
+  const size_t P = p->P;
+  TrpoPlan pl; GenPlan gp;
+  gen_plan(p, workspace, T, B, pl, gp);
+  if (gp.bytes > workspace_bytes) return pfail(p, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(gp.bytes));
+  PCHK(p, hipMemsetAsync(gp.c, 0, (size_t)T * P * sizeof(float), st));
+  GaussKlArgs gk{};
+  gk.mu = pl.qa.mu; gk.rho = pl.thetap + p->o_sigma; gk.rstride = P; gk.old_loc = old_loc; gk.old_scale = old_scale; gk.count = q_count;
+  gk.dmu = gp.k_dmu; gk.drho = gp.c + p->o_sigma; gk.gstride = P; gk.B = B; gk.A = p->A; gk.mode = KL_GRAD;
+  hipLaunchKernelGGL(gauss_kl_kernel, dim3(T), dim3(256), 0, st, gk);
+  PCHK(p, hipGetLastError());
+  int rc = mlp_backward(p, st, T, B, q_states, pl.thetap, P, pl.qa, gp.k_dmu, gp.k_d2, gp.k_d1, gp.c, gp.k_pre2, gp.k_pre1);
+  if (rc) return rc;
+  rc = tan_sweep(p, st, pl, T, B, theta, s_states, s_actions, s_count, gp.c, P, gp.sc, gp.scr);
+  if (rc || !kl_grad_out) return rc;
+  rc = support_hvp(p, st, pl, T, B, theta, s_states, s_actions, s_count, gp.c, pl.hv);
+  if (rc) return rc;
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, gp.c, P, pl.hv, inner_lr, (int)P, pl.tmpP);
+  hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, pl.tmpP, T, (int)P, 1.f / (float)T,
+                     (const float*)nullptr, 0.f, kl_grad_out);
+  PCHK(p, hipGetLastError());
+  return MI_OK;
+}
+
+// trpo.hessian_vector_product(mean KL, params, damping)(v) (rl.py:417) at the parameters of the preceding mi_trpo_surrogate +
+// mi_trpo_kl_prepare on this workspace, exact for new != old (ANIL-TRPO, rl/anil_trpo.py:129).
+extern "C" int mi_trpo_fvp_general(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
+                                   const int32_t* s_count, const float* q_states, const int32_t* q_count, const float* old_scale,
+                                   int tasks, int batch, float inner_lr, float damping, const float* v, float* out, void* workspace,
+                                   size_t workspace_bytes) {
+  if (!p || !theta || !s_states || !s_actions || !q_states || !old_scale || !v || !out || !workspace) return pfail(p, MI_ERR_ARG, "null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int T = tasks, B = batch;
+  const size_t P = p->P, TB = (size_t)T * B;
+  TrpoPlan pl; GenPlan gp;
+  gen_plan(p, workspace, T, B, pl, gp);
+  if (gp.bytes > workspace_bytes) return pfail(p, MI_ERR_WORKSPACE, "workspace too small");
+  // ---- u_t = J_t v
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, v, (size_t)0, pl.tmpP, 0.f, (int)P, pl.u);
+  PCHK(p, hipGetLastError());
+  int rc = support_hvp(p, st, pl, T, B, theta, s_states, s_actions, s_count, pl.u, pl.hv);
+  if (rc) return rc;
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.u, P, pl.hv, inner_lr, (int)P, pl.u);
+  PCHK(p, hipGetLastError());
+  // ---- w_t = Hess KL_t(theta'_t) u_t: tangent forward on the query pass, exact output Hessian, tangent backward
+  rc = mlp_tangent_forward(p, st, T, B, q_states, pl.thetap, P, pl.qa, pl.u, pl.ta);
+  if (rc) return rc;
+  PCHK(p, hipMemsetAsync(pl.w, 0, (size_t)T * P * sizeof(float), st));
+  GaussKlArgs gh{};
+  gh.mu = pl.qa.mu; gh.rho = pl.thetap + p->o_sigma; gh.rstride = P; gh.old_scale = old_scale; gh.mud = pl.ta.mu;
+  gh.rhod = pl.u + p->o_sigma; gh.vstride = P; gh.count = q_count; gh.dmu = pl.rdmu; gh.drho = pl.w + p->o_sigma; gh.gstride = P;
+  gh.B = B; gh.A = p->A; gh.mode = KL_HESS;
+  hipLaunchKernelGGL(gauss_kl_kernel, dim3(T), dim3(256), 0, st, gh);
+  PCHK(p, hipGetLastError());
+  rc = mlp_tangent_backward(p, st, T, B, q_states, pl.thetap, P, pl.qa, pl.ta, pl.u, gp.k_dmu, gp.k_d2, gp.k_d1, gp.k_pre2, gp.k_pre1,
+                            pl.rdmu, pl.r2, pl.r1, pl.w);
+  if (rc) return rc;
+  // ---- r_t = J_t^T w_t  (left in pl.w)
+  rc = support_hvp(p, st, pl, T, B, theta, s_states, s_actions, s_count, pl.w, pl.hv);
+  if (rc) return rc;
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.w, P, pl.hv, inner_lr, (int)P, pl.w);
+  PCHK(p, hipGetLastError());
+  // ---- s3_t = T_t[v, c_t]: v-tangent sweep, then the mixed sweep
+  rc = tan_sweep(p, st, pl, T, B, theta, s_states, s_actions, s_count, v, 0, gp.sv, gp.scr);
+  if (rc) return rc;
+  const TanSweep &C = gp.sc, &V = gp.sv;
+  const float* c = gp.c;
+  PCHK(p, hipMemsetAsync(gp.s3, 0, (size_t)T * P * sizeof(float), st));
+  PCHK(p, ew(st, p->act, EW_ACT_CV, TB * p->H1, pl.sa.h1, gp.hcv1, nullptr, C.z1, V.z1));
+  { FTerm tm[3] = {{V.h1, c + p->o_w2, P}, {C.h1, v + p->o_w2, 0}, {gp.hcv1, theta + p->o_w2, 0}};
+    PCHK(p, dense_fwd_n(st, T, B, p->H1, p->H2, tm, 3, nullptr, 0, gp.zcv2)); }
+  PCHK(p, ew(st, p->act, EW_ACT_CV, TB * p->H2, pl.sa.h2, gp.hcv2, gp.zcv2, C.z2, V.z2));
+  { FTerm tm[3] = {{V.h2, c + p->o_w3, P}, {C.h2, v + p->o_w3, 0}, {gp.hcv2, theta + p->o_w3, 0}};
+    PCHK(p, dense_fwd_n(st, T, B, p->H2, p->A, tm, 3, nullptr, 0, gp.mucv)); }
+  GaussKlArgs g2{};
+  g2.mu = pl.sa.mu; g2.rho = theta + p->o_sigma; g2.rstride = 0; g2.mud = gp.mucv; g2.muc = C.mu; g2.muv = V.mu;
+  g2.rhoc = c + p->o_sigma; g2.cstride = P; g2.rhov = v + p->o_sigma; g2.vvstride = 0; g2.act = s_actions; g2.coef = pl.s_coef;
+  g2.count = s_count; g2.dmu = gp.rdmu_cv; g2.drho = gp.s3 + p->o_sigma; g2.gstride = P; g2.B = B; g2.A = p->A; g2.mode = G_TAN2;
+  hipLaunchKernelGGL(gauss_kl_kernel, dim3(T), dim3(256), 0, st, g2);
+  PCHK(p, hipGetLastError());
+  { WTerm tm[4] = {{gp.rdmu_cv, pl.sa.h2}, {C.rdmu, V.h2}, {V.rdmu, C.h2}, {pl.s_dmu, gp.hcv2}};
+    PCHK(p, dense_bwd_w_n(st, T, B, p->H2, p->A, tm, 4, gp.s3 + p->o_w3, gp.s3 + p->o_b3, P)); }
+  { FTerm tm[3] = {{gp.rdmu_cv, theta + p->o_w3, 0}, {C.rdmu, v + p->o_w3, 0}, {V.rdmu, c + p->o_w3, P}};
+    PCHK(p, dense_bwd_x_n(st, T, B, p->H2, p->A, tm, 3, gp.dh2cv)); }
+  PCHK(p, ew(st, p->act, EW_GATE_CV, TB * p->H2, pl.sa.h2, gp.dz2cv, gp.dh2cv, V.z2, C.dh2, C.z2, V.dh2, gp.zcv2, pl.s_pre2));
+  { WTerm tm[4] = {{gp.dz2cv, pl.sa.h1}, {C.dz2, V.h1}, {V.dz2, C.h1}, {pl.s_d2, gp.hcv1}};
+    PCHK(p, dense_bwd_w_n(st, T, B, p->H1, p->H2, tm, 4, gp.s3 + p->o_w2, gp.s3 + p->o_b2, P)); }
+  { FTerm tm[3] = {{gp.dz2cv, theta + p->o_w2, 0}, {C.dz2, v + p->o_w2, 0}, {V.dz2, c + p->o_w2, P}};
+    PCHK(p, dense_bwd_x_n(st, T, B, p->H1, p->H2, tm, 3, gp.dh1cv)); }
+  PCHK(p, ew(st, p->act, EW_GATE_CV, TB * p->H1, pl.sa.h1, gp.dz1cv, gp.dh1cv, V.z1, C.dh1, C.z1, V.dh1, nullptr, pl.s_pre1));
+  { WTerm tm[1] = {{gp.dz1cv, s_states}};
+    PCHK(p, dense_bwd_w_n(st, T, B, p->S, p->H1, tm, 1, gp.s3 + p->o_w1, gp.s3 + p->o_b1, P)); }
+  // ---- out = mean_t (r_t - lr s3_t) + damping v
+  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.w, P, gp.s3, inner_lr, (int)P, pl.tmpP);
+  hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, pl.tmpP, T, (int)P, 1.f / (float)T, v, damping, out);
   PCHK(p, hipGetLastError());
   return MI_OK;
 }

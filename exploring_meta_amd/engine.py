@@ -352,8 +352,10 @@ class PolicyEngine:
             raise _lib.MiError(f'libmi_maml policy error {rc}: {self.lib.mi_policy_last_error(self._h).decode()}')
 
     def _workspace(self, T, B):
+        # the general (ANIL-TRPO) plan is a superset of the MAML-TRPO one with the same prefix: one buffer serves both, and a
+        # kl_prepare after surrogate finds the surrogate's cached passes where it left them
         b = C.c_size_t()
-        self._check(self.lib.mi_trpo_workspace_bytes(self._h, T, B, C.byref(b)))
+        self._check(self.lib.mi_trpo_general_workspace_bytes(self._h, T, B, C.byref(b)))
         if self._ws is None or self._ws.numel() < b.value:
             self._ws = torch.empty(b.value, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -457,6 +459,29 @@ class PolicyEngine:
             _ptr(qry['count'].contiguous()), T, B, kind, float(clip), float(inner_lr), int(head_only), int(not first_order),
             int(with_grad), _ptr(loss_t), _ptr(theta_out), _ptr(grad), _ptr(self._ws), self._ws.numel()))
         return loss_t, theta_out, grad
+
+    @_on_device
+    def kl_prepare(self, theta, sup, qry, old_loc, old_scale, inner_lr, want_grad=False):
+        """After ``surrogate`` at the same theta: the context of the exact KL Hessian-vector product for new != old (ANIL-TRPO).
+        Returns d mean KL / d theta [P] if ``want_grad``."""
+        T, B = sup['states'].shape[0], sup['states'].shape[1]
+        ws = self._workspace(T, B)
+        grad = torch.empty(self.param_count, device=self.device) if want_grad else None
+        self._check(self.lib.mi_trpo_kl_prepare(self._h, _stream(self.device), _ptr(theta), _ptr(sup['states']), _ptr(sup['actions']),
+                                                _ptr(sup['count']), _ptr(qry['states']), _ptr(qry['count']), _ptr(old_loc),
+                                                _ptr(old_scale), T, B, float(inner_lr), _ptr(grad), _ptr(ws), ws.numel()))
+        return grad
+
+    @_on_device
+    def fvp_general(self, theta, sup, qry, old_scale, inner_lr, damping, v):
+        """Exact Hessian-vector product of the mean KL at the theta of the preceding ``surrogate`` + ``kl_prepare`` calls."""
+        T, B = sup['states'].shape[0], sup['states'].shape[1]
+        ws = self._workspace(T, B)
+        out = torch.empty(self.param_count, device=self.device)
+        self._check(self.lib.mi_trpo_fvp_general(self._h, _stream(self.device), _ptr(theta), _ptr(sup['states']), _ptr(sup['actions']),
+                                                 _ptr(sup['count']), _ptr(qry['states']), _ptr(qry['count']), _ptr(old_scale), T, B,
+                                                 float(inner_lr), float(damping), _ptr(v.contiguous()), _ptr(out), _ptr(ws), ws.numel()))
+        return out
 
     @_on_device
     def fvp(self, theta, sup, qry, inner_lr, damping, v):

@@ -17,7 +17,8 @@ from copy import deepcopy
 import numpy as np
 import torch
 
-from ..core_functions import (DiagNormalPolicy, LinearValue, Particles2DRunner, fast_adapt_trpo, meta_optimize_trpo, set_device)
+from ..core_functions import (DiagNormalPolicy, DiagNormalPolicyANIL, LinearValue, Particles2DRunner, fast_adapt_trpo, meta_optimize_trpo,
+                              set_device)
 from ..sharding import shard_range
 
 params = {
@@ -27,7 +28,7 @@ params = {
 }
 
 
-def run(p, log=print):
+def run(p, log=print, anil=False):
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
     torch.cuda.set_device(local)
     if world > 1:
@@ -38,7 +39,8 @@ def run(p, log=print):
     rng = np.random.RandomState(p['seed'])
     gen = torch.Generator(device=dev).manual_seed(p['seed'] + rank)
     baseline = LinearValue(2, 2)                      # reference passes env.action_size as the ridge coefficient (:85)
-    policy = DiagNormalPolicy(2, 2).to(dev)
+    # anil: rl/anil_trpo.py:85 -- tanh body + linear head, inner updates with the body under no_grad (rl.py:381-382)
+    policy = (DiagNormalPolicyANIL(2, 2, p.get('fc_neurons', 100)) if anil else DiagNormalPolicy(2, 2)).to(dev)
     lo, hi = shard_range(p['meta_batch_size'], rank, world)
     for it in range(p['num_iterations']):
         goals = rng.uniform(-0.5, 0.5, size=(p['meta_batch_size'], 2))        # env.sample_tasks: identical on every rank
@@ -46,12 +48,12 @@ def run(p, log=print):
         for goal in goals[lo:hi]:
             learner = deepcopy(policy)
             task = Particles2DRunner(goal, p['max_path_length'], gen, dev)
-            learner, eval_loss, task_replay, task_rew, _ = fast_adapt_trpo(task, learner, baseline, p, first_order=True)
+            learner, eval_loss, task_replay, task_rew, _ = fast_adapt_trpo(task, learner, baseline, p, anil=anil, first_order=True)
             iter_reward += task_rew
             iter_loss += eval_loss.item()
             iter_replays.append(task_replay)
             iter_policies.append(learner)
-        out = meta_optimize_trpo(p, policy, baseline, iter_replays, iter_policies)
+        out = meta_optimize_trpo(p, policy, baseline, iter_replays, iter_policies, anil=anil)
         if rank == 0:
             log(f'iter {it}: average_return {iter_reward / (hi - lo):.3f} loss {iter_loss / (hi - lo):.4f} '
                 f'line-search step {out["accepted"]}')
@@ -64,7 +66,8 @@ if __name__ == '__main__':
     parser = argparse.ArgumentParser(description='MAML-TRPO on Particles2D (MI355X engine)')
     for k, v in params.items():
         parser.add_argument(f'--{k}', type=type(v), default=v)
+    parser.add_argument('--anil', action='store_true', help='ANIL-TRPO (reference rl/anil_trpo.py): DiagNormalPolicyANIL, head-only inner loop')
     args = parser.parse_args()
     for k in params:
         params[k] = getattr(args, k)
-    run(params)
+    run(params, anil=args.anil)

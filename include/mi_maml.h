@@ -314,6 +314,25 @@ int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const float* s_s
                 const int32_t* s_count, const float* q_states, const int32_t* q_count, int tasks, int batch, float inner_lr,
                 float damping, const float* v, float* out, void* workspace, size_t workspace_bytes);
 
+/* ANIL-TRPO (rl/anil_trpo.py:104-129, core_functions/rl.py:409-473 with anil=True): the stored old policies were adapted with
+ * the body under no_grad (rl.py:381-382) while meta_surrogate_loss re-adapts clone_module(policy) with every parameter
+ * (rl.py:447-453), so at the current parameters new != old and trpo.hessian_vector_product(kl) (rl.py:417) is the EXACT Hessian
+ * of the mean KL:  mean_t [ J_t^T Hess KL_t(theta'_t) J_t v - lr T_t[v, grad KL_t(theta'_t)] ] + damping v,  T_t = the third
+ * derivative of the inner loss (second-order tangent sweep, policy.hip).
+ *   mi_trpo_general_workspace_bytes: workspace for the three calls below (a superset of mi_trpo_workspace_bytes; use it for
+ *     mi_trpo_surrogate as well).
+ *   mi_trpo_kl_prepare: after mi_trpo_surrogate(theta, ...) on the same workspace; kl_grad_out (or NULL) [P] = d mean KL / d theta.
+ *   mi_trpo_fvp_general: the product, any number of times after the two calls above. */
+int mi_trpo_general_workspace_bytes(const mi_policy* p, int tasks, int batch, size_t* bytes);
+int mi_trpo_kl_prepare(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
+                       const int32_t* s_count, const float* q_states, const int32_t* q_count, const float* old_loc,
+                       const float* old_scale, int tasks, int batch, float inner_lr, float* kl_grad_out, void* workspace,
+                       size_t workspace_bytes);
+int mi_trpo_fvp_general(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
+                        const int32_t* s_count, const float* q_states, const int32_t* q_count, const float* old_scale, int tasks,
+                        int batch, float inner_lr, float damping, const float* v, float* out, void* workspace,
+                        size_t workspace_bytes);
+
 /* MAML inner loop of the policy with K updates and the VPG / PPO losses, all tasks per call (core_functions/rl.py:
  * fast_adapt_vpg :231-255 with vpg_a2c_loss :209-228 (dice=False), fast_adapt_ppo :267-318; drivers rl/maml_ppo.py, anil_ppo.py).
  *   theta_{k+1} = theta_k - inner_lr * grad L_k(theta_k), k < steps; update k replays support batch step_batch[k] (host array):

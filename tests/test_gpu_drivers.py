@@ -38,6 +38,16 @@ def test_maml_trpo_driver_runs():
     assert len(logs) == 2 and all(torch.isfinite(q).all() for q in policy.parameters())
 
 
+def test_anil_trpo_driver_runs():
+    """rl/anil_trpo.py counterpart: DiagNormalPolicyANIL, head-only inner loop, meta_optimize_trpo(anil=True) on the exact KL Hessian."""
+    from exploring_meta_amd.rl import anil_trpo
+    p = dict(anil_trpo.params, meta_batch_size=3, adapt_batch_size=4, max_path_length=20, num_iterations=2)
+    logs = []
+    policy = anil_trpo.run(p, log=logs.append)
+    assert len(logs) == 2 and all(torch.isfinite(q).all() for q in policy.parameters())
+    assert type(policy).__name__ == 'DiagNormalPolicyANIL'
+
+
 def test_anil_vision_driver_trains():
     from exploring_meta_amd.vision import anil_vision
     p = dict(anil_vision.params, ways=5, shots=1, adapt_steps=2, meta_batch_size=4, num_iterations=3, inner_lr=0.1)

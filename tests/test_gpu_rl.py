@@ -168,16 +168,16 @@ def _policy_tanh(theta):
     return pol.cuda()
 
 
-def _replays_tanh(anil=False):
+def _replays_tanh(anil=False, params=PARAMS):
     env = RL.Particles2D(seed=1)
     gen = torch.Generator().manual_seed(2)
     theta = _theta64_tanh()
     baseline = RL.LinearValue(2, 2)
     replays, olds = [], []
-    for task in env.sample_tasks(PARAMS['meta_batch_size']):
+    for task in env.sample_tasks(params['meta_batch_size']):
         env.set_task(task)
         learner = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
-        adapted, _, rep, _ = RL.fast_adapt_trpo(env, learner, baseline, PARAMS, gen, first_order=True, activation=torch.tanh, anil=anil)
+        adapted, _, rep, _ = RL.fast_adapt_trpo(env, learner, baseline, params, gen, first_order=True, activation=torch.tanh, anil=anil)
         replays.append(rep)
         olds.append(OrderedDict((k, v.detach()) for k, v in adapted.items()))
     return theta, replays, olds
@@ -218,8 +218,110 @@ def test_anil_trpo_update_moves_only_head_and_sigma():
         assert rel_err(d, dref) < 1e-4
         body = slice(2, 2 + 100 * 2 + 100 + 100 * 100 + 100)                 # W1, b1, W2, b2 in the engine's flat order
         assert np.all(d[body] == 0.0) and np.all(dref[body] == 0.0) and np.abs(d[:2]).max() > 0
-    with pytest.raises(NotImplementedError):
-        cf.meta_optimize_trpo(PARAMS, pol, cf.LinearValue(2, 2), replays, [pol] * len(replays), anil=True)
+
+
+def _anil_policy(theta):
+    raw = OrderedDict((ka, v) for ka, (k, v) in zip(RL.anil_policy_param_shapes().keys(), theta.items()))
+    pol = cf.DiagNormalPolicyANIL(2, 2, 100)
+    with torch.no_grad():
+        for k, p in pol.named_parameters():
+            p.copy_(raw[k].float())
+    return pol.cuda()
+
+
+@pytest.mark.parametrize('act', ['tanh', 'relu'])
+def test_general_kl_hvp_matches_autograd(act):
+    """ANIL-TRPO (rl/anil_trpo.py:129, rl.py:409-473 with anil=True): the old policies were adapted head-only, the surrogate
+    re-adapts every parameter, so new != old and trpo.hessian_vector_product(kl) is the exact Hessian of the mean KL --
+    J^T Hess KL J v - lr T[v, grad KL] with the third derivative of the inner loss (mi_trpo_kl_prepare / mi_trpo_fvp_general).
+    Checked against double-backward autograd of the oracle's meta_surrogate_loss: the KL value, its gradient and Hessian-vector
+    products along a random and a structured direction."""
+    activation = torch.tanh if act == 'tanh' else torch.relu
+    if act == 'tanh':
+        theta, replays, olds = _replays_tanh(anil=True)
+    else:                                        # ReLU body with head-only old policies: phi'' = 0, the other third-order paths remain
+        env, gen, theta, baseline = RL.Particles2D(seed=1), torch.Generator().manual_seed(2), _theta64(), RL.LinearValue(2, 2)
+        replays, olds = [], []
+        for task in env.sample_tasks(PARAMS['meta_batch_size']):
+            env.set_task(task)
+            learner = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+            adapted, _, rep, _ = RL.fast_adapt_trpo(env, learner, baseline, PARAMS, gen, first_order=True, anil=True)
+            replays.append(rep)
+            olds.append(OrderedDict((k, v.detach()) for k, v in adapted.items()))
+    p64 = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+    loss, kl = RL.meta_surrogate_loss(replays, olds, p64, RL.LinearValue(2, 2), PARAMS, activation=activation)
+    plist = list(p64.values())
+    assert float(kl) > 1e-6                                                # new != old: this is not the Fisher case
+    gkl = torch.cat([g.reshape(-1) for g in torch.autograd.grad(kl, plist, retain_graph=True)])
+    Hvp = RL.hessian_vector_product(kl, plist)
+    gen = torch.Generator().manual_seed(5)
+    vs = [torch.randn(gkl.shape, generator=gen, dtype=torch.float64), gkl / gkl.norm()]
+    refs = [Hvp(v).detach() for v in vs]
+
+    pol = _policy_tanh(theta) if act == 'tanh' else _policy(theta)
+    old_pols = [(_policy_tanh(o) if act == 'tanh' else _policy(o)) for o in olds]
+    from exploring_meta_amd.core_functions.rl import _SurrogateContext
+    ctx = _SurrogateContext(replays, old_pols, pol, cf.LinearValue(2, 2), PARAMS)
+    th = pol.flat()
+    l32, k32, _ = ctx.evaluate(th, want_grad=True)
+    g32 = ctx.engine.kl_prepare(th, ctx.sup, ctx.qry, ctx.old_loc, ctx.old_scale, ctx.inner_lr, want_grad=True)
+    ctx.general = True
+    errs = [rel_err(ctx.fvp(th, v.float().cuda()).cpu().numpy(), r.numpy()) for v, r in zip(vs, refs)]
+    # the Fisher form (valid only at new == old) must NOT reproduce these products: the third-order and cotangent terms matter
+    ctx.general = False
+    fisher_err = rel_err(ctx.fvp(th, vs[0].float().cuda()).cpu().numpy(), refs[0].numpy())
+    torch.cuda.synchronize()
+    eg = rel_err(g32.cpu().numpy(), gkl.detach().numpy())
+    report(f'general_kl_hvp[{act}]', kl=float(k32), kl_ref=float(kl), kl_grad_rel=eg, hvp_rel=errs, fisher_form_rel=fisher_err)
+    assert abs(float(k32) - float(kl)) < 1e-5 * max(float(kl), 1e-3)
+    assert eg < 1e-4
+    assert max(errs) < 1e-3
+    assert fisher_err > 10 * max(errs)
+
+
+def test_meta_optimize_anil_trpo_matches_oracle():
+    """One whole ANIL-TRPO meta-optimisation (conjugate gradient on the exact KL Hessian, line search) against the oracle."""
+    # inner_lr as in rl/anil_trpo.py:22.  (At the larger MAML-TRPO step the re-adapted policies sit far from the stored ones, the
+    # exact KL Hessian is indefinite, and the reference's own step is NaN: sqrt of a negative s.Hs -- no update either way.)
+    P = dict(PARAMS, inner_lr=0.01)
+    theta, replays, olds = _replays_tanh(anil=True, params=P)
+    p64 = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+    ref = RL.meta_optimize_trpo(P, p64, RL.LinearValue(2, 2), replays, olds, activation=torch.tanh)
+    assert ref['accepted'] is not None
+    pol = _anil_policy(theta)
+    old_pols = [_anil_policy(o) for o in olds]
+    out = cf.meta_optimize_trpo(P, pol, cf.LinearValue(2, 2), replays, old_pols, anil=True)
+    es = rel_err(out['step'].cpu().numpy(), ref['step'].numpy())
+    et = rel_err(pol.flat().cpu().numpy(), torch.cat([v.detach().reshape(-1) for v in p64.values()]).numpy())
+    eg = rel_err(out['grad'].cpu().numpy(), ref['grad'].numpy())
+    # the same conjugate-gradient recurrences in fp64 on the ENGINE's products: separates the product's accuracy from the
+    # sensitivity of ten CG iterations on a nearly singular system (damping 1e-5) to fp32 rounding in A p
+    ctx = out['context']
+    th0 = torch.cat([v.reshape(-1) for v in theta.values()]).float().cuda()
+    ctx.evaluate(th0, want_grad=True)
+    ctx.prepare_general_kl(th0)
+    step64 = RL.conjugate_gradient(lambda v: ctx.fvp(th0, v.float().cuda()).double().cpu(), ref['grad'])
+    shs = 0.5 * torch.dot(step64, ctx.fvp(th0, step64.float().cuda()).double().cpu())
+    step64 = step64 / torch.sqrt(shs / P['max_kl'])
+    ec = rel_err(step64.numpy(), ref['step'].numpy())
+    # ... and the oracle's own sensitivity: its fp64 products and right-hand side rounded to fp32 (what the reference's fp32 run does)
+    r32 = lambda x: x.float().double()
+    s32 = RL.conjugate_gradient(lambda v: r32(ref['fvp'](r32(v))), r32(ref['grad']))
+    s32 = s32 / torch.sqrt(0.5 * torch.dot(s32, ref['fvp'](s32)) / P['max_kl'])
+    e32 = rel_err(s32.numpy(), ref['step'].numpy())
+    report('meta_optimize_anil_trpo', step_rel=es, theta_rel=et, grad_rel=eg, step_rel_fp64_cg_on_engine_products=ec,
+           step_rel_oracle_with_fp32_rounded_products=e32, accepted=out['accepted'], accepted_ref=ref['accepted'])
+    assert out['accepted'] == ref['accepted']
+    assert eg < 1e-5
+    # Ten CG iterations on a nearly singular system (damping 1e-5) amplify a 6e-8 (fp32 rounding) perturbation of the right-hand
+    # side into e32 = O(0.04) of the step direction -- in the reference's own arithmetic.  With the exact right-hand side the
+    # engine's products reproduce the oracle's step as well as the oracle's fp32-rounded products do (ec ~ e32); the whole
+    # pipeline adds the engine's 1.6e-7 gradient error, amplified by the same factor.
+    assert ec <= max(2e-2, 2 * e32)
+    amp = e32 / 6e-8
+    assert es <= max(2e-2, 2 * e32 + 2 * amp * eg)
+    tn = float(torch.cat([v.detach().reshape(-1) for v in p64.values()]).norm())
+    assert et <= max(1e-3, es * float(ref['step'].norm()) * P['outer_lr'] / tn * 2)
 
 
 def test_tanh_surrogate_grad_fvp_match_oracle():
