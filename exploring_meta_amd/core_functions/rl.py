@@ -115,15 +115,17 @@ def _pad(eps_list, advs, S, A, dev):
     T = len(eps_list)
     B = max(int(e['states'].shape[0]) for e in eps_list)
     st, ac = np.zeros((T, B, S), np.float32), np.zeros((T, B, A), np.float32)
-    ad, cnt = np.zeros((T, B), np.float32), np.zeros(T, np.int32)
+    ad, cnt, dn = np.zeros((T, B), np.float32), np.zeros(T, np.int32), np.zeros((T, B), np.float32)
     for t, (e, a) in enumerate(zip(eps_list, advs)):
         n = int(e['states'].shape[0])
         st[t, :n] = _np(e['states']).reshape(n, S)
         ac[t, :n] = _np(e['actions']).reshape(n, A)
         ad[t, :n] = np.asarray(a, dtype=np.float32).reshape(-1)
+        if 'dones' in e:
+            dn[t, :n] = _np(e['dones']).reshape(n)
         cnt[t] = n
     up = lambda x: torch.from_numpy(x).to(dev)
-    return dict(states=up(st), actions=up(ac), adv=up(ad), count=up(cnt))
+    return dict(states=up(st), actions=up(ac), adv=up(ad), count=up(cnt), done=up(dn))
 
 
 # ---------------------------------------------------------------------------------------------- reference functions
@@ -344,7 +346,8 @@ def _stack(replays, advs, S, A, dev):
             return t
         pad = [0, 0] * (t.dim() - 1 - dim) + [0, n]
         return torch.nn.functional.pad(t, pad)
-    out = {k: torch.stack([padto(b[k], 1) if k != 'count' else b[k] for b in batches]).contiguous() for k in ('states', 'actions', 'adv', 'count')}
+    out = {k: torch.stack([padto(b[k], 1) if k != 'count' else b[k] for b in batches]).contiguous()
+           for k in ('states', 'actions', 'adv', 'count', 'done')}
     return out, B
 
 
@@ -355,7 +358,7 @@ def _replay_meta(pol, support, sup_adv, query, q_adv, inner_lr, loss, clip, epoc
     qry = _pad([query], [q_adv], S, A, dev)
     B = max(B1, qry['states'].shape[1])
     def fit(d, dim):
-        for k in ('states', 'actions', 'adv'):
+        for k in ('states', 'actions', 'adv', 'done'):
             n = B - d[k].shape[dim]
             if n:
                 pad = [0, 0] * (d[k].dim() - 1 - dim) + [0, n]
@@ -370,12 +373,12 @@ def _replay_meta(pol, support, sup_adv, query, q_adv, inner_lr, loss, clip, epoc
     return lt, th[0], g
 
 
-def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order):
+def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order, dice=False):
     pol = _unwrap(learner)
     gamma, tau = params['gamma'], params['tau']
     epochs = params['ppo_epochs'] if algo == 'ppo' else 1
     clip = params.get('ppo_clip_ratio', 0.1)
-    kind = 'ppo' if algo == 'ppo' else 'a2c'
+    kind = 'ppo' if algo == 'ppo' else ('dice' if dice else 'a2c')
 
     def adv_of(ep):
         a = compute_advantages(baseline, tau, gamma, ep['rewards'], ep['dones'], ep['states'], ep['next_states'])
@@ -412,10 +415,23 @@ def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order
     return valid_loss, rew, 0.0
 
 
-def fast_adapt_vpg(task, learner, baseline, params, anil=False, first_order=False, render=False):
+def fast_adapt_vpg(task, learner, baseline, params, anil=False, first_order=False, render=False, dice=False):
     """reference rl.py:231-255 -> (valid_loss, query reward, success rate); `valid_loss.backward()` accumulates the MAML
-    gradient (second order unless first_order) into the policy's parameters."""
-    return _adapt_and_validate(task, learner, baseline, params, 'vpg', anil, first_order)
+    gradient (second order unless first_order) into the policy's parameters.  ``dice`` (not a parameter of the reference's
+    fast_adapt_vpg, whose calls leave vpg_a2c_loss at dice=False): every vpg_a2c_loss of the adaptation -- the adapt losses and
+    the validation loss -- uses the DiCE objective of rl.py:219-226."""
+    return _adapt_and_validate(task, learner, baseline, params, 'vpg', anil, first_order, dice=dice)
+
+
+def vpg_a2c_loss(episodes, learner, baseline, gamma, tau, dice=False):
+    """reference rl.py:208-228, value only (the gradient path is the fused fast_adapt_vpg): -mean(log_prob * advantages), or with
+    ``dice`` -mean(magic_box(weighted_cumsum(log_probs, weights)) * advantages) = -mean(advantages) (magic_box evaluates to 1)."""
+    adv = compute_advantages(baseline, tau, gamma, episodes['rewards'], episodes['dones'], episodes['states'], episodes['next_states'])
+    adv_t = torch.from_numpy(adv).to(device=device, dtype=torch.float32)
+    if dice:
+        return -adv_t.mean()
+    lp = _unwrap(learner).log_prob(episodes['states'].to(device), episodes['actions'].to(device))
+    return -(lp * adv_t).mean()
 
 
 def fast_adapt_ppo(task, learner, baseline, params, anil=False, render=False):

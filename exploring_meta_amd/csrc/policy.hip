@@ -633,8 +633,43 @@ struct Gauss2Args {
   float* loss;            // [T]
   float clip;
   int B, A, kind, mode, value_ratio_one;
+  const float* done;      // [T][B] DiCE: 1 at the last step of every episode (cherry `dones`)
+  float* scratch;         // [T][B] DiCE tangent: per-sample scratch
 };
 enum { P_PRIMAL = 0, P_TANGENT = 1, P_LOGP = 2 };
+
+// DiCE objective (reference core_functions/rl.py:219-226, vpg_a2c_loss(dice=True)):
+//   weights_i = (1 - done_{i-1}) / E  (weights_0 = 1 / E,  E = number of episodes = sum of dones)
+//   c = weighted_cumsum(log_probs, weights):  c_i = lp_i + weights_i c_{i-1},  with the reference's Python wrap-around at i = 0
+//       (values[-1] is the LAST element, still unmodified): c_0 = lp_0 + weights_0 lp_{N-1}
+//   loss = a2c.policy_loss(magic_box(c), A) = -mean(exp(c - stop_gradient(c)) A):  value -mean(A), d loss / d c_i = a_i = -A_i / N,
+//   d^2 loss / d c_i^2 = a_i as well.  c = M lp with M fixed by the episode boundaries, so
+//       d loss / d lp = M^T a,        R{d loss / d lp} = M^T (a . (M lp_dot)).
+// Episodes are independent segments of the recurrence (weights_i = 0 at an episode start): whichever thread meets a segment's
+// first (last) sample runs the forward (adjoint) recurrence along it; the wrap term is a one-element fix-up.
+__device__ __forceinline__ bool dice_start(const float* dn, int i) { return i == 0 || dn[i - 1] != 0.f; }
+// out = M x (forward) for one task; x, out: [cnt] (may not alias)
+__device__ void dice_forward(const float* dn, int cnt, float invE, const float* x, float* out) {
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    if (!dice_start(dn, i)) continue;
+    float c = x[i] + (i == 0 ? invE * x[cnt - 1] : 0.f);
+    out[i] = c;
+    for (int k = i + 1; k < cnt && !dice_start(dn, k); ++k) { c = x[k] + invE * c; out[k] = c; }
+  }
+  __syncthreads();
+}
+// out = M^T x (adjoint) for one task
+__device__ void dice_adjoint(const float* dn, int cnt, float invE, const float* x, float* out) {
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    if (!(i == cnt - 1 || dn[i] != 0.f)) continue;           // last sample of a segment
+    float g = x[i];
+    out[i] = g;
+    for (int k = i; k > 0 && !dice_start(dn, k); --k) { g = x[k - 1] + invE * g; out[k - 1] = g; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && cnt > 0) out[cnt - 1] += invE * out[0];          // c_0 also reads lp_{N-1}
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void gauss2_kernel(Gauss2Args a) {
   __shared__ float red[256];
@@ -644,6 +679,50 @@ __global__ __launch_bounds__(256) void gauss2_kernel(Gauss2Args a) {
   float acc[7];   // loss, drho[0..5]
 #pragma unroll
   for (int k = 0; k < 7; ++k) acc[k] = 0.f;
+  const bool dice = a.kind == MI_PLOSS_DICE && a.mode != P_LOGP;
+  float invE = 0.f;
+  if (dice) {
+    // per-sample coefficients through the episode recurrences BEFORE the per-sample loop below (which then reads coef / scratch)
+    const float* dn = a.done + (size_t)t * B;
+    float e = 0.f;
+    for (int b = tid; b < cnt; b += 256) e += dn[b] != 0.f ? 1.f : 0.f;
+    red[tid] = e;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if (tid < s2) red[tid] += red[tid + s2];
+      __syncthreads();
+    }
+    invE = 1.f / red[0];
+    __syncthreads();
+    float* cf = a.coef + (size_t)t * B;
+    float* c2 = a.coef2 + (size_t)t * B;
+    if (a.mode == P_PRIMAL) {
+      for (int b = tid; b < B; b += 256) { c2[b] = b < cnt ? -a.adv[(size_t)t * B + b] * invB : 0.f; cf[b] = 0.f; }
+      __syncthreads();
+      dice_adjoint(dn, cnt, invE, c2, cf);                    // coef = M^T a
+    } else {
+      float* sc = a.scratch + (size_t)t * B;                  // sc <- lp_dot per sample
+      for (int b = tid; b < B; b += 256) {
+        const size_t ob = (size_t)t * B + b;
+        float lpd = 0.f;
+        for (int d = 0; d < A; ++d) {
+          const float rp = a.rho[(size_t)t * a.rstride + d];
+          const bool live = rp > LOG_EPS;
+          const float r = fmaxf(rp, LOG_EPS), sg = expf(r), iv = 1.f / (sg * sg);
+          const float rd = live ? a.rhod[(size_t)t * a.vstride + d] : 0.f;
+          const float df = a.act[ob * A + d] - a.mu[ob * A + d];
+          lpd += invD * (df * iv * a.mud[ob * A + d] + (df * df * iv - 1.f) * rd);
+        }
+        sc[b] = b < cnt ? lpd : 0.f;
+      }
+      __syncthreads();
+      float* tmp = a.dmu + (size_t)t * B * A;                 // [B*A] >= [B]: free until the per-sample loop writes it
+      dice_forward(dn, cnt, invE, sc, tmp);                   // tmp = M lp_dot
+      for (int b = tid; b < cnt; b += 256) tmp[b] *= c2[b];   // a . (M lp_dot)
+      __syncthreads();
+      dice_adjoint(dn, cnt, invE, tmp, sc);                   // sc = R{coef}
+    }
+  }
   for (int b = tid; b < B; b += 256) {
     const bool valid = b < cnt;
     const size_t ob = (size_t)t * B + b;
@@ -662,6 +741,10 @@ __global__ __launch_bounds__(256) void gauss2_kernel(Gauss2Args a) {
         if (a.kind == MI_PLOSS_A2C) {
           c = -ad * invB;
           acc[0] += a.value_ratio_one ? c : c * lp;          // PPO's validation loss: ratio == 1 exactly, value -mean(A)
+        } else if (a.kind == MI_PLOSS_DICE) {
+          c = a.coef[ob];                                     // (M^T a)_b, computed above
+          c2 = a.coef2[ob];
+          acc[0] += -ad * invB;                               // magic_box == 1: value -mean(A)
         } else {
           const float ratio = expf(lp - a.oldlp[ob]);
           const float o1 = ratio * ad, o2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * ad;
@@ -692,7 +775,7 @@ __global__ __launch_bounds__(256) void gauss2_kernel(Gauss2Args a) {
         const float df = a.act[ob * A + d] - a.mu[ob * A + d];
         lpd += invD * (df * iv * a.mud[ob * A + d] + (df * df * iv - 1.f) * rd);
       }
-      const float cd = c2 * lpd;                             // R{f'}
+      const float cd = dice ? (valid ? a.scratch[ob] : 0.f) : c2 * lpd;   // R{f'} (DiCE: through the episode recurrences, above)
       for (int d = 0; d < A; ++d) {
         const float rp = a.rho[(size_t)t * a.rstride + d];
         const bool live = rp > LOG_EPS;
@@ -764,15 +847,19 @@ extern "C" int mi_policy_meta_workspace_bytes(const mi_policy* p, int tasks, int
   return MI_OK;
 }
 
-extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* theta, int steps, const int32_t* step_batch,
-                                    const int32_t* step_new_old, int n_batches, const float* s_states, const float* s_actions,
-                                    const float* s_adv, const int32_t* s_count, const float* q_states, const float* q_actions,
-                                    const float* q_adv, const int32_t* q_count, int tasks, int batch, int loss_kind, float clip,
-                                    float inner_lr, int head_only, int second_order, int with_grad, float* loss_out,
-                                    float* theta_out, float* grad_out, void* workspace, size_t workspace_bytes) {
+static int policy_meta_batch_impl(mi_policy* p, void* stream, const float* theta, int steps, const int32_t* step_batch,
+                                  const int32_t* step_new_old, int n_batches, const float* s_states, const float* s_actions,
+                                  const float* s_adv, const int32_t* s_count, const float* s_done, const float* q_states,
+                                  const float* q_actions, const float* q_adv, const int32_t* q_count, const float* q_done, int tasks,
+                                  int batch, int loss_kind, float clip, float inner_lr, int head_only, int second_order,
+                                  int with_grad, float* loss_out, float* theta_out, float* grad_out, void* workspace,
+                                  size_t workspace_bytes) {
   if (!p || !theta || !q_states || !q_actions || !q_adv || !loss_out || !workspace) return pfail(p, MI_ERR_ARG, "null argument");
   if (steps > 0 && (!step_batch || !s_states || !s_actions || !s_adv || n_batches < 1)) return pfail(p, MI_ERR_ARG, "support batches missing");
-  if (loss_kind != MI_PLOSS_A2C && loss_kind != MI_PLOSS_PPO) return pfail(p, MI_ERR_ARG, "loss_kind must be MI_PLOSS_A2C or MI_PLOSS_PPO");
+  if (loss_kind != MI_PLOSS_A2C && loss_kind != MI_PLOSS_PPO && loss_kind != MI_PLOSS_DICE)
+    return pfail(p, MI_ERR_ARG, "loss_kind must be MI_PLOSS_A2C, MI_PLOSS_PPO or MI_PLOSS_DICE");
+  if (loss_kind == MI_PLOSS_DICE && (!q_done || (steps > 0 && !s_done)))
+    return pfail(p, MI_ERR_ARG, "the DiCE objective needs the episode-end flags of every replay (s_done / q_done)");
   if (loss_kind == MI_PLOSS_PPO && steps > 0 && !step_new_old) return pfail(p, MI_ERR_ARG, "PPO needs step_new_old");
   if (with_grad && !grad_out) return pfail(p, MI_ERR_ARG, "grad_out is NULL but with_grad != 0");
   for (int k = 0; k < steps; ++k)
@@ -791,14 +878,14 @@ extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* the
   hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, theta, (size_t)0, pl.g, 0.f, (int)P, pl.theta);
   PCHK(p, hipGetLastError());
   auto primal = [&](StepSet& s, const float* th, const float* states, const float* actions, const float* adv, const int32_t* count,
-                    int kind, const float* oldlp, int value_ratio_one, float* g, float* loss) -> int {
+                    int kind, const float* oldlp, int value_ratio_one, float* g, float* loss, const float* done) -> int {
     int rc = mlp_forward(p, st, T, B, states, th, P, s.a);
     if (rc) return rc;
     PCHK(p, hipMemsetAsync(g, 0, TP * sizeof(float), st));
     Gauss2Args ga{};
     ga.mu = s.a.mu; ga.rho = th + p->o_sigma; ga.rstride = P; ga.act = actions; ga.adv = adv; ga.count = count; ga.oldlp = oldlp;
     ga.coef = s.coef; ga.coef2 = s.coef2; ga.dmu = s.dmu; ga.drho = g + p->o_sigma; ga.gstride = P; ga.loss = loss; ga.clip = clip;
-    ga.B = B; ga.A = p->A; ga.kind = kind; ga.mode = P_PRIMAL; ga.value_ratio_one = value_ratio_one;
+    ga.B = B; ga.A = p->A; ga.kind = kind; ga.mode = P_PRIMAL; ga.value_ratio_one = value_ratio_one; ga.done = done;
     hipLaunchKernelGGL(gauss2_kernel, dim3(T), dim3(256), 0, st, ga);
     PCHK(p, hipGetLastError());
     return mlp_backward(p, st, T, B, states, th, P, s.a, s.dmu, s.d2, s.d1, g, s.pre2, s.pre1, false);
@@ -821,7 +908,8 @@ extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* the
       hipLaunchKernelGGL(gauss2_kernel, dim3(T), dim3(256), 0, st, gl);
       PCHK(p, hipGetLastError());
     }
-    int rc = primal(s, th, xs, as, ad, cn, loss_kind, olp, 0, pl.g, pl.hv /* scratch for the step loss */);
+    int rc = primal(s, th, xs, as, ad, cn, loss_kind, olp, 0, pl.g, pl.hv /* scratch for the step loss */,
+                    s_done ? s_done + (size_t)bi * TB : nullptr);
     if (rc) return rc;
     mask(pl.g);
     hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, th, P, pl.g, inner_lr, (int)P, th + TP);
@@ -830,7 +918,8 @@ extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* the
   float* thK = pl.theta + (size_t)K * TP;
   if (theta_out) PCHK(p, hipMemcpyAsync(theta_out, thK, TP * sizeof(float), hipMemcpyDeviceToDevice, st));
   // ---- query loss: VPG = a2c loss; PPO = ppo loss against the adapted policy itself (ratio == 1: value -mean(A), gradient of A2C form)
-  int rc = primal(pl.q, thK, q_states, q_actions, q_adv, q_count, MI_PLOSS_A2C, nullptr, loss_kind == MI_PLOSS_PPO ? 1 : 0, pl.lam, loss_out);
+  int rc = primal(pl.q, thK, q_states, q_actions, q_adv, q_count, loss_kind == MI_PLOSS_DICE ? MI_PLOSS_DICE : MI_PLOSS_A2C, nullptr,
+                  loss_kind == MI_PLOSS_PPO ? 1 : 0, pl.lam, loss_out, q_done);
   if (rc) return rc;
   if (!with_grad) return MI_OK;
   // ---- adjoint recursion through the updates
@@ -852,6 +941,10 @@ extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* the
       gt.mu = s.a.mu; gt.mud = pl.ta.mu; gt.rho = th + p->o_sigma; gt.rstride = P; gt.rhod = pl.vmask + p->o_sigma; gt.vstride = P;
       gt.act = as; gt.count = cn; gt.coef = s.coef; gt.coef2 = s.coef2; gt.dmu = pl.rdmu; gt.drho = pl.hv + p->o_sigma; gt.gstride = P;
       gt.B = B; gt.A = p->A; gt.mode = P_TANGENT;
+      if (loss_kind == MI_PLOSS_DICE) {                      // the episode recurrences couple the samples of a replay
+        gt.kind = MI_PLOSS_DICE; gt.done = s_done + (size_t)bi * TB; gt.adv = s_adv + (size_t)bi * TB;
+        gt.scratch = pl.oldlp + (size_t)bi * TB;             // free: old log-probs exist only for PPO
+      }
       hipLaunchKernelGGL(gauss2_kernel, dim3(T), dim3(256), 0, st, gt);
       PCHK(p, hipGetLastError());
       rc = mlp_tangent_backward(p, st, T, B, xs, th, P, s.a, pl.ta, pl.vmask, s.dmu, s.d2, s.d1, s.pre2, s.pre1, pl.rdmu, pl.r2, pl.r1, pl.hv);
@@ -864,6 +957,31 @@ extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* the
   hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, pl.lam, T, (int)P, 1.f, (const float*)nullptr, 0.f, grad_out);
   PCHK(p, hipGetLastError());
   return MI_OK;
+}
+
+extern "C" int mi_policy_meta_batch(mi_policy* p, void* stream, const float* theta, int steps, const int32_t* step_batch,
+                                    const int32_t* step_new_old, int n_batches, const float* s_states, const float* s_actions,
+                                    const float* s_adv, const int32_t* s_count, const float* q_states, const float* q_actions,
+                                    const float* q_adv, const int32_t* q_count, int tasks, int batch, int loss_kind, float clip,
+                                    float inner_lr, int head_only, int second_order, int with_grad, float* loss_out,
+                                    float* theta_out, float* grad_out, void* workspace, size_t workspace_bytes) {
+  if (loss_kind == MI_PLOSS_DICE) return pfail(p, MI_ERR_ARG, "MI_PLOSS_DICE needs the episode-end flags: call mi_policy_meta_batch_dones");
+  return policy_meta_batch_impl(p, stream, theta, steps, step_batch, step_new_old, n_batches, s_states, s_actions, s_adv, s_count, nullptr,
+                                q_states, q_actions, q_adv, q_count, nullptr, tasks, batch, loss_kind, clip, inner_lr, head_only,
+                                second_order, with_grad, loss_out, theta_out, grad_out, workspace, workspace_bytes);
+}
+// The same with the replays' episode-end flags (cherry `dones`: s_done [n_batches, tasks, batch], q_done [tasks, batch]; 1 at
+// the last step of every episode): required by MI_PLOSS_DICE, ignored by the other losses.
+extern "C" int mi_policy_meta_batch_dones(mi_policy* p, void* stream, const float* theta, int steps, const int32_t* step_batch,
+                                          const int32_t* step_new_old, int n_batches, const float* s_states, const float* s_actions,
+                                          const float* s_adv, const int32_t* s_count, const float* s_done, const float* q_states,
+                                          const float* q_actions, const float* q_adv, const int32_t* q_count, const float* q_done,
+                                          int tasks, int batch, int loss_kind, float clip, float inner_lr, int head_only,
+                                          int second_order, int with_grad, float* loss_out, float* theta_out, float* grad_out,
+                                          void* workspace, size_t workspace_bytes) {
+  return policy_meta_batch_impl(p, stream, theta, steps, step_batch, step_new_old, n_batches, s_states, s_actions, s_adv, s_count, s_done,
+                                q_states, q_actions, q_adv, q_count, q_done, tasks, batch, loss_kind, clip, inner_lr, head_only,
+                                second_order, with_grad, loss_out, theta_out, grad_out, workspace, workspace_bytes);
 }
 
 // =====================================================================================================================

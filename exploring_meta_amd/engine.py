@@ -439,7 +439,7 @@ class PolicyEngine:
         K = len(step_batch)
         T, B = qry['states'].shape[0], qry['states'].shape[1]
         NB = sup['states'].shape[0] if K else 0
-        kind = {'a2c': 0, 'ppo': 1}[loss]
+        kind = {'a2c': 0, 'ppo': 1, 'dice': 2}[loss]
         sb = (C.c_int32 * max(K, 1))(*[int(x) for x in step_batch])
         if step_new_old is None:
             step_new_old = [1 if (k == 0 or step_batch[k] != step_batch[k - 1]) else 0 for k in range(K)]
@@ -453,6 +453,16 @@ class PolicyEngine:
         theta_out = torch.empty(T, self.param_count, device=self.device)
         grad = torch.empty(self.param_count, device=self.device) if with_grad else None
         g = lambda d, k: _ptr(d[k].contiguous()) if d is not None and K else C.c_void_p(0)
+        if loss == 'dice':       # the DiCE objective couples the samples of an episode: the replays' `dones` travel with them
+            if 'done' not in qry or (K and 'done' not in sup):
+                raise ValueError("loss='dice' needs the episode-end flags of every replay (key 'done', float32, like 'adv')")
+            self._check(self.lib.mi_policy_meta_batch_dones(
+                self._h, _stream(self.device), _ptr(theta.contiguous()), K, sb, sn, NB, g(sup, 'states'), g(sup, 'actions'), g(sup, 'adv'),
+                g(sup, 'count'), g(sup, 'done'), _ptr(qry['states'].contiguous()), _ptr(qry['actions'].contiguous()),
+                _ptr(qry['adv'].contiguous()), _ptr(qry['count'].contiguous()), _ptr(qry['done'].contiguous()), T, B, kind, float(clip),
+                float(inner_lr), int(head_only), int(not first_order), int(with_grad), _ptr(loss_t), _ptr(theta_out), _ptr(grad),
+                _ptr(self._ws), self._ws.numel()))
+            return loss_t, theta_out, grad
         self._check(self.lib.mi_policy_meta_batch(
             self._h, _stream(self.device), _ptr(theta.contiguous()), K, sb, sn, NB, g(sup, 'states'), g(sup, 'actions'), g(sup, 'adv'),
             g(sup, 'count'), _ptr(qry['states'].contiguous()), _ptr(qry['actions'].contiguous()), _ptr(qry['adv'].contiguous()),

@@ -346,6 +346,7 @@ int mi_trpo_fvp_general(mi_policy* p, void* stream, const float* theta, const fl
  *   head_only: updates touch only sigma and the last Linear (ANIL, body under no_grad). */
 #define MI_PLOSS_A2C 0
 #define MI_PLOSS_PPO 1
+#define MI_PLOSS_DICE 2   /* vpg_a2c_loss(dice=True), rl.py:219-226: needs mi_policy_meta_batch_dones */
 int mi_policy_meta_workspace_bytes(const mi_policy* p, int tasks, int batch, int steps, int n_batches, int second_order,
                                    size_t* bytes);
 int mi_policy_meta_batch(mi_policy* p, void* stream, const float* theta, int steps, const int32_t* step_batch,
@@ -354,6 +355,17 @@ int mi_policy_meta_batch(mi_policy* p, void* stream, const float* theta, int ste
                          const float* q_adv, const int32_t* q_count, int tasks, int batch, int loss_kind, float clip,
                          float inner_lr, int head_only, int second_order, int with_grad, float* loss_out, float* theta_out,
                          float* grad_out, void* workspace, size_t workspace_bytes);
+/* The same with the replays' episode-end flags (cherry `dones`; s_done [n_batches, tasks, batch], q_done [tasks, batch], 1.0 at
+ * the last step of every episode).  Required by loss_kind MI_PLOSS_DICE -- vpg_a2c_loss(dice=True), rl.py:219-226: the adapt
+ * losses AND the validation loss use  a2c.policy_loss(magic_box(weighted_cumsum(log_probs, weights)), advantages)  with
+ * weights = (1 - dones shifted by one) / dones.sum(), including the reference's wrap-around at the first sample. */
+int mi_policy_meta_batch_dones(mi_policy* p, void* stream, const float* theta, int steps, const int32_t* step_batch,
+                               const int32_t* step_new_old, int n_batches, const float* s_states, const float* s_actions,
+                               const float* s_adv, const int32_t* s_count, const float* s_done, const float* q_states,
+                               const float* q_actions, const float* q_adv, const int32_t* q_count, const float* q_done, int tasks,
+                               int batch, int loss_kind, float clip, float inner_lr, int head_only, int second_order,
+                               int with_grad, float* loss_out, float* theta_out, float* grad_out, void* workspace,
+                               size_t workspace_bytes);
 
 /* MAML-TRPO with `steps` >= 1 inner updates (params['adapt_steps'], one support replay per update, rl.py:447-453): the
  * generalisation of mi_trpo_surrogate / mi_trpo_fvp.  Support arrays carry a leading [steps] axis:

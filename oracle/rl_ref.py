@@ -360,14 +360,44 @@ def _body_detached(p, head_only):
     return OrderedDict((k, v if (k == 'sigma' or k.startswith(f'mean.{last}.')) else v.detach()) for k, v in p.items())
 
 
-def replay_vpg(p, support, query, params, baseline, first_order=False, activation=torch.relu, anil=False):
-    """fast_adapt_vpg (rl.py:231-255) on given replays: one a2c update per support replay, validation loss = vpg_a2c_loss."""
+def magic_box(x):
+    """learn2learn.magic_box (rl.py:5,225): exp(x - stop_gradient(x)) -- evaluates to 1, differentiates like x."""
+    return torch.exp(x - x.detach())
+
+
+def dice_log_probs(log_probs, dones):
+    """rl.py:219-225 (vpg_a2c_loss, dice=True):
+        weights = ones_like(dones); weights[1:] -= dones[:-1]; weights /= dones.sum()
+        cum = weighted_cumsum(log_probs, weights)        # rl.py:202-205: for i in range(N): values[i] += values[i-1] * weights[i]
+        log_probs = magic_box(cum)
+    The loop is in place and starts at i = 0, where values[i-1] is Python's values[-1]: the LAST log-prob, still unmodified.
+    Restated out of place (autograd-friendly), same arithmetic."""
+    weights = torch.ones_like(dones)
+    weights[1:] = weights[1:] - dones[:-1]
+    weights = weights / dones.sum()
+    n = log_probs.shape[0]
+    cum = [log_probs[0] + log_probs[n - 1] * weights[0]]
+    for i in range(1, n):
+        cum.append(log_probs[i] + cum[i - 1] * weights[i])
+    return magic_box(torch.stack(cum))
+
+
+def vpg_a2c_loss(ep, p, baseline, gamma, tau, dice=False, activation=torch.relu, anil=False):
+    """rl.py:208-228 (advantages are not normalised here)."""
+    adv = compute_advantages(baseline, tau, gamma, ep).detach()
+    lp = policy_log_prob(_body_detached(p, anil), ep['states'], ep['actions'], activation)
+    if dice:
+        lp = dice_log_probs(lp, ep['dones'])
+    return a2c_policy_loss(lp, adv)
+
+
+def replay_vpg(p, support, query, params, baseline, first_order=False, activation=torch.relu, anil=False, dice=False):
+    """fast_adapt_vpg (rl.py:231-255) on given replays: one a2c update per support replay, validation loss = vpg_a2c_loss.
+    dice: every vpg_a2c_loss with dice=True (the reference's call sites leave the default False)."""
     for ep in support:
-        adv = compute_advantages(baseline, params['tau'], params['gamma'], ep).detach()
-        lp = policy_log_prob(_body_detached(p, anil), ep['states'], ep['actions'], activation)
-        p = maml_adapt_policy(a2c_policy_loss(lp, adv), p, params['inner_lr'], first_order, head_only=anil)
-    adv = compute_advantages(baseline, params['tau'], params['gamma'], query).detach()
-    return a2c_policy_loss(policy_log_prob(p, query['states'], query['actions'], activation), adv), p
+        loss = vpg_a2c_loss(ep, p, baseline, params['gamma'], params['tau'], dice, activation, anil)
+        p = maml_adapt_policy(loss, p, params['inner_lr'], first_order, head_only=anil)
+    return vpg_a2c_loss(query, p, baseline, params['gamma'], params['tau'], dice, activation), p
 
 
 def replay_ppo(p, support, query, params, baseline, activation=torch.relu, anil=False):

@@ -377,19 +377,24 @@ def _stack_batches(eps_per_task_per_batch, advs, dev='cuda'):
     NB, T = len(eps_per_task_per_batch), len(eps_per_task_per_batch[0])
     B = max(int(e['states'].shape[0]) for row in eps_per_task_per_batch for e in row)
     st, ac = torch.zeros(NB, T, B, 2), torch.zeros(NB, T, B, 2)
-    ad, cnt = torch.zeros(NB, T, B), torch.zeros(NB, T, dtype=torch.int32)
+    ad, cnt, dn = torch.zeros(NB, T, B), torch.zeros(NB, T, dtype=torch.int32), torch.zeros(NB, T, B)
     for b in range(NB):
         for t in range(T):
             e, a = eps_per_task_per_batch[b][t], advs[b][t]
             n = int(e['states'].shape[0])
             st[b, t, :n], ac[b, t, :n], ad[b, t, :n], cnt[b, t] = e['states'].float(), e['actions'].float(), a.reshape(-1).float(), n
-    return dict(states=st.to(dev), actions=ac.to(dev), adv=ad.to(dev), count=cnt.to(dev)), B
+            dn[b, t, :n] = e['dones'].reshape(-1).float()
+    return dict(states=st.to(dev), actions=ac.to(dev), adv=ad.to(dev), count=cnt.to(dev), done=dn.to(dev)), B
 
 
 @pytest.mark.parametrize('algo,act,anil,first_order,lr', [('vpg', 'relu', False, False, 0.05), ('vpg', 'tanh', True, False, 0.05),
                                                             ('vpg', 'relu', False, True, 0.05), ('ppo', 'relu', False, False, 0.05),
                                                             ('ppo', 'tanh', False, False, 0.05), ('ppo', 'tanh', True, False, 0.05),
-                                                            ('ppo', 'relu', False, False, 2.0)])   # large steps: the clip is active
+                                                            ('ppo', 'relu', False, False, 2.0),    # large steps: the clip is active
+                                                            # vpg_a2c_loss(dice=True), rl.py:219-226: the episode recurrences of
+                                                            # weighted_cumsum couple the samples (gradient M^T a, HVP M^T diag(a) M)
+                                                            ('dice', 'relu', False, False, 0.05), ('dice', 'tanh', True, False, 0.05),
+                                                            ('dice', 'relu', False, True, 0.05), ('dice', 'tanh', False, False, 0.5)])
 def test_policy_meta_batch_vpg_ppo(algo, act, anil, first_order, lr):
     """mi_policy_meta_batch against the autograd restatement of fast_adapt_vpg / fast_adapt_ppo on the same replays: validation
     loss, adapted parameters and the (second-order) meta-gradient `av_loss.backward()` leaves behind (rl/maml_ppo.py:129)."""
@@ -410,8 +415,9 @@ def test_policy_meta_batch_vpg_ppo(algo, act, anil, first_order, lr):
     losses, thetas, gsum = [], [], torch.zeros(sum(v.numel() for v in theta.values()), dtype=torch.float64)
     for t in range(T):
         s_t = [sup[b][t] for b in range(adapt_steps)]
-        if algo == 'vpg':
-            loss, pk = RL.replay_vpg(leaves, s_t, qry[t], P, RL.LinearValue(2, 2), first_order=first_order, activation=activation, anil=anil)
+        if algo in ('vpg', 'dice'):
+            loss, pk = RL.replay_vpg(leaves, s_t, qry[t], P, RL.LinearValue(2, 2), first_order=first_order, activation=activation, anil=anil,
+                                     dice=algo == 'dice')
         else:
             loss, pk = RL.replay_ppo(leaves, s_t, qry[t], P, RL.LinearValue(2, 2), activation=activation, anil=anil)
         g = torch.autograd.grad(loss, list(leaves.values()))
@@ -440,7 +446,8 @@ def test_policy_meta_batch_vpg_ppo(algo, act, anil, first_order, lr):
     eng = pol.engine()
     epochs = P['ppo_epochs'] if algo == 'ppo' else 1
     step_batch = [b for b in range(adapt_steps) for _ in range(epochs)]
-    loss, th_out, grad = eng.meta_batch(pol.flat(), sup_b, qry_b, step_batch, P['inner_lr'], loss='ppo' if algo == 'ppo' else 'a2c',
+    kind = {'ppo': 'ppo', 'vpg': 'a2c', 'dice': 'dice'}[algo]
+    loss, th_out, grad = eng.meta_batch(pol.flat(), sup_b, qry_b, step_batch, P['inner_lr'], loss=kind,
                                         clip=P['ppo_clip_ratio'], head_only=anil, first_order=first_order)
     torch.cuda.synchronize()
     e_th = max(rel_err(th_out[t].cpu().numpy() - pol.flat().cpu().numpy(),
@@ -454,7 +461,7 @@ def test_policy_meta_batch_vpg_ppo(algo, act, anil, first_order, lr):
         body = slice(2, 2 + 100 * 2 + 100 + 100 * 100 + 100)
         assert torch.equal(th_out[:, body], pol.flat()[body].expand(T, -1))
     # evaluation-only call: same loss, no gradient
-    l2, _, g2 = eng.meta_batch(pol.flat(), sup_b, qry_b, step_batch, P['inner_lr'], loss='ppo' if algo == 'ppo' else 'a2c',
+    l2, _, g2 = eng.meta_batch(pol.flat(), sup_b, qry_b, step_batch, P['inner_lr'], loss=kind,
                                clip=P['ppo_clip_ratio'], head_only=anil, first_order=first_order, with_grad=False)
     assert g2 is None and torch.allclose(l2, loss, rtol=1e-6, atol=1e-8)
 

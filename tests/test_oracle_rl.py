@@ -95,3 +95,37 @@ def test_meta_iteration_runs_and_improves_surrogate():
     # product is symmetric positive semi-definite
     v = torch.randn(out['grad'].shape, dtype=torch.float64)
     assert torch.dot(v, out['fvp'](v)) > 0
+
+
+def test_dice_restatement_equals_the_literal_in_place_loop():
+    """oracle dice_log_probs (out of place, differentiable) against the reference's literal lines rl.py:202-205,219-225 executed
+    in place -- including the wrap-around of values[i - 1] at i = 0 -- and magic_box's value / derivative."""
+    torch.manual_seed(0)
+    n = 23
+    lp = torch.randn(n, 1, dtype=torch.float64)
+    dones = torch.zeros(n, 1, dtype=torch.float64)
+    dones[[6, 14, 22]] = 1
+
+    weights = torch.ones_like(dones)                       # rl.py:220-222
+    weights[1:].add_(dones[:-1], alpha=-1.0)
+    weights /= dones.sum()
+    values = lp.clone()
+    for i in range(values.size(0)):                        # rl.py:203-204
+        values[i] += values[i - 1] * weights[i]
+
+    x = lp.clone().requires_grad_(True)
+    out = RL.dice_log_probs(x, dones)
+    assert torch.equal(out.detach(), torch.ones_like(out))                         # magic_box evaluates to 1
+    k = torch.randn(n, 1, dtype=torch.float64)
+    g = torch.autograd.grad((out * k).sum(), x)[0]                                   # = M^T k
+    # M from the literal loop: column j of M = the loop applied to the j-th unit vector (the recurrence is linear)
+    M = torch.zeros(n, n, dtype=torch.float64)
+    for j in range(n):
+        e = torch.zeros(n, 1, dtype=torch.float64)
+        e[j] = 1
+        for i in range(n):
+            e[i] += e[i - 1] * weights[i]
+        M[:, j] = e[:, 0]
+    assert torch.allclose(M @ lp, values)
+    assert torch.allclose(g, M.t() @ k)
+    assert M[0, n - 1] != 0                                                          # the wrap-around term is there
