@@ -20,6 +20,7 @@
 #define EPI_NONE 0
 #define EPI_STATS 1
 #define EPI_TSTATS 2
+#define EPI_BRED 3     // block-1 BatchNorm-backward sums in the epilogue of block 2's dgrad (kernels.h, ConvArgs::bp ...)
 
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void stats_block_reduce(double s, double q, double* ldsd, int lane, int wave, int nwaves,
@@ -312,6 +313,15 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
     mu_c = a.mu[(size_t)task * CO + cbase + j];
     r_c = a.rstd[(size_t)task * CO + cbase + j];
   }
+  mi_rsrc rbp = rout, rbzh = rout, rbzhd = rout, rbdp = rout;
+  if (EPI == EPI_BRED) {
+    rbp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bp + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+    rbzh = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bzh + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+    if (NTERMS == 2) {
+      rbzhd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bzhd + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+      rbdp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bdp + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+    }
+  }
   double s = 0.0, q = 0.0;
   // byte displacement of every tap (wave-uniform): forward reads in[o + d - 1], dgrad reads in[i + 1 - d]
   const int wci = W * CI * 4;
@@ -375,6 +385,40 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
       __builtin_amdgcn_sched_barrier(0);
     }
     // epilogue: rows m = (r&3) + 8*(r>>2) + 4h of the tile; rows past the end of the task are dropped by the range check
+    if (EPI == EPI_BRED) {
+      // block 1's pooled-resolution tensors at this lane's 16 output positions, eight at a time (register budget: the two-term
+      // variant must stay within 128 VGPRs for two 8-wave workgroups per CU): loads first, then the fp64 sums.  Rows past the
+      // end of the task read p = 0, i.e. "ReLU off".
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float pp[8], zz[8], zd[8], dq[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = half * 8 + rr;
+          const unsigned o = obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
+          pp[rr] = buf_ld(rbp, o);
+          zz[rr] = buf_ld(rbzh, o);
+          if (NTERMS == 2) { zd[rr] = buf_ld(rbzhd, o); dq[rr] = buf_ld(rbdp, o); }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = half * 8 + rr;
+          const unsigned o = obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
+          const float v = acc[r];
+          buf_st(rout, o, v);
+          const bool on = pp[rr] > 0.f;
+          const float vv = on ? v : 0.f;
+          if (NTERMS == 1) {
+            s = fma((double)vv, (double)zz[rr], s);
+          } else {
+            const float dv = on ? dq[rr] : 0.f;
+            s += (double)vv * (double)zz[rr] + (double)dv * (double)zd[rr];
+          }
+          q += (double)vv;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned ro = (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
@@ -750,18 +794,23 @@ static bool conv_s1_ok(const ConvArgs& a) {
 
 template <int CI, int NTERMS, int EPI>
 static hipError_t launch_conv_ms(hipStream_t st, ConvArgs& a, dim3 grid, int mode, int stride) {
-  if (conv_s1_ok(a)) {
-    if (mode == 0) return launch_conv_s1<CI, NTERMS, EPI, 0>(st, a, grid);
-    if (EPI == EPI_NONE && mode == 1) return launch_conv_s1<CI, NTERMS, EPI_NONE, 1>(st, a, grid);
+  if constexpr (EPI == EPI_BRED) {                           // only the stride-1 hidden -> hidden dgrad carries this epilogue
+    if (conv_s1_ok(a) && mode == 1) return launch_conv_s1<CI, NTERMS, EPI_BRED, 1>(st, a, grid);
+    return hipErrorInvalidValue;
+  } else {
+    if (conv_s1_ok(a)) {
+      if (mode == 0) return launch_conv_s1<CI, NTERMS, EPI, 0>(st, a, grid);
+      if (EPI == EPI_NONE && mode == 1) return launch_conv_s1<CI, NTERMS, EPI_NONE, 1>(st, a, grid);
+      return hipErrorInvalidValue;
+    }
+    if (mode == 0 && stride == 1) return launch_conv_t<CI, NTERMS, EPI, 0, 1>(st, a, grid);
+    if (mode == 0 && stride == 2) return launch_conv_t<CI, NTERMS, EPI, 0, 2>(st, a, grid);
+    if (EPI == EPI_NONE) {
+      if (mode == 1 && stride == 1) return launch_conv_t<CI, NTERMS, EPI_NONE, 1, 1>(st, a, grid);
+      if (mode == 1 && stride == 2) return launch_conv_t<CI, NTERMS, EPI_NONE, 1, 2>(st, a, grid);
+    }
     return hipErrorInvalidValue;
   }
-  if (mode == 0 && stride == 1) return launch_conv_t<CI, NTERMS, EPI, 0, 1>(st, a, grid);
-  if (mode == 0 && stride == 2) return launch_conv_t<CI, NTERMS, EPI, 0, 2>(st, a, grid);
-  if (EPI == EPI_NONE) {
-    if (mode == 1 && stride == 1) return launch_conv_t<CI, NTERMS, EPI_NONE, 1, 1>(st, a, grid);
-    if (mode == 1 && stride == 2) return launch_conv_t<CI, NTERMS, EPI_NONE, 1, 2>(st, a, grid);
-  }
-  return hipErrorInvalidValue;
 }
 
 // Generic conv launcher.  mode 0 = forward, 1 = dgrad.  epi as EPI_*.  Returns blocks per task (partials written).
@@ -791,10 +840,12 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
   if (nterms == 1) {                                                                              \
     if (epi == EPI_NONE) return launch_conv_ms<CI, 1, EPI_NONE>(st, a, grid, mode, s);             \
     if (epi == EPI_STATS) return launch_conv_ms<CI, 1, EPI_STATS>(st, a, grid, mode, s);           \
+    if (epi == EPI_BRED) return launch_conv_ms<CI, 1, EPI_BRED>(st, a, grid, mode, s);             \
     return launch_conv_ms<CI, 1, EPI_TSTATS>(st, a, grid, mode, s);                                \
   } else {                                                                                        \
     if (epi == EPI_NONE) return launch_conv_ms<CI, 2, EPI_NONE>(st, a, grid, mode, s);             \
     if (epi == EPI_TSTATS) return launch_conv_ms<CI, 2, EPI_TSTATS>(st, a, grid, mode, s);         \
+    if (epi == EPI_BRED) return launch_conv_ms<CI, 2, EPI_BRED>(st, a, grid, mode, s);             \
     return hipErrorInvalidValue;                                                                  \
   }
   if (a.g.ci == 32) { DISPATCH(32) }

@@ -16,6 +16,7 @@
 #define EPI_NONE 0
 #define EPI_STATS 1
 #define EPI_TSTATS 2
+#define EPI_BRED 3
 
 static thread_local std::string g_err;
 
@@ -41,6 +42,9 @@ struct mi_engine {
   // BatchNorm statistic / reduction partials are folded by the last workgroup of the producing kernel (finalize.h) instead of a
   // bn_finalize launch; counters: one zero-initialised arrival counter per task, owned by the engine.
   bool fuse_fin = true;
+  // block 1's BatchNorm-backward sums (dgamma, dbeta and their tangents) ride in the epilogue of block 2's dgrad instead of a
+  // streaming pooled_reduce pass over p, zhat, dp (needs the fused block 1 with stored zhat and a stride-1 hidden block 2)
+  bool fuse_b1red = true;
   unsigned* counters = nullptr;
   static constexpr int kMaxCounterTasks = 65536;
   struct SideCtx { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; } sc[1];
@@ -211,6 +215,13 @@ extern "C" int mi_engine_set_fused_block1(mi_engine* e, int on) {
 extern "C" int mi_engine_set_fused_finalize(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->fuse_fin = on != 0;
+  return MI_OK;
+}
+// Ablation / test switch: 1 (default) = block 1's BatchNorm-backward sums computed in the epilogue of block 2's dgrad kernel,
+// 0 = by a separate streaming pass (pooled_reduce).  Same fp64 sums in a different order: results agree to fp32 rounding.
+extern "C" int mi_engine_set_fused_block1_reduce(mi_engine* e, int on) {
+  if (!e) return MI_ERR_ARG;
+  e->fuse_b1red = on != 0;
   return MI_OK;
 }
 
@@ -507,12 +518,20 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
   return MI_OK;
 }
 
+// Block 2's dgrad produces the cotangent of block 1's pooled output; with a fused block 1 that kept zhat at the argmax, block 1's
+// BatchNorm-backward sums are an epilogue of that kernel (stride-1 hidden -> hidden conv, the geometry conv3x3_s1 covers).
+static bool b1_reduce_rides(const mi_engine* e, int l, const ActSet& A) {
+  if (!(e->fuse_b1red && l == 1 && e->fuse1 && A.zhm)) return false;
+  const Layer& L = e->L[1];
+  return L.stride == 1 && L.ci == L.co && L.co == e->L[0].co && L.h == L.ho && L.w == L.wo && (L.ci == 32 || L.ci == 64);
+}
+
 // Trunk backward from A.dp[last] (gradient w.r.t. the last block's output): writes gamma/beta/conv-weight gradients into g.
 static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
                           float* g, const double* gram = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;
-  bool forked = false;
+  bool forked = false, b1red_done = false;
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
@@ -521,7 +540,8 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       b1.dp = A.dp[0];
       int blk = 0;
       const FinArgs fin = fin_of(e, T, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P);
-      if (A.zhm) {   // dgamma / dbeta from pooled-resolution tensors (no conv recompute)
+      if (b1red_done) {   // already summed in the epilogue of block 2's dgrad
+      } else if (A.zhm) {   // dgamma / dbeta from pooled-resolution tensors (no conv recompute)
         PoolRedArgs pr{A.p[0], A.zhm, nullptr, A.dp[0], nullptr, pl.bnpart, n * L.hp * L.wp, L.co, fin};
         LAUNCH(e, st, OP_BN_BWD_REDUCE, 0, launch_pooled_reduce(st, pr, T, 0, &blk));
       } else {
@@ -529,7 +549,7 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
         LAUNCH(e, st, OP_BN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_BWD_REDUCE, &blk));
         b1.fin = FinArgs{};
       }
-      if (!fin.counter)
+      if (!fin.counter && !b1red_done)
         LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
       b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
       if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci)) {   // sparse part on the matrix pipe, dense parts from the Gram matrix: no conv recompute
@@ -582,7 +602,18 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       ca.out = A.dp[l - 1];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
-      LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_NONE, 1, nullptr));
+      if (b1_reduce_rides(e, l, A)) {   // dgamma / dbeta of block 1 in this kernel's epilogue
+        const Layer& L0 = e->L[0];
+        ca.bp = A.p[0]; ca.bzh = A.zhm; ca.partial = pl.bnpart;
+        ca.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L0.off_gamma, P, g + L0.off_beta, P);
+        int blk0 = 0;
+        LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_BRED, 1, &blk0));
+        if (!ca.fin.counter)
+          LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk0, T, L0.co, 1.0, FIN_SUMS, g + L0.off_gamma, P, g + L0.off_beta, P));
+        b1red_done = true;
+      } else {
+        LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_NONE, 1, nullptr));
+      }
     }
   }
   return side_join(e, st, pl.half, forked);
@@ -689,7 +720,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     fd = X.fd;
   }
   int cur = 0;
-  bool forked = false;
+  bool forked = false, b1red_done = false;
   HeadArgs ha{};
   ha.f = A.f; ha.fd = fd;
   ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
@@ -713,7 +744,8 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       b1.dp = A.dp[0]; b1.dpd = X.dpd[cur];
       int blk = 0;
       const FinArgs fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P);
-      if (A.zhm) {
+      if (b1red_done) {
+      } else if (A.zhm) {
         PoolRedArgs pr{A.p[0], A.zhm, X.zhdm, A.dp[0], X.dpd[cur], pl.bnpart, n * L.hp * L.wp, L.co, fin};
         LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, 0, launch_pooled_reduce(st, pr, T, 1, &blk));
       } else {
@@ -721,7 +753,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
         LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_REDUCE, &blk));
         b1.fin = FinArgs{};
       }
-      if (!fin.counter)
+      if (!fin.counter && !b1red_done)
         LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
       b1.rdgamma = hv + L.off_gamma; b1.rdbeta = hv + L.off_beta; b1.hstride = P;
       if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci)) {
@@ -781,7 +813,18 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       ca.out = X.dpd[cur ^ 1];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
-      LAUNCH(e, st, OP_TAN_DGRAD, l, launch_conv3x3(st, ca, T, 2, EPI_NONE, 1, nullptr));
+      if (b1_reduce_rides(e, l, A) && X.zhdm) {   // R{dgamma}, R{dbeta} of block 1 in this kernel's epilogue
+        const Layer& L0 = e->L[0];
+        ca.bp = A.p[0]; ca.bzh = A.zhm; ca.bzhd = X.zhdm; ca.bdp = A.dp[0]; ca.partial = pl.bnpart;
+        ca.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L0.off_gamma, P, hv + L0.off_beta, P);
+        int blk0 = 0;
+        LAUNCH(e, st, OP_TAN_DGRAD, l, launch_conv3x3(st, ca, T, 2, EPI_BRED, 1, &blk0));
+        if (!ca.fin.counter)
+          LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk0, T, L0.co, 1.0, FIN_SUMS, hv + L0.off_gamma, P, hv + L0.off_beta, P));
+        b1red_done = true;
+      } else {
+        LAUNCH(e, st, OP_TAN_DGRAD, l, launch_conv3x3(st, ca, T, 2, EPI_NONE, 1, nullptr));
+      }
       cur ^= 1;
     }
   }

@@ -13,6 +13,11 @@ struct ConvArgs {
   const float* rstd;    // EPI_TSTATS: [T][co]
   double* partial;      // EPI_*STATS: [T][blocks_per_task][2][co]
   FinArgs fin;          // EPI_*STATS: fold the partials in the last workgroup of each task (counter != nullptr)
+  // EPI_BRED (stride-1 dgrad of block 2 only): the BatchNorm-backward sums of a fused block 1 ride in the epilogue -- the output
+  // tile IS the cotangent of block 1's pooled output, and block 1 left p, zhat (tangent: zhat-dot) at the same positions:
+  //   1 term : dgamma = sum [p>0] out zh,                    dbeta = sum [p>0] out
+  //   2 terms: R{dgamma} = sum [p>0] (out zh + dp zhd),      R{dbeta} = sum [p>0] out        (out = R{dp}, dp = primal cotangent)
+  const float *bp, *bzh, *bzhd, *bdp;
   ConvGeom g;
   int mpix;             // n*ho*wo
   int ntiles, tiles_per_wave;

@@ -137,6 +137,10 @@ class MetaEngine:
         """BatchNorm partials folded inside the producing kernels (default on) or by separate launches; bit-identical results."""
         _lib.check(self.lib.mi_engine_set_fused_finalize(self._h, int(on)), self._h)
 
+    def set_fused_block1_reduce(self, on):
+        """Block 1's BatchNorm-backward sums in the epilogue of block 2's dgrad (default on) or as a separate streaming pass."""
+        _lib.check(self.lib.mi_engine_set_fused_block1_reduce(self._h, int(on)), self._h)
+
     def set_trace(self, tasks=0, adapt_steps=0):
         """Debug/test aid (mi_debug_set_trace): allocate a trace buffer for meta_batch calls with these sizes and return it as a
         dict of views {theta [K+1,T,P], g [K,T,P], lam_in [K,T,P], hv [K,T,P]} (reference parameter order); 0 tasks switches it off."""

@@ -66,6 +66,11 @@ int mi_engine_set_overlap(mi_engine* e, int on);
  * results either way; the switch exists for ablation and tests. */
 int mi_engine_set_fused_finalize(mi_engine* e, int on);
 
+/* 1 (default): the BatchNorm-backward sums of a fused block 1 (dgamma, dbeta and, in the Hessian-vector product, their tangents) are
+ * formed in the epilogue of block 2's dgrad kernel, whose output tile IS the cotangent of block 1's pooled output; 0: by a
+ * separate streaming pass over the pooled-resolution tensors.  Same fp64 sums in another order (results agree to fp32 rounding). */
+int mi_engine_set_fused_block1_reduce(mi_engine* e, int on);
+
 /* Debug/test aid: byte offsets of {theta, g, xs, sup[0].p[0], sup[0].dp[0], sup[0].mu[0], sup[0].rstd[0], sup[0].p[1],
  * qry.p[0], total} inside the workspace of a mi_meta_batch_maml call with these sizes (out: 10 entries). */
 int mi_debug_plan_offsets(const mi_engine* e, int tasks, int ways, int shots, int adapt_steps, int second_order, size_t* out);

@@ -179,6 +179,28 @@ def test_fused_finalize_is_bit_identical(dataset, ways, shots, K, tasks, fused1)
     assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).sum() > 0
 
 
+@pytest.mark.parametrize('dataset,ways,shots,K,tasks', [('min', 5, 5, 2, [3, 4, 5]), ('min', 5, 1, 1, [0, 1, 2, 3, 4, 5, 6])])
+def test_block1_reduce_in_dgrad_epilogue_matches_streaming_pass(dataset, ways, shots, K, tasks):
+    """dgamma / dbeta of block 1 (and their tangents in the Hessian-vector product) summed in the epilogue of block 2's dgrad
+    kernel (EPI_BRED) vs the separate pooled_reduce pass: the same fp64 sums in a different order -- outputs agree to fp32
+    rounding of the two BatchNorm gradients (and what depends on them), far inside every parity bar."""
+    spec, mspec = _spec(dataset, ways)
+    theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
+    data, labels = synthetic.make_meta_batch(dataset, tasks, ways, shots)
+    d, l = torch.from_numpy(data).cuda().contiguous(), torch.from_numpy(labels).cuda().contiguous()
+    outs = []
+    for on in (1, 0):
+        eng = MetaEngine(mspec)
+        eng.set_fused_block1_reduce(on)
+        loss, acc, grad, logits = eng.meta_batch(theta, d, l, shots, K, 0.4, first_order=False, return_logits=True)
+        torch.cuda.synchronize()
+        outs.append((loss.cpu().numpy(), grad.cpu().numpy(), logits.cpu().numpy()))
+    e_l = float(np.max(np.abs(outs[0][0] - outs[1][0]) / np.abs(outs[1][0])))
+    e_g = rel_err(outs[0][1], outs[1][1])
+    report(f'block1_reduce_epilogue[{dataset},{shots}shot,K{K}]', loss_rel=e_l, grad_rel=e_g)
+    assert e_l < 1e-6 and e_g < 2e-6
+
+
 def test_adam_matches_torch():
     spec, mspec = _spec('omni', 5)
     eng = MetaEngine(mspec)
