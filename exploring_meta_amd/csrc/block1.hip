@@ -289,6 +289,206 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
   }
 }
 
+// operand vector of one tap: CI0 contiguous channels through one raw buffer load
+typedef float b1_floatx3 __attribute__((ext_vector_type(3)));
+template <int CI0> struct B1Vec;
+template <> struct B1Vec<3> {
+  typedef b1_floatx3 type;
+  static __device__ __forceinline__ type load(mi_rsrc r, unsigned off) {
+    return __builtin_bit_cast(type, __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 0));
+  }
+  static __device__ __forceinline__ float get(const type& v, int c) { return v[c]; }
+};
+template <> struct B1Vec<1> {
+  typedef float type;
+  static __device__ __forceinline__ type load(mi_rsrc r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  }
+  static __device__ __forceinline__ float get(const type& v, int) { return v; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two block-1 kernels every pass runs -- FWD (conv1 + BN + ReLU + pool, storing p, zhat at the argmax and the argmax) and the
+// tangent forward from the stored argmax (ARG: one conv with the DIRECTION's weights) -- cut down to what the SIMD must issue.
+// fp32 MFMAs and VALU instructions share the vector lanes (64 cycles per MFMA + 4 per VALU instruction, tools/mfma_valu_coissue),
+// and the general kernel above spends ~255 VALU instructions per 15 MFMAs.  Here:
+//  * all operands and results go through raw buffer accesses: one byte offset per lane and tile, immediates for the four windows,
+//    the hardware range check drops the windows past the end of the task (no exec-mask branch regions around the stores);
+//  * the tile -> (image, window row, window column) decode is carried incrementally on the scalar unit (no divisions in the loop),
+//    the 3x3 bounds tests are four compares per tile combined as lane masks on the scalar unit;
+//  * the pooling argmax is taken on z itself, times the sign of gamma*rstd: u = gamma*zhat + beta is a monotone function of z, so
+//    max u = u(argmax z) bit for bit and BN-apply + ReLU run once per window instead of once per position (two positions whose u
+//    round to the same float although their z differ now resolve by z instead of by position; gamma == 0 keeps position 0);
+//  * this lane's 15 conv weights live in registers (no LDS at all), the first MFMA of a tile takes C = 0 as an inline constant.
+template <int CI0, bool ARG>
+__global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
+  constexpr int K = 9 * CI0, NTH = 5, KH = NTH * CI0;
+  typedef typename B1Vec<CI0>::type xvec;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y, cbase = blockIdx.z * 32, ch = cbase + j;
+  const int H = a.hh, W = a.ww, HP = H >> 1, WP = W >> 1, CO = a.co;
+  const int nwin = a.n * HP * WP;
+
+  // ---- this lane's conv weights: rows (5h + t)*CI0 + c of [9*CI0][CO], column ch
+  float wreg[KH];
+  {
+    const float* w0 = ARG ? a.wd + (size_t)task * a.vstride : a.w + (size_t)task * a.wstride;
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+      const int k = h * KH + kk;
+      wreg[kk] = *(k < K ? w0 + (size_t)k * CO + ch : mi_zero_word);
+    }
+  }
+  // ---- per-channel constants
+  const float mu = a.mu[(size_t)task * CO + ch], rs = a.rstd[(size_t)task * CO + ch];
+  const float gm = a.gamma[(size_t)task * a.pstride + ch], bt = a.beta[(size_t)task * a.pstride + ch];
+  float m1 = 0.f, m2 = 0.f, gmd = 0.f, btd = 0.f;
+  if (ARG) {
+    m1 = a.m1[(size_t)task * CO + ch];
+    m2 = a.m2[(size_t)task * CO + ch];
+    gmd = a.gammad[(size_t)task * a.vstride + ch];
+    btd = a.betad[(size_t)task * a.vstride + ch];
+  }
+  const float gr = gm * rs;
+  const float sg = gr > 0.f ? 1.f : (gr < 0.f ? -1.f : 0.f);
+
+  // ---- buffer descriptors of this task's tensors (num_records = the task's extent: accesses past it read 0 / are dropped)
+  const unsigned x_bytes = (unsigned)((size_t)a.n * H * W * CI0 * 4), p_elems = (unsigned)nwin * (unsigned)CO;
+  const mi_rsrc rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)task * a.n * H * W * CI0), 0, x_bytes, 0x00020000);
+  const mi_rsrc rout = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)task * p_elems), 0, p_elems * 4, 0x00020000);
+  const mi_rsrc rzho = __builtin_amdgcn_make_buffer_rsrc((void*)(a.zh_out ? a.zh_out + (size_t)task * p_elems : a.out), 0,
+                                                         a.zh_out ? p_elems * 4 : 0u, 0x00020000);
+  const bool want_arg = !ARG && a.arg_out;
+  const mi_rsrc rago = __builtin_amdgcn_make_buffer_rsrc((void*)(want_arg ? a.arg_out + (size_t)task * p_elems : (uint8_t*)a.out), 0,
+                                                         want_arg ? p_elems : 0u, 0x00020000);
+  const mi_rsrc rzhi = __builtin_amdgcn_make_buffer_rsrc((void*)(ARG ? a.zh_in + (size_t)task * p_elems : a.out), 0, ARG ? p_elems * 4 : 0u, 0x00020000);
+  const mi_rsrc ragi = __builtin_amdgcn_make_buffer_rsrc((void*)(ARG ? a.arg_in + (size_t)task * p_elems : (const uint8_t*)a.out), 0,
+                                                         ARG ? p_elems : 0u, 0x00020000);
+
+  // ---- per-lane tap table: byte displacement of tap 5h + t from the pixel under the kernel centre
+  int toff[NTH];
+#pragma unroll
+  for (int t = 0; t < NTH; ++t) {
+    const int tap = NTH * h + t;
+    toff[t] = ((tap / 3 - 1) * W + (tap % 3 - 1)) * CI0 * 4;
+  }
+  const int qy = (j >> 1) & 1, qx = j & 1, wj = j >> 2;        // this lane's pixel: window wj of the tile, position (qy, qx)
+  const unsigned lane_o32 = (unsigned)((h * CO + ch) * 4), lane_o8 = (unsigned)(h * CO + ch);
+
+  // ---- tile stream of this wave: tiles tile_base + wave, + 4, ...; (n, wy, wx) of the tile's first window carried on the scalar unit
+  const int tile_base = blockIdx.x * 4 * a.tiles_per_wave;
+  const int tile_end = min(tile_base + 4 * a.tiles_per_wave, a.ntiles);
+  int tile = tile_base + wave;
+  int sn, swy, swx;
+  {
+    const int wb = tile * 8;
+    sn = wb / (HP * WP);
+    const int rem = wb - sn * (HP * WP);
+    swy = rem / WP;
+    swx = rem - swy * WP;
+  }
+  auto advance32 = [&]() {                                     // 4 tiles = 32 windows further (scalar)
+    swx += 32;
+    while (swx >= WP) { swx -= WP; swy += 1; }
+    while (swy >= HP) { swy -= HP; sn += 1; }
+  };
+
+  struct TileOps { xvec av[NTH]; unsigned ag[4]; float zh[4]; };
+  const bool hh = h != 0;
+  // operands of the tile whose first window is (sn, swy, swx); advances that scalar state to the wave's next tile
+  auto load_tile = [&](int tl, TileOps& o) {
+    int wx = swx + wj, wy = swy, n = sn;
+    if (wx >= WP) { wx -= WP; wy += 1; }
+    if (wy >= HP) { wy = 0; n += 1; }
+    const bool pvalid = (tl * 8 + wj) < nwin;
+    const unsigned py = (unsigned)(2 * wy + qy), px = (unsigned)(2 * wx + qx);
+    const unsigned pbase = __umul24(__umul24(__umul24((unsigned)n, (unsigned)H) + py, (unsigned)W) + px, (unsigned)(CI0 * 4));   // < 2^24 (launcher)
+    const bool top = py >= 1u, bot = py + 1u < (unsigned)H, lef = px >= 1u, rig = px + 1u < (unsigned)W;
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) {
+      // taps t (lane half 0) and 5 + t (lane half 1): the row / column tests of each are compile-time choices among four lane masks,
+      // combined on the scalar unit
+      const int tA = t, tB = NTH + t;
+      const bool okA = (tA / 3 == 0 ? top : (tA / 3 == 2 ? bot : true)) && (tA % 3 == 0 ? lef : (tA % 3 == 2 ? rig : true));
+      const bool okB = tB < 9 && (tB / 3 == 0 ? top : (tB / 3 == 2 ? bot : true)) && (tB % 3 == 0 ? lef : (tB % 3 == 2 ? rig : true));
+      const bool ok = pvalid && ((okA && !hh) || (okB && hh));
+      o.av[t] = B1Vec<CI0>::load(rx, ok ? pbase + (unsigned)toff[t] : MI_OOB);
+    }
+    if (ARG) {
+      const unsigned o8 = lane_o8 + (unsigned)(tl * 8 * CO), o32 = lane_o32 + (unsigned)(tl * 8 * CO * 4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        o.ag[g] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ragi, o8 + (unsigned)(2 * g * CO), 0, 0);
+        o.zh[g] = buf_ld(rzhi, o32 + (unsigned)(2 * g * CO * 4));
+      }
+    }
+    advance32();
+  };
+  auto compute_tile = [&](int tl, const TileOps& o) {
+    const unsigned o32 = lane_o32 + (unsigned)(tl * 8 * CO * 4), o8 = lane_o8 + (unsigned)(tl * 8 * CO);
+    floatx16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTH; ++t)
+#pragma unroll
+      for (int c = 0; c < CI0; ++c)
+        z = __builtin_amdgcn_mfma_f32_32x32x2f32(B1Vec<CI0>::get(o.av[t], c), wreg[t * CI0 + c], z, 0, 0, 0);
+    // ---- epilogue: window 2g + h of the tile sits in registers 4g .. 4g + 3 (positions 0..3)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned go32 = o32 + (unsigned)(2 * g * CO * 4), go8 = o8 + (unsigned)(2 * g * CO);
+      if (ARG) {
+        // z holds zd (the conv ran with the direction's weights): pd = [on] (gammad zh + gamma zhd + betad), zhd = r (zd - m1 - zh m2)
+        const unsigned agv = o.ag[g];
+        float zd_at = z[4 * g];
+        zd_at = agv == 1u ? z[4 * g + 1] : zd_at;
+        zd_at = agv == 2u ? z[4 * g + 2] : zd_at;
+        zd_at = agv == 3u ? z[4 * g + 3] : zd_at;
+        const float zhd_s = rs * (zd_at - m1 - o.zh[g] * m2);
+        const bool on = agv < 4u;
+        buf_st(rout, go32, on ? gmd * o.zh[g] + gm * zhd_s + btd : 0.f);
+        buf_st(rzho, go32, on ? zhd_s : 0.f);
+      } else {
+        // first maximum of sg*z == first maximum of u (u is monotone in sg*z); sg == 0 (gamma*rstd == 0) keeps position 0
+        float best = z[4 * g] * sg, zsel = z[4 * g];
+        unsigned arg = 0u;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const float tq = z[4 * g + q] * sg;
+          const bool gt = tq > best;
+          best = gt ? tq : best;
+          zsel = gt ? z[4 * g + q] : zsel;
+          arg = gt ? (unsigned)q : arg;
+        }
+        const float zh_at = bn_zh(zsel, mu, rs);
+        const float u = bn_u(zh_at, gm, bt);
+        const bool on = u > 0.f;
+        buf_st(rout, go32, on ? u : 0.f);
+        buf_st(rzho, go32, zh_at);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(on ? arg : 4u), rago, go8, 0, 0);
+      }
+    }
+  };
+
+  // two register sets in ping-pong: the next tile's operands are in flight under this tile's MFMAs and epilogue, no copies
+  TileOps A, B;
+  if (tile < tile_end) load_tile(tile, A);
+  while (tile < tile_end) {
+    if (tile + 4 < tile_end) load_tile(tile + 4, B);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_tile(tile, A);
+    tile += 4;
+    if (tile >= tile_end) break;
+    if (tile + 4 < tile_end) load_tile(tile + 4, A);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_tile(tile, B);
+    tile += 4;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co) {
   return (ci == 1 || ci == 3) && stride == 1 && pool && (h % 2 == 0) && (w % 2 == 0) && (w / 2 >= 8) && (co % 32 == 0);
@@ -320,6 +520,9 @@ int block1_blocks_per_task(int n, int h, int w, int co, int tasks) {
   return mx;
 }
 
+static int g_block1_fast = 1;
+void block1_set_fast(int on) { g_block1_fast = on; }
+
 hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task) {
   int ntiles, tpw;
   dim3 grid;
@@ -327,6 +530,20 @@ hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, 
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   if (blocks_per_task) *blocks_per_task = grid.x;
+  // the two forward modes have a leaner kernel (32-bit byte offsets inside one task's tensors)
+  const size_t x_task_bytes = (size_t)a.n * a.hh * a.ww * ci * 4, p_task_bytes = (size_t)a.n * (a.hh / 2) * (a.ww / 2) * a.co * 4;
+  if (g_block1_fast && (mode == B1_FWD || mode == B1_TFWD_ARG) && x_task_bytes < (1u << 24) && p_task_bytes < MI_OOB) {
+    if (ci == 3) {
+      if (mode == B1_FWD) hipLaunchKernelGGL((block1_fwd_kernel<3, false>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((block1_fwd_kernel<3, true>), grid, dim3(256), 0, st, a);
+    } else if (ci == 1) {
+      if (mode == B1_FWD) hipLaunchKernelGGL((block1_fwd_kernel<1, false>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((block1_fwd_kernel<1, true>), grid, dim3(256), 0, st, a);
+    } else {
+      return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
 #define B1_LAUNCH(CI0, M) hipLaunchKernelGGL((block1_kernel<CI0, M>), grid, dim3(256), 0, st, a)
 #define B1_MODES(CI0)                                   \
   switch (mode) {                                       \

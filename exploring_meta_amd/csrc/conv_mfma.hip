@@ -84,15 +84,6 @@ __device__ __forceinline__ void conv_prefetch_z(float* zpre, const float* __rest
   }
 }
 
-// Operands come through raw buffer loads: one descriptor per (tensor, task), 32-bit byte offsets, and the hardware range
-// check returns 0 for any offset >= the task's tensor size -- so image padding costs no predicated loads and no selects:
-// an invalid ROW poisons the lane's row offset with OOB, an invalid COLUMN poisons the (wave-uniform, scalar) column addend.
-#define MI_OOB 0x40000000u   // >= any per-task tensor size; OOB + OOB does not wrap
-typedef __amdgpu_buffer_rsrc_t mi_rsrc;
-__device__ __forceinline__ float buf_ld(mi_rsrc r, unsigned off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Generic conv: CI multiple of 32 (template), CO multiple of 32 (grid.z tiles).
 // MODE 0: forward   out[o] = sum_tap in[o*S + d - 1] * W[tap]            weights [9][CI][CO]
@@ -240,16 +231,6 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_m
 // multiplies in the main loop.  The epilogue stores through a buffer descriptor as well (rows past the end of the task are
 // dropped by the range check) and the statistics need no validity test: a pixel past the end has all-zero operands, hence
 // acc == 0 exactly.  Requires co == CI (hidden -> hidden blocks) and fewer than 2^24 pixels per task.
-typedef unsigned int mi_u32x4 __attribute__((ext_vector_type(4)));
-// NOTE: the loaded vector must be re-typed as a WHOLE (bit_cast to floatx4).  Extracting the four lanes of the integer vector
-// one by one (bit_cast(float, v.x) ...) makes hipcc 7.2 narrow the instruction to buffer_load_dword and leave three of the four
-// values undefined (reproduced in isolation; this is the "miscompiled b128" of round 1).
-__device__ __forceinline__ floatx4 buf_ld16(mi_rsrc r, unsigned off) {
-  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ __forceinline__ void buf_st(mi_rsrc r, unsigned off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
-}
 // x / d and x % d for x < 2^24 with the reciprocal of d in fp32: the fp32 quotient is off by at most one
 __device__ __forceinline__ void divmod24(unsigned x, unsigned d, float rd, unsigned& q, unsigned& r) {
   q = (unsigned)((float)x * rd);

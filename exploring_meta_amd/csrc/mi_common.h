@@ -40,5 +40,25 @@ __device__ __forceinline__ float bn_u(float zh, float g, float b) { return fmaf(
 // the MFMAs of the previous, already loaded, tile.
 static __device__ __attribute__((aligned(64))) float mi_zero_word[16] = {0.f};   // not const: must live in the global address space
 
+// Operands come through raw buffer loads: one descriptor per (tensor, task), 32-bit byte offsets, and the hardware range
+// check returns 0 for any offset >= the task's tensor size -- so image padding costs no predicated loads and no selects:
+// an invalid ROW poisons the lane's row offset with OOB, an invalid COLUMN poisons the (wave-uniform, scalar) column addend.
+#define MI_OOB 0x40000000u   // >= any per-task tensor size; OOB + OOB does not wrap
+typedef __amdgpu_buffer_rsrc_t mi_rsrc;
+__device__ __forceinline__ float buf_ld(mi_rsrc r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+typedef unsigned int mi_u32x4 __attribute__((ext_vector_type(4)));
+// NOTE: the loaded vector must be re-typed as a WHOLE (bit_cast to floatx4).  Extracting the four lanes of the integer vector
+// one by one (bit_cast(float, v.x) ...) makes hipcc 7.2 narrow the instruction to buffer_load_dword and leave three of the four
+// values undefined (reproduced in isolation; this is the "miscompiled b128" of round 1).
+__device__ __forceinline__ floatx4 buf_ld16(mi_rsrc r, unsigned off) {
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_st(mi_rsrc r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
