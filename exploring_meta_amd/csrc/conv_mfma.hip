@@ -718,21 +718,24 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host launchers
-static inline void conv_grid(int mpix, int tasks, int cot, int nw, int& ntiles, int& tpw, dim3& grid) {
+static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int nterms, int& ntiles, int& tpw, dim3& grid) {
   ntiles = ceil_div(mpix, 32);
-  // One balanced round: the chip holds 256 CUs x 4 SIMDs x 4 waves of this kernel (LDS-limited), so give every wave
-  // ceil(tiles / 4096) tiles -- more, shorter waves would run as 2.x rounds whose last round is mostly idle.
+  // One balanced round: give every resident wave ceil(tiles / slots) tiles -- more, shorter waves would run as 2.x rounds whose last
+  // round is mostly idle.  Resident waves: 4 per SIMD by registers (<= 128 VGPRs in every variant), limited by the LDS copy of the
+  // weights (160 KB per CU): 36 KB per 32-channel term and workgroup -> 4096 waves on the chip; the 64-channel kernels stage 74 KB
+  // (one term, two workgroups of 4 waves per CU) or 147 KB (two terms, one workgroup) -> 2048 / 1024 waves.
+  const long slots = ci >= 64 ? (nterms == 2 ? 1024 : 2048) : 4096;
   long total = (long)ntiles * tasks * cot;
-  tpw = (int)((total + 4095) / 4096);
+  tpw = (int)((total + slots - 1) / slots);
   if (tpw < 1) tpw = 1;
-  if (tpw > 32) tpw = 32;
+  if (tpw > 128) tpw = 128;
   grid = dim3(ceil_div(ntiles, nw * tpw), tasks, cot);
 }
 
 int conv_tiles_per_wave(int mpix, int tasks, int cot) {
   int ntiles, tpw;
   dim3 grid;
-  conv_grid(mpix, tasks, cot, 4, ntiles, tpw, grid);
+  conv_grid(mpix, tasks, cot, 4, 32, 1, ntiles, tpw, grid);
   return tpw;
 }
 
@@ -800,7 +803,7 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
   int ntiles, tpw;
   dim3 grid;
   const int nw = (nterms == 2 && a.g.ci == 32) ? 8 : 4;     // ConvWaves<CI, NTERMS>
-  conv_grid(a.mpix, tasks, cot, nw, ntiles, tpw, grid);
+  conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   if (blocks_per_task) *blocks_per_task = grid.x;
@@ -860,11 +863,21 @@ static void rows_split(const ConvGeom& g, int tasks, int& rh, int& nunits, int& 
   rh = rows_pick_rh(g.w);
   nunits = g.n * ((g.h + 1) / 2) * ceil_div(g.w, rh);
   const int nz = (g.ci / 32) * (g.co / 32);
-  int bpt = ceil_div(1024, tasks * nz);               // ~2 workgroups per CU, twice over
-  const int max_bpt = ceil_div(nunits, 32);           // >= 8 units per wave so the LDS reduction epilogue stays small
-  if (bpt > max_bpt) bpt = max_bpt;
-  if (bpt < 1) bpt = 1;
-  upb = ceil_div(nunits, bpt);
+  // Workgroups per task: the kernel keeps 9 x 16 accumulator registers, two workgroups per CU are resident (512 on the chip).  A
+  // launch takes ceil(workgroups / 512) rounds of (units per workgroup + the LDS reduction epilogue, worth ~16 units) each: pick
+  // the split with the smallest product, never fewer than 8 units per wave.  (T = 32 tasks of 5 images: 16 workgroups per task =
+  // ONE round of 40 units instead of 20 = 1.25 rounds of 32.)
+  int max_bpt = ceil_div(nunits, 32);
+  if (max_bpt > 128) max_bpt = 128;
+  if (max_bpt < 1) max_bpt = 1;
+  int best = 1;
+  long best_cost = -1;
+  for (int bpt = 1; bpt <= max_bpt; ++bpt) {
+    const long rounds = ((long)tasks * nz * bpt + 511) / 512;
+    const long cost = rounds * (ceil_div(nunits, bpt) + 16);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bpt; }
+  }
+  upb = ceil_div(nunits, best);
   blocks = ceil_div(nunits, upb);
 }
 

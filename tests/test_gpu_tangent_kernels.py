@@ -1,7 +1,7 @@
 """Per-kernel parity of the TANGENT (R-operator) kernels and of the fused block-1 kernels: every kernel behind the second-order
 path, called through its C-ABI test entry (include/mi_maml.h, "Tangent ... unit-test entry points") against the fp64
 restatement in oracle/kernels_ref.py on the same seeded inputs.  Includes cases at the sizes bench.py times (32 tasks x 25
-images): the conv kernels then run their multi-tile loop (tiles_per_wave = 11; the cap of 32 is reached with 96 tasks), which
+images): the conv kernels then run their multi-tile loop (tiles_per_wave = 11; 33 with 96 tasks), which
 the small cases never enter.  fp32 kernels vs fp64 oracle: tolerances stated per test."""
 import ctypes as C
 
@@ -161,7 +161,7 @@ BIG_CONV = [('bench_l2_T32', 32, 25, 42, 42, 32, 32, [0, 31]), ('cap32_T96', 96,
 @pytest.mark.parametrize('name,T,n,h,w,ci,co,check', BIG_CONV)
 def test_conv_fwd_bwd_at_bench_sizes(lib, name, T, n, h, w, ci, co, check):
     """The ONE-term kernels (forward + BatchNorm statistics, dgrad, weight gradient) at the sizes the benchmark times: the
-    multi-tile loop of conv3x3_mfma_kernel<32,1,*> (tiles_per_wave 11 at 32 tasks, capped at 32 with 96 tasks)."""
+    multi-tile loop of conv3x3_mfma_kernel<32,1,*> (tiles_per_wave 11 at 32 tasks, 33 at 96 tasks)."""
     nd = 8                                   # distinct tasks, repeated: the kernels do not know
     x = _rand(70, (nd, n, h, w, ci), 0.0, 2.0)
     w9 = _rand(71, (nd, 9, ci, co), -0.3, 0.3)
@@ -187,7 +187,7 @@ def test_conv_fwd_bwd_at_bench_sizes(lib, name, T, n, h, w, ci, co, check):
     if name == 'bench_l2_T32':
         assert tpw == 11
     if name == 'cap32_T96':
-        assert tpw == 32
+        assert tpw == 33          # 96 tasks: beyond the 32-tile cap of round 1 (the cap is 128 tiles per wave now)
     errs = dict(z=0.0, mu=0.0, rstd=0.0, dx=0.0, dw=0.0)
     for t in check:
         k = t % nd
