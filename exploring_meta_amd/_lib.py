@@ -160,11 +160,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MiError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+    path = os.environ.get('MI_MAML_LIB', LIB_PATH)          # A/B runs of two builds of the same sources on one box
+    if not os.path.exists(path):
+        raise MiError(f'{path} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                       '(hipcc --offload-arch=gfx950). There is no CPU fallback for the MAML hot path.')
     import torch  # noqa: F401  -- torch's bundled HIP runtime must be the one in the process before ours is resolved
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res

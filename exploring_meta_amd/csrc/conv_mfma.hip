@@ -275,7 +275,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
       dst[0] = v[0]; dst[32] = v[1]; dst[64] = v[2]; dst[96] = v[3];
     }
   }
-  __syncthreads();
+  // (no barrier yet: the first operand loads go out before the wait for the staged weights, see below)
 
   const int mpix = a.mpix;
   const unsigned hw = (unsigned)(H * W);
@@ -310,18 +310,49 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   const unsigned lane_out = (unsigned)(((4 * h) * CO + cbase + j) * 4);
 
   constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC, DEPTH = 2, RING = DEPTH + 1;
+  static_assert(NSTEP % RING == 0, "the operand ring must be in phase at every tile boundary");
   const int tile_base = blockIdx.x * NW * a.tiles_per_wave;
   const int tile_end = min(tile_base + NW * a.tiles_per_wave, a.ntiles);
-  for (int tile = tile_base + wave; tile < tile_end; tile += NW) {
-    const unsigned pix = (unsigned)(tile * 32 + j);
+  // The operand pipeline runs ACROSS tiles: the last DEPTH steps of a tile already issue the first loads of the wave's next
+  // tile, and the very first loads are issued before the barrier that ends the weight staging -- a wave never drains its loads at a
+  // tile boundary (matters most where a wave has few tiles: blocks 3 and 4, few-image launches).
+#ifndef MI_CONV_XTILE
+#define MI_CONV_XTILE 1
+#endif
+  struct TileSt { unsigned base; bool rowok[3], colok[3]; };
+  auto decode = [&](int tl) {
+    TileSt t;
+    const unsigned pix = (unsigned)(tl * 32 + j);
     unsigned nimg, rem, oy, ox;
     divmod24(pix, hw, rhw, nimg, rem);
     divmod24(rem, (unsigned)W, rw, oy, ox);
-    const bool valid = pix < (unsigned)mpix;
+    const bool valid = tl < tile_end && pix < (unsigned)mpix;       // past the wave's last tile: every load reads out of range (zeros)
     // row / column validity of the three vertical and horizontal displacements (index 0, 1, 2 <-> -1, 0, +1)
-    const bool rowok[3] = {valid && oy >= 1u, valid, valid && oy + 1u < (unsigned)H};
-    const bool colok[3] = {ox >= 1u, true, ox + 1u < (unsigned)W};
-    const unsigned base = pix * (unsigned)(CI * 4) + lane_in;
+    t.rowok[0] = valid && oy >= 1u; t.rowok[1] = valid; t.rowok[2] = valid && oy + 1u < (unsigned)H;
+    t.colok[0] = ox >= 1u; t.colok[1] = true; t.colok[2] = ox + 1u < (unsigned)W;
+    t.base = pix * (unsigned)(CI * 4) + lane_in;
+    return t;
+  };
+  auto issue = [&](const TileSt& t, int step, floatx4* dst) {
+    const int cc = step % NCC, tt = step / NCC, tap = tt % 9, term = tt / 9;
+    const int ddy = (MODE == 0) ? tap / 3 - 1 : 1 - tap / 3;
+    const int ddx = (MODE == 0) ? tap % 3 - 1 : 1 - tap % 3;
+    const bool ok = t.rowok[ddy + 1] && t.colok[ddx + 1];
+    const unsigned off = ok ? t.base + (unsigned)(ddy * wci + ddx * CI * 4) : MI_OOB;
+    dst[0] = buf_ld16(rin[term], off + cc * 128);
+    dst[1] = buf_ld16(rin[term], off + cc * 128 + 16);
+    dst[2] = buf_ld16(rin[term], off + cc * 128 + 32);
+    dst[3] = buf_ld16(rin[term], off + cc * 128 + 48);
+  };
+  floatx4 ring[RING][4];
+  int tile = tile_base + wave;
+  TileSt cur = decode(tile);
+#pragma unroll
+  for (int st = 0; st < DEPTH; ++st) issue(cur, st, ring[st % RING]);
+  __syncthreads();                                            // weights staged (the first operand loads are already in flight)
+
+  for (; tile < tile_end; tile += NW) {
+    const TileSt nxt = decode(tile + NW);
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -335,23 +366,10 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
         zpre[r] = buf_ld(rz, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro);
       }
     }
-    floatx4 ring[RING][4];
-    auto issue = [&](int step, floatx4* dst) {
-      const int cc = step % NCC, tt = step / NCC, tap = tt % 9, term = tt / 9;
-      const int ddy = (MODE == 0) ? tap / 3 - 1 : 1 - tap / 3;
-      const int ddx = (MODE == 0) ? tap % 3 - 1 : 1 - tap % 3;
-      const bool ok = rowok[ddy + 1] && colok[ddx + 1];
-      const unsigned off = ok ? base + (unsigned)(ddy * wci + ddx * CI * 4) : MI_OOB;
-      dst[0] = buf_ld16(rin[term], off + cc * 128);
-      dst[1] = buf_ld16(rin[term], off + cc * 128 + 16);
-      dst[2] = buf_ld16(rin[term], off + cc * 128 + 32);
-      dst[3] = buf_ld16(rin[term], off + cc * 128 + 48);
-    };
-#pragma unroll
-    for (int st = 0; st < DEPTH && st < NSTEP; ++st) issue(st, ring[st % RING]);
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
-      if (step + DEPTH < NSTEP) issue(step + DEPTH, ring[(step + DEPTH) % RING]);
+      if (step + DEPTH < NSTEP) issue(cur, step + DEPTH, ring[(step + DEPTH) % RING]);
+      else if (MI_CONV_XTILE) issue(nxt, step + DEPTH - NSTEP, ring[(step + DEPTH) % RING]);
       __builtin_amdgcn_sched_barrier(0);
       const int cc = step % NCC, tt = step / NCC;           // tt = term*9 + tap
       const floatx4* av = ring[step % RING];
@@ -365,25 +383,31 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    cur = nxt;
+    if (!MI_CONV_XTILE) {
+#pragma unroll
+      for (int st = 0; st < DEPTH; ++st) issue(cur, st, ring[st % RING]);
+    }
     // epilogue: rows m = (r&3) + 8*(r>>2) + 4h of the tile; rows past the end of the task are dropped by the range check
     if (EPI == EPI_BRED) {
-      // block 1's pooled-resolution tensors at this lane's 16 output positions, eight at a time (register budget: the two-term
-      // variant must stay within 128 VGPRs for two 8-wave workgroups per CU): loads first, then the fp64 sums.  Rows past the
+      // block 1's pooled-resolution tensors at this lane's 16 output positions, a group of rows at a time (register budget: the
+      // two-term variant must stay within 128 VGPRs for two 8-wave workgroups per CU): loads first, then the fp64 sums.  Rows past the
       // end of the task read p = 0, i.e. "ReLU off".
+      constexpr int GR = NTERMS == 2 ? 4 : 8;                 // rows per group: 4 x GR transient registers
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        float pp[8], zz[8], zd[8], dq[8];
+      for (int grp = 0; grp < 16 / GR; ++grp) {
+        float pp[GR], zz[GR], zd[GR], dq[GR];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          const int r = half * 8 + rr;
+        for (int rr = 0; rr < GR; ++rr) {
+          const int r = grp * GR + rr;
           const unsigned o = obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
           pp[rr] = buf_ld(rbp, o);
           zz[rr] = buf_ld(rbzh, o);
           if (NTERMS == 2) { zd[rr] = buf_ld(rbzhd, o); dq[rr] = buf_ld(rbdp, o); }
         }
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          const int r = half * 8 + rr;
+        for (int rr = 0; rr < GR; ++rr) {
+          const int r = grp * GR + rr;
           const unsigned o = obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
           const float v = acc[r];
           buf_st(rout, o, v);
