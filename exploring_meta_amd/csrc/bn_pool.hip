@@ -192,6 +192,12 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = fmaxf(w.umax[c], 0.f);
     store4(out_t + w.poff, o);
+    if (a.zh_out) {
+      float zo[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) zo[c] = w.at_arg(w.zh, c);
+      store4(a.zh_out + (size_t)task * p_task + w.poff, zo);
+    }
   }
 }
 
@@ -264,14 +270,16 @@ __global__ __launch_bounds__(256) void bn_tan_fwd_kernel(BnArgs a) {
     if (!w.pooled) continue;
     floatx4 umax, zh_at, zd_at;
     scan_window<POOL, true>(w, z_t, zd_t, k, umax, zh_at, zd_at);
-    floatx4 o;
+    floatx4 o, zo;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float zhd = k.r[c] * (zd_at[c] - m1[c] - zh_at[c] * m2[c]);
       const float ud = gd[c] * zh_at[c] + k.g[c] * zhd + bd[c];
       o[c] = (umax[c] > 0.f) ? ud : 0.f;
+      zo[c] = zhd;
     }
     *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
+    if (a.zh_out) *reinterpret_cast<floatx4*>(a.zh_out + (size_t)task * p_task + w.poff) = zo;
   }
 }
 

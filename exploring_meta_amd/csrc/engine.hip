@@ -114,6 +114,15 @@ static ConvGeom geom_dgrad(const Layer& l, int n) {  // op input = dz (ho,wo,co)
   return ConvGeom{n, l.ho, l.wo, l.h, l.w, l.co, l.ci, l.stride};
 }
 
+// The dgrad of block l (l >= 1) produces the cotangent of block l-1's pooled output.  If block l-1 left zhat at the argmax next to
+// p (fused block 1: zhm; hidden blocks: zhl), its BatchNorm-backward sums are an epilogue of that dgrad (EPI_BRED) -- available
+// for the geometry conv3x3_s1 covers: stride-1 hidden -> hidden conv of 32 or 64 channels.
+static bool dgrad_carries_reduce(const mi_engine* e, int l) {
+  if (!e->fuse_b1red || l < 1 || l >= (int)e->L.size()) return false;
+  const Layer& L = e->L[l];
+  return L.stride == 1 && L.ci == L.co && L.co == e->L[l - 1].co && L.h == L.ho && L.w == L.wo && (L.ci == 32 || L.ci == 64);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" const char* mi_version(void) { return "mi_maml 0.1 (gfx950)"; }
 extern "C" const char* mi_last_error(const mi_engine* e) { return e ? e->err.c_str() : g_err.c_str(); }
@@ -300,12 +309,15 @@ struct Bump {
 
 struct ActSet {
   float *z[8], *p[8], *dz[8], *dp[8], *mu[8], *rstd[8];
+  float* zhl[8];  // blocks >= 2 whose BatchNorm-backward sums ride in the next block's dgrad epilogue: zhat at the argmax of every
+                  // pooled output (same shape as p[l]), else nullptr
   float* zhm;     // fused block 1 with backward: zhat at every pooling window's argmax (same shape as p[0]), else nullptr
   uint8_t* arg0;  // ... and the argmax position itself (4 = did not pass the ReLU)
   float *f, *df, *prob, *dl;
 };
 struct TanSet {
   float *zd[8], *pd[8], *m1[8], *m2[8];
+  float* zhdl[8]; // tangent of ActSet::zhl
   float* zhdm;    // fused block 1: tangent of zhat at the argmax
   float* rdz[8];   // R{dz} per block (kept per block: the side-stream weight gradient of block l reads it while block l-1 is written)
   float *dpd[2], *fd, *rdf;
@@ -331,6 +343,7 @@ static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bo
   const int nl = (int)e->L.size();
   A.zhm = nullptr;
   A.arg0 = nullptr;
+  for (int l = 0; l < 8; ++l) A.zhl[l] = nullptr;
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
     const size_t zs = (size_t)T * n * L.ho * L.wo * L.co, ps = (size_t)T * n * L.hp * L.wp * L.co;
@@ -340,6 +353,7 @@ static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bo
     A.dz[l] = (with_bwd && !fused) ? b.take<float>(zs) : nullptr;
     A.dp[l] = with_bwd ? b.take<float>(ps) : nullptr;
     if (fused && with_bwd && e->gram1) { A.zhm = b.take<float>(ps); A.arg0 = b.take<uint8_t>(ps); }
+    A.zhl[l] = (!fused && with_bwd && l >= 1 && L.pool && dgrad_carries_reduce(e, l + 1)) ? b.take<float>(ps) : nullptr;
     A.mu[l] = b.take<float>((size_t)T * L.co);
     A.rstd[l] = b.take<float>((size_t)T * L.co);
   }
@@ -412,6 +426,7 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
       X.zd[l] = (l == 0 && e->fuse1) ? nullptr : b.take<float>((size_t)T * ns * L.ho * L.wo * L.co);
       X.pd[l] = b.take<float>((size_t)T * ns * L.hp * L.wp * L.co);
       if (l == 0) X.zhdm = e->fuse1 ? b.take<float>((size_t)T * ns * L.hp * L.wp * L.co) : nullptr;
+      X.zhdl[l] = (!(l == 0 && e->fuse1) && l >= 1 && L.pool && dgrad_carries_reduce(e, l + 1)) ? b.take<float>((size_t)T * ns * L.hp * L.wp * L.co) : nullptr;
       X.m1[l] = b.take<float>((size_t)T * L.co);
       X.m2[l] = b.take<float>((size_t)T * L.co);
     }
@@ -512,18 +527,16 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
     ba.z = A.z[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
     ba.out = A.p[l];
+    ba.zh_out = A.zhl[l];
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     LAUNCH(e, st, OP_BN_FWD, l, launch_bn_fwd(st, ba, T, L.pool));
   }
   return MI_OK;
 }
 
-// Block 2's dgrad produces the cotangent of block 1's pooled output; with a fused block 1 that kept zhat at the argmax, block 1's
-// BatchNorm-backward sums are an epilogue of that kernel (stride-1 hidden -> hidden conv, the geometry conv3x3_s1 covers).
-static bool b1_reduce_rides(const mi_engine* e, int l, const ActSet& A) {
-  if (!(e->fuse_b1red && l == 1 && e->fuse1 && A.zhm)) return false;
-  const Layer& L = e->L[1];
-  return L.stride == 1 && L.ci == L.co && L.co == e->L[0].co && L.h == L.ho && L.w == L.wo && (L.ci == 32 || L.ci == 64);
+// zhat at the argmax of block `lower`'s pooled outputs, if the forward pass kept it (fused block 1: zhm; hidden blocks: zhl)
+static const float* zh_at_argmax(const mi_engine* e, const ActSet& A, int lower) {
+  return (lower == 0 && e->fuse1) ? A.zhm : A.zhl[lower];
 }
 
 // Trunk backward from A.dp[last] (gradient w.r.t. the last block's output): writes gamma/beta/conv-weight gradients into g.
@@ -531,10 +544,11 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
                           float* g, const double* gram = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;
-  bool forked = false, b1red_done = false;
+  bool forked = false, red_done[9] = {false, false, false, false, false, false, false, false, false};   // [l]: block l's sums rode in block l+1's dgrad
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
+    const bool b1red_done = red_done[0];
     if (l == 0 && e->fuse1) {
       B1Args b1 = b1_args(e, pl, A, x0, n, theta);
       b1.dp = A.dp[0];
@@ -576,10 +590,12 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
-    ba.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P);
-    LAUNCH(e, st, OP_BN_BWD_REDUCE, l, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
-    if (!ba.fin.counter)
-      LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
+    if (!red_done[l]) {
+      ba.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P);
+      LAUNCH(e, st, OP_BN_BWD_REDUCE, l, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
+      if (!ba.fin.counter)
+        LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
+    }
     ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
     ba.out = A.dz[l];
     LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
@@ -602,15 +618,16 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       ca.out = A.dp[l - 1];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
-      if (b1_reduce_rides(e, l, A)) {   // dgamma / dbeta of block 1 in this kernel's epilogue
-        const Layer& L0 = e->L[0];
-        ca.bp = A.p[0]; ca.bzh = A.zhm; ca.partial = pl.bnpart;
+      const float* zh_lo = dgrad_carries_reduce(e, l) ? zh_at_argmax(e, A, l - 1) : nullptr;
+      if (zh_lo) {   // dgamma / dbeta of the block below in this kernel's epilogue
+        const Layer& L0 = e->L[l - 1];
+        ca.bp = A.p[l - 1]; ca.bzh = zh_lo; ca.partial = pl.bnpart;
         ca.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L0.off_gamma, P, g + L0.off_beta, P);
         int blk0 = 0;
         LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_BRED, 1, &blk0));
         if (!ca.fin.counter)
-          LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk0, T, L0.co, 1.0, FIN_SUMS, g + L0.off_gamma, P, g + L0.off_beta, P));
-        b1red_done = true;
+          LAUNCH(e, st, OP_BN_FINALIZE, l - 1, launch_bn_finalize(st, pl.bnpart, blk0, T, L0.co, 1.0, FIN_SUMS, g + L0.off_gamma, P, g + L0.off_beta, P));
+        red_done[l - 1] = true;
       } else {
         LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_NONE, 1, nullptr));
       }
@@ -711,6 +728,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
     ba.gammad = v + L.off_gamma; ba.betad = v + L.off_beta; ba.vstride = P;
     ba.out = X.pd[l];
+    ba.zh_out = A.zhl[l] ? X.zhdl[l] : nullptr;
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     LAUNCH(e, st, OP_BN_TAN_FWD, l, launch_bn_tan_fwd(st, ba, T, L.pool));
   }
@@ -720,7 +738,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     fd = X.fd;
   }
   int cur = 0;
-  bool forked = false, b1red_done = false;
+  bool forked = false, red_done[9] = {false, false, false, false, false, false, false, false, false};
   HeadArgs ha{};
   ha.f = A.f; ha.fd = fd;
   ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
@@ -735,6 +753,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
+    const bool b1red_done = red_done[0];
     if (l == 0 && e->fuse1) {
       B1Args b1 = b1_args(e, pl, A, x0, n, theta);
       b1.wd = v + L.off_w; b1.vstride = P;
@@ -786,10 +805,12 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
-    ba.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P);
-    LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, l, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
-    if (!ba.fin.counter)
-      LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
+    if (!red_done[l]) {
+      ba.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P);
+      LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, l, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
+      if (!ba.fin.counter)
+        LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
+    }
     ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
     ba.out = X.rdz[l];
     LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
@@ -813,15 +834,17 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       ca.out = X.dpd[cur ^ 1];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
-      if (b1_reduce_rides(e, l, A) && X.zhdm) {   // R{dgamma}, R{dbeta} of block 1 in this kernel's epilogue
-        const Layer& L0 = e->L[0];
-        ca.bp = A.p[0]; ca.bzh = A.zhm; ca.bzhd = X.zhdm; ca.bdp = A.dp[0]; ca.partial = pl.bnpart;
+      const float* zh_lo = dgrad_carries_reduce(e, l) ? zh_at_argmax(e, A, l - 1) : nullptr;
+      const float* zhd_lo = (l - 1 == 0 && e->fuse1) ? X.zhdm : X.zhdl[l - 1];
+      if (zh_lo && zhd_lo) {   // R{dgamma}, R{dbeta} of the block below in this kernel's epilogue
+        const Layer& L0 = e->L[l - 1];
+        ca.bp = A.p[l - 1]; ca.bzh = zh_lo; ca.bzhd = zhd_lo; ca.bdp = A.dp[l - 1]; ca.partial = pl.bnpart;
         ca.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L0.off_gamma, P, hv + L0.off_beta, P);
         int blk0 = 0;
         LAUNCH(e, st, OP_TAN_DGRAD, l, launch_conv3x3(st, ca, T, 2, EPI_BRED, 1, &blk0));
         if (!ca.fin.counter)
-          LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk0, T, L0.co, 1.0, FIN_SUMS, hv + L0.off_gamma, P, hv + L0.off_beta, P));
-        b1red_done = true;
+          LAUNCH(e, st, OP_BN_FINALIZE, l - 1, launch_bn_finalize(st, pl.bnpart, blk0, T, L0.co, 1.0, FIN_SUMS, hv + L0.off_gamma, P, hv + L0.off_beta, P));
+        red_done[l - 1] = true;
       } else {
         LAUNCH(e, st, OP_TAN_DGRAD, l, launch_conv3x3(st, ca, T, 2, EPI_NONE, 1, nullptr));
       }

@@ -45,6 +45,8 @@ struct BnArgs {
   const float* dp;      // [T][n][hp][wp][c]
   const float* dpd;
   float* out;
+  float* zh_out;        // forward kernels, optional [T][n][hp][wp][c]: zhat (tangent forward: its tangent) at every pooled output's argmax --
+                        // what the BatchNorm-backward sums need besides p and dp, so they can ride in the next block's dgrad epilogue
   double* partial;      // [T][nblk][2][c]
   FinArgs fin;          // reduction kernels: fold the partials in the last workgroup of each task (counter != nullptr)
   int n, ho, wo, c;
