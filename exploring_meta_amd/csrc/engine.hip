@@ -1293,7 +1293,13 @@ extern "C" int mi_head_fwd_bwd(void* stream, const float* f, const float* wl, co
   ha.n = n; ha.feat = feat; ha.ways = ways;
   if (!df || (size_t)feat < 2) return fail(nullptr, MI_ERR_ARG, "mi_head_fwd_bwd needs df (its first 2*tasks*n floats double as row scratch)");
   ha.rowloss = df; ha.rowhit = df + (size_t)tasks * n;   // consumed by the reduce launch before the gradient launch overwrites df
-  HIPCHK0(launch_head_fwd_bwd(reinterpret_cast<hipStream_t>(stream), ha, tasks, dwl != nullptr));
+  // (the engine's own passes give the rows kernel separate scratch and let the gradient launch fold loss / acc; here the row
+  // scratch aliases df, so the three launches stay separate)
+  HIPCHK0(launch_head_fwd_bwd(reinterpret_cast<hipStream_t>(stream), ha, tasks, 0));
+  if (dwl) {
+    ha.loss = nullptr; ha.acc = nullptr;
+    HIPCHK0(launch_head_grads(reinterpret_cast<hipStream_t>(stream), ha, tasks));
+  }
   return MI_OK;
 }
 

@@ -122,6 +122,14 @@ __global__ __launch_bounds__(256) void head_grads_kernel(HeadArgs a) {
       for (int n = 0; n < N; ++n) s += s_a[n * WY + w];
       dbl_t[w] = s;
     }
+    // loss[t] = mean_n rowloss, acc[t] = mean_n rowhit (fixed order) -- the job of head_reduce_kernel, folded in here when a
+    // gradient launch follows the rows launch anyway
+    if (!TANGENT && a.loss && tid == 64) {
+      float ls = 0.f, cs = 0.f;
+      for (int k = 0; k < N; ++k) { ls += a.rowloss[(size_t)task * N + k]; cs += a.rowhit[(size_t)task * N + k]; }
+      a.loss[task] = ls / (float)N;
+      a.acc[task] = cs / (float)N;
+    }
   }
 }
 
@@ -156,10 +164,11 @@ __global__ void spatial_mean_bwd_kernel(const float* __restrict__ df, float* __r
 hipError_t launch_head_fwd_bwd(hipStream_t st, const HeadArgs& a, int tasks, int with_grad) {
   if (a.ways > 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(head_rows_kernel<false>, dim3(tasks, ceil_div(a.n, 4)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(head_reduce_kernel, dim3(ceil_div(tasks, 64)), dim3(64), 0, st, a.rowloss, a.rowhit, tasks, a.n, a.loss, a.acc);
-  if (with_grad) {
+  if (with_grad) {     // the gradient launch also folds the row losses / hits into loss[t], acc[t]
     const size_t sm = (size_t)(a.n * a.ways) * sizeof(float);
     hipLaunchKernelGGL(head_grads_kernel<false>, dim3(tasks, ceil_div(a.feat, 256)), dim3(256), sm, st, a);
+  } else {
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(ceil_div(tasks, 64)), dim3(64), 0, st, a.rowloss, a.rowhit, tasks, a.n, a.loss, a.acc);
   }
   return hipGetLastError();
 }
