@@ -147,8 +147,12 @@ def pick_dominant(spec, prof, n_img):
     (op, layer) with the largest HIP-event time in one fully profiled step."""
     cands = {}
     for (op, layer), (ms, cnt) in prof.items():
-        if 'wgrad' in op and layer >= 1:
-            continue            # weight gradients of blocks >= 2 run on the engine's side stream concurrently with other work
+        if ('wgrad' in op or 'dgrad' in op) and layer >= 1:
+            # weight gradients of blocks >= 2 run on the engine's side stream, and the dgrad of the same block is launched beside
+            # them on the main stream: two matrix-bound kernels share the chip, so their launch durations in the timed region
+            # (and in a rocprofv3 trace) are about twice their isolated ones and say nothing about the kernel.  Their isolated
+            # figures are in `roofline.single_stream_step` below.
+            continue
         if layer >= spec.n_layers or RF.op_costs(spec, op, layer, n_img) is None:
             continue
         cands[(op, layer)] = ms
@@ -170,6 +174,8 @@ def run_vision(args, wl, rank, world, local, dist):
     else:
         spec = ModelSpec.mini_imagenet(wl['ways']) if wl['dataset'] == 'min' else ModelSpec.omniglot(wl['ways'])
     eng = MetaEngine(spec)
+    use_graph = wl.get('graph', False) if args.graph < 0 else bool(args.graph)
+    eng.set_graph(use_graph)          # theta is updated in place and the task batches stay resident: every step repeats the same call
     run_batch = eng.meta_batch_anil if wl.get('anil') else eng.meta_batch
     theta0 = init_theta(spec)
     theta = theta0.cuda()
@@ -276,11 +282,26 @@ def run_vision(args, wl, rank, world, local, dist):
         tpath = os.path.join(REPO, 'profiles', 'pmc_traffic.json')       # HBM bytes/launch from rocprofv3 --pmc passes (profiles/README.md)
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(f'{args.workload},{dom[0]},{dom[1]}')
+        # every conv-family / streaming kernel of the untimed single-stream step (no concurrency: durations add up to the iteration)
+        iso = []
+        for (op, layer), (ms1, cnt1) in sorted(first.items(), key=lambda kv: -kv[1][0]):
+            c = RF.op_costs(spec, op, layer, n_img) if layer < spec.n_layers else None
+            if c is None or len(iso) >= 12:
+                continue
+            fl, by = c
+            b1 = RF.bound_of(fl, by)
+            sec1 = ms1 / cnt1 * 1e-3
+            a1, p1 = (fl / sec1 / 1e12, FP32_MFMA_PEAK_TF) if b1 == 'mfma' else (by / sec1 / 1e9, HBM_PEAK_GBS)
+            iso.append(dict(op=op, block=layer + 1, launches=int(cnt1), avg_launch_ms=round(ms1 / cnt1, 4), bound=b1,
+                            achieved=round(a1, 1), frac=round(a1 / p1, 3)))
         roofline = dict(kernel=f'{RF.kernel_name(spec, dom[0], dom[1])}, block {dom[1] + 1} ({h}x{w}, {ci}->{co} filters)', op=dom[0],
                         bound=bound, achieved=round(achieved, 2), peak=peak, unit=unit, frac=round(achieved / peak, 4), traffic=traffic,
                         launches=int(cnt), avg_launch_ms=round(ms / cnt, 4), flops_per_launch=flops,
                         algorithmic_bytes_per_launch=nbytes, images_per_launch=n_img,
-                        hbm_stream_copy_measured_GBps=round(hbm_copy_gbps, 1))
+                        hbm_stream_copy_measured_GBps=round(hbm_copy_gbps, 1), single_stream_step=iso,
+                        note='dominant kernel among those that run alone on the chip (dgrad / wgrad of blocks >= 2 share it with each '
+                             'other in the timed region); single_stream_step: per-kernel figures of one untimed step with the side '
+                             'stream off, HIP events around every launch')
 
     if args.breakdown:                          # every rank runs the extra step (it contains the all-reduce); rank 0 writes
         eng.set_overlap(False)                  # one stream: the per-kernel times add up to the iteration
@@ -491,6 +512,8 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--tasks', type=int, default=0, help='override the tasks per GPU of the workload (sweeps; not a BASELINE configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=-1, help='replay the fused call as a captured hipGraph (mi_engine_set_graph): 1 on, 0 off, '
+                    '-1 = the workload default (on for the launch-bound few-image configurations cfg1 and cfg4)')
     ap.add_argument('--breakdown', default='', help='write a per-kernel event-time breakdown (one extra untimed step) to this file')
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])

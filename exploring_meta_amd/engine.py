@@ -141,6 +141,43 @@ class MetaEngine:
         """Block 1's BatchNorm-backward sums in the epilogue of block 2's dgrad (default on) or as a separate streaming pass."""
         _lib.check(self.lib.mi_engine_set_fused_block1_reduce(self._h, int(on)), self._h)
 
+    def set_graph(self, on):
+        """Replay repeated identical fused calls as one hipGraphLaunch (mi_engine_set_graph).  While on, `meta_batch` /
+        `meta_batch_anil` return views of PERSISTENT output buffers (one set per call shape), because a replay writes where the
+        captured call wrote: results are valid until the next call of the same shape; copy what must outlive it.  The caller keeps
+        theta / data / labels in place between iterations (in-place optimizer step, resident task batches) to benefit."""
+        _lib.check(self.lib.mi_engine_set_graph(self._h, int(on)), self._h)
+        self._graph = bool(on)
+        self._persist = {}
+        # stream capture is not permitted on the legacy default stream torch hands out as "current": graph-mode calls run on an
+        # engine-owned stream, ordered after / before the caller's current stream with events
+        self._gstream = torch.cuda.Stream(device=self.device) if on else None
+
+    def _fused_call(self, fn, *args):
+        """Issue one fused C call on the caller's current stream, or (graph mode) on the engine's capture-capable stream, fenced
+        against the current stream on both sides."""
+        gs = getattr(self, '_gstream', None)
+        if gs is None:
+            return fn(self._h, _stream(self.device), *args)
+        cur = torch.cuda.current_stream(self.device)
+        gs.wait_stream(cur)
+        rc = fn(self._h, C.c_void_p(gs.cuda_stream), *args)
+        cur.wait_stream(gs)
+        return rc
+
+    def _outputs(self, kind, T, nlog, with_grad, return_logits):
+        """(loss, acc, grad, logits) buffers of one fused call: fresh tensors, or the persistent set of this shape in graph mode."""
+        def fresh():
+            return (torch.empty(T, dtype=torch.float32, device=self.device), torch.empty(T, dtype=torch.float32, device=self.device),
+                    torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None,
+                    torch.empty(T, nlog, self.spec.ways, dtype=torch.float32, device=self.device) if return_logits else None)
+        if not getattr(self, '_graph', False):
+            return fresh()
+        key = (kind, T, nlog, bool(with_grad), bool(return_logits))
+        if key not in self._persist:
+            self._persist[key] = fresh()
+        return self._persist[key]
+
     def set_trace(self, tasks=0, adapt_steps=0):
         """Debug/test aid (mi_debug_set_trace): allocate a trace buffer for meta_batch calls with these sizes and return it as a
         dict of views {theta [K+1,T,P], g [K,T,P], lam_in [K,T,P], hv [K,T,P]} (reference parameter order); 0 tasks switches it off."""
@@ -187,13 +224,10 @@ class MetaEngine:
                 raise ValueError('theta/data must be contiguous fp32 CUDA tensors and labels contiguous int64 CUDA')
         so = (not first_order) and with_grad
         ws = self._workspace(self.workspace_bytes(T, shots, adapt_steps, so))
-        loss = torch.empty(T, dtype=torch.float32, device=self.device)
-        acc = torch.empty(T, dtype=torch.float32, device=self.device)
-        grad = torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None
-        logits = torch.empty(T, shots * s.ways, s.ways, dtype=torch.float32, device=self.device) if return_logits else None
-        rc = self.lib.mi_meta_batch_maml(self._h, _stream(self.device), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
-                                         adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
-                                         _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
+        loss, acc, grad, logits = self._outputs('maml', T, shots * s.ways, with_grad, return_logits)
+        rc = self._fused_call(self.lib.mi_meta_batch_maml, _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
+                              adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
+                              _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
         _lib.check(rc, self._h)
         return loss, acc, grad, logits
 
@@ -215,13 +249,10 @@ class MetaEngine:
         b = C.c_size_t()
         _lib.check(self.lib.mi_anil_workspace_bytes(self._h, T, s.ways, shots, adapt_steps, C.byref(b)), self._h)
         ws = self._workspace(b.value)
-        loss = torch.empty(T, dtype=torch.float32, device=self.device)
-        acc = torch.empty(T, dtype=torch.float32, device=self.device)
-        grad = torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None
-        logits = torch.empty(T, shots * s.ways, s.ways, dtype=torch.float32, device=self.device) if return_logits else None
-        rc = self.lib.mi_meta_batch_anil(self._h, _stream(self.device), _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
-                                         adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
-                                         _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
+        loss, acc, grad, logits = self._outputs('anil', T, shots * s.ways, with_grad, return_logits)
+        rc = self._fused_call(self.lib.mi_meta_batch_anil, _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
+                              adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
+                              _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
         _lib.check(rc, self._h)
         return loss, acc, grad, logits
 

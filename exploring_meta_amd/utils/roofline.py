@@ -38,10 +38,18 @@ def op_costs(spec, op, layer, images):
              'tangent_conv_fwd': (2 * f, x), 'bn_tangent_fwd': (f, x + 3 * p + a), 'bn_tangent_bwd_reduce': (0, 5 * p),
              'tangent_wgrad': (2 * f, x + 2 * p + a)}
     else:
-        t = {'conv_fwd_stats': (f, x + z), 'dgrad': (f, z + x), 'wgrad': (f, x + z),
-             'tangent_conv_fwd': (2 * f, 2 * x + 2 * z), 'tangent_dgrad': (2 * f, 2 * z + x), 'tangent_wgrad': (2 * f, 2 * x + 2 * z),
-             'bn_relu_pool_fwd': (0, z + p), 'bn_bwd_reduce': (0, z + p), 'bn_bwd_apply': (0, 2 * z + p),
-             'bn_tangent_fwd': (0, 2 * z + p), 'bn_tangent_bwd_reduce': (0, 2 * z + 2 * p), 'bn_tangent_bwd_apply': (0, 3 * z + 2 * p)}
+        # The dgrad of a stride-1 hidden block also forms the BatchNorm-backward sums of the block below in its epilogue (EPI_BRED):
+        # it reads that block's p and zhat-at-argmax (tangent: + zhat-dot and the primal cotangent) at its output positions -- tensors
+        # of the shape of this block's input x -- and the forward kernels of a block whose sums will ride above it also store zhat at
+        # the argmax (one more pooled-shape tensor).
+        rides = spec.max_pool and layer >= 1                 # this block's dgrad carries the sums of block layer-1
+        ridden = spec.max_pool and layer + 1 < spec.n_layers   # this block's own sums ride in block layer+1's dgrad
+        t = {'conv_fwd_stats': (f, x + z), 'dgrad': (f, z + x + (2 * x if rides else 0)), 'wgrad': (f, x + z),
+             'tangent_conv_fwd': (2 * f, 2 * x + 2 * z), 'tangent_dgrad': (2 * f, 2 * z + x + (4 * x if rides else 0)),
+             'tangent_wgrad': (2 * f, 2 * x + 2 * z),
+             'bn_relu_pool_fwd': (0, z + p + (p if ridden else 0)), 'bn_bwd_reduce': (0, z + p), 'bn_bwd_apply': (0, 2 * z + p),
+             'bn_tangent_fwd': (0, 2 * z + p + (p if ridden else 0)), 'bn_tangent_bwd_reduce': (0, 2 * z + 2 * p),
+             'bn_tangent_bwd_apply': (0, 3 * z + 2 * p)}
         if layer == 0:          # first block without a tangent input: one GEMM term
             t['tangent_conv_fwd'] = (f, x + 2 * z)
             t['tangent_wgrad'] = (f, x + z)
@@ -59,15 +67,15 @@ def bound_of(flops, nbytes):
 
 
 KERNEL_NAMES = {
-    'conv_fwd_stats': 'conv3x3_mfma_kernel<{ci},1,EPI_STATS,fwd>', 'dgrad': 'conv3x3_mfma_kernel<{ci},1,EPI_NONE,dgrad>',
-    'wgrad': 'wgrad3x3_rows_mfma_kernel (1 term)', 'tangent_conv_fwd': 'conv3x3_mfma_kernel<{ci},2,EPI_TSTATS,fwd>',
-    'tangent_dgrad': 'conv3x3_mfma_kernel<{ci},2,EPI_NONE,dgrad>', 'tangent_wgrad': 'wgrad3x3_rows_mfma_kernel (2 terms)',
+    'conv_fwd_stats': 'conv3x3_s1_mfma_kernel<{ci},1,EPI_STATS,fwd>', 'dgrad': 'conv3x3_s1_mfma_kernel<{ci},1,EPI_BRED,dgrad>',
+    'wgrad': 'wgrad3x3_rows_mfma_kernel (1 term)', 'tangent_conv_fwd': 'conv3x3_s1_mfma_kernel<{ci},2,EPI_TSTATS,fwd>',
+    'tangent_dgrad': 'conv3x3_s1_mfma_kernel<{ci},2,EPI_BRED,dgrad>', 'tangent_wgrad': 'wgrad3x3_rows_mfma_kernel (2 terms)',
     'bn_relu_pool_fwd': 'bn_fwd_kernel', 'bn_bwd_reduce': 'bn_bwd_reduce_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel',
     'bn_tangent_fwd': 'bn_tan_fwd_kernel', 'bn_tangent_bwd_reduce': 'bn_tan_bwd_reduce_kernel',
     'bn_tangent_bwd_apply': 'bn_tan_bwd_apply_kernel',
 }
 BLOCK1_KERNEL_NAMES = {
-    'bn_relu_pool_fwd': 'block1_kernel<{ci},FWD>', 'bn_tangent_fwd': 'block1_kernel<{ci},TFWD_ARG>', 'wgrad': 'sparse_wgrad_kernel<{ci},false>',
+    'bn_relu_pool_fwd': 'block1_fwd_kernel<{ci},FWD>', 'bn_tangent_fwd': 'block1_fwd_kernel<{ci},TFWD_ARG>', 'wgrad': 'sparse_wgrad_kernel<{ci},false>',
     'tangent_wgrad': 'sparse_wgrad_kernel<{ci},true>', 'bn_bwd_reduce': 'pooled_reduce_kernel<false>',
     'bn_tangent_bwd_reduce': 'pooled_reduce_kernel<true>', 'conv_fwd_stats': 'block1_kernel<{ci},STATS>',
 }

@@ -61,6 +61,14 @@ int mi_engine_set_fused_block1(mi_engine* e, int on);
  * (per-launch times from mi_profile_* are only additive with 0). */
 int mi_engine_set_overlap(mi_engine* e, int on);
 
+/* 1: a call of mi_meta_batch_maml / mi_meta_batch_anil whose arguments (every pointer, size and scalar, the stream included) equal
+ * those of an earlier call on this engine is replayed as ONE hipGraphLaunch of the captured launch sequence (first sight of a
+ * signature runs eagerly, the second is captured and instantiated; a small cache holds up to 8 signatures).  For callers that keep
+ * their parameter / data / output / workspace buffers in place between meta-iterations (bench.py, the drivers): it removes the host
+ * launch cost of the ~75-280 kernel launches of a call, which dominates the few-image configurations.  Default 0.  Results are
+ * those of the eager call.  mi_profile_enable and mi_debug_set_trace suspend it for their calls. */
+int mi_engine_set_graph(mi_engine* e, int on);
+
 /* 1 (default): the per-workgroup fp64 partials of every BatchNorm statistic / reduction are folded, in a fixed order, by the
  * last workgroup of the producing kernel (arrival counter per task); 0: by separate bn_finalize launches.  Bit-identical
  * results either way; the switch exists for ablation and tests. */

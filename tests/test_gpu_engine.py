@@ -201,6 +201,45 @@ def test_block1_reduce_in_dgrad_epilogue_matches_streaming_pass(dataset, ways, s
     assert e_l < 1e-6 and e_g < 2e-6
 
 
+@pytest.mark.parametrize('dataset,ways,shots,K,fo', [('omni', 5, 1, 1, True), ('min', 5, 1, 1, False), ('min', 5, 5, 2, False)])
+def test_graph_replay_matches_eager(dataset, ways, shots, K, fo):
+    """mi_engine_set_graph: the first call of a signature runs eagerly, the second is captured, later ones replay the captured
+    launch sequence (side stream included).  Replays must reproduce the eager results bit for bit, also after the CONTENTS of the
+    parameter / data buffers changed in place (same pointers), and a call with other arguments must not be served by the cached graph."""
+    spec, mspec = _spec(dataset, ways)
+    th_a = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
+    th_b = R.flatten_params(model_params(spec, 12)).float().cuda().contiguous()
+    da, la = synthetic.make_meta_batch(dataset, [0, 1, 2], ways, shots)
+    db, lb = synthetic.make_meta_batch(dataset, [7, 8, 9], ways, shots)
+    da, la, db, lb = (torch.from_numpy(x).cuda().contiguous() for x in (da, la, db, lb))
+    eager = MetaEngine(mspec)
+    ref = {}
+    for name, (th, d, l) in dict(aa=(th_a, da, la), ba=(th_b, da, la), bb=(th_b, db, lb)).items():
+        loss, acc, grad, _ = eager.meta_batch(th, d, l, shots, K, 0.4, first_order=fo)
+        torch.cuda.synchronize()
+        ref[name] = (loss.cpu().numpy().copy(), grad.cpu().numpy().copy())
+    eng = MetaEngine(mspec)
+    eng.set_graph(True)
+    theta, data, labels = th_a.clone(), da.clone(), la.clone()          # the buffers the replayed calls keep pointing at
+    def call():
+        loss, acc, grad, _ = eng.meta_batch(theta, data, labels, shots, K, 0.4, first_order=fo)
+        torch.cuda.synchronize()
+        return loss.cpu().numpy().copy(), grad.cpu().numpy().copy()
+    for i in range(4):                                                  # eager, capture, replay, replay
+        out = call()
+        assert np.array_equal(out[0], ref['aa'][0]) and np.array_equal(out[1], ref['aa'][1]), i
+    theta.copy_(th_b)                                                   # in-place update, as the optimizer does
+    out = call()
+    assert np.array_equal(out[0], ref['ba'][0]) and np.array_equal(out[1], ref['ba'][1])
+    data.copy_(db); labels.copy_(lb)
+    out = call()
+    assert np.array_equal(out[0], ref['bb'][0]) and np.array_equal(out[1], ref['bb'][1])
+    # other arguments (another data buffer): not the cached graph
+    loss, acc, grad, _ = eng.meta_batch(theta, da, la, shots, K, 0.4, first_order=fo)
+    torch.cuda.synchronize()
+    assert np.array_equal(loss.cpu().numpy(), ref['ba'][0]) and np.array_equal(grad.cpu().numpy(), ref['ba'][1])
+
+
 def test_adam_matches_torch():
     spec, mspec = _spec('omni', 5)
     eng = MetaEngine(mspec)
