@@ -587,7 +587,7 @@ struct WgUnit {
   float b[RH];
 };
 
-template <int RH>
+template <int RH, bool EXACT>
 __device__ __forceinline__ void wg_load_unit(WgUnit<RH>& u, int unit, mi_rsrc rx, mi_rsrc rdz, unsigned lane_x, unsigned lane_dz,
                                              int H, int W, int CI, int CO, int hp2, int nseg, int h) {
   // unit, and everything decoded from it, is wave-uniform (scalar unit)
@@ -598,6 +598,25 @@ __device__ __forceinline__ void wg_load_unit(WgUnit<RH>& u, int unit, mi_rsrc rx
   const int y = 2 * yp + h;                                  // per lane half
   const bool rowok = y < H;
   const unsigned dzoff = rowok ? lane_dz + (unsigned)(((n * H + y) * W + x0) * CO) * 4u : MI_OOB;
+  if (EXACT) {
+    // W is a multiple of RH and CI == CO == 32: every dz column and the x columns 1..RH of a segment are inside the image, their
+    // displacements are compile-time immediates of the load; only the halo columns 0 (first segment) and RH+1 (last segment) can fall
+    // outside, selected per unit on a scalar condition.  One vector offset per row instead of one add per load.
+#pragma unroll
+    for (int i = 0; i < RH; ++i) u.b[i] = buf_ld(rdz, dzoff + (unsigned)(i * 32 * 4));
+    const bool lok = s > 0, rok_c = s + 1 < nseg;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = y + r - 1;
+      const bool rok = rowok && (unsigned)iy < (unsigned)H;
+      const unsigned xoff = rok ? lane_x + (unsigned)(((n * H + iy) * W + x0) * 32) * 4u : MI_OOB;      // pixel x0 of the row
+      u.xa[r][0] = buf_ld(rx, lok ? xoff - 128u : MI_OOB);
+#pragma unroll
+      for (int c = 1; c <= RH; ++c) u.xa[r][c] = buf_ld(rx, xoff + (unsigned)((c - 1) * 128));
+      u.xa[r][RH + 1] = buf_ld(rx, rok_c ? xoff + (unsigned)(RH * 128) : MI_OOB);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < RH; ++i) {
     const unsigned col = (x0 + i) < W ? (unsigned)(i * CO) * 4u : MI_OOB;          // scalar select
@@ -625,7 +644,7 @@ __device__ __forceinline__ void wg_compute_unit(const WgUnit<RH>& u, floatx16* a
       acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.xa[tap / 3][i + tap % 3], u.b[i], acc[tap], 0, 0, 0);
 }
 
-template <int RH>
+template <int RH, bool EXACT>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_rows_mfma_kernel(WgradArgs a) {
   __shared__ float red[4 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -657,8 +676,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_rows_mfma_kernel(WgradArgs a)
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   auto load = [&](WgUnit<RH>& un, int v) {
-    if (v >= nunits) wg_load_unit<RH>(un, v - nunits, rx1, rd1, lane_x, lane_dz, H, W, CI, CO, hp2, nseg, h);   // wave-uniform branch
-    else wg_load_unit<RH>(un, v, rx0, rd0, lane_x, lane_dz, H, W, CI, CO, hp2, nseg, h);
+    if (v >= nunits) wg_load_unit<RH, EXACT>(un, v - nunits, rx1, rd1, lane_x, lane_dz, H, W, CI, CO, hp2, nseg, h);   // wave-uniform branch
+    else wg_load_unit<RH, EXACT>(un, v, rx0, rd0, lane_x, lane_dz, H, W, CI, CO, hp2, nseg, h);
   };
   WgUnit<RH> u0, u1;
   int u = ub0 + wave;
@@ -917,10 +936,18 @@ size_t wgrad_partial_floats(const ConvGeom& g, int tasks) {
 }
 
 static void launch_rows(hipStream_t st, const WgradArgs& a, dim3 grid, int rh) {
-  if (rh == 7) hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<7>), grid, dim3(256), 0, st, a);
-  else if (rh == 8) hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<8>), grid, dim3(256), 0, st, a);
-  else if (rh == 5) hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<5>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<4>), grid, dim3(256), 0, st, a);
+  // EXACT: segments tile the row exactly and both channel counts are 32 (the 4-conv-32 classifier): immediates instead of per-load adds
+  const bool exact = a.g.w % rh == 0 && a.g.ci == 32 && a.g.co == 32;
+#define ROWS(R)                                                                                                   \
+  do {                                                                                                            \
+    if (exact) hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<R, true>), grid, dim3(256), 0, st, a);               \
+    else hipLaunchKernelGGL((wgrad3x3_rows_mfma_kernel<R, false>), grid, dim3(256), 0, st, a);                    \
+  } while (0)
+  if (rh == 7) ROWS(7);
+  else if (rh == 8) ROWS(8);
+  else if (rh == 5) ROWS(5);
+  else ROWS(4);
+#undef ROWS
 }
 
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out) {
