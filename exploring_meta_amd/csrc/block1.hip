@@ -520,19 +520,19 @@ int block1_blocks_per_task(int n, int h, int w, int co, int tasks) {
   return mx;
 }
 
-static int g_block1_fast = 1;
-void block1_set_fast(int on) { g_block1_fast = on; }
-
 hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task) {
+  const bool force_general = (mode & B1_FORCE_GENERAL) != 0;      // tests: keep the general kernel's forward modes honest
+  mode &= ~B1_FORCE_GENERAL;
   int ntiles, tpw;
   dim3 grid;
   block1_grid(a, tasks, mode, ntiles, tpw, grid);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   if (blocks_per_task) *blocks_per_task = grid.x;
-  // the two forward modes have a leaner kernel (32-bit byte offsets inside one task's tensors)
+  // the two forward modes have a leaner kernel (24-bit element arithmetic / 32-bit byte offsets inside one task's tensors; larger
+  // tasks -- more than ~198 84x84x3 images per task -- fall back to the general kernel)
   const size_t x_task_bytes = (size_t)a.n * a.hh * a.ww * ci * 4, p_task_bytes = (size_t)a.n * (a.hh / 2) * (a.ww / 2) * a.co * 4;
-  if (g_block1_fast && (mode == B1_FWD || mode == B1_TFWD_ARG) && x_task_bytes < (1u << 24) && p_task_bytes < MI_OOB) {
+  if (!force_general && (mode == B1_FWD || mode == B1_TFWD_ARG) && x_task_bytes < (1u << 24) && p_task_bytes < MI_OOB) {
     if (ci == 3) {
       if (mode == B1_FWD) hipLaunchKernelGGL((block1_fwd_kernel<3, false>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((block1_fwd_kernel<3, true>), grid, dim3(256), 0, st, a);

@@ -111,7 +111,7 @@ struct B1Args {
   int ntiles, tiles_per_wave;
 };
 enum { B1_STATS = 0, B1_FWD = 1, B1_BWD_REDUCE = 2, B1_BWD_WGRAD = 3, B1_TSTATS = 4, B1_TFWD = 5, B1_TBWD_REDUCE = 6, B1_TBWD_WGRAD = 7,
-       B1_TFWD_ARG = 8 };   // tangent forward from the stored argmax / zhat: one conv (with the direction's weights) instead of two
+       B1_TFWD_ARG = 8, B1_FORCE_GENERAL = 0x100 };   // tangent forward from the stored argmax / zhat: one conv (with the direction's weights) instead of two
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co);
 int block1_blocks_per_task(int n, int h, int w, int co, int tasks);
 hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, int* blocks_per_task);

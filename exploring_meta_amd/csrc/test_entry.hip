@@ -149,6 +149,8 @@ extern "C" int mi_block1_run(void* stream, int mode, const mi_block1_args* a, fl
   b.arg_in = a->arg_in; b.zh_in = a->zh_in;
   const double inv_m = 1.0 / ((double)a->n * a->h * a->w_);
   int blk = 0;
+  const int force = mode & B1_FORCE_GENERAL;      // 0x100: run the general block1_kernel where a lean forward kernel exists
+  mode &= ~B1_FORCE_GENERAL;
   switch (mode) {
     case B1_STATS:
       TCHK(launch_block1(S(stream), b, a->tasks, a->ci, B1_STATS, &blk));
@@ -167,7 +169,7 @@ extern "C" int mi_block1_run(void* stream, int mode, const mi_block1_args* a, fl
     case B1_TFWD:
     case B1_TFWD_ARG:
       if (!p_out) return mi_internal_fail(MI_ERR_ARG, "mi_block1_run: forward modes need p_out");
-      TCHK(launch_block1(S(stream), b, a->tasks, a->ci, mode, nullptr));
+      TCHK(launch_block1(S(stream), b, a->tasks, a->ci, mode | force, nullptr));
       break;
     case B1_BWD_WGRAD:
     case B1_TBWD_WGRAD:

@@ -258,6 +258,8 @@ typedef struct {
   int32_t tasks, n, h, w_, ci, co;
 } mi_block1_args;
 size_t mi_block1_scratch_bytes(int tasks, int n, int h, int w, int ci, int co);
+/* mode | 0x100 (forward modes MI_B1_FWD / MI_B1_TFWD_ARG): run the general block1_kernel instead of the lean block1_fwd_kernel the
+ * engine uses for tasks of fewer than ~198 84x84x3 images (tests keep the fallback honest). */
 int mi_block1_run(void* stream, int mode, const mi_block1_args* a, float* p_out, float* zh_out, uint8_t* arg_out, float* out0,
                   float* out1, size_t ostride, void* scratch, size_t scratch_bytes);
 /* dgamma / dbeta of a fused block 1 (zhd, dpd != NULL: their tangents) from pooled-resolution tensors [tasks, rows, c]. */

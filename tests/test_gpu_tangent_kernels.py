@@ -334,6 +334,20 @@ def test_block1_kernels(lib, name, T, n, h, w, ci, co, check):
     run(4, out0=m1, out1=m2, ostride=co)                                          # TSTATS
     run(5, p_out=pd, zh_out=zhdm)                                                 # TFWD
     run(8, p_out=pd2, zh_out=zhdm2)                                               # TFWD_ARG
+    # modes 1 and 8 ran through the lean block1_fwd_kernel; the general block1_kernel (fallback for very large tasks) must agree:
+    # pooled values bit for bit (u is monotone in sign(gamma*rstd)*z), the argmax except where two u's collide in fp32
+    p_g, zh_g, pd_g, zhd_g = (f32(T, n, hp, wp, co) for _ in range(4))
+    arg_g = torch.full((T, n, hp, wp, co), 255, dtype=torch.uint8, device='cuda')
+    run(1 | 0x100, p_out=p_g, zh_out=zh_g, arg_out=arg_g)
+    torch.cuda.synchronize()
+    assert torch.equal(p_g, p)
+    differ = (arg_g != arg)
+    assert differ.float().mean().item() < 1e-5
+    assert torch.equal(zh_g[~differ], zhm[~differ])
+    arg_keep = arg.clone()
+    run(8 | 0x100, p_out=pd_g, zh_out=zhd_g)
+    torch.cuda.synchronize()
+    assert torch.allclose(pd_g, pd2, rtol=0, atol=0) and torch.equal(zhd_g, zhdm2) and torch.equal(arg, arg_keep)
     run(6, out0=hb, out1=hb[:, co:], ostride=gstride)                             # TBWD_REDUCE
     run(7, out0=hb[:, 2 * co:], ostride=gstride)                                  # TBWD_WGRAD
     # pooled-resolution reductions and the Gram-matrix weight gradient (the path the engine takes by default)
