@@ -69,15 +69,36 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs a) {
     const float* xr = a.x[term] + ((size_t)t * a.B + (rok ? row : 0)) * Kd;
     const float* wt = a.w[term] + (size_t)t * a.wstride[term];
     constexpr int CH = 10;
+    // a lane's consecutive reduction indices are consecutive floats of its row: 8-byte loads where the half-row split keeps them
+    // 8-byte aligned (the 100-wide hidden layers: rows of 400 B, halves of 200 B)
+    const bool vec2 = (Kd % 2 == 0) && (Kh % 2 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(xr + kbase) | (TRANS_W ? reinterpret_cast<uintptr_t>(wt + (size_t)(cok ? col : 0) * Kd + kbase) : 0)) & 7) == 0;
     for (int s0 = 0; s0 < Kh; s0 += CH) {
       float av[CH], bv[CH];
+      if (vec2) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int k = kbase + s0 + c;
-        const bool kok = (s0 + c < Kh) && (k < Kd);
-        av[c] = (kok && rok) ? xr[k] : 0.f;
-        if (TRANS_W) bv[c] = (kok && cok) ? wt[(size_t)col * Kd + k] : 0.f;
-        else bv[c] = (kok && cok) ? wt[(size_t)k * N + col] : 0.f;
+        for (int c = 0; c < CH; c += 2) {
+          const int k = kbase + s0 + c;
+          const bool kok = (s0 + c < Kh) && (k < Kd);               // pairs never straddle Kh or Kd (both even)
+          float2 a2 = make_float2(0.f, 0.f), b2 = make_float2(0.f, 0.f);
+          if (kok && rok) a2 = *reinterpret_cast<const float2*>(xr + k);
+          if (TRANS_W) {
+            if (kok && cok) b2 = *reinterpret_cast<const float2*>(wt + (size_t)col * Kd + k);
+          } else if (kok && cok) {
+            b2.x = wt[(size_t)k * N + col];
+            b2.y = wt[(size_t)(k + 1) * N + col];
+          }
+          av[c] = a2.x; av[c + 1] = a2.y; bv[c] = b2.x; bv[c + 1] = b2.y;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int k = kbase + s0 + c;
+          const bool kok = (s0 + c < Kh) && (k < Kd);
+          av[c] = (kok && rok) ? xr[k] : 0.f;
+          if (TRANS_W) bv[c] = (kok && cok) ? wt[(size_t)col * Kd + k] : 0.f;
+          else bv[c] = (kok && cok) ? wt[(size_t)k * N + col] : 0.f;
+        }
       }
 #pragma unroll
       for (int c = 0; c < CH; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[c], acc, 0, 0, 0);
