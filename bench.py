@@ -448,8 +448,9 @@ def run_trpo(args, wl, rank, world, local, dist):
     roofline = dict(kernel='mi_trpo_fvp (dense_fwd / dense_bwd_x / dense_bwd_w / gauss kernels of policy.hip, one call = about 20 launches)',
                     op='fisher_vector_product', bound='mfma', achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
                     frac=round(achieved / FP32_MFMA_PEAK_TF, 5), traffic=None, launches=nf, avg_launch_ms=round(fvp_ms, 4),
-                    flops_per_launch=flops, note='2x100 MLP on 2000-row batches: launch- and latency-bound fp32 VALU arithmetic '
-                    '(an MFMA tile would be mostly padding); the peak quoted is the fp32 vector = fp32 MFMA peak')
+                    flops_per_launch=flops, note='2x100 MLP on 2000-row batches: about 35 launches of 0.4..1.6 GFLOP per product (dense '
+                    'products on the fp32 matrix pipe, one wave per 32x32 tile, operands straight from global memory): launch- and '
+                    'latency-bound; one step also spends ~10 ms on the host (GAE, LinearValue fits, padding: tools/trpo_step_timing.py)')
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
