@@ -24,8 +24,9 @@
 
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void stats_block_reduce(double s, double q, double* ldsd, int lane, int wave, int nwaves,
-                                                   double* partial_task, int co_total, int cbase, const FinArgs& fin, int task) {
-  double* partial_blk = partial_task + (size_t)blockIdx.x * 2 * co_total;
+                                                   double* partial_task, int co_total, int cbase, const FinArgs& fin, int task,
+                                                   int bx = -1) {
+  double* partial_blk = partial_task + (size_t)(bx < 0 ? (int)blockIdx.x : bx) * 2 * co_total;
   // lanes l and l^32 hold the same channel
   s += __shfl_xor(s, 32, 64);
   q += __shfl_xor(q, 32, 64);
@@ -247,7 +248,20 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int task = blockIdx.y, ct = blockIdx.z;
+  // XCD-aware placement: workgroups are dealt to the 8 XCDs round-robin in linear launch order, so the 16..32 workgroups of one task
+  // (adjacent bands of the same images, the same staged weights) would land on all eight L2s.  Re-deal the linear index so that
+  // XCD k works through a contiguous run of (task, band) pairs: a task's halo rows and weights are fetched into ONE L2.
+  int bx = blockIdx.x, task = blockIdx.y, ct = blockIdx.z;
+  {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 7u) == 0u) {
+      const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const unsigned nl = (lin & 7u) * (total >> 3) + (lin >> 3);
+      bx = (int)(nl % gridDim.x);
+      task = (int)((nl / gridDim.x) % gridDim.y);
+      ct = (int)(nl / (gridDim.x * gridDim.y));
+    }
+  }
   const int H = a.g.h, W = a.g.w;
   const int cbase = ct * 32;
 
@@ -311,7 +325,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
 
   constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC, DEPTH = 2, RING = DEPTH + 1;
   static_assert(NSTEP % RING == 0, "the operand ring must be in phase at every tile boundary");
-  const int tile_base = blockIdx.x * NW * a.tiles_per_wave;
+  const int tile_base = bx * NW * a.tiles_per_wave;
   const int tile_end = min(tile_base + NW * a.tiles_per_wave, a.ntiles);
   // The operand pipeline runs ACROSS tiles: the last DEPTH steps of a tile already issue the first loads of the wave's next
   // tile, and the very first loads are issued before the barrier that ends the weight staging -- a wave never drains its loads at a
@@ -442,7 +456,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   }
   if (EPI != EPI_NONE) {
     double* pb = a.partial + (size_t)task * gridDim.x * 2 * CO;
-    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase, a.fin, task);
+    stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase, a.fin, task, bx);
   }
 }
 
