@@ -407,34 +407,47 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
       // block 1's pooled-resolution tensors at this lane's 16 output positions, a group of rows at a time (register budget: the
       // two-term variant must stay within 128 VGPRs for two 8-wave workgroups per CU): loads first, then the fp64 sums.  Rows past the
       // end of the task read p = 0, i.e. "ReLU off".
-      constexpr int GR = NTERMS == 2 ? 4 : 8;                 // rows per group: 4 x GR transient registers
-#pragma unroll
-      for (int grp = 0; grp < 16 / GR; ++grp) {
-        float pp[GR], zz[GR], zd[GR], dq[GR];
+      constexpr int GR = NTERMS == 2 ? 2 : 8, NG = 16 / GR;  // rows per group; two groups of 2 (two terms: 4) x GR registers in flight
+      // (two terms: groups of 2 rows keep the kernel within 128 VGPRs -- two 8-wave workgroups per CU)
+      struct Grp { float pp[GR], zz[GR], zd[GR], dq[GR]; };
+      auto row_off = [&](int r) {
+        return obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
+      };
+      auto fetch = [&](int grp, Grp& gq) {
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) {
-          const int r = grp * GR + rr;
-          const unsigned o = obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
-          pp[rr] = buf_ld(rbp, o);
-          zz[rr] = buf_ld(rbzh, o);
-          if (NTERMS == 2) { zd[rr] = buf_ld(rbzhd, o); dq[rr] = buf_ld(rbdp, o); }
+          const unsigned o = row_off(grp * GR + rr);
+          gq.pp[rr] = buf_ld(rbp, o);
+          gq.zz[rr] = buf_ld(rbzh, o);
+          if (NTERMS == 2) { gq.zd[rr] = buf_ld(rbzhd, o); gq.dq[rr] = buf_ld(rbdp, o); }
         }
+      };
+      auto consume = [&](int grp, const Grp& gq) {
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) {
           const int r = grp * GR + rr;
-          const unsigned o = obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
           const float v = acc[r];
-          buf_st(rout, o, v);
-          const bool on = pp[rr] > 0.f;
+          buf_st(rout, row_off(r), v);
+          const bool on = gq.pp[rr] > 0.f;
           const float vv = on ? v : 0.f;
           if (NTERMS == 1) {
-            s = fma((double)vv, (double)zz[rr], s);
+            s = fma((double)vv, (double)gq.zz[rr], s);
           } else {
-            const float dv = on ? dq[rr] : 0.f;
-            s += (double)vv * (double)zz[rr] + (double)dv * (double)zd[rr];
+            const float dv = on ? gq.dq[rr] : 0.f;
+            s += (double)vv * (double)gq.zz[rr] + (double)dv * (double)gq.zd[rr];
           }
           q += (double)vv;
         }
+      };
+      // the next group's loads are issued before this group's fp64 arithmetic (the lanes' sums are independent of the order)
+      Grp ga, gb;
+      fetch(0, ga);
+#pragma unroll
+      for (int grp = 0; grp < NG; grp += 2) {
+        if (grp + 1 < NG) fetch(grp + 1, gb);
+        consume(grp, ga);
+        if (grp + 2 < NG) fetch(grp + 2, ga);
+        if (grp + 1 < NG) consume(grp + 1, gb);
       }
       continue;
     }
