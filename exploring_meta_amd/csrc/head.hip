@@ -31,17 +31,56 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadArgs a) {
   const float* bl_t = a.bl + (size_t)task * a.pstride;
   const float* wld_t = TANGENT ? a.wld + (size_t)task * a.vstride : nullptr;
   const float* bld_t = TANGENT ? a.bld + (size_t)task * a.vstride : nullptr;
-  // lane w (< WY) ends up holding logit w of this row
+  // lane w (< WY) ends up holding logit w of this row.  All `ways` dot products of the row advance together: one pass over the
+  // feature row, 16-byte loads, every load of the pass independent of the others (the former one-dot-at-a-time loop with 4-byte
+  // loads waited for memory once per 64 features and dot product: 57 us for a 5-way tangent row kernel).
   float mine = 0.f;
-  for (int w = 0; w < WY; ++w) {
-    float d;
-    if (!TANGENT) {
-      d = wave_dot(f_n, wl_t + (size_t)w * F, F, lane) + bl_t[w];
-    } else {
-      d = wave_dot(f_n, wld_t + (size_t)w * F, F, lane) + bld_t[w];
-      if (fd_n) d += wave_dot(fd_n, wl_t + (size_t)w * F, F, lane);
+  const bool vec = (F % 4 == 0) && WY <= 8 &&
+                   ((reinterpret_cast<uintptr_t>(f_n) | reinterpret_cast<uintptr_t>(wl_t) | reinterpret_cast<uintptr_t>(fd_n) |
+                     reinterpret_cast<uintptr_t>(wld_t)) & 15) == 0;
+  if (vec) {
+    float part[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) part[w] = 0.f;
+    for (int i = lane * 4; i < F; i += 256) {
+      const floatx4 fv = *reinterpret_cast<const floatx4*>(f_n + i);
+      floatx4 fdv = {0.f, 0.f, 0.f, 0.f};
+      if (TANGENT && fd_n) fdv = *reinterpret_cast<const floatx4*>(fd_n + i);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        if (w < WY) {
+          if (!TANGENT) {
+            const floatx4 wv = *reinterpret_cast<const floatx4*>(wl_t + (size_t)w * F + i);
+            part[w] = fmaf(fv[0], wv[0], fmaf(fv[1], wv[1], fmaf(fv[2], wv[2], fmaf(fv[3], wv[3], part[w]))));
+          } else {
+            const floatx4 wdv = *reinterpret_cast<const floatx4*>(wld_t + (size_t)w * F + i);
+            part[w] = fmaf(fv[0], wdv[0], fmaf(fv[1], wdv[1], fmaf(fv[2], wdv[2], fmaf(fv[3], wdv[3], part[w]))));
+            if (fd_n) {
+              const floatx4 wv = *reinterpret_cast<const floatx4*>(wl_t + (size_t)w * F + i);
+              part[w] = fmaf(fdv[0], wv[0], fmaf(fdv[1], wv[1], fmaf(fdv[2], wv[2], fmaf(fdv[3], wv[3], part[w]))));
+            }
+          }
+        }
+      }
     }
-    if (lane == w) mine = d;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      if (w < WY) {
+        const float d = wave_sum(part[w]) + (TANGENT ? bld_t[w] : bl_t[w]);
+        if (lane == w) mine = d;
+      }
+    }
+  } else {
+    for (int w = 0; w < WY; ++w) {
+      float d;
+      if (!TANGENT) {
+        d = wave_dot(f_n, wl_t + (size_t)w * F, F, lane) + bl_t[w];
+      } else {
+        d = wave_dot(f_n, wld_t + (size_t)w * F, F, lane) + bld_t[w];
+        if (fd_n) d += wave_dot(fd_n, wl_t + (size_t)w * F, F, lane);
+      }
+      if (lane == w) mine = d;
+    }
   }
   const size_t o = ((size_t)task * N + n) * WY;
   const bool act = lane < WY;
@@ -94,7 +133,46 @@ __global__ __launch_bounds__(256) void head_grads_kernel(HeadArgs a) {
   const float* wld_t = TANGENT ? a.wld + (size_t)task * a.vstride : nullptr;
   float* dwl_t = a.dwl + (size_t)task * a.gstride;
   const int i = blockIdx.y * 256 + tid;
-  if (i < F) {
+  if (i < F && WY <= 8) {
+    // dwl[w][i] = sum_n a[n][w] f[n][i] (+ b[n][w] fd[n][i]): one pass over the rows, every row's feature loaded once for all ways
+    float dw[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dw[w] = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float fv = f_t[(size_t)n * F + i];
+      const float fdv = (TANGENT && fd_t) ? fd_t[(size_t)n * F + i] : 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        if (w < WY) {
+          dw[w] = fmaf(s_a[n * WY + w], fv, dw[w]);
+          if (TANGENT && fd_t) dw[w] = fmaf(s_b[n * WY + w], fdv, dw[w]);
+        }
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+      if (w < WY) dwl_t[(size_t)w * F + i] = dw[w];
+    if (a.df) {                                    // df[n][i] = sum_w a[n][w] wl[w][i] (+ b[n][w] wld[w][i]): weights in registers
+      float wv[8], wdv[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        wv[w] = w < WY ? wl_t[(size_t)w * F + i] : 0.f;
+        wdv[w] = (TANGENT && w < WY) ? wld_t[(size_t)w * F + i] : 0.f;
+      }
+      float* df_t = a.df + (size_t)task * N * F;
+      for (int n = 0; n < N; ++n) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          if (w < WY) {
+            s = fmaf(s_a[n * WY + w], wv[w], s);
+            if (TANGENT) s = fmaf(s_b[n * WY + w], wdv[w], s);
+          }
+        }
+        df_t[(size_t)n * F + i] = s;
+      }
+    }
+  } else if (i < F) {
     for (int w = 0; w < WY; ++w) {                 // dwl[w][i] = sum_n a[n][w] f[n][i] (+ b[n][w] fd[n][i])
       float s = 0.f;
       for (int n = 0; n < N; ++n) {
