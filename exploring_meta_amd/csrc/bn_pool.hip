@@ -183,21 +183,18 @@ template <int POOL>
 __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
   BN_THREAD_SETUP(POOL)
   float* out_t = a.out + (size_t)task * p_task;
+  float* zh_t = a.zh_out ? a.zh_out + (size_t)task * p_task : nullptr;
   Window<POOL> w;
   for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
     w.locate(a, it, win, c0);
     if (!w.pooled) continue;
-    w.analyse(z_t, k);
-    float o[4];
+    floatx4 umax, zh_at, zd_at;
+    scan_window<POOL, false>(w, z_t, nullptr, k, umax, zh_at, zd_at);      // running maximum, zhat carried along (no per-position arrays)
+    floatx4 o;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = fmaxf(w.umax[c], 0.f);
-    store4(out_t + w.poff, o);
-    if (a.zh_out) {
-      float zo[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) zo[c] = w.at_arg(w.zh, c);
-      store4(a.zh_out + (size_t)task * p_task + w.poff, zo);
-    }
+    for (int c = 0; c < 4; ++c) o[c] = fmaxf(umax[c], 0.f);
+    *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
+    if (zh_t) *reinterpret_cast<floatx4*>(zh_t + w.poff) = zh_at;
   }
 }
 
