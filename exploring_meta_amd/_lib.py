@@ -62,6 +62,7 @@ _SIGS = {
     'mi_engine_set_fused_block1': (C.c_int, [C.c_void_p, C.c_int]),
     'mi_engine_set_overlap': (C.c_int, [C.c_void_p, C.c_int]),
     'mi_engine_set_graph': (C.c_int, [C.c_void_p, C.c_int]),
+    'mi_engine_set_bn_export': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'mi_engine_set_fused_finalize': (C.c_int, [C.c_void_p, C.c_int]),
     'mi_engine_set_fused_block1_reduce': (C.c_int, [C.c_void_p, C.c_int]),
     'mi_debug_plan_offsets': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),

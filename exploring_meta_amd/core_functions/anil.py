@@ -46,6 +46,17 @@ class _FusedAnil(torch.autograd.Function):
         return (None,) * 8 + tuple(outs)
 
 
+def anil_engine(features, ways, in_h, device):
+    """The MetaEngine (one per architecture and device) that runs `features` + a `ways`-way linear head on in_h x in_h images."""
+    base = _find_convbase(features)
+    spec = ModelSpec.anil(ways, base.hidden, base.channels, base.max_pool, base.layers, in_h)
+    device = torch.device(device)
+    key = (spec, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _engines:
+        _engines[key] = MetaEngine(spec, device)
+    return _engines[key]
+
+
 def meta_batch_adapt_anil(learner, features, data, labels, adaptation_steps, shots, ways):
     """Batched ANIL entry: data [T, 2*S*W, C, H, W], labels [T, 2*S*W] on the GPU -> (loss_sum, loss[T], acc[T])."""
     head = learner.module if isinstance(learner, MAML) else learner
@@ -53,12 +64,7 @@ def meta_batch_adapt_anil(learner, features, data, labels, adaptation_steps, sho
         raise ValueError('ANIL learner must wrap torch.nn.Linear(fc_neurons, ways) (reference anil_vision.py:93)')
     base = _find_convbase(features)
     _, _, c, h, w = data.shape
-    spec = ModelSpec.anil(ways, base.hidden, base.channels, base.max_pool, base.layers, h)
-    dev = data.device
-    key = (spec, dev.index)
-    if key not in _engines:
-        _engines[key] = MetaEngine(spec, dev)
-    engine = _engines[key]
+    engine = anil_engine(features, ways, h, data.device)
     params = list(base.parameters()) + [head.weight, head.bias]          # reference optimizer order (anil_vision.py:97)
     if head.in_features * ways + ways + sum(p.numel() for p in base.parameters()) != engine.param_count:
         raise ValueError(f'head.in_features={head.in_features} does not match the trunk output for {h}x{w} inputs')

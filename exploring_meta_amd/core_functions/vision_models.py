@@ -52,6 +52,70 @@ class ConvBase(torch.nn.Sequential):
         self.hidden, self.channels, self.max_pool, self.layers = hidden, channels, bool(max_pool), layers
 
 
+def running_stats_contribution(stats, positions, total, momentum=0.1):
+    """Weighted sum of the batch statistics of some of the `total` forward passes of one meta-iteration, [2, C_total]:
+    sum_i momentum (1 - momentum)^(total - 1 - positions[i]) stats[i].  torch.nn.BatchNorm2d's running-statistics recurrence
+    (running <- (1 - momentum) running + momentum batch, once per forward pass in train mode) is linear, so the buffers after the
+    iteration are (1 - momentum)^total running_0 + the SUM of the contributions of all passes -- which lets each rank of a
+    task-sharded run fold its own passes and the sum ride in the gradient all-reduce (`apply_running_stats`).
+
+    stats:     [..., 2, C_total] batch mean / biased variance per pass (engine export, `MetaEngine.set_bn_export`).
+    positions: [...] index of each pass in the reference's call order (maml_vision.py:102-124: per task, adapt_steps support
+               passes and the query pass of the train task, then the same of the validation task)."""
+    pos = torch.as_tensor(positions, device=stats.device, dtype=torch.float64)
+    w = momentum * (1.0 - momentum) ** (total - 1 - pos)
+    return (w.reshape(-1, 1, 1) * stats.reshape(-1, 2, stats.shape[-1]).double()).sum(0).float()
+
+
+def apply_running_stats(base, spec, contribution, total, images, momentum=0.1):
+    """The buffers torch.nn.BatchNorm2d (reference vision_models.py:168-174) leaves after `total` train-mode forward passes of
+    `images` images each: learn2learn's clone_module copies parameters but shares buffers, so every `learner(x)` of the reference's
+    loop updates the running_mean / running_var / num_batches_tracked that utils/experiment.py:85-90 saves with the model.  The
+    running variance uses the UNBIASED batch variance (x n/(n-1), n = images x conv-output pixels of the block); the batch
+    statistics themselves never enter the computation (the reference never calls .eval())."""
+    from ..utils.roofline import layer_geometry
+    blocks = [b for b in base if isinstance(b, ConvBlock)]
+    decay = (1.0 - momentum) ** total
+    off = 0
+    for blk, (_, _, _, co, ho, wo, _, _) in zip(blocks, layer_geometry(spec)):
+        n = images * ho * wo
+        rm, rv = blk.normalize.running_mean, blk.normalize.running_var
+        c = contribution[:, off:off + co].to(rm.device)
+        with torch.no_grad():
+            rm.mul_(decay).add_(c[0])
+            rv.mul_(decay).add_(c[1] * (n / (n - 1.0) if n > 1 else 1.0))
+            blk.normalize.num_batches_tracked += total
+        off += co
+
+
+class RunningStatsFold:
+    """One meta-iteration's BatchNorm buffer update for a driver (maml_vision.py / anil_vision.py loops): switch the engine's
+    export on, `collect(phase)` after each fused call (phase 0 = the train tasks, 1 = the validation tasks the reference adapts
+    right after each train task), put `contribution` into the gradient all-reduce and `apply` the reduced sum.
+
+    engine/base/spec: the MetaEngine, the ConvBase holding the buffers and the engine's ModelSpec.
+    tasks/lo/hi:      meta_batch_size and this rank's task range.
+    passes/images:    forward passes per task per phase (adapt_steps + 1 for MAML, 1 for ANIL) and images per pass."""
+
+    def __init__(self, engine, base, spec, tasks, lo, hi, passes, images, phases=2, momentum=0.1):
+        self.engine, self.base, self.spec = engine, base, spec
+        self.tasks, self.lo, self.hi, self.passes, self.images, self.phases, self.momentum = tasks, lo, hi, passes, images, phases, momentum
+        self.total = tasks * phases * passes
+        ctot = spec.hidden * spec.n_layers
+        self.contribution = torch.zeros(2, ctot, dtype=torch.float32, device=engine.device)
+        self.export = engine.set_bn_export(hi - lo, passes) if hi > lo else None
+
+    def collect(self, phase):
+        p = torch.arange(self.passes, dtype=torch.float64).reshape(-1, 1)
+        t = torch.arange(self.lo, self.hi, dtype=torch.float64).reshape(1, -1)
+        positions = (t * self.phases + phase) * self.passes + p                               # [passes, local tasks]
+        self.contribution += running_stats_contribution(self.export, positions, self.total, self.momentum)
+
+    def apply(self, reduced=None):
+        self.engine.set_bn_export(0)
+        apply_running_stats(self.base, self.spec, self.contribution if reduced is None else reduced, self.total, self.images, self.momentum)
+
+
 class _EngineModel(torch.nn.Module):
     _engines = {}
 

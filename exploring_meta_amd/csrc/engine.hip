@@ -57,6 +57,11 @@ struct mi_engine {
   bool graph_on = false;
   struct GraphEntry { std::vector<unsigned long long> key; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; int seen = 0; };
   std::vector<GraphEntry> graphs;
+  // BatchNorm batch statistics of every forward pass (mi_engine_set_bn_export): what torch.nn.BatchNorm2d's running_mean / running_var
+  // update consumes.  Layout [pass][T][2][sum of channels over the blocks]: batch mean, biased batch variance.
+  float* bn_export = nullptr;
+  size_t bn_export_floats = 0;
+  int export_pass = 0;
   // debug trace (mi_debug_set_trace): per-step theta_k / g_k / lam fed to the k-th Hessian-vector product / H lam, reference order
   float* trace = nullptr;
   size_t trace_floats = 0;
@@ -301,6 +306,19 @@ static int side_join(mi_engine* e, hipStream_t st, int half, bool used) {
 // Debug/test aid: while set, every second-order mi_meta_batch_maml call with with_grad != 0 also writes, per task and in the
 // reference's parameter order, theta_k (k = 0..K), g_k = grad L_support(theta_k), the vector lam_{k+1} fed to the k-th
 // Hessian-vector product and H_support(theta_k) lam_{k+1} into `buf`:  [K+1][T][P] | [K][T][P] | [K][T][P] | [K][T][P] floats.
+// While set, every forward pass of mi_meta_batch_maml (support steps 0..K-1, then the query pass) / mi_meta_batch_anil (the one trunk
+// pass) also writes the BatchNorm batch statistics of every block: buf [passes][tasks][2][C_total] floats (C_total = sum of the blocks'
+// filters, block-major): [0] = batch mean, [1] = biased batch variance (1/rstd^2 - eps).  The reference's BatchNorm2d layers update
+// their running_mean / running_var buffers from exactly these on every learner(x) (torch momentum 0.1, unbiased variance; learn2learn's
+// clone shares the buffers with the base model), and utils/experiment.py:85-90 saves them: the host side folds them into the
+// model's buffers in the reference's call order (core_functions/vision_models.py::fold_running_stats).
+extern "C" int mi_engine_set_bn_export(mi_engine* e, float* buf, size_t floats) {
+  if (!e) return MI_ERR_ARG;
+  e->bn_export = buf;
+  e->bn_export_floats = buf ? floats : 0;
+  return MI_OK;
+}
+
 extern "C" int mi_debug_set_trace(mi_engine* e, float* buf, size_t floats) {
   if (!e) return MI_ERR_ARG;
   e->trace = buf;
@@ -679,12 +697,32 @@ static int head_pass(mi_engine* e, hipStream_t st, float* hscr, const float* f, 
   return MI_OK;
 }
 
+// mi_engine_set_bn_export: batch mean / biased variance of every block of the pass just run, into slot e->export_pass
+static int export_bn_stats(mi_engine* e, hipStream_t st, const ActSet& A, int T) {
+  if (!e->bn_export) return MI_OK;
+  const int nl = (int)e->L.size();
+  int ctot = 0;
+  for (const Layer& L : e->L) ctot += L.co;
+  const size_t need = (size_t)(e->export_pass + 1) * T * 2 * ctot;
+  if (need > e->bn_export_floats) return fail(e, MI_ERR_WORKSPACE, "BatchNorm export buffer too small: need " + std::to_string(need) + " floats");
+  BnExportArgs ea{};
+  ea.nl = nl; ea.ctot = ctot;
+  int off = 0;
+  for (int l = 0; l < nl; ++l) { ea.mu[l] = A.mu[l]; ea.rstd[l] = A.rstd[l]; ea.c[l] = e->L[l].co; ea.off[l] = off; off += e->L[l].co; }
+  ea.out = e->bn_export + (size_t)e->export_pass * T * 2 * ctot;
+  HIPCHK(e, launch_bn_export(st, ea, T));
+  e->export_pass += 1;
+  return MI_OK;
+}
+
 // One forward (+ backward) pass of the whole net on n images per task.
 static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, const int32_t* y, int n, int T,
                         const float* theta, float* g, float* loss, float* acc, float* logits, bool with_grad,
                         const double* gram = nullptr) {
   const int nl = (int)e->L.size();
   int rc = trunk_forward(e, st, pl, A, x0, n, T, theta, gram);
+  if (rc) return rc;
+  rc = export_bn_stats(e, st, A, T);
   if (rc) return rc;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
   if (with_grad) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * e->PS * sizeof(float), st));
@@ -887,6 +925,7 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int T = tasks, K = adapt_steps, ns = ways * shots, nq = ways * shots;
   const int so = (second_order && with_grad) ? 1 : 0;
+  e->export_pass = 0;
   Plan pl;
   make_plan(e, workspace, T, ns, nq, K, so, pl);
   if (pl.bytes > workspace_bytes)
@@ -1029,6 +1068,9 @@ static int meta_batch_anil_impl(mi_engine* e, void* stream, const float* theta, 
     LAUNCH(e, st, OP_GRAM, 0, launch_input_gram(st, ap.x, T, 2 * n, e->L[0].h, e->L[0].w, e->L[0].ci, ap.scratch.gram_part, ap.scratch.gram_s));
   int rc = trunk_forward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta, gram);     // features(data) on all rows
   if (rc) return rc;
+  e->export_pass = 0;
+  rc = export_bn_stats(e, st, ap.act, T);
+  if (rc) return rc;
   LAUNCH(e, st, OP_MISC, 4, launch_split_rows(st, ap.act.p[nl - 1], T, 2 * n, e->feat, ap.fs, ap.fq));
   for (int k = 0; k < K; ++k) {                                                    // head-only inner loop
     float* th = ap.theta + (size_t)k * TP;
@@ -1076,7 +1118,7 @@ static int meta_batch_entry(MetaBatchFn fn, int which, mi_engine* e, void* strea
                             const int64_t* labels, int tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order,
                             int with_grad, float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out, void* workspace,
                             size_t workspace_bytes) {
-  if (!e || !e->graph_on || e->prof_on || e->trace || !stream)     // (capture is not permitted on the legacy default stream)
+  if (!e || !e->graph_on || e->prof_on || e->trace || e->bn_export || !stream)     // (capture is not permitted on the legacy default stream)
     return fn(e, stream, theta, data, labels, tasks, ways, shots, adapt_steps, inner_lr, second_order, with_grad, loss_out, acc_out,
               meta_grad_out, logits_out, workspace, workspace_bytes);
   unsigned lr_bits;

@@ -194,5 +194,12 @@ hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* src, size_t images, 
 hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* perm, int p, int pstride, int tasks, float* out_ref);
 hipError_t launch_axpy(hipStream_t st, const float* a, const float* b, float alpha, size_t n, float* out);
 hipError_t launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes);
+struct BnExportArgs {
+  const float* mu[8]; const float* rstd[8];     // [T][c_l] per block
+  int c[8], off[8];
+  int nl, ctot;
+  float* out;                                   // [T][2][ctot]
+};
+hipError_t launch_bn_export(hipStream_t st, const BnExportArgs& a, int tasks);
 hipError_t launch_adam(hipStream_t st, float* theta, const float* grad, float* m, float* v, size_t n, int step, float lr,
                        float b1, float b2, float eps, float gscale);

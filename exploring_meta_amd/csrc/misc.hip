@@ -246,3 +246,21 @@ hipError_t launch_adam(hipStream_t st, float* theta, const float* grad, float* m
                      gscale, bc1, bc2);
   return hipGetLastError();
 }
+
+// Batch mean and biased batch variance of every block of one forward pass, for the host-side running-statistics update
+// (mi_engine_set_bn_export): var = 1/rstd^2 - eps.
+__global__ void bn_export_kernel(BnExportArgs a) {
+  const int t = blockIdx.x;
+  for (int i = threadIdx.x; i < a.ctot; i += blockDim.x) {
+    int l = 0;
+    while (l + 1 < a.nl && i >= a.off[l + 1]) ++l;
+    const int c = i - a.off[l];
+    const float r = a.rstd[l][(size_t)t * a.c[l] + c];
+    a.out[((size_t)t * 2 + 0) * a.ctot + i] = a.mu[l][(size_t)t * a.c[l] + c];
+    a.out[((size_t)t * 2 + 1) * a.ctot + i] = 1.f / (r * r) - (float)MI_BN_EPS;
+  }
+}
+hipError_t launch_bn_export(hipStream_t st, const BnExportArgs& a, int tasks) {
+  hipLaunchKernelGGL(bn_export_kernel, dim3(tasks), dim3(256), 0, st, a);
+  return hipGetLastError();
+}

@@ -178,6 +178,19 @@ class MetaEngine:
             self._persist[key] = fresh()
         return self._persist[key]
 
+    def set_bn_export(self, tasks=0, passes=0):
+        """mi_engine_set_bn_export: while on, every fused call also leaves the BatchNorm batch statistics of each of its forward
+        passes in the returned tensor [passes, tasks, 2, C_total] (mean, biased variance; C_total = blocks x filters, block-major).
+        passes = adapt_steps + 1 for meta_batch (inner steps, then the query pass), 1 for meta_batch_anil.  tasks = 0 switches it off."""
+        if not tasks:
+            _lib.check(self.lib.mi_engine_set_bn_export(self._h, C.c_void_p(0), 0), self._h)
+            self._bn_export = None
+            return None
+        ctot = self.spec.hidden * self.spec.n_layers
+        self._bn_export = torch.zeros(passes, tasks, 2, ctot, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mi_engine_set_bn_export(self._h, _ptr(self._bn_export), self._bn_export.numel()), self._h)
+        return self._bn_export
+
     def set_trace(self, tasks=0, adapt_steps=0):
         """Debug/test aid (mi_debug_set_trace): allocate a trace buffer for meta_batch calls with these sizes and return it as a
         dict of views {theta [K+1,T,P], g [K,T,P], lam_in [K,T,P], hv [K,T,P]} (reference parameter order); 0 tasks switches it off."""

@@ -17,18 +17,22 @@ def shard_range(num_tasks, rank, world):
 
 def reduce_meta_batch(meta_grad, loss_sum, acc_sum, group=None, extra=()):
     """Sum (meta_grad, loss_sum, acc_sum, *extra) over ranks with a single all-reduce: the scalars (train loss / accuracy sums and
-    whatever else the caller logs, e.g. the validation sums) ride behind the gradient.  Returns the reduced
-    (meta_grad, loss_sum, acc_sum) -- with ``extra`` a 4-tuple whose last element is the list of reduced extras.
+    whatever else the caller logs, e.g. the validation sums) and any small tensors (e.g. the BatchNorm running-statistics
+    contribution of this rank's forward passes) ride behind the gradient.  Returns the reduced (meta_grad, loss_sum, acc_sum) --
+    with ``extra`` a 4-tuple whose last element is the list of reduced extras, each in the shape it was given.
     Single-process (no initialised process group): identity."""
     extra = list(extra)
     if not (dist.is_available() and dist.is_initialized()):
         return (meta_grad, loss_sum, acc_sum, extra) if extra else (meta_grad, loss_sum, acc_sum)
-    scalars = [torch.as_tensor(x, device=meta_grad.device).reshape(()).to(meta_grad.dtype) for x in [loss_sum, acc_sum] + extra]
-    flat = torch.cat([meta_grad.reshape(-1), torch.stack(scalars)])
+    tail = [torch.as_tensor(x, device=meta_grad.device).to(meta_grad.dtype) for x in [loss_sum, acc_sum] + extra]
+    flat = torch.cat([meta_grad.reshape(-1)] + [t.reshape(-1) for t in tail])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    n = meta_grad.numel()
-    out = (flat[:n].view_as(meta_grad), flat[n], flat[n + 1])
-    return out + ([flat[n + 2 + i] for i in range(len(extra))],) if extra else out
+    parts, off = [], meta_grad.numel()
+    for t in tail:
+        parts.append(flat[off:off + t.numel()].view(t.shape))
+        off += t.numel()
+    out = (flat[:meta_grad.numel()].view_as(meta_grad), parts[0].reshape(()), parts[1].reshape(()))
+    return out + (parts[2:],) if extra else out
 
 
 class MetaTrainer:

@@ -18,7 +18,8 @@ import numpy as np
 import torch
 
 from ..core_functions import MAML, ConvBase
-from ..core_functions.anil import meta_batch_adapt_anil
+from ..core_functions.anil import anil_engine, meta_batch_adapt_anil
+from ..core_functions.vision_models import RunningStatsFold
 from ..sharding import reduce_meta_batch, shard_range
 from .maml_vision import SyntheticTasks
 
@@ -75,20 +76,32 @@ def run(dataset, p, log=print):
     for it in range(p['num_iterations']):
         opt.zero_grad()
         ids = list(range(it * T + lo, it * T + hi))
+        # BatchNorm buffers of `features` (saved with every checkpoint): one features(data) pass per task and phase (anil.py fast_adapt)
+        fold = None
+        if save_dir:
+            eng = anil_engine(features, p['ways'], 28 if dataset == 'omni' else 84, device)
+            fold = RunningStatsFold(eng, features[0], eng.spec, T, lo, hi, 1, 2 * p['ways'] * p['shots'])
         if ids:
             d, l = train.sample_batch(ids)
             total, losses, accs = meta_batch_adapt_anil(head.clone(), features, d.to(device), l.to(device), p['adapt_steps'],
                                                         p['shots'], p['ways'])
             total.backward()
+            if fold:
+                fold.collect(0)
             with torch.no_grad():
                 d, l = valid.sample_batch([10 ** 6 + i for i in ids])
                 _, vlosses, vaccs = meta_batch_adapt_anil(head.clone(), features, d.to(device), l.to(device), p['adapt_steps'],
                                                           p['shots'], p['ways'])
+            if fold:
+                fold.collect(1)
             sums = [losses.sum(), accs.sum(), vlosses.sum(), vaccs.sum()]
         else:                                    # meta_batch_size < world size: this rank owns no task, contributes zeros
             sums = [zero, zero, zero, zero]
         flat = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in all_parameters])
-        flat, lsum, asum, (vlsum, vasum) = reduce_meta_batch(flat, sums[0], sums[1], extra=sums[2:])   # one all-reduce, valid sums included
+        flat, lsum, asum, ex = reduce_meta_batch(flat, sums[0], sums[1], extra=sums[2:] + ([fold.contribution] if fold else []))
+        vlsum, vasum = ex[0], ex[1]                                           # one all-reduce, valid sums (and buffers) included
+        if fold:
+            fold.apply(ex[2])
         off = 0
         for q in all_parameters:                                                     # anil_vision.py:139-140
             g = flat[off:off + q.numel()].view_as(q) * (1.0 / T)

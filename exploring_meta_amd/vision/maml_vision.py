@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from ..core_functions import MAML, MiniImagenetCNN, OmniglotCNN, evaluate, meta_batch_adapt
+from ..core_functions.vision_models import RunningStatsFold
 from ..sharding import reduce_meta_batch, shard_range
 from ..utils import synthetic
 
@@ -67,18 +68,28 @@ def run(dataset, p, first_order=False, log=print):
     for it in range(p['num_iterations']):
         opt.zero_grad()
         ids = list(range(it * T + lo, it * T + hi))
+        # BatchNorm buffers (saved with every checkpoint, utils/experiment.py:85-90): tracked when checkpoints are written
+        fold = RunningStatsFold(model.engine(), model.base, model.spec(), T, lo, hi, p['adapt_steps'] + 1,
+                                p['ways'] * p['shots']) if save_dir else None
         if ids:
             d, l = train.sample_batch(ids)
             total, losses, accs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
             total.backward()                                                 # accumulates the SUM over this rank's tasks
+            if fold:
+                fold.collect(0)
             with torch.no_grad():
                 d, l = valid.sample_batch([10 ** 6 + i for i in ids])
                 _, vlosses, vaccs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
+            if fold:
+                fold.collect(1)
             sums = [losses.sum(), accs.sum(), vlosses.sum(), vaccs.sum()]
         else:                                    # meta_batch_size < world size: this rank owns no task, contributes zeros
             sums = [zero, zero, zero, zero]
         flat = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in maml.parameters()])
-        flat, lsum, asum, (vlsum, vasum) = reduce_meta_batch(flat, sums[0], sums[1], extra=sums[2:])   # one all-reduce, valid sums included
+        flat, lsum, asum, ex = reduce_meta_batch(flat, sums[0], sums[1], extra=sums[2:] + ([fold.contribution] if fold else []))
+        vlsum, vasum = ex[0], ex[1]                                           # one all-reduce, valid sums (and buffers) included
+        if fold:
+            fold.apply(ex[2])
         off = 0
         for q in maml.parameters():                                          # maml_vision.py:139-140
             g = flat[off:off + q.numel()].view_as(q) * (1.0 / T)

@@ -69,6 +69,13 @@ int mi_engine_set_overlap(mi_engine* e, int on);
  * those of the eager call.  mi_profile_enable and mi_debug_set_trace suspend it for their calls. */
 int mi_engine_set_graph(mi_engine* e, int on);
 
+/* While buf != NULL every forward pass of mi_meta_batch_maml (inner steps 0..K-1, then the query pass) and the trunk pass of
+ * mi_meta_batch_anil also writes the BatchNorm batch statistics of every block: buf [passes][tasks][2][C_total] floats (C_total = sum
+ * of the blocks' filters, block-major; [0] batch mean, [1] biased batch variance).  torch.nn.BatchNorm2d updates running_mean /
+ * running_var from these on every learner(x) of the reference (vision_models.py:168-174; the buffers are shared by learn2learn's clones
+ * and saved by utils/experiment.py:85-90); core_functions/vision_models.py (running_stats_contribution / apply_running_stats) folds them in the reference's call order. */
+int mi_engine_set_bn_export(mi_engine* e, float* buf, size_t floats);
+
 /* 1 (default): the per-workgroup fp64 partials of every BatchNorm statistic / reduction are folded, in a fixed order, by the
  * last workgroup of the producing kernel (arrival counter per task); 0: by separate bn_finalize launches.  Bit-identical
  * results either way; the switch exists for ablation and tests. */

@@ -1,0 +1,40 @@
+"""bench.py's output contract on the GPU box: ONE JSON line on stdout with the driver's keys, BASELINE's metric / unit, the
+`roofline` and `cpu_baseline` objects, and a `config.workload` naming the BASELINE configuration -- checked on the quickest workload
+(cfg1: Omniglot 5-way 1-shot first-order MAML, meta-batch 4), as a child process exactly as the driver runs it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', 'cfg1'],
+                       capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                    # exactly one line on stdout
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['metric'] == 'tasks/sec' and d['unit'] == 'tasks/s' and d['higher_is_better'] is True
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] in ('weak', 'strong')
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config'] and 'Omniglot' in d['config']['workload']
+    assert d['value'] > 0 and abs(d['value'] - 4 * 1e3 / d['ms_per_step']) < 1e-2 * d['value']      # 4 tasks per step
+    rf = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in rf, k
+    assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] in ('GB/s', 'TFLOP/s') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    cb = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in cb, k
+    assert cb['kind'] in ('port', 'reference') and cb['value'] > 0 and cb['cores'] >= 1
+    # the engine's post-adaptation figures sit beside the oracle's on the same tasks
+    pa = d['post_adapt']
+    assert pa['compared_tasks'] >= 1 and pa['max_abs_acc_diff_per_task'] == 0.0 and pa['max_abs_loss_diff_per_task'] < 1e-3

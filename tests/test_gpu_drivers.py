@@ -28,6 +28,11 @@ def test_maml_vision_driver_writes_reference_checkpoints(tmp_path, golden_small)
     assert all(torch.equal(sd[k].cpu(), v.cpu()) for k, v in model.state_dict().items())
     fresh = maml_vision.OmniglotCNN(5)
     fresh.load_state_dict(sd)                                 # round trip through the reference key layout
+    # BatchNorm buffers as the reference's loop leaves them: every forward pass counted (3 iterations x 2 tasks x train+valid x
+    # (adapt_steps + 1) passes), running statistics moved off their initial 0 / 1 (tests/test_gpu_running_stats.py checks the values)
+    for i in range(4):
+        assert int(sd[f'base.{i}.normalize.num_batches_tracked']) == 3 * 2 * 2 * 2
+        assert float(sd[f'base.{i}.normalize.running_mean'].abs().max()) > 0 and float((sd[f'base.{i}.normalize.running_var'] - 1).abs().max()) > 0
 
 
 def test_maml_trpo_driver_runs():

@@ -115,6 +115,9 @@ def _reduce_extras(rank, world, port):
     out = reduce_meta_batch(g, torch.tensor(1.0 * rank), torch.tensor(2.0), extra=[torch.tensor(3.0), 4.0])
     assert torch.equal(out[0], torch.full((5,), 3.0)) and float(out[1]) == 1.0 and float(out[2]) == 4.0
     assert [float(x) for x in out[3]] == [6.0, 8.0]
+    # small tensors ride too and come back in their own shape (the BatchNorm running-statistics contribution, [2, C_total])
+    out = reduce_meta_batch(g, torch.tensor(0.0), torch.tensor(0.0), extra=[1.0, torch.full((2, 3), float(rank))])
+    assert float(out[3][0]) == 2.0 and out[3][1].shape == (2, 3) and torch.equal(out[3][1], torch.ones(2, 3))
     assert len(reduce_meta_batch(g, torch.tensor(1.0), torch.tensor(2.0))) == 3
     dist.destroy_process_group()
 
