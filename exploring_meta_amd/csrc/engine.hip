@@ -605,7 +605,7 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       if (!fin.counter && !b1red_done)
         LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
       b1.dgamma = g + L.off_gamma; b1.dbeta = g + L.off_beta; b1.gstride = P;
-      if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci)) {   // sparse part on the matrix pipe, dense parts from the Gram matrix: no conv recompute
+      if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci, L.co)) {   // sparse part on the matrix pipe, dense parts from the Gram matrix: no conv recompute
         SparseWgArgs sw{};
         sw.x = x0; sw.arg = A.arg0; sw.dp = A.dp[0]; sw.wpartial = pl.wgpart; sw.n = n; sw.hh = L.ho; sw.ww = L.wo; sw.co = L.co;
         LAUNCH(e, st, OP_WGRAD, 0, launch_sparse_wgrad(st, sw, T, L.ci, 0, &blk));
@@ -834,7 +834,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       if (!fin.counter && !b1red_done)
         LAUNCH(e, st, OP_BN_FINALIZE, 0, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
       b1.rdgamma = hv + L.off_gamma; b1.rdbeta = hv + L.off_beta; b1.hstride = P;
-      if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci)) {
+      if (gram && A.arg0 && sparse_wgrad_supported(L.wo, L.ci, L.co)) {
         SparseWgArgs sw{};
         sw.x = x0; sw.arg = A.arg0; sw.dp = A.dp[0]; sw.dpd = X.dpd[cur]; sw.rstd = A.rstd[0]; sw.m2 = X.m2[0];
         sw.gamma = theta + L.off_gamma; sw.pstride = P; sw.gammad = v + L.off_gamma; sw.vstride = P;

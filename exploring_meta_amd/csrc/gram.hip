@@ -173,31 +173,43 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const double* __restric
 // as four masked MFMA accumulations (one per position q): A operand = patch entries of the window's q-th pixel (lane = entry k,
 // two windows per K step), B operand = cot where arg == q else 0.  cot = dp (primal) or c1 dp + gr dpd (tangent, the sparse
 // part of R{dz}).  No BatchNorm arithmetic, no conv: 64 MFMAs per 32 windows against 124 in block1_kernel<*_WGRAD>.
-template <int CI0, bool TAN>
+// All operands come through raw buffer loads whose descriptors are rebuilt per pooled row / input row on the scalar unit (base =
+// start of the row, num_records = the row's bytes, 0 for a row outside the image): windows past the end of a row, rows above /
+// below the image and the lanes past the end of an input row read 0 from the range check, the K steps of a chunk are load
+// IMMEDIATES, and no address arithmetic, predicate or select is left on the vector unit -- fp32 MFMAs and VALU instructions share
+// the SIMD's lanes, so what remains per K step is the four argmax compares + selects (and the c1 / gr combination in tangent mode).
+struct SparseB {   // B-side operands of one chunk of CH K steps, as loaded (combined at use: nothing waits at the prefetch)
+  float q[8], qd[8];
+  unsigned ag[8];
+};
+template <int CI0, bool TAN, int CO, int CH>
 __global__ __launch_bounds__(256) void sparse_wgrad_kernel(SparseWgArgs a) {
   constexpr int K = 9 * CI0;
-  // LDS: per wave the 4 input rows a pooled row touches, [4][RP] with a zero halo pixel left and right; the pitch is padded to
-  // 12 (mod 32) floats so the three tap rows land on disjoint banks.  The cross-wave reduction at the end re-uses the buffer.
+  constexpr unsigned RSRC = 0x00020000u;
+  // LDS: per wave two sets (ping-pong over tiles) of the 4 input rows a pooled row touches, [2][4][RP] with a zero halo pixel left
+  // and right; the pitch is padded to 12 (mod 32) floats so the three tap rows land on disjoint banks, and is at least CI0 + 256 so
+  // that the 4 x 64 lanes of a row store never leave the row.  The cross-wave reduction at the end re-uses the buffer.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int task = blockIdx.y, ct = blockIdx.z, cbase = ct * 32, ch = cbase + j;
-  const int H = a.hh, W = a.ww, HP = H >> 1, WP = W >> 1, CO = a.co;
+  const int task = blockIdx.y, cbase = blockIdx.z * 32, ch = cbase + j;
+  const int H = a.hh, W = a.ww, HP = H >> 1, WP = W >> 1;
   const int RP = a.row_pitch, ROWF = W * CI0;
-  float* rows = lds + wave * 4 * RP;
+  float* rows = lds + wave * 8 * RP;
   const float* x_t = a.x + (size_t)task * a.n * H * W * CI0;
   const size_t p_task = (size_t)a.n * HP * WP * CO;
   const uint8_t* arg_t = a.arg + (size_t)task * p_task;
   const float* dp_t = a.dp + (size_t)task * p_task;
-  const float* dpd_t = TAN ? a.dpd + (size_t)task * p_task : nullptr;
-  // A-operand role of this lane: patch entry k = j (tap, channel); lanes j >= K feed zeros (they read a halo zero)
+  const float* dpd_t = TAN ? a.dpd + (size_t)task * p_task : dp_t;
+  // A-operand role of this lane: patch entry k = j (tap, channel) of the window pair's window h; rows k >= K of the product are
+  // never stored.  Offset of pixel (qy = 0, qx = 0) of window h of pair 0 for this lane's tap, halo pixel included.
   const bool kval = j < K;
   const int tap = kval ? j / CI0 : 0, kc = kval ? j % CI0 : 0;
   const int kdy = tap / 3 - 1, kdx = tap % 3 - 1;
-  // LDS offset of pixel (qy = 0, qx = 0) of window 0 for this lane's tap: row (kdy + 1), column (kdx + 1) pixels incl. the halo
-  const int aoff = kval ? (kdy + 1) * RP + (kdx + 1) * CI0 + kc : 0;
-  // B-operand role: output channel ch
+  const float* arow = rows + (kval ? (kdy + 1) * RP + (kdx + 1) * CI0 + kc : 0) + 2 * h * CI0;
+  // B-operand role: output channel ch of window h of the pair
+  const unsigned lane_b = (unsigned)(h * CO + ch), lane_x = (unsigned)lane * 4u;
   float sA = 1.f, sB = 0.f;
   if (TAN) {
     const float rs = a.rstd[(size_t)task * CO + ch], gm = a.gamma[(size_t)task * a.pstride + ch];
@@ -207,88 +219,221 @@ __global__ __launch_bounds__(256) void sparse_wgrad_kernel(SparseWgArgs a) {
   floatx16 acc, acc2;          // two accumulation chains: consecutive MFMAs never wait for each other's result
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-  for (int e = lane; e < 4 * RP; e += 64) rows[e] = 0.f;      // halos (and padding) stay zero for the whole kernel
+  for (int e = lane; e < 8 * RP; e += 64) rows[e] = 0.f;      // halos (and padding) stay zero for the whole kernel
 
-  // one tile = one pooled row (img, wy): WP windows, ceil(WP / 2) K steps of two windows
+  // one tile = one pooled row (img, wy): WP windows, ceil(WP / 2) K steps of two windows, in chunks of CH steps
   const int nsteps = (WP + 1) >> 1;
-  const int tile_base = blockIdx.x * 4 * a.tiles_per_wave;
-  const int tile_end = min(tile_base + 4 * a.tiles_per_wave, a.ntiles);
-  // Latency is hidden by the wave itself: the next tile's input rows travel in registers while this tile computes, and the B
-  // operands (arg, dp, dpd) are fetched one chunk of CH K-steps ahead.
-  constexpr int CH = 8, RL = 4;                       // RL * 64 >= W * CI0 (checked by the launcher)
-  float rbuf[4][RL];
-  auto fetch_rows = [&](int tile) {
+  // this workgroup's share of the task's tiles: an even split (shares differ by at most one tile)
+  const int tile_base = (int)((long)blockIdx.x * a.ntiles / gridDim.x);
+  const int tile_end = (int)((long)(blockIdx.x + 1) * a.ntiles / gridDim.x);
+  float rbuf[4][4];
+  auto fetch_rows = [&](int tile) {           // the 4 input rows of a tile -> registers (zeros outside the image / past the row)
     const int img = tile / HP, wy = tile - img * HP;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int y = 2 * wy - 1 + r;
       const bool rv = (unsigned)y < (unsigned)H;
-      const float* src = x_t + (size_t)(img * H + (rv ? y : 0)) * ROWF;
+      const mi_rsrc rr = __builtin_amdgcn_make_buffer_rsrc((void*)(x_t + (size_t)(img * H + (rv ? y : 0)) * ROWF), 0, rv ? ROWF * 4 : 0, RSRC);
 #pragma unroll
-      for (int i = 0; i < RL; ++i) {
-        const int e = lane + 64 * i;
-        rbuf[r][i] = *((rv && e < ROWF) ? src + e : mi_zero_word);
-      }
+      for (int i = 0; i < 4; ++i) rbuf[r][i] = buf_ld(rr, lane_x + 256u * i);
     }
   };
-  auto fetch_b = [&](size_t prow, int s0, float* cot, int* ag) {
+  auto store_rows = [&](int set) {            // registers -> LDS set (row r <-> input row 2wy - 1 + r)
+    float* dst = rows + set * 4 * RP + CI0 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[r * RP + 64 * i] = rbuf[r][i];
+  };
+  auto fetch_b = [&](int tile, int s0, SparseB& b) {
+    const size_t prow = (size_t)tile * WP * CO;
+    const mi_rsrc ra = __builtin_amdgcn_make_buffer_rsrc((void*)(arg_t + prow), 0, WP * CO, RSRC);
+    const mi_rsrc rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dp_t + prow), 0, WP * CO * 4, RSRC);
+    const mi_rsrc rdd = __builtin_amdgcn_make_buffer_rsrc((void*)(dpd_t + prow), 0, WP * CO * 4, RSRC);
+    unsigned vb = lane_b + (unsigned)(s0 * 2 * CO), vb4 = vb * 4u;
+    asm volatile("" : "+v"(vb), "+v"(vb4));        // opaque bases: the K steps below become load immediates, not re-associated adds
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int wx = 2 * (s0 + i) + h;
-      const bool wv = wx < WP;
-      const size_t po = (prow + (wv ? wx : 0)) * CO + ch;
-      ag[i] = wv ? (int)arg_t[po] : 4;
-      float c = dp_t[po];
-      if (TAN) c = sA * c + sB * dpd_t[po];
-      cot[i] = c;
+      b.ag[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, vb + (unsigned)(i * 2 * CO), 0, 0);
+      b.q[i] = buf_ld(rd, vb4 + (unsigned)(i * 8 * CO));
+      if (TAN) b.qd[i] = buf_ld(rdd, vb4 + (unsigned)(i * 8 * CO));
     }
   };
-  // flat stream of (tile, chunk) work items so the B prefetch also runs across tile boundaries
-  int tile = tile_base + wave, s0 = 0;
-  float cotA[CH];
-  int agA[CH];
+  // flat stream of (tile, chunk) work items: the B operands are fetched one item ahead (also across tile boundaries), the input
+  // rows one tile ahead into the other LDS set and two tiles ahead into registers
+  int tile = tile_base + ((wave + blockIdx.x) & 3), s0 = 0, set = 0;      // (rotated: a share's odd tile lands on a different SIMD per workgroup)
+  SparseB bA, bB;
   if (tile < tile_end) {
     fetch_rows(tile);
-    fetch_b((size_t)tile * WP, 0, cotA, agA);
+    fetch_b(tile, 0, bA);
+    store_rows(0);
+    if (tile + 4 < tile_end) fetch_rows(tile + 4);
   }
-  while (tile < tile_end) {
-    if (s0 == 0) {
-      // this tile's rows: registers -> LDS (row r <-> input row 2wy - 1 + r, zeros outside the image)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int i = 0; i < RL; ++i) {
-          const int e = lane + 64 * i;
-          if (e < ROWF) rows[r * RP + CI0 + e] = rbuf[r][i];
-        }
-      if (tile + 4 < tile_end) fetch_rows(tile + 4);
+  auto item = [&](const SparseB& cur, SparseB& nxt) {
+    if (s0 == 0 && tile + 4 < tile_end) {
+      store_rows(set ^ 1);
+      if (tile + 8 < tile_end) fetch_rows(tile + 8);
     }
-    int ntile = tile, ns0 = s0 + CH;
-    if (ns0 >= nsteps) { ns0 = 0; ntile += 4; }
-    float cotB[CH];
-    int agB[CH];
-    if (ntile < tile_end) fetch_b((size_t)ntile * WP, ns0, cotB, agB);
+    int ntile = tile, ns0 = s0 + CH, nset = set;
+    if (ns0 >= nsteps) { ns0 = 0; ntile += 4; nset ^= 1; }
+    if (ntile < tile_end) fetch_b(ntile, ns0, nxt);
+    const float* ac = arow + set * 4 * RP + 4 * s0 * CI0;
+    const float* ac1 = ac + RP;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      if (s0 + i < nsteps) {
-        const int wx = 2 * (s0 + i) + h;
-        const float* ap = rows + aoff + 2 * (wx < WP ? wx : 0) * CI0;      // pixel (2wy, 2wx) + tap; LDS ops of a wave are in order
-        const float a0 = ap[0], a1 = ap[CI0], a2 = ap[RP], a3 = ap[RP + CI0];
-        const int ag = agA[i];
-        const float cot = cotA[i];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ag == 0 ? cot : 0.f, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ag == 1 ? cot : 0.f, acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, ag == 2 ? cot : 0.f, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, ag == 3 ? cot : 0.f, acc2, 0, 0, 0);
+      if (CH == 7 || s0 + i < nsteps) {            // chunks of 7 are launched only when they tile the row exactly
+        const float a0 = ac[4 * i * CI0], a1 = ac[4 * i * CI0 + CI0], a2 = ac1[4 * i * CI0], a3 = ac1[4 * i * CI0 + CI0];
+        const unsigned ag = cur.ag[i];
+        const float cot = TAN ? fmaf(sB, cur.qd[i], sA * cur.q[i]) : cur.q[i];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ag == 0u ? cot : 0.f, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ag == 1u ? cot : 0.f, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, ag == 2u ? cot : 0.f, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, ag == 3u ? cot : 0.f, acc2, 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) { cotA[i] = cotB[i]; agA[i] = agB[i]; }
-    tile = ntile; s0 = ns0;
+    tile = ntile; s0 = ns0; set = nset;
+  };
+  while (tile < tile_end) {
+    item(bA, bB);
+    if (tile >= tile_end) break;
+    item(bB, bA);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
   // 4 waves -> one partial per workgroup (same layout as block1_kernel<*_WGRAD>'s partials)
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lds[wave * 1024 + r * 64 + lane] = acc[r];
+  __syncthreads();
+  float* pt = a.wpartial + ((size_t)task * gridDim.x + blockIdx.x) * K * CO;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int e = tid + 256 * qq;
+    const float v = lds[e] + lds[1024 + e] + lds[2048 + e] + lds[3072 + e];
+    const int r = e >> 6, l = e & 63;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    if (row < K) pt[(size_t)row * CO + cbase + col] = v;
+  }
+}
+
+// The same product for rows of exactly NCH chunks of CH K steps (84-wide RGB: 7 x 3), as a loop over PAIRS of tiles
+// with every load issued unconditionally (descriptors of tiles past the wave's range have 0 records: the loads return 0 without
+// touching memory).  The number of loads in flight at every point is then the same on every path, so the compiler's s_waitcnt
+// counts are exact -- in the work-item loop above the conditional row fetches make it assume the worst and wait for the chunk it
+// has just issued, which exposes a full memory latency per chunk.
+template <int CI0, bool TAN, int CO, int CH, int NCH>
+__global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs a) {
+  constexpr int K = 9 * CI0;
+  constexpr unsigned RSRC = 0x00020000u;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y, cbase = blockIdx.z * 32, ch = cbase + j;
+  const int H = a.hh, W = a.ww, HP = H >> 1, WP = W >> 1;
+  const int RP = a.row_pitch, ROWF = W * CI0;
+  float* rows = lds + wave * 8 * RP;
+  const float* x_t = a.x + (size_t)task * a.n * H * W * CI0;
+  const size_t p_task = (size_t)a.n * HP * WP * CO;
+  const uint8_t* arg_t = a.arg + (size_t)task * p_task;
+  const float* dp_t = a.dp + (size_t)task * p_task;
+  const float* dpd_t = TAN ? a.dpd + (size_t)task * p_task : dp_t;
+  const bool kval = j < K;
+  const int tap = kval ? j / CI0 : 0, kc = kval ? j % CI0 : 0;
+  const int kdy = tap / 3 - 1, kdx = tap % 3 - 1;
+  const float* arow = rows + (kval ? (kdy + 1) * RP + (kdx + 1) * CI0 + kc : 0) + 2 * h * CI0;
+  const float* arow1 = arow + RP;
+  const unsigned lane_b = (unsigned)(h * CO + ch), lane_b4 = lane_b * 4u, lane_x = (unsigned)lane * 4u;
+  float sA = 1.f, sB = 0.f;
+  if (TAN) {
+    const float rs = a.rstd[(size_t)task * CO + ch], gm = a.gamma[(size_t)task * a.pstride + ch];
+    sA = a.gammad[(size_t)task * a.vstride + ch] * rs + gm * (-rs * rs * a.m2[(size_t)task * CO + ch]);   // c1
+    sB = gm * rs;                                                                                             // gr
+  }
+  floatx16 acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+  for (int e = lane; e < 8 * RP; e += 64) rows[e] = 0.f;
+  // this workgroup's share of the task's tiles: an even split (shares differ by at most one tile)
+  const int tile_base = (int)((long)blockIdx.x * a.ntiles / gridDim.x);
+  const int tile_end = (int)((long)(blockIdx.x + 1) * a.ntiles / gridDim.x);
+  float rbuf[4][4];
+  auto fetch_rows = [&](int tile) {
+    const bool tv = tile < tile_end;
+    const int tl = tv ? tile : 0;
+    const int img = tl / HP, wy = tl - img * HP;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = 2 * wy - 1 + r;
+      const bool rv = tv && (unsigned)y < (unsigned)H;
+      const mi_rsrc rr = __builtin_amdgcn_make_buffer_rsrc((void*)(x_t + (size_t)(img * H + (rv ? y : 0)) * ROWF), 0, rv ? ROWF * 4 : 0, RSRC);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rbuf[r][i] = buf_ld(rr, lane_x + 256u * i);
+    }
+  };
+  auto store_rows = [&](int set) {
+    float* dst = rows + set * 4 * RP + CI0 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[r * RP + 64 * i] = rbuf[r][i];
+  };
+  auto fetch_b = [&](int tile, int c, SparseB& b) {
+    const bool tv = tile < tile_end;
+    const size_t prow = (size_t)(tv ? tile : 0) * WP * CO;
+    const int rec = tv ? WP * CO : 0;
+    const mi_rsrc ra = __builtin_amdgcn_make_buffer_rsrc((void*)(arg_t + prow), 0, rec, RSRC);
+    const mi_rsrc rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dp_t + prow), 0, rec * 4, RSRC);
+    const mi_rsrc rdd = __builtin_amdgcn_make_buffer_rsrc((void*)(dpd_t + prow), 0, rec * 4, RSRC);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      b.ag[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(ra, lane_b + (unsigned)((c * CH + i) * 2 * CO), 0, 0);
+      b.q[i] = buf_ld(rd, lane_b4 + (unsigned)((c * CH + i) * 8 * CO));
+      if (TAN) b.qd[i] = buf_ld(rdd, lane_b4 + (unsigned)((c * CH + i) * 8 * CO));
+    }
+  };
+  auto compute = [&](int set, int c, const SparseB& b) {
+    const float* ac = arow + set * 4 * RP, * ac1 = arow1 + set * 4 * RP;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int o = 4 * (c * CH + i) * CI0;
+      const float a0 = ac[o], a1 = ac[o + CI0], a2 = ac1[o], a3 = ac1[o + CI0];
+      const unsigned ag = b.ag[i];
+      const float cot = TAN ? fmaf(sB, b.qd[i], sA * b.q[i]) : b.q[i];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ag == 0u ? cot : 0.f, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ag == 1u ? cot : 0.f, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, ag == 2u ? cot : 0.f, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, ag == 3u ? cot : 0.f, acc2, 0, 0, 0);
+    }
+  };
+  int tile = tile_base + ((wave + blockIdx.x) & 3);   // this wave's tiles: tile, tile + 4, ... (start rotated per workgroup); pairs per iteration
+  SparseB bb[2];
+  fetch_rows(tile);
+  store_rows(0);
+  fetch_rows(tile + 4);
+  fetch_b(tile, 0, bb[0]);                       // (after the rows, as at the end of every loop half: same loads in flight on both paths into the loop)
+  __builtin_amdgcn_sched_barrier(0);
+  while (tile < tile_end) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {       // half 0: tile (LDS set 0), half 1: tile + 4 (set 1)
+      const int cur_tile = tile + 4 * half, nxt_tile = cur_tile + 4;
+      store_rows(half ^ 1);                      // rows of the next tile (in registers since the previous half) -> the other set
+      fetch_rows(cur_tile + 8);
+      __builtin_amdgcn_sched_barrier(0);         // the prefetches stay where they are written: ahead of the MFMAs that hide them
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int m = half * NCH + c;            // chunk index within the iteration: B buffers alternate
+        if (c + 1 < NCH) fetch_b(cur_tile, c + 1, bb[(m + 1) & 1]);
+        else fetch_b(nxt_tile, 0, bb[(m + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur_tile < tile_end) compute(half, c, bb[m & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    tile += 8;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 16; ++r) lds[wave * 1024 + r * 64 + lane] = acc[r];
@@ -348,24 +493,36 @@ __global__ __launch_bounds__(64) void gram_wgrad_kernel(GramWgArgs a, int ng, in
 }
 
 static int sparse_row_pitch(int w, int ci) {
-  int rp = (w + 2) * ci;
+  int rp = (w + 4) * ci;                       // halo pixel + row + halo pixel (+ the pixels an odd row's last half window reaches)
+  if (rp < ci + 256) rp = ci + 256;            // a row store writes 4 x 64 lanes (zeros past the row)
   while (rp % 32 != 12) ++rp;
   return rp;
 }
-bool sparse_wgrad_supported(int w, int ci) { return w * ci <= 256; }   // one input row = at most 4 floats per lane (RL)
+// one input row = at most 4 floats per lane; 32 or 64 filters per column tile group; per-task tensors addressable by 32-bit offsets
+bool sparse_wgrad_supported(int w, int ci, int co) { return w * ci <= 256 && (ci == 1 || ci == 3) && (co == 32 || co == 64); }
 static void sparse_wgrad_grid(int n, int h, int w, int co, int tasks, int& ntiles, int& tpw, dim3& grid) {
   ntiles = n * (h / 2);                       // pooled rows
-  const long slots = 1024L * 4;
-  const long total = (long)ntiles * tasks * (co / 32);
-  tpw = (int)((total + slots - 1) / slots);
-  if (tpw < 1) tpw = 1;
-  grid = dim3(ceil_div(ntiles, 4 * tpw), tasks, co / 32);
+  // 4 workgroups of 4 waves are resident per CU (LDS, 128 VGPRs): aim at exactly one resident set (1024 workgroups) with even shares
+  // -- a last, partly filled round of workgroups costs its full time, and so does a share one tile larger on a few SIMDs only
+  const long col_tiles = (long)tasks * (co / 32);
+  long nblk = 1024 / col_tiles;
+  if (nblk < 1) nblk = 1;
+  if (nblk > ceil_div(ntiles, 4)) nblk = ceil_div(ntiles, 4);       // at least one tile per wave
+  tpw = ceil_div(ceil_div(ntiles, (int)nblk), 4);
+  grid = dim3((unsigned)nblk, tasks, co / 32);
 }
 int sparse_wgrad_blocks_per_task(int n, int h, int w, int co, int tasks) {
   int ntiles, tpw;
   dim3 grid;
   sparse_wgrad_grid(n, h, w, co, tasks, ntiles, tpw, grid);
   return (int)grid.x;
+}
+template <int CI, bool TAN>
+static void launch_sparse_t(hipStream_t st, dim3 grid, size_t smem, const SparseWgArgs& a, bool rows) {
+  if (CI == 3 && rows && a.co == 32) hipLaunchKernelGGL((sparse_wgrad_rows_kernel<3, TAN, 32, 3, 7>), grid, dim3(256), smem, st, a);
+  else if (CI == 3 && rows) hipLaunchKernelGGL((sparse_wgrad_rows_kernel<3, TAN, 64, 3, 7>), grid, dim3(256), smem, st, a);
+  else if (a.co == 32) hipLaunchKernelGGL((sparse_wgrad_kernel<CI, TAN, 32, 8>), grid, dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((sparse_wgrad_kernel<CI, TAN, 64, 8>), grid, dim3(256), smem, st, a);
 }
 hipError_t launch_sparse_wgrad(hipStream_t st, SparseWgArgs a, int tasks, int ci, int tangent, int* blocks_per_task) {
   int ntiles, tpw;
@@ -374,16 +531,17 @@ hipError_t launch_sparse_wgrad(hipStream_t st, SparseWgArgs a, int tasks, int ci
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   a.row_pitch = sparse_row_pitch(a.ww, ci);
-  if (!sparse_wgrad_supported(a.ww, ci)) return hipErrorInvalidValue;
-  size_t smem = (size_t)a.row_pitch * 16 * sizeof(float);
+  if (!sparse_wgrad_supported(a.ww, ci, a.co)) return hipErrorInvalidValue;
+  if (a.co != 32 && a.co != 64) return hipErrorInvalidValue;
+  size_t smem = (size_t)a.row_pitch * 32 * sizeof(float);          // 4 waves x 2 sets x 4 rows
   if (smem < 4 * 1024 * sizeof(float)) smem = 4 * 1024 * sizeof(float);
   if (blocks_per_task) *blocks_per_task = grid.x;
+  const int nsteps = (a.ww / 2 + 1) / 2;
+  const bool rows = ci == 3 && a.ww == 84;       // rows of exactly 7 chunks of 3 steps: the mini-ImageNet input
   if (ci == 3) {
-    if (tangent) hipLaunchKernelGGL((sparse_wgrad_kernel<3, true>), grid, dim3(256), smem, st, a);
-    else hipLaunchKernelGGL((sparse_wgrad_kernel<3, false>), grid, dim3(256), smem, st, a);
+    if (tangent) launch_sparse_t<3, true>(st, grid, smem, a, rows); else launch_sparse_t<3, false>(st, grid, smem, a, rows);
   } else if (ci == 1) {
-    if (tangent) hipLaunchKernelGGL((sparse_wgrad_kernel<1, true>), grid, dim3(256), smem, st, a);
-    else hipLaunchKernelGGL((sparse_wgrad_kernel<1, false>), grid, dim3(256), smem, st, a);
+    if (tangent) launch_sparse_t<1, true>(st, grid, smem, a, rows); else launch_sparse_t<1, false>(st, grid, smem, a, rows);
   } else {
     return hipErrorInvalidValue;
   }

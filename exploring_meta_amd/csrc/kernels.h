@@ -130,7 +130,7 @@ struct SparseWgArgs {
   int n, hh, ww, co;
   int ntiles, tiles_per_wave, row_pitch;
 };
-bool sparse_wgrad_supported(int w, int ci);
+bool sparse_wgrad_supported(int w, int ci, int co);
 int sparse_wgrad_blocks_per_task(int n, int h, int w, int co, int tasks);
 hipError_t launch_sparse_wgrad(hipStream_t st, SparseWgArgs a, int tasks, int ci, int tangent, int* blocks_per_task);
 struct GramWgArgs {

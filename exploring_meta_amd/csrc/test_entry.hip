@@ -203,7 +203,7 @@ extern "C" int mi_block1_wgrad_gram(void* stream, const mi_block1_args* a, const
                                     void* scratch, size_t scratch_bytes) {
   if (!a || !a->x || !a->w || !a->arg_in || !a->dp || !g || !dw || !scratch || (tangent && (!a->dpd || !a->wd)))
     return mi_internal_fail(MI_ERR_ARG, "mi_block1_wgrad_gram: null argument");
-  if (!sparse_wgrad_supported(a->w_, a->ci)) return mi_internal_fail(MI_ERR_ARG, "mi_block1_wgrad_gram: input row too wide");
+  if (!sparse_wgrad_supported(a->w_, a->ci, a->co)) return mi_internal_fail(MI_ERR_ARG, "mi_block1_wgrad_gram: input row too wide");
   if (scratch_bytes < mi_block1_scratch_bytes(a->tasks, a->n, a->h, a->w_, a->ci, a->co)) return mi_internal_fail(MI_ERR_WORKSPACE, "mi_block1_wgrad_gram: scratch too small");
   SparseWgArgs sw{};
   sw.x = a->x; sw.arg = a->arg_in; sw.dp = a->dp; sw.dpd = a->dpd; sw.rstd = a->rstd; sw.m2 = a->m2;

@@ -36,7 +36,7 @@ def op_costs(spec, op, layer, images):
         a = p // 4
         t = {'conv_fwd_stats': (f, x), 'bn_relu_pool_fwd': (f, x + 2 * p + a), 'bn_bwd_reduce': (0, 3 * p), 'wgrad': (f, x + p + a),
              'tangent_conv_fwd': (2 * f, x), 'bn_tangent_fwd': (f, x + 3 * p + a), 'bn_tangent_bwd_reduce': (0, 5 * p),
-             'tangent_wgrad': (2 * f, x + 2 * p + a)}
+             'tangent_wgrad': (f, x + 2 * p + a)}        # (x has no tangent: R{dW1} = x^T R{dz} is one product)
     else:
         # The dgrad of a stride-1 hidden block also forms the BatchNorm-backward sums of the block below in its epilogue (EPI_BRED):
         # it reads that block's p and zhat-at-argmax (tangent: + zhat-dot and the primal cotangent) at its output positions -- tensors
@@ -75,8 +75,8 @@ KERNEL_NAMES = {
     'bn_tangent_bwd_apply': 'bn_tan_bwd_apply_kernel',
 }
 BLOCK1_KERNEL_NAMES = {
-    'bn_relu_pool_fwd': 'block1_fwd_kernel<{ci},FWD>', 'bn_tangent_fwd': 'block1_fwd_kernel<{ci},TFWD_ARG>', 'wgrad': 'sparse_wgrad_kernel<{ci},false>',
-    'tangent_wgrad': 'sparse_wgrad_kernel<{ci},true>', 'bn_bwd_reduce': 'pooled_reduce_kernel<false>',
+    'bn_relu_pool_fwd': 'block1_fwd_kernel<{ci},FWD>', 'bn_tangent_fwd': 'block1_fwd_kernel<{ci},TFWD_ARG>', 'wgrad': 'sparse_wgrad_rows_kernel<{ci},false>',
+    'tangent_wgrad': 'sparse_wgrad_rows_kernel<{ci},true>', 'bn_bwd_reduce': 'pooled_reduce_kernel<false>',
     'bn_tangent_bwd_reduce': 'pooled_reduce_kernel<true>', 'conv_fwd_stats': 'block1_kernel<{ci},STATS>',
 }
 
