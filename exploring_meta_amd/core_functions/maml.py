@@ -59,10 +59,11 @@ class MAML(torch.nn.Module):
         rc_vision.py:70): g = grad(loss, fast weights); p <- p - lr * g, out of place.
 
         `loss` must come from `learner(x)` of this learner.  The gradient is one mi_learner_backward call.  The update keeps the
-        identity path to the base parameters, so a later `.backward()` yields the FIRST-ORDER meta-gradient; when the learner
-        is second-order (first_order=False) the curvature term would be needed too, and autograd raises
-        ("...marked with @once_differentiable") instead of silently dropping it -- second-order training goes through
-        `fast_adapt` / `meta_batch_adapt` (one fused HIP call for the K steps, the query pass and the outer backward)."""
+        identity path to the base parameters; a first-order learner detaches the gradient (first-order meta-gradient), a
+        second-order one keeps it in the graph (create_graph) and a later `.backward()` differentiates through it with
+        mi_learner_hvp -- the exact second-order meta-gradient, one Hessian-vector sweep per adapt step.  Training loops are
+        faster through `fast_adapt` / `meta_batch_adapt` (one fused HIP call for the K steps, the query pass and the outer
+        backward for a whole meta-batch)."""
         if first_order is None:
             first_order = self.first_order
         second_order = not first_order

@@ -1,5 +1,7 @@
 """``fast_adapt`` / ``accuracy`` / ``evaluate`` with the reference's signatures (core_functions/vision.py:6-42), backed by
 the batched HIP engine, plus the batched entry the engine is designed for (``meta_batch_adapt``)."""
+import os
+
 import torch
 
 from ..engine import flatten_parameters
@@ -13,6 +15,14 @@ def _check_loss(loss):
                          'vision script uses (maml_vision.py:86, anil_vision.py:99)')
 
 
+# The meta-gradient is normally produced WITH the loss (one fused call).  A caller that adapts under enabled gradients but never
+# calls backward -- the reference's validation half, maml_vision.py:117-124, which is not wrapped in no_grad -- then pays for an
+# outer backward it discards (about 2/3 of a second-order call).  With this switch on (or MI_MAML_DEFERRED_BACKWARD=1) the forward
+# runs the evaluation-only call and `backward` re-runs the fused call with the gradient: cheaper when fewer than about two thirds
+# of the calls are followed by backward, dearer otherwise (the drivers here wrap validation in no_grad instead and leave it off).
+DEFERRED_OUTER_BACKWARD = os.environ.get('MI_MAML_DEFERRED_BACKWARD', '0') == '1'
+
+
 class _FusedFastAdapt(torch.autograd.Function):
     """T tasks through mi_meta_batch_maml.  The meta-gradient is produced together with the loss (the outer backward is
     part of the fused call); ``backward`` hands it to autograd so ``eval_loss.backward()`` accumulates into ``.grad``."""
@@ -20,6 +30,10 @@ class _FusedFastAdapt(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, data, labels, shots, steps, lr, first_order, need_grad, *params):
         theta = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
+        ctx.deferred = None
+        if need_grad and DEFERRED_OUTER_BACKWARD:
+            ctx.deferred = (engine, theta, data, labels, shots, steps, lr, first_order)
+            need_grad = False
         loss, acc, grad, _ = engine.meta_batch(theta, data, labels, shots, steps, lr, first_order=first_order,
                                                with_grad=need_grad)
         ctx.shapes = [p.shape for p in params]
@@ -33,6 +47,9 @@ class _FusedFastAdapt(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gsum, gloss, gacc):
         (grad,) = ctx.saved_tensors
+        if ctx.deferred is not None:
+            engine, theta, data, labels, shots, steps, lr, first_order = ctx.deferred
+            grad = engine.meta_batch(theta, data, labels, shots, steps, lr, first_order=first_order, with_grad=True)[2]
         if grad.numel() == 0:
             raise RuntimeError('fast_adapt was run without gradients (torch.no_grad or no parameter requires grad)')
         outs, off = [], 0

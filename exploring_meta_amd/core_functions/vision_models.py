@@ -168,23 +168,39 @@ class _EngineModel(torch.nn.Module):
 
 class _LearnerForward(torch.autograd.Function):
     """logits = net(x; theta) through mi_learner_forward; backward = mi_learner_backward (re-runs the forward, keeps nothing
-    but x and theta).  Once differentiable: a second-order meta-gradient through step-wise calls raises -- use fast_adapt /
-    meta_batch_adapt, which fuse the K inner steps with the second-order backward."""
+    but x and theta) and is itself differentiable (mi_learner_hvp), so `learner.adapt(loss)` of a second-order learner -- learn2learn
+    `grad(loss, params, create_graph=True)` -- back-propagates the curvature term.  Training loops should still prefer
+    fast_adapt / meta_batch_adapt, which fuse the K inner steps with the second-order backward into one call."""
 
     @staticmethod
     def forward(ctx, engine, x, theta):
         if x.requires_grad:
             raise RuntimeError('gradients with respect to the input images are not provided by the HIP engine')
-        theta_d = theta.detach().contiguous()
         ctx.engine = engine
-        ctx.save_for_backward(x, theta_d)
-        return engine.learner_forward(theta_d, x.unsqueeze(0))[0][0]
+        ctx.save_for_backward(x, theta)
+        return engine.learner_forward(theta.detach().contiguous(), x.unsqueeze(0))[0][0]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, theta = ctx.saved_tensors
+        return None, None, _LearnerBackward.apply(ctx.engine, x, theta, dlogits)
+
+
+class _LearnerBackward(torch.autograd.Function):
+    """g = d sum(logits * dlogits) / d theta (mi_learner_backward) as a differentiable function of (theta, dlogits)."""
+
+    @staticmethod
+    def forward(ctx, engine, x, theta, dlogits):
+        ctx.engine = engine
+        ctx.save_for_backward(x, theta, dlogits)
+        return engine.learner_backward(theta.detach().contiguous(), x.unsqueeze(0), dlogits.detach().unsqueeze(0))[0]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dlogits):
-        x, theta = ctx.saved_tensors
-        return None, None, ctx.engine.learner_backward(theta, x.unsqueeze(0), dlogits.unsqueeze(0))[0]
+    def backward(ctx, v):
+        x, theta, dlogits = ctx.saved_tensors
+        gtheta, ldot = ctx.engine.learner_hvp(theta.detach().contiguous(), x.unsqueeze(0), dlogits.detach().unsqueeze(0), v)
+        return None, None, gtheta[0], ldot[0]
 
 
 class MiniImagenetCNN(_EngineModel):

@@ -733,8 +733,11 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
 }
 
 // hv = H(theta) v for the saved support pass A (activations) / g (its gradient): forward-over-reverse.
+// dl_fixed != nullptr: the loss is sum(logits * dl_fixed) with a GIVEN cotangent (the step-wise learner's double backward): no
+// cross-entropy curvature at the head, and the logit tangents J v go to ld_out.
 static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
-                    const float* g, const float* v, float* hv, const double* gram = nullptr) {
+                    const float* g, const float* v, float* hv, const double* gram = nullptr, const float* dl_fixed = nullptr,
+                    float* ld_out = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   TanSet& X = pl.tan;
@@ -803,6 +806,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
   ha.wld = v + e->off_wl; ha.bld = v + e->off_bl; ha.vstride = P;
   ha.prob = A.prob; ha.dl = A.dl;
+  if (dl_fixed) { ha.dl = const_cast<float*>(dl_fixed); ha.fixed_dl = 1; ha.ld_out = ld_out; }
   ha.dwl = hv + e->off_wl; ha.dbl = hv + e->off_bl; ha.gstride = P;
   ha.df = e->d.head_mean_pool ? X.rdf : X.dpd[cur];
   ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
@@ -1282,6 +1286,64 @@ extern "C" int mi_learner_backward(mi_engine* e, void* stream, const float* thet
     LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, tasks, grad_out));
   } else {
     LAUNCH(e, st, OP_MISC, 3, launch_scatter_tasks(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, tasks, grad_out));
+  }
+  return MI_OK;
+}
+
+// Double backward of the step-wise learner: with s(theta) = sum(logits(theta) * dlogits) and g = ds/dtheta (mi_learner_backward),
+// autograd asks for the vector-Jacobian products of (theta, dlogits) -> g with a cotangent v on g:
+//   grad_theta_out = (d^2 s / dtheta^2) v   (forward-over-reverse, dlogits held fixed),   logits_dot_out = J(theta) v.
+// This is what makes `learner.adapt(loss)` of a second-order learner differentiable (learn2learn MAML.adapt with create_graph,
+// driven step-wise at misc_scripts/rc_vision.py:67-70); the cross-entropy's own curvature reaches theta through logits_dot_out
+// and an ordinary mi_learner_backward, by the chain rule autograd already applies.
+extern "C" int mi_learner_hvp_workspace_bytes(const mi_engine* e, int tasks, int n, size_t* bytes) {
+  if (!e || !bytes || tasks < 1 || n < 1) return MI_ERR_ARG;
+  Plan pl;
+  make_plan(e, nullptr, tasks, n, n, 1, 1, pl);
+  *bytes = pl.bytes;
+  return MI_OK;
+}
+
+extern "C" int mi_learner_hvp(mi_engine* e, void* stream, const float* theta, int theta_tasks, const float* x, const float* dlogits,
+                              const float* v, int tasks, int n, float* grad_theta_out, float* logits_dot_out, void* workspace,
+                              size_t workspace_bytes) {
+  if (!e) return fail(nullptr, MI_ERR_ARG, "null engine");
+  if (!theta || !x || !dlogits || !v || !grad_theta_out || !logits_dot_out || !workspace || tasks < 1 || n < 1)
+    return fail(e, MI_ERR_ARG, "bad mi_learner_hvp arguments");
+  if (theta_tasks != 1 && theta_tasks != tasks) return fail(e, MI_ERR_ARG, "theta_tasks must be 1 (shared) or == tasks");
+  Plan pl;
+  make_plan(e, workspace, tasks, n, n, 1, 1, pl);
+  if (pl.bytes > workspace_bytes)
+    return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nl = (int)e->L.size();
+  const size_t pstride = theta_tasks == 1 ? 0 : e->P;
+  ActSet& A = pl.sup[0];
+  LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, pstride, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
+  LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, v, pstride, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.lam));
+  int rc = trunk_forward(e, st, pl, A, pl.xs, n, tasks, pl.theta);
+  if (rc) return rc;
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, tasks * n, e->head_hw, e->head_c));
+  // primal backward with the given cotangent: the tangent sweep needs its BatchNorm sums (g) and layer cotangents (A.dp)
+  HIPCHK(e, hipMemsetAsync(pl.g, 0, (size_t)tasks * e->PS * sizeof(float), st));
+  HeadArgs ha{};
+  ha.f = A.f;
+  ha.wl = pl.theta + e->off_wl; ha.bl = pl.theta + e->off_bl; ha.pstride = e->PS;
+  ha.dl = const_cast<float*>(dlogits);
+  ha.dwl = pl.g + e->off_wl; ha.dbl = pl.g + e->off_bl; ha.gstride = e->PS;
+  ha.df = A.df;
+  ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+  LAUNCH(e, st, OP_HEAD, 0, launch_head_grads(st, ha, tasks));
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], tasks * n, e->head_hw, e->head_c));
+  rc = trunk_backward(e, st, pl, A, pl.xs, n, tasks, pl.theta, pl.g);
+  if (rc) return rc;
+  rc = pass_hvp(e, st, pl, A, pl.xs, n, tasks, pl.theta, pl.g, pl.lam, pl.hv, nullptr, dlogits, logits_dot_out);
+  if (rc) return rc;
+  if (theta_tasks == 1) {
+    LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, tasks, grad_theta_out));
+  } else {
+    LAUNCH(e, st, OP_MISC, 3, launch_scatter_tasks(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, tasks, grad_theta_out));
   }
   return MI_OK;
 }

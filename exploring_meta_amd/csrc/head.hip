@@ -108,9 +108,14 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadArgs a) {
       a.rowhit[(size_t)task * N + n] = (am == y) ? 1.f : 0.f;
     }
   } else {
-    const float pr = act ? a.prob[o + lane] : 0.f;
-    const float dot = wave_sum(pr * mine);
-    if (act) a.rdl[o + lane] = pr * (mine - dot) * invn;
+    if (a.ld_out && act) a.ld_out[o + lane] = mine;
+    if (a.fixed_dl) {
+      if (act) a.rdl[o + lane] = 0.f;
+    } else {
+      const float pr = act ? a.prob[o + lane] : 0.f;
+      const float dot = wave_sum(pr * mine);
+      if (act) a.rdl[o + lane] = pr * (mine - dot) * invn;
+    }
   }
 }
 

@@ -167,6 +167,8 @@ struct HeadArgs {
   float* logits;        // [T][n][ways] (may be null)
   float* prob; float* dl;           // [T][n][ways] saved (tangent pass reads them)
   float* rdl;                       // [T][n][ways] scratch: R{dl} (tangent)
+  float* ld_out = nullptr;          // tangent: also store the logit tangents J v [T][n][ways]
+  int fixed_dl = 0;                 // tangent: dl is a given cotangent, not the cross-entropy's -- R{dl} = 0 (mi_learner_hvp)
   float* rowloss; float* rowhit;    // [T][n] scratch: per-row loss / hit
   float* dwl; float* dbl; size_t gstride;   // outputs (primal grads or tangent grads)
   float* df;            // [T][n][F] output (df or R{df}); may be null

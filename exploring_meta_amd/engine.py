@@ -321,6 +321,24 @@ class MetaEngine:
         return grad
 
     @_on_device
+    def learner_hvp(self, theta, x, dlogits, v):
+        """mi_learner_hvp: the vector-Jacobian products of (theta, dlogits) -> learner_backward(theta, x, dlogits) for a cotangent v
+        [theta_tasks, P] on that gradient: ((d^2 sum(logits*dlogits)/dtheta^2) v  [theta_tasks, P],  J(theta) v  [T, n, ways])."""
+        theta, x, T, n, _ = self._learner_args(theta, x)
+        dlogits = dlogits.to(torch.float32).contiguous()
+        v = v.to(torch.float32).reshape(theta.shape).contiguous()
+        if tuple(dlogits.shape) != (T, n, self.spec.ways):
+            raise ValueError(f'dlogits must be {(T, n, self.spec.ways)}, got {tuple(dlogits.shape)}')
+        b = C.c_size_t()
+        _lib.check(self.lib.mi_learner_hvp_workspace_bytes(self._h, T, n, C.byref(b)), self._h)
+        ws = self._workspace(b.value)
+        gtheta = torch.empty(theta.shape[0], self.param_count, dtype=torch.float32, device=self.device)
+        ldot = torch.empty(T, n, self.spec.ways, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mi_learner_hvp(self._h, _stream(self.device), _ptr(theta), theta.shape[0], _ptr(x), _ptr(dlogits), _ptr(v), T, n,
+                                           _ptr(gtheta), _ptr(ldot), _ptr(ws), ws.numel()), self._h)
+        return gtheta, ldot
+
+    @_on_device
     def head_logits(self, f, wl, bl):
         """`linear(f)` for f [n, F] with explicit weights (reference get_rep_layer(x, -1)); mi_head_fwd_bwd, forward only."""
         f, wl, bl = f.contiguous(), wl.contiguous().float(), bl.contiguous().float()

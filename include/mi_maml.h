@@ -144,12 +144,23 @@ int mi_forward_logits(mi_engine* e, void* stream, const float* theta, const floa
  *   rep_layer in 1..layers, NCHW [tasks, n, hidden, h', w'] (`Sequential(*base.children()[:layer])(x)`; layers = base(x)).
  * mi_learner_backward: grad_out [theta_tasks, P] = d sum(logits * dlogits) / d theta (summed over task batches when theta
  *   is shared): the vector-Jacobian product autograd asks of `learner(x)`; conv biases get exact zeros (batch-stat BN).
- *   First derivatives only: second-order meta-gradients go through mi_meta_batch_maml.
+ *   Its own derivative is mi_learner_hvp; the fused second-order path is mi_meta_batch_maml.
  * Workspace: mi_forward_workspace_bytes(e, tasks, n). */
 int mi_learner_forward(mi_engine* e, void* stream, const float* theta, int theta_tasks, const float* x, int tasks, int n,
                        float* logits_out, int rep_layer, float* rep_out, void* workspace, size_t workspace_bytes);
 int mi_learner_backward(mi_engine* e, void* stream, const float* theta, int theta_tasks, const float* x, const float* dlogits,
                         int tasks, int n, float* grad_out, void* workspace, size_t workspace_bytes);
+
+/* Double backward of the step-wise learner (learn2learn `MAML.adapt` of a second-order learner differentiates through
+ * `grad(loss, params, create_graph=True)`, learn2learn maml.py adapt / maml_update; driven step-wise at misc_scripts/rc_vision.py:67-70).
+ * With s(theta) = sum(logits(theta) * dlogits) and g = ds/dtheta (mi_learner_backward), for a cotangent v [theta_tasks, P] on g:
+ *   grad_theta_out [theta_tasks, P] = (d^2 s / dtheta^2) v with dlogits held fixed (forward-over-reverse sweep),
+ *   logits_dot_out [tasks, n, ways] = J(theta) v  -- the vector-Jacobian product with respect to dlogits.
+ * Workspace: mi_learner_hvp_workspace_bytes(e, tasks, n). */
+int mi_learner_hvp_workspace_bytes(const mi_engine* e, int tasks, int n, size_t* bytes);
+int mi_learner_hvp(mi_engine* e, void* stream, const float* theta, int theta_tasks, const float* x, const float* dlogits,
+                   const float* v, int tasks, int n, float* grad_theta_out, float* logits_dot_out, void* workspace,
+                   size_t workspace_bytes);
 
 /* Adam step on the flat meta-parameters with torch.optim.Adam defaults (maml_vision.py:85,139-141):
  * grad is first scaled by grad_scale (= 1/meta_batch_size). step is the 1-based step count after increment. */

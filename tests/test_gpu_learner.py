@@ -144,17 +144,93 @@ def test_stepwise_first_order_meta_gradient(golden_fa):
     assert total == pytest.approx(golden_fa[f'g3_{tag}_f64_loss'].sum(), rel=1e-4)
 
 
-def test_stepwise_second_order_backward_raises():
-    """A second-order meta-gradient cannot come out of step-wise calls: fail loudly, never return a first-order one."""
-    ways, shots = 5, 1
+@pytest.mark.parametrize('kind,shots', [('min', 1), ('omni', 1), ('min', 5)])
+def test_learner_double_backward_matches_oracle(kind, shots):
+    """mi_learner_hvp = the vector-Jacobian products of (theta, dlogits) -> d sum(logits*dlogits)/d theta for a cotangent v on that
+    gradient: (d^2 s/dtheta^2) v with dlogits fixed, and J v -- against fp64 autograd double backward of the oracle network."""
+    ways = 5
+    spec, theta, model = _setup(kind, ways)
+    datas, labelss = task_tensors(kind, [3], ways, shots)
+    x = R.prepare_batch(datas[0], labelss[0], shots, ways)[0]
+    n = x.shape[0]
+    dl = (torch.from_numpy(synthetic.hash_normalish(77, (n, ways))).double() / n).requires_grad_(True)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in theta.items()}
+    names = list(leaves)
+    P = sum(v.numel() for v in leaves.values())
+    v = torch.from_numpy(synthetic.hash_normalish(78, (P,))).double() * 0.1
+    g = torch.autograd.grad((R.model_forward(x, leaves, spec) * dl).sum(), [leaves[k] for k in names], create_graph=True)
+    ref = torch.autograd.grad((torch.cat([t.reshape(-1) for t in g]) * v).sum(), [leaves[k] for k in names] + [dl], allow_unused=True)
+    ref = [torch.zeros_like(w) if r is None else r for r, w in zip(ref, [leaves[k] for k in names] + [dl])]   # (conv biases: batch-stat BN)
+    ref_theta, ref_dl = torch.cat([t.reshape(-1) for t in ref[:-1]]).numpy(), ref[-1].numpy()
+
+    th = model.flat_parameters().detach().contiguous()
+    gth, ldot = model.engine().learner_hvp(th, x.float().cuda().unsqueeze(0), dl.detach().float().cuda().unsqueeze(0), v.float().cuda())
+    e_t, e_d = rel_err(gth[0].cpu().numpy(), ref_theta), rel_err(ldot[0].cpu().numpy(), ref_dl)
+    report(f'learner_hvp_{kind}_{shots}s', grad_theta_rel=e_t, logits_dot_rel=e_d)
+    assert e_d < 1e-5 and e_t < 2e-5
+    # and through autograd: grad(grad(...), create_graph) on the module itself
+    params = list(model.parameters())
+    gg = torch.autograd.grad((model(x.float().cuda()) * dl.detach().float().cuda()).sum(), params, create_graph=True)
+    hv = torch.autograd.grad((torch.cat([t.reshape(-1) for t in gg]) * v.float().cuda()).sum(), params, allow_unused=True)
+    hv = [torch.zeros_like(q) if r is None else r for r, q in zip(hv, params)]
+    assert rel_err(torch.cat([t.reshape(-1) for t in hv]).cpu().numpy(), ref_theta) < 2e-5
+
+
+@pytest.mark.parametrize('tag,dataset', [('cfg4r_min_5w1s_K1_so', 'min')])
+def test_stepwise_second_order_meta_gradient(golden_refinit, tag, dataset):
+    """learn2learn semantics of a second-order learner driven step by step (rc_vision.py:67-70 style): learner.adapt keeps the
+    inner gradient in the graph and the query loss's backward runs the Hessian-vector sweep (mi_learner_hvp) -- the same
+    meta-gradient as the fused call, and within 1e-4 of the reference's own fast_adapt (reference-initialiser golden, config 4)."""
+    from collections import OrderedDict
+    from exploring_meta_amd.engine import MetaEngine
+    meta = golden_refinit[f'g7_{tag}_meta']
+    ways, shots, K, fo = (int(v) for v in meta[:4])
+    tasks = [int(t) for t in meta[4:]]
+    lr = float(golden_refinit[f'g7_{tag}_lr'][0])
+    spec = R.mini_imagenet_spec(ways)
+    theta = OrderedDict((k, torch.from_numpy(v)) for k, v in synthetic.ref_init_weights(R.param_shapes(spec), 11).items())
+    model = _load(cf.MiniImagenetCNN(ways), theta)
+    maml = cf.MAML(model, lr=lr, first_order=bool(fo))
+    loss = torch.nn.CrossEntropyLoss()
+    for i, t in enumerate(tasks[:2]):
+        d, l = synthetic.uniform_task(dataset, t, ways, shots)
+        batch = (torch.from_numpy(d), torch.from_numpy(l))
+        ad, al, ed, el = cf.prepare_batch(batch, shots, ways, torch.device('cuda'))
+        for q in maml.parameters():
+            q.grad = None
+        learner = maml.clone()
+        for _ in range(K):
+            learner.adapt(loss(learner(ad), al))
+        valid = loss(learner(ed), el)
+        valid.backward()
+        grad = torch.cat([q.grad.reshape(-1) for q in maml.parameters()]).cpu().numpy()
+        fl, fa, fg, _ = model.engine().meta_batch(model.flat_parameters().detach(), torch.from_numpy(d).cuda().unsqueeze(0).contiguous(),
+                                                  torch.from_numpy(l).cuda().unsqueeze(0).contiguous(), shots, K, lr, first_order=bool(fo))
+        e_f, e64 = rel_err(grad, fg.cpu().numpy()), rel_err(grad, golden_refinit[f'g7_{tag}_f64_grad'][i])
+        report(f'stepwise_so_meta_grad[{tag}][{t}]', vs_fused=e_f, vs_ref_fp64=e64, loss=valid.item(), fused_loss=float(fl[0]))
+        assert e_f < 2e-5 and e64 < 1e-4
+        assert valid.item() == pytest.approx(golden_refinit[f'g7_{tag}_f64_loss'][i], rel=1e-5)
+
+
+def test_stepwise_two_second_order_steps_match_fused():
+    """Two adapt steps of a second-order learner (the second step's gradient is taken at fast weights that are themselves in the
+    graph): the meta-gradient equals the fused call's adjoint recursion."""
+    ways, shots, K, lr = 5, 1, 2, 0.05
     spec, theta, model = _setup('omni', ways)
-    learner = cf.MAML(model, lr=0.5, first_order=False).clone()
-    d, l = synthetic.make_task('omni', 0, ways, shots)
+    maml = cf.MAML(model, lr=lr, first_order=False)
+    d, l = synthetic.make_task('omni', 4, ways, shots)
     ad, al, ed, el = cf.prepare_batch((torch.from_numpy(d), torch.from_numpy(l)), shots, ways, torch.device('cuda'))
     loss = torch.nn.CrossEntropyLoss()
-    learner.adapt(loss(learner(ad), al))
-    with pytest.raises(RuntimeError, match='once_differentiable'):
-        loss(learner(ed), el).backward()
+    learner = maml.clone()
+    for _ in range(K):
+        learner.adapt(loss(learner(ad), al))
+    loss(learner(ed), el).backward()
+    grad = torch.cat([q.grad.reshape(-1) for q in maml.parameters()]).cpu().numpy()
+    _, _, fg, _ = model.engine().meta_batch(model.flat_parameters().detach(), torch.from_numpy(d).cuda().unsqueeze(0).contiguous(),
+                                            torch.from_numpy(l).cuda().unsqueeze(0).contiguous(), shots, K, lr, first_order=False)
+    e = rel_err(grad, fg.cpu().numpy())
+    report('stepwise_so_two_steps_vs_fused', grad_rel=e)
+    assert e < 1e-4
 
 
 @pytest.mark.parametrize('kind', ['min', 'omni'])
