@@ -53,7 +53,18 @@ class LinearValue:
 
     def __init__(self, input_size, reg=1e-5):
         self.input_size, self.reg = input_size, reg
-        self.weight = np.zeros((2 * input_size + 4, 1))
+        self._weight, self._weight_dev = np.zeros((2 * input_size + 4, 1)), None
+
+    @property
+    def weight(self):
+        """The last fitted weights.  A fit done on the GPU (mi_gae_advantages) leaves them on the device; they are fetched on demand."""
+        if self._weight_dev is not None:
+            self._weight, self._weight_dev = self._weight_dev.detach().cpu().numpy().astype(np.float64).reshape(-1, 1), None
+        return self._weight
+
+    @weight.setter
+    def weight(self, value):
+        self._weight, self._weight_dev = value, None
 
     def _features(self, states):
         n = states.shape[0]
@@ -107,6 +118,41 @@ def _host_replays(replay_list):
             o[k] = big[off:off + n]
             off += n
     return out
+
+
+def _device_batch(replay_list, S, A, dev):
+    """Replays (dicts of tensors / arrays) -> one padded fp32 device batch {states [R,B,S], actions [R,B,A], next_states, rewards
+    [R,B], dones [R,B], count [R] int32}, assembled ON the device: one stack per field, no host round trip."""
+    lens = [int(r['states'].shape[0]) for r in replay_list]
+    B = max(lens)
+
+    def field(k, width):
+        parts = []
+        for r, n in zip(replay_list, lens):
+            t = r[k] if torch.is_tensor(r[k]) else torch.as_tensor(np.asarray(r[k]))
+            t = t.detach().to(dev, torch.float32).reshape(n, width)
+            parts.append(t if n == B else torch.nn.functional.pad(t, (0, 0, 0, B - n)))
+        return torch.stack(parts).contiguous()
+
+    out = dict(states=field('states', S), actions=field('actions', A), next_states=field('next_states', S),
+               rewards=field('rewards', 1).reshape(len(lens), B), dones=field('dones', 1).reshape(len(lens), B))
+    out['count'] = torch.tensor(lens, dtype=torch.int32, device=dev)
+    return out
+
+
+def _advantages_device(batch, baseline, gamma, tau):
+    """compute_advantages + ch.normalize (rl.py:95-110,355) of every replay of a device batch in one launch; the baseline is left
+    fitted to the LAST replay, as after the reference's replay-by-replay walk."""
+    from ..engine import gae_advantages
+    adv, wts = gae_advantages(batch['states'], batch['next_states'], batch['rewards'], batch['dones'], batch['count'], gamma, tau,
+                              baseline.reg, normalize=True, want_weights=True)
+    baseline._weight_dev = wts[-1]
+    return adv
+
+
+def _gae_on_device(dev, S, rows):
+    from ..engine import gae_max_rows
+    return torch.device(dev).type == 'cuda' and 0 < rows <= gae_max_rows(S)
 
 
 def _pad(eps_list, advs, S, A, dev):
@@ -183,13 +229,25 @@ class _SurrogateContext:
         self.steps = K
         adv = lambda e: _advantages(e, baseline, params['gamma'], params['tau'])
         nT = len(iter_replays)
-        host = _host_replays([r[k] for k in range(K + 1) for r in iter_replays])     # [k][task], one D2H copy per field
-        sups = []
-        for k in range(K):                                       # the reference walks task by task, replay by replay (rl.py:444-465);
-            eps = host[k * nT:(k + 1) * nT]                      # the baseline is re-fitted per replay, so the order is immaterial
-            sups.append(_pad(eps, [adv(e) for e in eps], S, A, dev))
-        qry_eps = host[K * nT:]
-        self.qry = _pad(qry_eps, [adv(e) for e in qry_eps], S, A, dev)
+        flat = [r[k] for k in range(K + 1) for r in iter_replays]                    # [k][task]
+        if _gae_on_device(dev, S, max(int(r['states'].shape[0]) for r in flat)):
+            # advantages of all (K + 1) x tasks replays in ONE launch, the batch assembled on the device (the reference re-fits the
+            # baseline and re-runs GAE per task and replay on the CPU at every evaluation of the surrogate, rl.py:444-465)
+            batch = _device_batch(flat, S, A, dev)
+            advs = _advantages_device(batch, baseline, params['gamma'], params['tau'])
+            part = lambda k: dict(states=batch['states'][k * nT:(k + 1) * nT], actions=batch['actions'][k * nT:(k + 1) * nT],
+                                  adv=advs[k * nT:(k + 1) * nT], count=batch['count'][k * nT:(k + 1) * nT],
+                                  done=batch['dones'][k * nT:(k + 1) * nT])
+            sups = [part(k) for k in range(K)]
+            self.qry = part(K)
+        else:
+            host = _host_replays(flat)                               # one D2H copy per field
+            sups = []
+            for k in range(K):                                       # the reference walks task by task, replay by replay;
+                eps = host[k * nT:(k + 1) * nT]                      # the baseline is re-fitted per replay, so the order is immaterial
+                sups.append(_pad(eps, [adv(e) for e in eps], S, A, dev))
+            qry_eps = host[K * nT:]
+            self.qry = _pad(qry_eps, [adv(e) for e in qry_eps], S, A, dev)
         B = max([d['states'].shape[1] for d in sups] + [self.qry['states'].shape[1]])
         for d in sups + [self.qry]:                              # one common padded length
             if d['states'].shape[1] < B:

@@ -536,7 +536,6 @@ hipError_t launch_sparse_wgrad(hipStream_t st, SparseWgArgs a, int tasks, int ci
   size_t smem = (size_t)a.row_pitch * 32 * sizeof(float);          // 4 waves x 2 sets x 4 rows
   if (smem < 4 * 1024 * sizeof(float)) smem = 4 * 1024 * sizeof(float);
   if (blocks_per_task) *blocks_per_task = grid.x;
-  const int nsteps = (a.ww / 2 + 1) / 2;
   const bool rows = ci == 3 && a.ww == 84;       // rows of exactly 7 chunks of 3 steps: the mini-ImageNet input
   if (ci == 3) {
     if (tangent) launch_sparse_t<3, true>(st, grid, smem, a, rows); else launch_sparse_t<3, false>(st, grid, smem, a, rows);

@@ -379,6 +379,31 @@ class MetaEngine:
                                          theta.numel(), state['step'], lr, betas[0], betas[1], eps, grad_scale))
 
 
+def gae_max_rows(state_dim):
+    """Longest replay mi_gae_advantages takes for this state dimension (0: unsupported dimension)."""
+    return int(_lib.load().mi_gae_max_rows(int(state_dim)))
+
+
+def gae_advantages(states, next_states, rewards, dones, count, gamma, tau, reg, normalize=True, want_weights=False):
+    """mi_gae_advantages: cherry-semantics returns -> LinearValue fit -> bootstraps -> GAE (-> ch.normalize) for R replays in one
+    launch (reference core_functions/rl.py:95-110,355).  states / next_states [R, B, S], rewards / dones [R, B] fp32 CUDA tensors,
+    count [R] int32 (rows in use) or None.  Returns adv [R, B] fp32 (and the fitted baseline weights [R, 2S+4] fp64)."""
+    lib = _lib.load()
+    dev = states.device
+    R, B, S = states.shape
+    f32 = lambda t, shape: t.to(dev, torch.float32).reshape(shape).contiguous()
+    states, next_states = f32(states, (R, B, S)), f32(next_states, (R, B, S))
+    rewards, dones = f32(rewards, (R, B)), f32(dones, (R, B))
+    if count is not None:
+        count = count.to(dev, torch.int32).contiguous()
+    adv = torch.empty(R, B, dtype=torch.float32, device=dev)
+    wts = torch.empty(R, 2 * S + 4, dtype=torch.float64, device=dev) if want_weights else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_gae_advantages(_stream(dev), _ptr(states), _ptr(next_states), _ptr(rewards), _ptr(dones), _ptr(count), R, B, S,
+                                         float(gamma), float(tau), float(reg), int(bool(normalize)), _ptr(adv), _ptr(wts)))
+    return (adv, wts) if want_weights else adv
+
+
 def flatten_parameters(module):
     """Flat fp32 vector in module.parameters() order (what the C ABI calls theta)."""
     return torch.cat([p.detach().reshape(-1) for p in module.parameters()]).float().contiguous()

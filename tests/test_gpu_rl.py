@@ -509,3 +509,72 @@ def test_trpo_two_adapt_steps_match_oracle(act):
     es = rel_err(out['step'].cpu().numpy(), ref['step'].numpy())
     report(f'trpo_two_steps_meta_optimize[{act}]', step_rel=es, accepted=out['accepted'])
     assert es < (5e-3 if act == 'relu' else 3e-2)
+
+
+# ---------------------------------------------------------------------------------------------- advantages on the GPU
+def _random_replay(seed, n, S, ep_len, truncated=False):
+    g = torch.Generator().manual_seed(seed)
+    dones = torch.zeros(n, 1, dtype=torch.float64)
+    dones[ep_len - 1::ep_len] = 1.0
+    if n > 9:
+        dones[7] = 1.0                               # one early termination
+    if truncated:
+        dones[-1] = 0.0                              # the last episode is cut by the replay's end, not by a done
+    f32 = lambda t: t.float().double()               # values the kernel's fp32 inputs represent exactly
+    return dict(states=f32(torch.randn(n, S, generator=g, dtype=torch.float64)), actions=torch.randn(n, 2, generator=g, dtype=torch.float64),
+                rewards=f32(-torch.rand(n, 1, generator=g, dtype=torch.float64)), dones=dones,
+                next_states=f32(torch.randn(n, S, generator=g, dtype=torch.float64)))
+
+
+@pytest.mark.parametrize('S,lens,ep_len,truncated,normalize', [(2, [2000, 2000, 2000], 100, False, True), (2, [85, 60, 17, 1], 17, False, True),
+                                                              (2, [120, 77], 25, True, False), (5, [300, 150], 50, True, True),
+                                                              (8, [64], 16, False, True)])
+def test_gae_kernel_matches_oracle(S, lens, ep_len, truncated, normalize):
+    """mi_gae_advantages (returns -> LinearValue fit -> bootstraps -> GAE -> normalise, one workgroup per replay, fp64) against the
+    oracle's restatement of compute_advantages / ch.normalize (rl.py:95-110,355) on each replay: ragged lengths, an early
+    termination, a replay whose last episode is truncated, 2..8 state dimensions; and the fitted baseline weights."""
+    from exploring_meta_amd.engine import gae_advantages
+    from exploring_meta_amd.core_functions.rl import _device_batch
+    gamma, tau, reg = 0.99, 0.95, 2.0
+    eps = [_random_replay(40 + i, n, S, ep_len, truncated) for i, n in enumerate(lens)]
+    batch = _device_batch(eps, S, 2, torch.device('cuda'))
+    adv, wts = gae_advantages(batch['states'], batch['next_states'], batch['rewards'], batch['dones'], batch['count'], gamma, tau, reg,
+                              normalize=normalize, want_weights=True)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i, (ep, n) in enumerate(zip(eps, lens)):
+        base = RL.LinearValue(S, reg)
+        ref = RL.compute_advantages(base, tau, gamma, ep, True)
+        if normalize:
+            ref = RL.normalize(ref)
+        ref = ref.reshape(-1).numpy()
+        got = adv[i, :n].double().cpu().numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        worst = max(worst, float(np.abs(got - ref).max()) / scale)
+        assert float(adv[i, n:].abs().sum()) == 0.0
+        # the baseline's predictions (the weights themselves are ill-determined along near-null directions of F^T F)
+        f = base._features(ep['states'])
+        pred_ref, pred = (f @ base.weight).reshape(-1).numpy(), (f @ wts[i].cpu().reshape(-1, 1)).reshape(-1).numpy()
+        assert np.abs(pred - pred_ref).max() <= 1e-6 * max(1.0, np.abs(pred_ref).max())
+    report(f'gae_kernel[S{S},{lens}]', max_rel=worst)
+    assert worst < 5e-7                               # fp32 output rounding
+
+
+def test_surrogate_context_on_device_matches_host_path(monkeypatch):
+    """_SurrogateContext built on the device (one mi_gae_advantages launch, no host round trip) == built by the host numpy walk."""
+    from exploring_meta_amd.core_functions import rl as prl
+    theta, replays, olds = _replays()
+    pol = _policy(theta)
+    old_pols = [_policy(o) for o in olds]
+    dev_ctx = prl._SurrogateContext(replays, old_pols, pol, cf.LinearValue(2, 2), PARAMS)
+    monkeypatch.setattr(prl, '_gae_on_device', lambda *a: False)
+    host_base = cf.LinearValue(2, 2)
+    host_ctx = prl._SurrogateContext(replays, old_pols, pol, host_base, PARAMS)
+    for k in ('states', 'actions', 'adv', 'count'):
+        a, b = dev_ctx.qry[k], host_ctx.qry[k]
+        assert a.shape == b.shape and torch.allclose(a.float(), b.float(), rtol=0, atol=2e-6), k
+        a, b = dev_ctx.sup[k], host_ctx.sup[k]
+        assert a.shape == b.shape and torch.allclose(a.float(), b.float(), rtol=0, atol=2e-6), k
+    l1, k1, g1 = dev_ctx.evaluate(pol.flat(), want_grad=True)
+    l2, k2, g2 = host_ctx.evaluate(pol.flat(), want_grad=True)
+    assert rel_err(g1.cpu().numpy(), g2.cpu().numpy()) < 1e-5 and abs(float(l1[0]) - float(l2[0])) < 1e-6

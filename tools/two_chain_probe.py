@@ -15,7 +15,7 @@ from exploring_meta_amd.engine import MetaEngine, ModelSpec  # noqa: E402
 
 
 def main():
-    wl = bench.WORKLOADS['cfg2']
+    wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'cfg2']
     spec = ModelSpec.mini_imagenet(wl['ways'])
     theta = bench.init_theta(spec).cuda()
     data, labels = bench.make_batch(wl, list(range(32)))
@@ -43,10 +43,11 @@ def main():
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(20):
+        reps = 20 if wl['steps'] > 1 else 200
+        for _ in range(reps):
             fn()
         torch.cuda.synchronize()
-        print(f'{name}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per 32 tasks')
+        print(f'{name}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per 32 tasks', flush=True)
 
 
 if __name__ == '__main__':
