@@ -86,8 +86,8 @@ _SIGS = {
     'mi_learner_hvp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'mi_gae_max_rows': (C.c_int, [C.c_int]),
-    'mi_gae_advantages': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                    C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    'mi_gae_advantages': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     'mi_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_float]),
     'mi_prepare_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -150,6 +150,21 @@ def _advantages_device(batch, baseline, gamma, tau):
     return adv
 
 
+def _replay_on_device(ep, baseline, gamma, tau, S, A, dev, normalize=True, update_vf=True):
+    """One replay as a device batch with its advantages: {states [1,B,S], actions, adv [1,B], count, done} (mi_gae_advantages;
+    update_vf=False evaluates the baseline as last fitted, rl.py:401)."""
+    from ..engine import gae_advantages
+    b = _device_batch([ep], S, A, dev)
+    weights = None
+    if not update_vf:
+        weights = baseline._weight_dev if baseline._weight_dev is not None else torch.from_numpy(np.ascontiguousarray(baseline.weight)).reshape(1, -1)
+    adv, wts = gae_advantages(b['states'], b['next_states'], b['rewards'], b['dones'], b['count'], gamma, tau, baseline.reg,
+                              normalize=normalize, want_weights=True, weights=weights)
+    if update_vf:
+        baseline._weight_dev = wts[-1]
+    return dict(states=b['states'], actions=b['actions'], adv=adv, count=b['count'], done=b['dones'])
+
+
 def _gae_on_device(dev, S, rows):
     from ..engine import gae_max_rows
     return torch.device(dev).type == 'cuda' and 0 < rows <= gae_max_rows(S)
@@ -160,6 +175,10 @@ def _pad(eps_list, advs, S, A, dev):
     upload per field."""
     T = len(eps_list)
     B = max(int(e['states'].shape[0]) for e in eps_list)
+    if advs and torch.is_tensor(advs[0]) and advs[0].is_cuda:      # advantages already on the device (mi_gae_advantages): stay there
+        b = _device_batch(eps_list, S, A, dev)
+        adv = torch.stack([torch.nn.functional.pad(a.reshape(-1).float(), (0, B - a.numel())) for a in advs]).contiguous()
+        return dict(states=b['states'], actions=b['actions'], adv=adv, count=b['count'], done=b['dones'])
     st, ac = np.zeros((T, B, S), np.float32), np.zeros((T, B, A), np.float32)
     ad, cnt, dn = np.zeros((T, B), np.float32), np.zeros(T, np.int32), np.zeros((T, B), np.float32)
     for t, (e, a) in enumerate(zip(eps_list, advs)):
@@ -177,6 +196,11 @@ def _pad(eps_list, advs, S, A, dev):
 # ---------------------------------------------------------------------------------------------- reference functions
 def trpo_a2c_loss(episodes, learner, baseline, gamma, tau, update_vf=True):
     """reference rl.py:346-358: -mean(log_prob * normalised advantages) (value only; the gradient path is trpo_update)."""
+    dev = learner.sigma.device
+    if _gae_on_device(dev, learner.input_size, int(episodes['states'].shape[0])):
+        b = _replay_on_device(episodes, baseline, gamma, tau, learner.input_size, learner.output_size, dev, update_vf=update_vf)
+        lp = learner.log_prob(b['states'][0], b['actions'][0])
+        return -(lp * b['adv'][0].reshape(-1, 1).to(lp)).mean()
     adv = _advantages(episodes, baseline, gamma, tau, update_vf)
     lp = learner.log_prob(episodes['states'].to(device), episodes['actions'].to(device))
     return -(lp * torch.from_numpy(adv).to(lp)).mean()
@@ -188,9 +212,12 @@ def trpo_update(episodes, learner, baseline, inner_lr, gamma, tau, anil=False, f
     # anil only sets allow_unused (rl.py:371): which parameters move is decided by the policy's own switch -- with
     # DiagNormalPolicyANIL.turn_off_body_grads() the body's gradients are None and maml_update leaves it unchanged.
     head_only = bool(getattr(learner, 'features_no_grad', False))
-    adv = _advantages(episodes, baseline, gamma, tau)
     eng = learner.engine()
-    batch = _pad([episodes], [adv], learner.input_size, learner.output_size, learner.sigma.device)
+    dev = learner.sigma.device
+    if _gae_on_device(dev, learner.input_size, int(episodes['states'].shape[0])):
+        batch = _replay_on_device(episodes, baseline, gamma, tau, learner.input_size, learner.output_size, dev)
+    else:
+        batch = _pad([episodes], [_advantages(episodes, baseline, gamma, tau)], learner.input_size, learner.output_size, dev)
     theta_new, _ = eng.adapt(learner.flat(), batch['states'], batch['actions'], batch['adv'], batch['count'], inner_lr,
                              head_only=head_only)
     new = deepcopy(learner)
@@ -439,6 +466,10 @@ def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order
     kind = 'ppo' if algo == 'ppo' else ('dice' if dice else 'a2c')
 
     def adv_of(ep):
+        n = int(ep['states'].shape[0])
+        if _gae_on_device(pol.sigma.device, pol.input_size, n):         # stays on the device: [n] fp32
+            return _replay_on_device(ep, baseline, gamma, tau, pol.input_size, pol.output_size, pol.sigma.device,
+                                     normalize=(algo == 'ppo'))['adv'][0, :n]
         a = compute_advantages(baseline, tau, gamma, ep['rewards'], ep['dones'], ep['states'], ep['next_states'])
         return normalize(a) if algo == 'ppo' else a                     # vpg_a2c_loss does not normalise (rl.py:217)
 

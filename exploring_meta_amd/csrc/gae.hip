@@ -24,6 +24,7 @@ struct GaeArgs {
   const int32_t* count;                                  // [R] rows in use (<= B), or null = B
   float* adv;                                            // [R][B]
   double* weight;                                        // [R][D] baseline weights (may be null)
+  const double* weight_in;                               // [R][D] given weights: no fit (update_vf = False), or null
   int B, S;
   double gamma, tau, reg;
   int normalize;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
   }
   for (int e = tid; e < n * S; e += 256) st[e] = st_g[e];
   __syncthreads();
+  if (!a.weight_in) {
   gae_scan(rw, dn, x, n, a.gamma, tid);
   __syncthreads();
   // normal equations: one (i <= j) entry of F^T F or one entry of F^T returns per thread "pair", the rows split over G groups
@@ -145,6 +147,10 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
       if (a.weight) a.weight[(size_t)r * D + i] = w[i];
     }
   }
+  } else if (tid < D) {
+    w[tid] = a.weight_in[(size_t)r * D + tid];
+    if (a.weight) a.weight[(size_t)r * D + tid] = w[tid];
+  }
   __syncthreads();
   // bootstraps -> x, deltas -> rw
   for (int t = tid; t < n; t += 256) {
@@ -188,8 +194,8 @@ extern "C" int mi_gae_max_rows(int state_dim) {
 }
 
 extern "C" int mi_gae_advantages(void* stream, const float* states, const float* next_states, const float* rewards, const float* dones,
-                                 const int32_t* count, int replays, int rows, int state_dim, double gamma, double tau, double reg,
-                                 int normalize, float* adv_out, double* weight_out) {
+                                 const int32_t* count, const double* weight_in, int replays, int rows, int state_dim, double gamma,
+                                 double tau, double reg, int normalize, float* adv_out, double* weight_out) {
   if (!states || !next_states || !rewards || !dones || !adv_out || replays < 1 || rows < 1)
     return mi_internal_fail(MI_ERR_ARG, "mi_gae_advantages: null pointer or empty batch");
   if (state_dim < 1 || 2 * state_dim + 4 > GAE_MAX_D)
@@ -197,7 +203,7 @@ extern "C" int mi_gae_advantages(void* stream, const float* states, const float*
   if (rows > mi_gae_max_rows(state_dim))
     return mi_internal_fail(MI_ERR_ARG, ("mi_gae_advantages: a replay of " + std::to_string(rows) + " rows does not fit in LDS (max " +
                                          std::to_string(mi_gae_max_rows(state_dim)) + ")").c_str());
-  GaeArgs a{states, next_states, rewards, dones, count, adv_out, weight_out, rows, state_dim, gamma, tau, reg, normalize};
+  GaeArgs a{states, next_states, rewards, dones, count, adv_out, weight_out, weight_in, rows, state_dim, gamma, tau, reg, normalize};
   const size_t smem = gae_smem_bytes(rows, state_dim);
   hipError_t s = hipSuccess;
   if (smem > 64 * 1024) s = hipFuncSetAttribute(reinterpret_cast<const void*>(gae_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

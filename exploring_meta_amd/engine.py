@@ -384,10 +384,11 @@ def gae_max_rows(state_dim):
     return int(_lib.load().mi_gae_max_rows(int(state_dim)))
 
 
-def gae_advantages(states, next_states, rewards, dones, count, gamma, tau, reg, normalize=True, want_weights=False):
+def gae_advantages(states, next_states, rewards, dones, count, gamma, tau, reg, normalize=True, want_weights=False, weights=None):
     """mi_gae_advantages: cherry-semantics returns -> LinearValue fit -> bootstraps -> GAE (-> ch.normalize) for R replays in one
     launch (reference core_functions/rl.py:95-110,355).  states / next_states [R, B, S], rewards / dones [R, B] fp32 CUDA tensors,
-    count [R] int32 (rows in use) or None.  Returns adv [R, B] fp32 (and the fitted baseline weights [R, 2S+4] fp64)."""
+    count [R] int32 (rows in use) or None; weights [R, 2S+4] fp64: use these baseline weights instead of fitting (update_vf=False).
+    Returns adv [R, B] fp32 (and the baseline weights [R, 2S+4] fp64)."""
     lib = _lib.load()
     dev = states.device
     R, B, S = states.shape
@@ -398,8 +399,10 @@ def gae_advantages(states, next_states, rewards, dones, count, gamma, tau, reg, 
         count = count.to(dev, torch.int32).contiguous()
     adv = torch.empty(R, B, dtype=torch.float32, device=dev)
     wts = torch.empty(R, 2 * S + 4, dtype=torch.float64, device=dev) if want_weights else None
+    if weights is not None:
+        weights = weights.to(dev, torch.float64).reshape(R, 2 * S + 4).contiguous()
     with torch.cuda.device(dev):
-        _lib.check(lib.mi_gae_advantages(_stream(dev), _ptr(states), _ptr(next_states), _ptr(rewards), _ptr(dones), _ptr(count), R, B, S,
+        _lib.check(lib.mi_gae_advantages(_stream(dev), _ptr(states), _ptr(next_states), _ptr(rewards), _ptr(dones), _ptr(count), _ptr(weights), R, B, S,
                                          float(gamma), float(tau), float(reg), int(bool(normalize)), _ptr(adv), _ptr(wts)))
     return (adv, wts) if want_weights else adv
 

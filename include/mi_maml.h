@@ -167,12 +167,14 @@ int mi_learner_hvp(mi_engine* e, void* stream, const float* theta, int theta_tas
  * t = row/100, ridge normal equations with `reg`; rl/maml_trpo.py:85 passes env.action_size as reg), bootstraps,
  * cherry.pg.generalized_advantage; normalize != 0 applies ch.normalize (rl.py:355) -- (adv - mean) / (unbiased std + 1e-8)).
  *   states, next_states [replays, rows, state_dim]; rewards, dones [replays, rows]; count [replays] rows in use (NULL = rows);
- *   adv_out [replays, rows] (0 past a replay's count); weight_out [replays, 2*state_dim+4] fitted baseline weights (fp64) or NULL.
+ *   adv_out [replays, rows] (0 past a replay's count); weight_out [replays, 2*state_dim+4] fitted baseline weights (fp64) or NULL;
+ *   weight_in [replays, 2*state_dim+4] != NULL: use these baseline weights instead of fitting (compute_advantages' update_vf=False,
+ *   rl.py:401 -- the query replay's loss is computed with the baseline fitted to the last support replay).
  * fp64 arithmetic throughout; state_dim <= 8 and rows <= mi_gae_max_rows(state_dim) (the replay is staged in LDS). */
 int mi_gae_max_rows(int state_dim);
 int mi_gae_advantages(void* stream, const float* states, const float* next_states, const float* rewards, const float* dones,
-                      const int32_t* count, int replays, int rows, int state_dim, double gamma, double tau, double reg,
-                      int normalize, float* adv_out, double* weight_out);
+                      const int32_t* count, const double* weight_in, int replays, int rows, int state_dim, double gamma, double tau,
+                      double reg, int normalize, float* adv_out, double* weight_out);
 
 /* Adam step on the flat meta-parameters with torch.optim.Adam defaults (maml_vision.py:85,139-141):
  * grad is first scaled by grad_scale (= 1/meta_batch_size). step is the 1-based step count after increment. */

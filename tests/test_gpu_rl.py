@@ -578,3 +578,26 @@ def test_surrogate_context_on_device_matches_host_path(monkeypatch):
     l1, k1, g1 = dev_ctx.evaluate(pol.flat(), want_grad=True)
     l2, k2, g2 = host_ctx.evaluate(pol.flat(), want_grad=True)
     assert rel_err(g1.cpu().numpy(), g2.cpu().numpy()) < 1e-5 and abs(float(l1[0]) - float(l2[0])) < 1e-6
+
+
+def test_per_task_losses_on_device_match_host_walk(monkeypatch):
+    """trpo_update / trpo_a2c_loss (update_vf True and False: the query loss uses the baseline as fitted to the support replay,
+    rl.py:401) with the advantages from mi_gae_advantages == with the host numpy walk."""
+    from exploring_meta_amd.core_functions import rl as prl
+    theta, replays, _ = _replays()
+    pol = _policy(theta)
+    cf.set_device(torch.device('cuda'))
+    out = {}
+    for mode in ('device', 'host'):
+        if mode == 'host':
+            monkeypatch.setattr(prl, '_gae_on_device', lambda *a: False)
+        base = cf.LinearValue(2, 2)
+        sup, qry = replays[1][0], replays[1][1]
+        new = prl.trpo_update(sup, pol, base, 0.1, 0.99, 1.0)
+        l_fit = prl.trpo_a2c_loss(sup, pol, base, 0.99, 1.0, update_vf=True)
+        l_keep = prl.trpo_a2c_loss(qry, new, base, 0.99, 1.0, update_vf=False)
+        out[mode] = (new.flat().detach().cpu().numpy(), float(l_fit), float(l_keep), np.array(base.weight).reshape(-1))
+    assert rel_err(out['device'][0], out['host'][0]) < 1e-6
+    assert abs(out['device'][1] - out['host'][1]) < 1e-6 and abs(out['device'][2] - out['host'][2]) < 1e-6
+    f = cf.LinearValue(2, 2)._features(np.asarray(replays[1][0]['states'], dtype=np.float64))
+    assert np.abs(f @ out['device'][3] - f @ out['host'][3]).max() < 1e-6
