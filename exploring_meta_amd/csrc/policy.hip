@@ -133,7 +133,11 @@ template <bool TRANS_W>
 static void launch_dense(hipStream_t st, int T, const DenseArgs& a) {
   // (an LDS-tiled variant -- 128 rows x all columns per workgroup, 32-wide reduction chunks staged with coalesced loads -- was built
   // and measured: 1.09 ms per Fisher-vector product against 1.01 ms for this kernel with 8-byte operand loads; two barriers per
-  // chunk and the staging cost outweigh the better coalescing on these 100-wide layers.)
+  // chunk and the staging cost outweigh the better coalescing on these 100-wide layers.  A second variant -- every wave copies its
+  // own contiguous 32-row operand blocks into a private LDS slice with 16-byte loads, no barriers, 2 waves per workgroup -- ran the
+  // 100x100 forward product in 116 us against 87 us: 25.6 KB of LDS per wave leaves 6 waves per CU and the copy's latency is no
+  // longer hidden.  The product is address-unit bound (32 rows per operand load) but short of a kernel that keeps the whole 2x100
+  // MLP of a row tile on chip, occupancy is worth more than coalescing here.)
   const int N = TRANS_W ? a.O : a.I;
   hipLaunchKernelGGL(dense_mfma_kernel<TRANS_W>, dim3(ceil_div(ceil_div(a.B, 32) * ceil_div(N, 32), 4), T), dim3(256), 0, st, a);
 }
