@@ -232,3 +232,32 @@ def test_cfg3_anil_T32_batched_looped_oracle():
     # same near-tie decisions as above (golden G3-ANIL bar of round 1: 2e-3 on 2 tasks; measured here 6e-3 on one of two tasks)
     assert max(el) < 1e-5 and e_sum < 1e-4
     assert max(lo) < 1e-4 and min(eo) < 2e-3 and max(eo) < 2e-2
+
+
+def test_hessian_vector_sweep_properties_at_cfg2_size():
+    """Size-independent properties of the Hessian-vector sweep at BASELINE config 2's per-task size (25 images, 84x84, 32 filters),
+    where the oracle would take minutes: with s(theta) = sum(logits * c) for a fixed cotangent c, H = d^2 s / dtheta^2 is
+    symmetric and the sweep is linear in its direction -- <w, H v> = <v, H w>, H(a v + b w) = a H v + b H w, and J(a v + b w) =
+    a J v + b J w for the logit tangents (mi_learner_hvp, the same tangent kernels the fused second-order path runs)."""
+    ways, shots = 5, 5
+    spec, mspec = R.mini_imagenet_spec(ways), ModelSpec.mini_imagenet(ways)
+    theta = R.flatten_params(_ref_theta(spec, 42)).float().cuda().contiguous()
+    data, labels = synthetic.make_meta_batch('min', [0, 1], ways, shots)
+    x = torch.from_numpy(data[:, ::2]).float().cuda().contiguous()                  # the support halves: [2, 25, 3, 84, 84]
+    T, n = x.shape[0], x.shape[1]
+    eng = MetaEngine(mspec)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    c = torch.randn(T, n, ways, device='cuda', generator=g) / n
+    v = torch.randn(eng.param_count, device='cuda', generator=g) * 0.05
+    w = torch.randn(eng.param_count, device='cuda', generator=g) * 0.05
+    hv, jv = eng.learner_hvp(theta, x, c, v)
+    hw, jw = eng.learner_hvp(theta, x, c, w)
+    a, b = 0.7, -1.3
+    hc, jc = eng.learner_hvp(theta, x, c, a * v + b * w)
+    torch.cuda.synchronize()
+    hv, hw, hc = hv[0].double(), hw[0].double(), hc[0].double()
+    sym = abs(float(torch.dot(w.double(), hv) - torch.dot(v.double(), hw))) / max(abs(float(torch.dot(w.double(), hv))), 1e-30)
+    lin = float((hc - (a * hv + b * hw)).norm() / hc.norm())
+    linj = float((jc.double() - (a * jv.double() + b * jw.double())).norm() / jc.double().norm())
+    report('hvp_properties_cfg2_size', symmetry_rel=sym, linearity_rel=lin, jvp_linearity_rel=linj)
+    assert sym < 1e-4 and lin < 1e-5 and linj < 1e-5
