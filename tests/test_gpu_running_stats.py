@@ -69,20 +69,3 @@ def test_running_stats_match_torch_batchnorm_pass_by_pass(dataset, ways, shots, 
             err = float((got.double().cpu() - want).abs().max() / want.abs().max())
             assert err < 2e-5, (i, err)
     assert model.state_dict()['base.0.normalize.running_var'].abs().sum() > 0
-
-
-def test_contributions_of_task_shards_add_up():
-    """Two ranks folding their own halves (global pass positions) == one rank folding everything: what rides in the all-reduce."""
-    g = torch.Generator().manual_seed(3)
-    P, T, C = 3, 5, 8
-    stats = torch.rand(P, T, 2, C, generator=g).cuda()
-    pos = (torch.arange(T).reshape(1, -1) * 2 + 1) * P + torch.arange(P).reshape(-1, 1)       # phase 1 of 2
-    whole = running_stats_contribution(stats, pos, 2 * T * P)
-    parts = running_stats_contribution(stats[:, :2], pos[:, :2], 2 * T * P) + running_stats_contribution(stats[:, 2:], pos[:, 2:], 2 * T * P)
-    assert torch.allclose(whole, parts, rtol=1e-6, atol=1e-9)
-    # and the recurrence it stands for
-    r = torch.zeros(2, C, dtype=torch.float64)
-    seq = {int(pos[p, t]): stats[p, t].double().cpu() for p in range(P) for t in range(T)}
-    for i in range(2 * T * P):
-        r = 0.9 * r + (0.1 * seq[i] if i in seq else 0.0)
-    assert torch.allclose(whole.double().cpu(), r, rtol=1e-6, atol=1e-9)
