@@ -461,8 +461,15 @@ __global__ __launch_bounds__(64) void gram_wgrad_kernel(GramWgArgs a, int ng, in
     const int e = k * co + c;
     double S = 0.0;
     const float* sp = a.spartial + (size_t)task * a.nblk * kp * co + e;
-#pragma unroll 8
-    for (int b = 0; b < a.nblk; ++b) S += (double)sp[(size_t)b * kp * co];     // fixed order; unrolled so the loads overlap
+    int b = 0;                                                                 // fixed order; 16 loads in flight per round
+    for (; b + 16 <= a.nblk; b += 16) {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = sp[(size_t)(b + q) * kp * co];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) S += (double)v[q];
+    }
+    for (; b < a.nblk; ++b) S += (double)sp[(size_t)b * kp * co];
     const float* wc = a.w + (size_t)task * a.wstride + c;
     const float* vc = tangent ? a.wd + (size_t)task * a.vstride + c : wc;
     double gw = 0.0, gwd = 0.0;
