@@ -42,22 +42,38 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadArgs a) {
     float part[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w) part[w] = 0.f;
-    for (int i = lane * 4; i < F; i += 256) {
-      const floatx4 fv = *reinterpret_cast<const floatx4*>(f_n + i);
-      floatx4 fdv = {0.f, 0.f, 0.f, 0.f};
-      if (TANGENT && fd_n) fdv = *reinterpret_cast<const floatx4*>(fd_n + i);
+    // two 256-float steps per round with all of their loads issued before the first multiply-add (a 5-way tangent row has 24 16-byte
+    // loads per round; one step at a time the wave waited for memory four times per 800-feature row); same accumulation order
+    const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = lane * 4; i0 < F; i0 += 512) {
+      floatx4 fv[2], fdv[2], wv[2][8], wdv[2][8];
 #pragma unroll
-      for (int w = 0; w < 8; ++w) {
-        if (w < WY) {
-          if (!TANGENT) {
-            const floatx4 wv = *reinterpret_cast<const floatx4*>(wl_t + (size_t)w * F + i);
-            part[w] = fmaf(fv[0], wv[0], fmaf(fv[1], wv[1], fmaf(fv[2], wv[2], fmaf(fv[3], wv[3], part[w]))));
-          } else {
-            const floatx4 wdv = *reinterpret_cast<const floatx4*>(wld_t + (size_t)w * F + i);
-            part[w] = fmaf(fv[0], wdv[0], fmaf(fv[1], wdv[1], fmaf(fv[2], wdv[2], fmaf(fv[3], wdv[3], part[w]))));
-            if (fd_n) {
-              const floatx4 wv = *reinterpret_cast<const floatx4*>(wl_t + (size_t)w * F + i);
-              part[w] = fmaf(fdv[0], wv[0], fmaf(fdv[1], wv[1], fmaf(fdv[2], wv[2], fmaf(fdv[3], wv[3], part[w]))));
+      for (int u = 0; u < 2; ++u) {
+        const int i = i0 + 256 * u;
+        const bool ok = i < F;
+        fv[u] = ok ? *reinterpret_cast<const floatx4*>(f_n + i) : z4;
+        fdv[u] = (TANGENT && fd_n && ok) ? *reinterpret_cast<const floatx4*>(fd_n + i) : z4;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          wv[u][w] = z4; wdv[u][w] = z4;
+          if (w < WY && ok) {
+            if (!TANGENT || fd_n) wv[u][w] = *reinterpret_cast<const floatx4*>(wl_t + (size_t)w * F + i);
+            if (TANGENT) wdv[u][w] = *reinterpret_cast<const floatx4*>(wld_t + (size_t)w * F + i);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (i0 + 256 * u >= F) continue;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          if (w < WY) {
+            if (!TANGENT) {
+              part[w] = fmaf(fv[u][0], wv[u][w][0], fmaf(fv[u][1], wv[u][w][1], fmaf(fv[u][2], wv[u][w][2], fmaf(fv[u][3], wv[u][w][3], part[w]))));
+            } else {
+              part[w] = fmaf(fv[u][0], wdv[u][w][0], fmaf(fv[u][1], wdv[u][w][1], fmaf(fv[u][2], wdv[u][w][2], fmaf(fv[u][3], wdv[u][w][3], part[w]))));
+              if (fd_n)
+                part[w] = fmaf(fdv[u][0], wv[u][w][0], fmaf(fdv[u][1], wv[u][w][1], fmaf(fdv[u][2], wv[u][w][2], fmaf(fdv[u][3], wv[u][w][3], part[w]))));
             }
           }
         }
