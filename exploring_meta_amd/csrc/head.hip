@@ -159,14 +159,24 @@ __global__ __launch_bounds__(256) void head_grads_kernel(HeadArgs a) {
     float dw[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w) dw[w] = 0.f;
-    for (int n = 0; n < N; ++n) {
-      const float fv = f_t[(size_t)n * F + i];
-      const float fdv = (TANGENT && fd_t) ? fd_t[(size_t)n * F + i] : 0.f;
+    for (int n0 = 0; n0 < N; n0 += 8) {              // 8 rows' features in flight per round; same accumulation order
+      float fv[8], fdv[8];
 #pragma unroll
-      for (int w = 0; w < 8; ++w) {
-        if (w < WY) {
-          dw[w] = fmaf(s_a[n * WY + w], fv, dw[w]);
-          if (TANGENT && fd_t) dw[w] = fmaf(s_b[n * WY + w], fdv, dw[w]);
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = n0 + u < N;
+        fv[u] = ok ? f_t[(size_t)(n0 + u) * F + i] : 0.f;
+        fdv[u] = (TANGENT && fd_t && ok) ? fd_t[(size_t)(n0 + u) * F + i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = n0 + u;
+        if (n >= N) break;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          if (w < WY) {
+            dw[w] = fmaf(s_a[n * WY + w], fv[u], dw[w]);
+            if (TANGENT && fd_t) dw[w] = fmaf(s_b[n * WY + w], fdv[u], dw[w]);
+          }
         }
       }
     }
