@@ -280,7 +280,7 @@ def test_bn_tangent_fwd_bwd(lib, name, T, n, ho, wo, c, pool):
 
 
 # ---------------------------------------------------------------------------------------------------- fused block 1
-B1_CASES = [('min_small', 2, 3, 84, 84, 3, 32, None), ('rect', 2, 2, 36, 42, 3, 32, None), ('ci1', 3, 4, 28, 28, 1, 32, None),
+B1_CASES = [('min_small', 2, 3, 84, 84, 3, 32, None), ('one_image', 1, 1, 84, 84, 3, 32, None), ('tall', 3, 2, 20, 84, 3, 32, None), ('rect', 2, 2, 36, 42, 3, 32, None), ('ci1', 3, 4, 28, 28, 1, 32, None),
             ('anil64', 1, 2, 84, 84, 3, 64, None), ('bench_T32', 32, 25, 84, 84, 3, 32, [0, 31])]
 
 
