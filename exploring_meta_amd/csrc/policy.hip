@@ -68,6 +68,40 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs a) {
   for (int term = 0; term < a.nterms; ++term) {
     const float* xr = a.x[term] + ((size_t)t * a.B + (rok ? row : 0)) * Kd;
     const float* wt = a.w[term] + (size_t)t * a.wstride[term];
+    if (Kd % 4 == 0 && Kd >= 16) {
+      // 16-byte operand loads: the reduction index is dealt to the two lane halves in groups of four (half h takes k = 8c + 4h .. + 3),
+      // so a lane's four consecutive MFMAs read four consecutive floats of its row.  An operand load touches 32 different rows
+      // (64 cache lines) whatever its width: the address unit, not the matrix pipe, bounds these products, and twice the width is
+      // half the loads.  (Rows are multiples of 16 bytes; weights inside the parameter vector are only 8-byte aligned: dword-aligned
+      // vector type.)
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+      const int nch = (Kd + 7) >> 3;
+#ifndef MI_DENSE_CU
+#define MI_DENSE_CU 2
+#endif
+      constexpr int CU = MI_DENSE_CU;                         // chunks (of 4 MFMAs) in flight
+      for (int c0 = 0; c0 < nch; c0 += CU) {
+        f4u av[CU], bv[CU];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+          const int k = 8 * (c0 + u) + 4 * h;
+          const bool kok = (c0 + u < nch) && (k < Kd);
+          av[u] = (f4u){0.f, 0.f, 0.f, 0.f}; bv[u] = (f4u){0.f, 0.f, 0.f, 0.f};
+          if (kok && rok) av[u] = *reinterpret_cast<const f4u*>(xr + k);
+          if (TRANS_W) {
+            if (kok && cok) bv[u] = *reinterpret_cast<const f4u*>(wt + (size_t)col * Kd + k);
+          } else if (kok && cok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[u][q] = wt[(size_t)(k + q) * N + col];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < CU; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q], bv[u][q], acc, 0, 0, 0);
+      }
+      continue;
+    }
     constexpr int CH = 10;
     // a lane's consecutive reduction indices are consecutive floats of its row: 8-byte loads where the half-row split keeps them
     // 8-byte aligned (the 100-wide hidden layers: rows of 400 B, halves of 200 B)
