@@ -449,8 +449,8 @@ def run_trpo(args, wl, rank, world, local, dist):
                     op='fisher_vector_product', bound='mfma', achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
                     frac=round(achieved / FP32_MFMA_PEAK_TF, 5), traffic=None, launches=nf, avg_launch_ms=round(fvp_ms, 4),
                     flops_per_launch=flops, note='2x100 MLP on 2000-row batches: about 35 launches of 0.4..1.6 GFLOP per product (dense '
-                    'products on the fp32 matrix pipe, one wave per 32x32 tile, operands straight from global memory): launch- and '
-                    'latency-bound: 11 Fisher-vector products of ~1 ms are 11 ms of a 15 ms step; the advantages of the 40 replays (returns, LinearValue fits, GAE, '
+                    'products on the fp32 matrix pipe, one wave per 32x32 tile, 16-byte operand loads straight from global memory): '
+                    'address-unit / padding bound: 11 Fisher-vector products of ~0.86 ms are 9.5 ms of a 13 ms step; the advantages of the 40 replays (returns, LinearValue fits, GAE, '
                     'normalisation) are one mi_gae_advantages launch, 1.4 ms with the device-side batch assembly (tools/trpo_step_timing.py)')
 
     cpu = None
