@@ -348,6 +348,8 @@ def conjugate_gradient(Ax, b, num_iterations=10, tol=1e-10, eps=1e-8):
     """cherry.algorithms.trpo.conjugate_gradient (reference rl.py:418).  The recurrences (dot products, axpys on 10,604
     elements) are carried in fp64 on the device; every A p is one fp32 Fisher-vector product through the engine."""
     dt = b.dtype
+    if b.is_cuda:
+        return _conjugate_gradient_device(Ax, b, num_iterations, tol, eps)
     b = b.double()
     x = torch.zeros_like(b)
     r, p = b.clone(), b.clone()
@@ -363,6 +365,27 @@ def conjugate_gradient(Ax, b, num_iterations=10, tol=1e-10, eps=1e-8):
         if r_dot_new.item() < tol:
             break
     return x.to(dt)
+
+
+def _conjugate_gradient_device(Ax, b, num_iterations, tol, eps):
+    """The same recurrences with the whole loop body after `Ap = Ax(p)` as one launch (mi_cg_update)."""
+    import ctypes as C
+    from .. import _lib
+    from ..engine import _ptr, _stream
+    lib = _lib.load()
+    dev, n = b.device, b.numel()
+    r = b.detach().double().reshape(-1).contiguous()
+    x, p = torch.zeros_like(r), r.clone()
+    p32 = r.float()
+    rr = torch.zeros(2, dtype=torch.float64, device=dev)
+    rr[0] = torch.dot(r, r)
+    for _ in range(num_iterations):
+        ap = Ax(p32.to(b.dtype)).detach().float().reshape(-1).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(lib.mi_cg_update(_stream(dev), _ptr(x), _ptr(r), _ptr(p), _ptr(ap), _ptr(rr), _ptr(p32), n, float(eps)))
+        if rr[0].item() < tol:
+            break
+    return x.to(b.dtype).reshape(b.shape)
 
 
 def meta_optimize_trpo(params, policy, baseline, iter_replays, iter_policies, anil=False):

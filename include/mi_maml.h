@@ -162,6 +162,11 @@ int mi_learner_hvp(mi_engine* e, void* stream, const float* theta, int theta_tas
                    const float* v, int tasks, int n, float* grad_theta_out, float* logits_dot_out, void* workspace,
                    size_t workspace_bytes);
 
+/* One recurrence of cherry.algorithms.trpo.conjugate_gradient (reference rl.py:418, the loop body) on device vectors, fp64, one launch:
+ *   alpha = rr[0] / (p . ap + eps);  x += alpha p;  r -= alpha ap;  rr_new = r . r;  p = r + (rr_new / rr[0]) p;  rr[0] = rr_new, rr[1] = alpha.
+ * x, r, p: fp64 [n];  ap: fp32 [n] (the Fisher-vector product of p32);  p32: fp32 [n], the new p for the next product. */
+int mi_cg_update(void* stream, double* x, double* r, double* p, const float* ap, double* rr, float* p32, size_t n, double eps);
+
 /* Generalised advantage estimation with cherry's LinearValue baseline for a list of replays, one launch (reference
  * core_functions/rl.py:95-110 compute_advantages: ch.td.discount, LinearValue.fit / __call__ (features [s, s^2, t, t^2, t^3, 1],
  * t = row/100, ridge normal equations with `reg`; rl/maml_trpo.py:85 passes env.action_size as reg), bootstraps,

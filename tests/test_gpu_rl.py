@@ -601,3 +601,30 @@ def test_per_task_losses_on_device_match_host_walk(monkeypatch):
     assert abs(out['device'][1] - out['host'][1]) < 1e-6 and abs(out['device'][2] - out['host'][2]) < 1e-6
     f = cf.LinearValue(2, 2)._features(np.asarray(replays[1][0]['states'], dtype=np.float64))
     assert np.abs(f @ out['device'][3] - f @ out['host'][3]).max() < 1e-6
+
+
+def test_fused_conjugate_gradient_matches_the_plain_loop():
+    """mi_cg_update (the recurrences of cherry's conjugate_gradient as one launch per iteration) against the same loop written with
+    torch operations, on a random symmetric positive definite system: same iterates, same early exit."""
+    from exploring_meta_amd.core_functions import rl as prl
+    g = torch.Generator().manual_seed(9)
+    n = 700
+    M = torch.randn(n, n, generator=g, dtype=torch.float64) / n ** 0.5
+    A = (M.t() @ M + 0.5 * torch.eye(n, dtype=torch.float64))
+    b = torch.randn(n, generator=g, dtype=torch.float64).float()
+    A32 = A.float()
+    ref = prl.conjugate_gradient(lambda v: A32 @ v, b, num_iterations=10)                       # CPU tensors: the plain loop
+    A_dev, calls = A32.cuda(), []
+
+    def Ax(v):
+        calls.append(1)
+        return A_dev @ v
+
+    got = prl.conjugate_gradient(Ax, b.cuda(), num_iterations=10)
+    assert len(calls) == 10 and rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5                 # (fp32 products on two devices)
+    # early exit: a well conditioned system converges below tol before the iteration cap on both paths
+    A2 = (torch.eye(n, dtype=torch.float64) * 2.0).float()
+    calls.clear()
+    A2d = A2.cuda()
+    got2 = prl.conjugate_gradient(lambda v: (calls.append(1), A2d @ v)[1], b.cuda(), num_iterations=10)
+    assert len(calls) == 1 and torch.allclose(got2.cpu(), b / 2.0, rtol=1e-6, atol=1e-7)
