@@ -10,6 +10,14 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The CPU oracle legs are many small fp64 products: on the GPU box's 256-logical-core host torch's default of 128 intra-op
+    # threads makes them 4-5x slower than 16 (measured: the cfg5 full-size test 61 s -> 12 s), and the suite has a wall-clock budget.
+    import torch
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, cores)))
 
 
 @pytest.fixture(scope='session')
