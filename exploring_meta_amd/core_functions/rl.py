@@ -28,7 +28,10 @@ def discount(gamma, rewards, dones):
     """cherry.td.discount: R_t = r_t + gamma (1 - d_t) R_{t+1}.  A `done` cuts the recursion, so the replay splits into episodes;
     they are padded with zeros at the END to a common length (zeros behind the last step leave the backward recursion at exactly
     0) and the whole replay is one linear-filter call along the time axis -- bit-identical to the step-by-step loop."""
-    from scipy.signal import lfilter
+    try:
+        from scipy.signal import lfilter
+    except ImportError:                                    # scipy is optional (not in the reference's requirements): plain recursion
+        lfilter = None
     r = rewards[:, 0]
     n = r.shape[0]
     ends = np.flatnonzero(dones[:, 0] != 0.0)
@@ -41,7 +44,12 @@ def discount(gamma, rewards, dones):
     pos = np.arange(n) - starts[ep]                        # position inside its episode
     pad = np.zeros((lens.size, L))
     pad[ep, pos] = r
-    disc = lfilter([1.0], [1.0, -gamma], pad[:, ::-1], axis=1)[:, ::-1]
+    if lfilter is not None:
+        disc = lfilter([1.0], [1.0, -gamma], pad[:, ::-1], axis=1)[:, ::-1]
+    else:
+        disc = pad.copy()
+        for i in range(L - 2, -1, -1):
+            disc[:, i] = pad[:, i] + gamma * disc[:, i + 1]
     out = np.empty_like(rewards)
     out[:, 0] = disc[ep, pos]
     return out
@@ -374,7 +382,7 @@ def _conjugate_gradient_device(Ax, b, num_iterations, tol, eps):
     from ..engine import _ptr, _stream
     lib = _lib.load()
     dev, n = b.device, b.numel()
-    r = b.detach().double().reshape(-1).contiguous()
+    r = b.detach().to(torch.float64, copy=True).reshape(-1).contiguous()      # a copy: mi_cg_update overwrites r in place
     x, p = torch.zeros_like(r), r.clone()
     p32 = r.float()
     rr = torch.zeros(2, dtype=torch.float64, device=dev)

@@ -316,9 +316,10 @@ template <> struct B1Vec<1> {
 //    the hardware range check drops the windows past the end of the task (no exec-mask branch regions around the stores);
 //  * the tile -> (image, window row, window column) decode is carried incrementally on the scalar unit (no divisions in the loop),
 //    the 3x3 bounds tests are four compares per tile combined as lane masks on the scalar unit;
-//  * the pooling argmax is taken on z itself, times the sign of gamma*rstd: u = gamma*zhat + beta is a monotone function of z, so
-//    max u = u(argmax z) bit for bit and BN-apply + ReLU run once per window instead of once per position (two positions whose u
-//    round to the same float although their z differ now resolve by z instead of by position; gamma == 0 keeps position 0);
+//  * the pooling argmax is the FIRST maximum of u = gamma*zhat + beta over the four positions, the reference's MaxPool2d rule bit for
+//    bit (round 2 took it on sign(gamma*rstd)*z, one BN-apply per window instead of four: two positions whose u round to the same
+//    float although their z differ then resolved by z instead of by position -- about one window per 10^6, each worth up to
+//    ~1e-3 of a task's block-1 weight gradient; 24 more VALU instructions per tile buy the exact rule);
 //  * this lane's 15 conv weights live in registers (no LDS at all), the first MFMA of a tile takes C = 0 as an inline constant.
 template <int CI0, bool ARG>
 __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
@@ -351,9 +352,6 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
     gmd = a.gammad[(size_t)task * a.vstride + ch];
     btd = a.betad[(size_t)task * a.vstride + ch];
   }
-  const float gr = gm * rs;
-  const float sg = gr > 0.f ? 1.f : (gr < 0.f ? -1.f : 0.f);
-
   // ---- buffer descriptors of this task's tensors (num_records = the task's extent: accesses past it read 0 / are dropped)
   const unsigned x_bytes = (unsigned)((size_t)a.n * H * W * CI0 * 4), p_elems = (unsigned)nwin * (unsigned)CO;
   const mi_rsrc rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)task * a.n * H * W * CI0), 0, x_bytes, 0x00020000);
@@ -452,19 +450,20 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
         buf_st(rout, go32, on ? gmd * o.zh[g] + gm * zhd_s + btd : 0.f);
         buf_st(rzho, go32, on ? zhd_s : 0.f);
       } else {
-        // first maximum of sg*z == first maximum of u (u is monotone in sg*z); sg == 0 (gamma*rstd == 0) keeps position 0
-        float best = z[4 * g] * sg, zsel = z[4 * g];
+        // the reference's rule exactly (MaxPool2d after BN + ReLU, vision_models.py:188-193): FIRST maximum of u itself, so two
+        // positions whose u round to the same float resolve by position even when their z differ
+        float zh_at = bn_zh(z[4 * g], mu, rs);
+        float u = bn_u(zh_at, gm, bt);
         unsigned arg = 0u;
 #pragma unroll
         for (int q = 1; q < 4; ++q) {
-          const float tq = z[4 * g + q] * sg;
-          const bool gt = tq > best;
-          best = gt ? tq : best;
-          zsel = gt ? z[4 * g + q] : zsel;
+          const float zq = bn_zh(z[4 * g + q], mu, rs);
+          const float uq = bn_u(zq, gm, bt);
+          const bool gt = uq > u;
+          u = gt ? uq : u;
+          zh_at = gt ? zq : zh_at;
           arg = gt ? (unsigned)q : arg;
         }
-        const float zh_at = bn_zh(zsel, mu, rs);
-        const float u = bn_u(zh_at, gm, bt);
         const bool on = u > 0.f;
         buf_st(rout, go32, on ? u : 0.f);
         buf_st(rzho, go32, zh_at);

@@ -715,6 +715,15 @@ static int export_bn_stats(mi_engine* e, hipStream_t st, const ActSet& A, int T)
   return MI_OK;
 }
 
+// The BatchNorm export covers the fused calls only (mi_meta_batch_maml / mi_meta_batch_anil number their passes from 0): the
+// step-wise entry points run with the export paused, so a learner(x) inside an export window neither writes a stale slot nor
+// fails on the buffer size.
+struct ExportPause {
+  mi_engine* e; float* buf;
+  explicit ExportPause(mi_engine* e_) : e(e_), buf(e_ ? e_->bn_export : nullptr) { if (e) e->bn_export = nullptr; }
+  ~ExportPause() { if (e) e->bn_export = buf; }
+};
+
 // One forward (+ backward) pass of the whole net on n images per task.
 static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, const int32_t* y, int n, int T,
                         const float* theta, float* g, float* loss, float* acc, float* logits, bool with_grad,
@@ -1198,6 +1207,7 @@ extern "C" int mi_forward_logits(mi_engine* e, void* stream, const float* theta,
                                  float* logits_out, void* workspace, size_t workspace_bytes) {
   if (!e) return fail(nullptr, MI_ERR_ARG, "null engine");
   if (!theta || !x || !logits_out || !workspace || tasks < 1 || n < 1) return fail(e, MI_ERR_ARG, "bad forward arguments");
+  ExportPause no_export(e);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   Plan pl;
   make_plan(e, workspace, tasks, n, n, 0, 0, pl);
@@ -1239,6 +1249,7 @@ extern "C" int mi_learner_forward(mi_engine* e, void* stream, const float* theta
   Plan pl;
   int rc = learner_args(e, theta, theta_tasks, x, tasks, n, workspace, workspace_bytes, pl);
   if (rc) return rc;
+  ExportPause no_export(e);
   const int nl = (int)e->L.size();
   if (rep_out && (rep_layer < 1 || rep_layer > nl)) return fail(e, MI_ERR_ARG, "rep_layer must be in 1..layers");
   if (!logits_out && !rep_out) return fail(e, MI_ERR_ARG, "nothing to compute: logits_out and rep_out are both NULL");
@@ -1261,6 +1272,7 @@ extern "C" int mi_learner_backward(mi_engine* e, void* stream, const float* thet
   Plan pl;
   int rc = learner_args(e, theta, theta_tasks, x, tasks, n, workspace, workspace_bytes, pl);
   if (rc) return rc;
+  ExportPause no_export(e);
   if (!dlogits || !grad_out) return fail(e, MI_ERR_ARG, "null dlogits / grad_out");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nl = (int)e->L.size();
@@ -1311,6 +1323,7 @@ extern "C" int mi_learner_hvp(mi_engine* e, void* stream, const float* theta, in
   if (!theta || !x || !dlogits || !v || !grad_theta_out || !logits_dot_out || !workspace || tasks < 1 || n < 1)
     return fail(e, MI_ERR_ARG, "bad mi_learner_hvp arguments");
   if (theta_tasks != 1 && theta_tasks != tasks) return fail(e, MI_ERR_ARG, "theta_tasks must be 1 (shared) or == tasks");
+  ExportPause no_export(e);
   Plan pl;
   make_plan(e, workspace, tasks, n, n, 1, 1, pl);
   if (pl.bytes > workspace_bytes)

@@ -115,7 +115,10 @@ __device__ __forceinline__ void mi_finalize_last(const FinArgs& f, const double*
   int* flag = reinterpret_cast<int*>(red + 512);
   // this thread's write-through stores must be ACKNOWLEDGED before the barrier that precedes the counter increment (a
   // workgroup-scope release fence does not wait for vmcnt on gfx950: waves of a workgroup share the CU's L1 / the XCD's L2)
-  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0); expcnt / lgkmcnt unconstrained
+  // inline asm with a memory clobber, not __builtin_amdgcn_s_waitcnt: the builtin is IntrNoMem, so nothing would stop the compiler
+  // from sinking the sc1 stores below it, and a builtin wait can make a later pass drop waits it believes redundant
+  // (MI355X_MICROARCH.md, "Compiler hazard"); the asm statement is opaque to both
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned prev = __hip_atomic_fetch_add(f.counter + task, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -125,5 +128,8 @@ __device__ __forceinline__ void mi_finalize_last(const FinArgs& f, const double*
   }
   __syncthreads();
   if (!*flag) return;                            // uniform per workgroup
+  // the fold's sc1 loads must not be hoisted above the counter read that made this workgroup the folder (compiler ordering only:
+  // they bypass the L1, and the last arriver's fetch_add returned after every other workgroup's stores were acknowledged)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   mi_fold_partials<true>(partial_task, nblk, c, f, task, red);
 }

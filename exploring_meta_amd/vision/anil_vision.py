@@ -113,8 +113,12 @@ def run(dataset, p, log=print):
         if rank == 0:
             log(f'iter {it}: {metrics}')
             if save_dir and it % p['save_every'] == 0:                                # anil_vision.py:143-145
-                torch.save(features.state_dict(), os.path.join(save_dir, 'model_checkpoints', f'features_{it + 1}.pt'))
-                torch.save(head.state_dict(), os.path.join(save_dir, 'model_checkpoints', f'head_{it + 1}.pt'))
+                # save_model_checkpoint(m, 'features_<it+1>') -> model_checkpoints/model_features_<it+1>.pt (utils/experiment.py:89-90)
+                torch.save(features.state_dict(), os.path.join(save_dir, 'model_checkpoints', f'model_features_{it + 1}.pt'))
+                torch.save(head.state_dict(), os.path.join(save_dir, 'model_checkpoints', f'model_head_{it + 1}.pt'))
+    if rank == 0 and save_dir:                                                        # anil_vision.py:163-164
+        torch.save(features.state_dict(), os.path.join(save_dir, 'features.pt'))
+        torch.save(head.state_dict(), os.path.join(save_dir, 'head.pt'))
     if world > 1:
         torch.distributed.destroy_process_group()
     return (features, head), metrics
@@ -125,7 +129,7 @@ if __name__ == '__main__':
     parser.add_argument('--dataset', type=str, default='min', help='omni or min')
     for k, v in params.items():
         parser.add_argument(f'--{k}', type=type(v), default=v)
-    parser.add_argument('--save_dir', type=str, default='', help='write model_checkpoints/{features,head}_<it>.pt every save_every iterations')
+    parser.add_argument('--save_dir', type=str, default='', help='write model_checkpoints/model_{features,head}_<it+1>.pt every save_every iterations and features.pt / head.pt at the end')
     args = parser.parse_args()
     for k in params:
         params[k] = getattr(args, k)

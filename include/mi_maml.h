@@ -74,6 +74,7 @@ int mi_engine_set_graph(mi_engine* e, int on);
  * of the blocks' filters, block-major; [0] batch mean, [1] biased batch variance).  torch.nn.BatchNorm2d updates running_mean /
  * running_var from these on every learner(x) of the reference (vision_models.py:168-174; the buffers are shared by learn2learn's clones
  * and saved by utils/experiment.py:85-90); core_functions/vision_models.py (running_stats_contribution / apply_running_stats) folds them in the reference's call order. */
+/* Only the fused calls export (their passes are numbered from 0 per call); mi_forward_logits / mi_learner_* run with the export paused. */
 int mi_engine_set_bn_export(mi_engine* e, float* buf, size_t floats);
 
 /* 1 (default): the per-workgroup fp64 partials of every BatchNorm statistic / reduction are folded, in a fixed order, by the

@@ -35,6 +35,23 @@ def test_maml_vision_driver_writes_reference_checkpoints(tmp_path, golden_small)
         assert float(sd[f'base.{i}.normalize.running_mean'].abs().max()) > 0 and float((sd[f'base.{i}.normalize.running_var'] - 1).abs().max()) > 0
 
 
+def test_anil_vision_driver_writes_reference_checkpoints(tmp_path):
+    """ANIL --save_dir: the reference calls save_model_checkpoint(features, 'features_<it+1>') -> model_checkpoints/
+    model_features_<it+1>.pt / model_head_<it+1>.pt (utils/experiment.py:89-90, anil_vision.py:151-153) and, after the loop,
+    save_model(features, 'features') / save_model(head, 'head') -> features.pt / head.pt (anil_vision.py:163-164)."""
+    import os
+    from exploring_meta_amd.vision import anil_vision
+    p = dict(anil_vision.params, ways=5, shots=1, adapt_steps=1, meta_batch_size=2, num_iterations=3, save_every=2, inner_lr=0.1,
+             save_dir=str(tmp_path))
+    (features, head), _ = anil_vision.run('omni', p, log=lambda *_: None)
+    assert sorted(os.listdir(tmp_path / 'model_checkpoints')) == ['model_features_1.pt', 'model_features_3.pt', 'model_head_1.pt',
+                                                                  'model_head_3.pt']
+    for name, module in (('features.pt', features), ('head.pt', head)):
+        sd = torch.load(tmp_path / name)
+        assert list(sd.keys()) == list(module.state_dict().keys())
+        assert all(torch.equal(sd[k].cpu(), v.cpu()) for k, v in module.state_dict().items())
+
+
 def test_maml_trpo_driver_runs():
     from exploring_meta_amd.rl import maml_trpo
     p = dict(maml_trpo.params, meta_batch_size=3, adapt_batch_size=4, max_path_length=20, num_iterations=2)
