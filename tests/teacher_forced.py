@@ -32,8 +32,8 @@ def _unflatten(flat, shapes):
 
 
 TAU = 1e-5          # a decision is a "near-tie" if its fp64 margin (|u| at the window's maximum, or the gap to the runner-up) is below this
-EXPLAIN_G, EXPLAIN_H = 2e-5, 2e-4      # steps above these get the near-tie analysis
-MAX_TRIALS = 8
+EXPLAIN_G, EXPLAIN_H = 1e-5, 1e-4      # steps above these get the near-tie analysis (the search stops below half of them)
+MAX_TRIALS = 28
 
 
 def _windows(u, hp, wp):
@@ -52,13 +52,12 @@ class DecisionNet:
         import torch
         self.torch, self.x, self.y, self.spec = torch, x, y, spec
 
-    def forward(self, p, sels=None, record=None):
+    def trunk(self, x, p, base, prefix, sels=None, record=None):
         import torch.nn.functional as F
         torch = self.torch
-        x, base = self.x, self.spec['base']
         for i in range(base['layers']):
-            z = F.conv2d(x, p[f'base.{i}.conv.weight'], p[f'base.{i}.conv.bias'], stride=1, padding=1)
-            u = F.batch_norm(z, None, None, p[f'base.{i}.normalize.weight'], p[f'base.{i}.normalize.bias'], training=True, momentum=0.1, eps=1e-5)
+            z = F.conv2d(x, p[f'{prefix}{i}.conv.weight'], p[f'{prefix}{i}.conv.bias'], stride=1, padding=1)
+            u = F.batch_norm(z, None, None, p[f'{prefix}{i}.normalize.weight'], p[f'{prefix}{i}.normalize.bias'], training=True, momentum=0.1, eps=1e-5)
             hp, wp = u.shape[2] // 2, u.shape[3] // 2
             uw = _windows(u, hp, wp)
             if sels is None or sels[i] is None:
@@ -70,6 +69,11 @@ class DecisionNet:
             if record is not None:
                 record.append((uw.detach(), sel.detach() if torch.is_tensor(sel) else sel))
             x = (uw * sel).sum(dim=4)
+        return x
+
+    def forward(self, p, sels=None, record=None):
+        import torch.nn.functional as F
+        x = self.trunk(self.x, p, self.spec['base'], 'base.', sels, record)
         return F.linear(x.reshape(-1, self.spec['fc_in']), p['linear.weight'], p['linear.bias'])
 
     def grad_hvp(self, theta_flat, shapes, v_flat=None, sels=None, record=None, keep_graph=False):
@@ -113,33 +117,16 @@ def _apply(sels, cand):
         s[n, c, y, x, cand['a']], s[n, c, y, x, cand['b']] = vb, va
 
 
-def explain_step(net, theta_k, shapes, g_e, v, hv_e, g0, hv0):
+def explain(evaluate, rec, g_e, hv_e, g0, hv0):
     """The engine's (g_e, hv_e) against the fp64 arithmetic under the best decision assignment that differs from the fp64 one only at
-    near-ties (margin < TAU).  Ranking of the candidates: first-order effect of every selection weight on <g_e - g0, g(sel)> (one
-    double backward for all of them); then up to MAX_TRIALS exact re-evaluations, each flip kept if it lowers the combined residual.
-    -> (err_g, err_h, flips kept)."""
-    torch = net.torch
-    rec = []
-    net.forward(_unflatten(theta_k, shapes), None, rec)
+    near-ties (margin < TAU).  `evaluate(sels, want_hv, graph)` -> (g, hv): the exact fp64 gradient (and Hessian-vector product)
+    under the decision tensors `sels` (graph=True: g stays attached to `sels` for the ranking); `rec`: the (u windows, sel) record
+    of the fp64 forward.  Search: candidates ranked by the first-order effect of their selection weights on <residual, g(sel)>
+    (one double backward ranks all of them), then by ascending margin; each trial is an exact re-evaluation, a flip is kept if it
+    lowers the combined residual, and the ranking is redone after every kept flip.  -> (err_g, err_h, flips kept)."""
+    import torch
     cands = _candidates(rec, TAU)
     sels = [sel.clone() for _, sel in rec]
-    if not cands:
-        return rel_err(g_e.numpy(), g0.numpy()), (rel_err(hv_e.numpy(), hv0.numpy()) if hv_e is not None else 0.0), []
-    # scores: d<r, g(sel)>/d sel, contracted with every candidate's change of sel
-    sreq = [s_.clone().requires_grad_(True) for s_ in sels]
-    gf, _, _ = net.grad_hvp(theta_k, shapes, None, sreq, None, keep_graph=True)
-    r = (g_e - g0)
-    ds = torch.autograd.grad((gf * r).sum(), sreq, allow_unused=True)
-    for cd in cands:
-        n, c, y, x = cd['at']
-        d = ds[cd['block']]
-        if d is None:
-            cd['score'] = 0.0
-        elif cd['kind'] == 'relu':
-            cd['score'] = float(d[n, c, y, x, cd['a']]) * (1.0 - 2.0 * float(sels[cd['block']][n, c, y, x, cd['a']]))
-        else:
-            cd['score'] = float(d[n, c, y, x, cd['b']] - d[n, c, y, x, cd['a']])
-    cands.sort(key=lambda cd: -cd['score'])
 
     def objective(g, hv):
         eg = rel_err(g_e.numpy(), g.numpy())
@@ -147,19 +134,106 @@ def explain_step(net, theta_k, shapes, g_e, v, hv_e, g0, hv0):
         return (eg / 1e-5) ** 2 + (eh / 1e-4) ** 2, eg, eh
 
     best, eg, eh = objective(g0, hv0)
-    kept = []
-    for cd in cands[:MAX_TRIALS]:
-        if cd['score'] <= 0.0 and kept:
-            break
-        _apply(sels, cd)
-        g1, hv1, _ = net.grad_hvp(theta_k, shapes, v, sels)
-        j1, eg1, eh1 = objective(g1, hv1)
-        if j1 < best:
-            best, eg, eh = j1, eg1, eh1
-            kept.append(dict(block=cd['block'], at=cd['at'], kind=cd['kind'], margin=cd['margin']))
-        else:
+    kept, g_cur, trials = [], g0, 0
+    while cands and trials < MAX_TRIALS and (eg > EXPLAIN_G / 2 or eh > EXPLAIN_H / 2):
+        sreq = [s_.clone().requires_grad_(True) for s_ in sels]
+        gf, _ = evaluate(sreq, False, True)
+        ds = torch.autograd.grad((gf * (g_e - g_cur)).sum(), sreq, allow_unused=True)
+        for cd in cands:
+            n, c, y, x = cd['at']
+            d = ds[cd['block']]
+            if d is None:
+                cd['score'] = 0.0
+            elif cd['kind'] == 'relu':
+                cd['score'] = float(d[n, c, y, x, cd['a']]) * (1.0 - 2.0 * float(sels[cd['block']][n, c, y, x, cd['a']]))
+            else:
+                cd['score'] = float(d[n, c, y, x, cd['b']] - d[n, c, y, x, cd['a']])
+        by_score = [cd for cd in sorted(cands, key=lambda cd: -cd['score']) if cd['score'] > 0.0][:6]
+        by_margin = [cd for cd in sorted(cands, key=lambda cd: abs(cd['margin'])) if all(cd is not o for o in by_score)]
+        improved = False
+        for cd in by_score + by_margin:
+            if trials >= MAX_TRIALS:
+                break
+            trials += 1
+            cands = [o for o in cands if o is not cd]
+            _apply(sels, cd)
+            g1, hv1 = evaluate(sels, hv_e is not None, False)
+            j1, eg1, eh1 = objective(g1, hv1)
+            if j1 < 0.9 * best:          # a true flip removes its whole contribution; a chance 2 % gain is not an explanation
+                best, eg, eh, g_cur = j1, eg1, eh1, g1
+                kept.append(dict(block=cd['block'], at=cd['at'], kind=cd['kind'], margin=cd['margin']))
+                improved = True
+                break
             _apply(sels, cd)          # undo
+        if not improved:
+            break
     return eg, eh, kept
+
+
+def explain_step(net, theta_k, shapes, g_e, v, hv_e, g0, hv0):
+    """`explain` for one support (or query) pass of the classifier at theta_k."""
+    rec = []
+    net.forward(_unflatten(theta_k, shapes), None, rec)
+
+    def evaluate(sels, want_hv, graph):
+        g, hv, _ = net.grad_hvp(theta_k, shapes, v if want_hv else None, sels, None, keep_graph=graph)
+        return g, hv
+
+    return explain(evaluate, rec, g_e, hv_e, g0, hv0)
+
+
+def anil_task(job):
+    """ANIL (reference vision/anil_vision.py:86-99,116-122): job = dict(t, theta_feat, theta_head (flat fp32, reference order),
+    grad (engine, [P]), data, labels, shots, ways, K, lr, hidden).  -> dict(t, e64, e32 raw errors of the engine's per-task
+    meta-gradient against the two legs, ex = near-tie adjusted, loss64, flips)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import vision_ref as R
+    torch.set_num_threads(int(job.get('threads', 4)))
+    ways, shots, K, lr = int(job['ways']), int(job['shots']), int(job['K']), float(job['lr'])
+    base = R.convbase_spec(hidden=int(job['hidden']), channels=3, max_pool=True)
+    fshapes = R.param_shapes(dict(base=base, in_shape=(3, 84, 84)), '0.', False)
+    fc = int(job['hidden']) * 25
+    hshapes = OrderedDict([('weight', (ways, fc)), ('bias', (ways,))])
+    tf32, th32 = torch.from_numpy(np.asarray(job['theta_feat'])), torch.from_numpy(np.asarray(job['theta_head']))
+    g_e = torch.from_numpy(np.asarray(job['grad'])).double()
+    data, labels = torch.from_numpy(job['data']), torch.from_numpy(job['labels'])
+    out = dict(t=int(job['t']))
+    for dt, tag in ((torch.float64, '64'), (torch.float32, '32')):
+        tfd = OrderedDict((k, v.to(dt)) for k, v in _unflatten(tf32, fshapes).items())
+        thd = OrderedDict((k, v.to(dt)) for k, v in _unflatten(th32, hshapes).items())
+        l, a, gf, gh = R.anil_meta_batch(tfd, thd, base, fc, [data.to(dt)], [labels], K, shots, ways, lr, False)
+        g = torch.cat([R.flatten_params(gf), R.flatten_params(gh)]).double()
+        out['e' + tag] = rel_err(g_e.numpy(), g.numpy())
+        out['loss' + tag], out['acc' + tag] = float(l[0]), float(a[0])
+        if tag == '64':
+            g64 = g
+    out['ex'], out['flips'] = out['e64'], []
+    if out['e64'] > EXPLAIN_G and bool(job.get('explain', True)):
+        net = DecisionNet(data.double(), None, dict(base=base))
+        tf64, th64 = tf32.double(), th32.double()
+        si, qi = R.prepare_batch_indices(data.shape[0], shots, ways)
+        si, qi = torch.from_numpy(si), torch.from_numpy(qi)
+
+        def evaluate(sels, want_hv, graph, record=None):
+            pf = OrderedDict((n, t.clone().requires_grad_(True)) for n, t in _unflatten(tf64, fshapes).items())
+            ph = OrderedDict((n, t.clone().requires_grad_(True)) for n, t in _unflatten(th64, hshapes).items())
+            feats = net.trunk(net.x, pf, base, '0.', sels, record).reshape(-1, fc)
+            h = OrderedDict((n, t.clone()) for n, t in ph.items())
+            for _ in range(K):
+                ls = F.cross_entropy(F.linear(feats[si], h['weight'], h['bias']), labels[si])
+                gs = torch.autograd.grad(ls, list(h.values()), create_graph=True)
+                h = OrderedDict((n, t - lr * gg) for (n, t), gg in zip(h.items(), gs))
+            lq = F.cross_entropy(F.linear(feats[qi], h['weight'], h['bias']), labels[qi])
+            g = torch.autograd.grad(lq, list(pf.values()) + list(ph.values()), create_graph=graph)
+            gfl = torch.cat([t.reshape(-1) for t in g])
+            return (gfl if graph else gfl.detach()), None
+
+        rec = []
+        g0, _ = evaluate(None, False, False, rec)
+        assert rel_err(g0.numpy(), g64.numpy()) < 1e-9, 'the decision-explicit ANIL restatement left the oracle'
+        out['ex'], _, out['flips'] = explain(evaluate, rec, g_e, None, g0, None)
+    return out
 
 
 def teacher_forced_task(job):
@@ -214,31 +288,29 @@ def teacher_forced_task(job):
     return out
 
 
-def teacher_forced_all(trace, data, labels, shots, ways, tasks, workers=None, threads=4, timeout=900, explain=True):
-    """Run `teacher_forced_task` for every task in `tasks` in CPU worker processes (plain `python teacher_forced.py jobs.npz
-    out.json` children: the parent keeps the GPU, the workers never touch it).  trace: dict of [*, T, P] tensors from
-    MetaEngine.set_trace."""
+def _run_workers(jobs, workers, threads, timeout):
+    """jobs: list of (kind, dict of numpy arrays / scalars).  Runs them in `python teacher_forced.py jobs.npz out.json` children (the
+    parent keeps the GPU; importing torch opens the device, so the children count against the GPU box's 6-process guard: <= 4)."""
     import json
+    import pickle
     import subprocess
     import tempfile
-    tr = {k: trace[k].detach().cpu().numpy() for k in ('theta', 'g', 'lam_in', 'hv')}
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    tasks = list(tasks)
     if workers is None:
-        workers = max(1, min(len(tasks), cores // threads, 4))       # + the parent: within the GPU box's 6-process guard (importing torch opens the device)
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+        workers = max(1, min(len(jobs), cores // threads, 4))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     with tempfile.TemporaryDirectory() as tmp:
         procs = []
         for w in range(workers):
-            mine = tasks[w::workers]
+            mine = jobs[w::workers]
             if not mine:
                 continue
-            job, out = os.path.join(tmp, f'job{w}.npz'), os.path.join(tmp, f'out{w}.json')
-            np.savez(job, tasks=np.array(mine), shots=shots, ways=ways, threads=threads, explain=int(explain), data=data[mine], labels=labels[mine],
-                     **{k: v[:, mine] for k, v in tr.items()})
+            job, out = os.path.join(tmp, f'job{w}.pkl'), os.path.join(tmp, f'out{w}.json')
+            with open(job, 'wb') as f:
+                pickle.dump(mine, f)
             procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), job, out], env=env), out))
         res = []
         for p, out in procs:
@@ -247,22 +319,37 @@ def teacher_forced_all(trace, data, labels, shots, ways, tasks, workers=None, th
             except subprocess.TimeoutExpired:
                 for q, _ in procs:
                     q.kill()
-                raise RuntimeError('teacher-forced oracle worker timed out')
+                raise RuntimeError('oracle worker timed out')
             if rc != 0:
-                raise RuntimeError(f'teacher-forced oracle worker failed (exit {rc})')
+                raise RuntimeError(f'oracle worker failed (exit {rc})')
             with open(out) as f:
                 res += json.load(f)
     return sorted(res, key=lambda r: r['t'])
 
 
+def teacher_forced_all(trace, data, labels, shots, ways, tasks, workers=None, threads=4, timeout=900, explain=True):
+    """`teacher_forced_task` for every task in `tasks` in CPU worker processes.  trace: dict of [*, T, P] tensors from
+    MetaEngine.set_trace."""
+    tr = {k: trace[k].detach().cpu().numpy() for k in ('theta', 'g', 'lam_in', 'hv')}
+    jobs = [('maml', dict(t=int(t), theta=tr['theta'][:, t], g=tr['g'][:, t], lam_in=tr['lam_in'][:, t], hv=tr['hv'][:, t], data=data[t],
+                          labels=labels[t], shots=shots, ways=ways, threads=threads, explain=explain)) for t in tasks]
+    return _run_workers(jobs, workers, threads, timeout)
+
+
+def anil_all(theta_feat, theta_head, grads, data, labels, shots, ways, K, lr, hidden, tasks, workers=None, threads=4, timeout=900):
+    """`anil_task` for every task in `tasks` (grads: {task: engine per-task meta-gradient [P]})."""
+    jobs = [('anil', dict(t=int(t), theta_feat=np.asarray(theta_feat), theta_head=np.asarray(theta_head), grad=np.asarray(grads[t]),
+                          data=data[t], labels=labels[t], shots=shots, ways=ways, K=K, lr=lr, hidden=hidden, threads=threads))
+            for t in tasks]
+    return _run_workers(jobs, workers, threads, timeout)
+
+
 def _worker_main(job_path, out_path):
     import json
-    j = np.load(job_path)
-    res = []
-    for i, t in enumerate(j['tasks']):
-        res.append(teacher_forced_task(dict(t=int(t), theta=j['theta'][:, i], g=j['g'][:, i], lam_in=j['lam_in'][:, i], hv=j['hv'][:, i],
-                                            data=j['data'][i], labels=j['labels'][i], shots=int(j['shots']), ways=int(j['ways']),
-                                            threads=int(j['threads']), explain=bool(int(j['explain'])))))
+    import pickle
+    with open(job_path, 'rb') as f:
+        jobs = pickle.load(f)
+    res = [(teacher_forced_task if kind == 'maml' else anil_task)(job) for kind, job in jobs]
     with open(out_path, 'w') as f:
         json.dump(res, f)
 

@@ -5,15 +5,23 @@ Why the checks are per step: with 5 inner steps at lr 0.5 the map theta_0 -> met
 measured with oracle/vision_ref.py, numbers in DESIGN.md section 7), so an end-to-end comparison cannot tell a correct
 kernel from one with a 10 % error in the fifth Hessian-vector product.  The engine therefore dumps its per-step state
 (mi_debug_set_trace: theta_k, g_k, the vector fed to every Hessian-vector product and its result) and the oracle is
-TEACHER-FORCED: evaluated at the engine's own theta_k, in fp64 and in fp32 (the reference's own precision).  Each step is then
-a single forward/backward (or one Hessian-vector product).  Bar, against either leg: the MEDIAN step agrees to 1e-5 (1e-4 for
-the Hessian-vector products) and NO step deviates by more than 1e-3 (5e-3).  Measured on MI355X: most steps agree to 3e-7; a
-minority sit at 2e-5..8e-4 -- the objective is only piecewise smooth, one pass takes ~1.9 million max-pool / ReLU decisions per
-task, and about one of them per pass has a margin below fp32 rounding and resolves differently in two arithmetics (the
-reference's fp32 and fp64 legs differ from EACH OTHER by the same amounts at the same theta_k; sometimes the engine sides with
-one leg, sometimes with neither).  A kernel error of 10 % in one Hessian-vector product -- what the end-to-end bar cannot see --
-fails every one of these bounds by two orders of magnitude; systematic errors below 1e-3 are the business of the per-kernel
-tests (tests/test_gpu_tangent_kernels.py, 1e-6 at these sizes)."""
+TEACHER-FORCED: evaluated at the engine's own theta_k, in fp64 and in fp32 (the reference's own precision), for ALL 32 tasks.
+Each step is then a single forward/backward (or one Hessian-vector product).
+
+What the steps look like (profiles/r3/teacher_forced_cfg2_T32.md, all 160 steps): the median step agrees to 4e-7; 8-10 % of the
+steps sit above 1e-4 and 2.5 % above 1e-3 (up to 6.5e-3) against EITHER leg -- and the two legs differ from each other by the
+same amounts on other steps.  Cause, localised with tools/parity_localise.py and proved step by step here: the objective is only
+piecewise smooth, one pass takes 1.9 million max-pool / ReLU decisions per task, and a handful of them per pass have an fp64
+margin below fp32 rounding (|u| or the gap between the two largest u of a window < 1e-6).  ONE such decision moves a task's
+gradient by up to ~5e-3 (it re-routes one element of a cotangent that carries ~1e-3 of the layer's gradient norm) and its
+Hessian-vector product by as much (the tangent of the pooled value jumps to another position).  No fp32 arithmetic can reproduce
+them: the reference's own fp32 leg flips a different subset.  So the bar has two parts:
+  (1) raw, against each leg: median <= 1e-5 (HVP 1e-4), at most OUTLIER_SHARE of the steps above 1e-4, none above RAW_MAX;
+  (2) NEAR-TIE ADJUSTED, for every step above 1e-5 (HVP 1e-4): tests/teacher_forced.py::explain_step searches the decisions whose
+      fp64 margin is below 1e-5 for the assignment under which the fp64 arithmetic reproduces the engine; every step must then
+      agree to ADJ_G (HVP ADJ_H).  A kernel error cannot pass (2): flipping near-tied decisions only adds the handful of discrete
+      vectors those decisions control, it cannot imitate a dense error -- and systematic errors below 1e-5 are the business of the
+      per-kernel tests (tests/test_gpu_tangent_kernels.py, 1e-6 at these sizes)."""
 from collections import OrderedDict
 
 import numpy as np
@@ -29,8 +37,8 @@ import teacher_forced as TF
 
 pytestmark = pytest.mark.gpu
 
-# outlier budget of the teacher-forced test (stated in its docstring)
-GRAD_MAX, HVP_MAX, OUTLIER_SHARE = 1e-3, 5e-3, 0.05
+# bars of the teacher-forced test (module docstring): raw maxima / outlier share against each leg, and the near-tie-adjusted maxima
+RAW_MAX, OUTLIER_SHARE, ADJ_G, ADJ_H = 3e-2, 0.15, 2e-5, 2e-4
 
 
 def _ref_theta(spec, seed=11):
@@ -48,8 +56,9 @@ def _unflatten(flat, shapes):
 
 def test_cfg2_T32_teacher_forced_per_step():
     """BASELINE config 2 exactly as benchmarked (32 tasks, 5-way 5-shot, K = 5, lr 0.5, second order, the bench's synthetic
-    tasks and initial parameters): every inner-step gradient and every Hessian-vector product of three tasks against the fp64
-    oracle at the engine's own theta_k; the theta recursion and the adjoint recursion themselves are checked exactly."""
+    tasks and initial parameters): every inner-step gradient and every Hessian-vector product of ALL 32 tasks against the
+    oracle at the engine's own theta_k (oracle legs in CPU worker processes); the theta recursion and the adjoint recursion
+    themselves are checked exactly."""
     ways, shots, K, lr, T = 5, 5, 5, 0.5, 32
     spec, mspec = R.mini_imagenet_spec(ways), ModelSpec.mini_imagenet(ways)
     shapes = R.param_shapes(spec)
@@ -86,14 +95,22 @@ def test_cfg2_T32_teacher_forced_per_step():
         assert abs(float(loss[t]) - r['q64'][0]) <= 1e-5 * max(1.0, abs(r['q64'][0]))
         assert abs(float(loss[t]) - r['q32'][0]) <= 1e-5 * max(1.0, abs(r['q32'][0]))
         assert float(acc[t]) == r['q64'][1]
-    for leg in ('64', '32'):      # against the reference arithmetic in fp64 and in the reference's own precision
+    for leg in ('64', '32'):      # (1) raw, against the reference arithmetic in fp64 and in the reference's own precision
         g, h, q = (np.array(legs[k + leg]) for k in 'ghq')
         report(f'cfg2_T32_teacher_forced[all {T} tasks, leg fp{leg}]', grad_median=float(np.median(g)), grad_max=float(g.max()),
                grad_share_above_1e4=float((g > 1e-4).mean()), hvp_median=float(np.median(h)), hvp_max=float(h.max()),
                hvp_share_above_1e4=float((h > 1e-4).mean()), query_max=float(q.max()))
-        assert np.median(g) < 1e-5 and g.max() < GRAD_MAX and (g > 1e-4).mean() <= OUTLIER_SHARE, sorted(g)[-8:]
-        assert np.median(h) < 1e-4 and h.max() < HVP_MAX and (h > 1e-4).mean() <= OUTLIER_SHARE, sorted(h)[-8:]
-        assert np.median(q) < 1e-5 and q.max() < GRAD_MAX, sorted(q)[-4:]
+        assert np.median(g) < 1e-5 and g.max() < RAW_MAX and (g > 1e-4).mean() <= OUTLIER_SHARE, sorted(g)[-8:]
+        assert np.median(h) < 1e-4 and h.max() < RAW_MAX and (h > 1e-4).mean() <= OUTLIER_SHARE, sorted(h)[-8:]
+        assert np.median(q) < 1e-5 and q.max() < RAW_MAX, sorted(q)[-4:]
+    # (2) near-tie adjusted: every step, every task
+    gx, hx, qx = (np.array(legs[k]) for k in ('gx', 'hx', 'qx'))
+    margins = [abs(fl['margin']) for fl in flips]
+    report(f'cfg2_T32_teacher_forced[all {T} tasks, near-tie adjusted]', grad_max=float(gx.max()), hvp_max=float(hx.max()),
+           query_max=float(qx.max()), flipped_decisions=len(flips), largest_flipped_margin=max(margins) if margins else 0.0)
+    assert gx.max() < ADJ_G and qx.max() < ADJ_G, (sorted(gx)[-4:], sorted(qx)[-4:])
+    assert hx.max() < ADJ_H, sorted(hx)[-4:]
+    assert all(m < TF.TAU for m in margins)
 
 
 def test_cfg2_T32_batched_vs_one_task_at_a_time():
@@ -145,6 +162,7 @@ def test_cfg4_full_T_batched_looped_oracle(T):
     torch.cuda.synchronize()
     per_task = (trace['lam_in'][0].double() - lr * trace['hv'][0].double()).cpu()
     assert rel_err(grad.double().cpu().numpy(), per_task.sum(dim=0).numpy()) < 1e-6
+    trace_all = {k: v.clone() for k, v in trace.items()}
     tr1 = eng.set_trace(1, K)
     eg, el = [], []
     check = sorted(set(range(0, T, max(1, T // 16))) | {T - 1})
@@ -169,19 +187,35 @@ def test_cfg4_full_T_batched_looped_oracle(T):
         eo.append(best)
     e64 = [b[0] for b in eo]
     ebest = [min(b) for b in eo]
+    # per step, teacher-forced, with the near-tie analysis of the cfg2 test (module docstring): 32 tasks (every 8th of 256)
+    tf_tasks = sorted(set(range(0, T, max(1, T // 32))) | {T - 1})
+    res = TF.teacher_forced_all(trace_all, data, labels, shots, ways, tf_tasks)
+    raw = np.array([max(r['g64'][0], r['h64'][0], r['q64'][2]) for r in res])
+    raw32 = np.array([max(r['g32'][0], r['h32'][0], r['q32'][2]) for r in res])
+    adj_g = np.array([max(r['gx'][0], r['qx']) for r in res])
+    adj_h = np.array([r['hx'][0] for r in res])
+    margins = [abs(fl['margin']) for r in res for step in r['flips'] for fl in step]
     report(f'cfg4_T{T}', batched_vs_looped_grad_rel_median=float(np.median(eg)), batched_vs_looped_grad_rel_max=max(eg),
-           batched_vs_looped_loss_rel=max(el), vs_fp64_grad_rel=e64, vs_fp64_or_ref_fp32_grad_rel=ebest, vs_fp64_loss_rel=lo)
-    # One step at lr 0.5 from random weights overshoots (query loss 12..17): a task whose pass contains no near-tied pooling / ReLU
-    # decision agrees to ~1e-6; one that does moves by 1e-4..5e-2 -- in the engine AND in the reference's own fp32 run (a task at
-    # 4.5e-2 from fp64 sits at 5e-6 from the reference's fp32 leg).  Hence: medians tight, maxima bounded by that envelope.
+           batched_vs_looped_loss_rel=max(el), vs_fp64_grad_rel=e64, vs_fp64_or_ref_fp32_grad_rel=ebest, vs_fp64_loss_rel=lo,
+           teacher_forced_tasks=len(res), teacher_forced_raw_max_vs_fp64=float(raw.max()), teacher_forced_raw_max_vs_fp32=float(raw32.max()),
+           teacher_forced_adjusted_grad_max=float(adj_g.max()), teacher_forced_adjusted_hvp_max=float(adj_h.max()),
+           flipped_decisions=len(margins), largest_flipped_margin=max(margins) if margins else 0.0)
+    # One step at lr 0.5 from random weights overshoots (query loss 12..17): a task whose passes contain no near-tied pooling / ReLU
+    # decision agrees to ~1e-6 end to end; one that does moves by 1e-4..5e-2 -- in the engine AND in the reference's own fp32 run (a
+    # task at 4.5e-2 from fp64 sits at 5e-6 from the reference's fp32 leg).  Hence: end-to-end medians tight and maxima inside that
+    # envelope against the NEARER leg; and, per step, every checked task agrees with the fp64 arithmetic to ADJ_G / ADJ_H once the
+    # decisions with an fp64 margin below 1e-5 are allowed to fall either way.
     assert max(el) < 1e-6 and np.median(eg) < 1e-5 and max(eg) < 5e-3
     assert np.median(lo) < 1e-5 and max(lo) < 5e-3
-    assert np.median(e64) < 1e-4 and np.median(ebest) < 2e-5 and max(e64) < 0.2
+    assert np.median(e64) < 1e-4 and np.median(ebest) < 2e-5 and max(e64) < 0.2 and max(ebest) < 5e-2
+    assert np.median(raw) < 1e-5 and raw.max() < RAW_MAX and raw32.max() < RAW_MAX
+    assert adj_g.max() < ADJ_G and adj_h.max() < ADJ_H, (sorted(adj_g)[-4:], sorted(adj_h)[-4:])
+    assert all(m < TF.TAU for m in margins)
 
 
 def test_cfg3_anil_T32_batched_looped_oracle():
     """BASELINE config 3 (ANIL, 64-filter trunk on all 50 rows of a task, head-only inner loop, K = 1) at 32 tasks: the batched
-    call vs the sum of single-task calls, and two single-task calls vs the fp64 oracle."""
+    call vs the sum of single-task calls, and nine single-task calls vs the oracle in fp64 and fp32."""
     ways, shots, K, lr, T = 5, 5, 1, 0.5, 32
     base = R.convbase_spec(hidden=64, channels=3, max_pool=True)
     tf = OrderedDict((k, torch.from_numpy(v)) for k, v in synthetic.ref_init_weights(R.param_shapes(base, '0.', False), 13).items())
@@ -203,19 +237,23 @@ def test_cfg3_anil_T32_batched_looped_oracle():
         el.append(abs(float(l1[0]) - float(loss[t])) / abs(float(loss[t])))
         assert float(a1[0]) == float(acc[t])
     e_sum = rel_err(grad.double().cpu().numpy(), gsum.cpu().numpy())
-    eo, lo = [], []
-    for t in (0, T - 1):
-        l64, a64, gf, gh = R.anil_meta_batch(tf, th, base, 1600, [torch.from_numpy(data[t]).double()], [torch.from_numpy(labels[t])],
-                                             K, shots, ways, lr, False)
-        g64 = torch.cat([R.flatten_params(gf), R.flatten_params(gh)]).numpy()
-        eo.append(rel_err(per[t][1], g64))
-        lo.append(abs(per[t][0] - float(l64[0])) / abs(float(l64[0])))
-    report('cfg3_anil_T32', batched_vs_looped_sum_grad_rel=e_sum, batched_vs_looped_loss_rel=max(el), vs_oracle_grad_rel=max(eo),
-           vs_oracle_loss_rel=max(lo))
-    # batched vs looped: identical arithmetic per task (measured 1e-7); vs the fp64 oracle the trunk's one-pass gradient carries the
-    # same near-tie decisions as above (golden G3-ANIL bar of round 1: 2e-3 on 2 tasks; measured here 6e-3 on one of two tasks)
+    # 9 tasks against BOTH legs, with the near-tie analysis (tests/teacher_forced.py::anil_task): ANIL's trunk gradient is one
+    # backward pass at theta -- not chaotic -- so a task either agrees to rounding or differs by the few near-tied decisions of
+    # that pass, and then the fp64 arithmetic with those decisions flipped must reproduce it
+    chk = sorted(set(range(0, T, 4)) | {T - 1})
+    res = TF.anil_all(R.flatten_params(tf).float().numpy(), R.flatten_params(th).float().numpy(), {t: per[t][1] for t in chk}, data, labels,
+                      shots, ways, K, lr, 64, chk)
+    e64, e32, ex = (np.array([r[k] for r in res]) for k in ('e64', 'e32', 'ex'))
+    lo = [abs(per[r['t']][0] - r['loss64']) / abs(r['loss64']) for r in res]
+    margins = [abs(fl['margin']) for r in res for fl in r['flips']]
+    report('cfg3_anil_T32', batched_vs_looped_sum_grad_rel=e_sum, batched_vs_looped_loss_rel=max(el), tasks_vs_oracle=len(res),
+           vs_fp64_grad_rel=[float(x) for x in e64], vs_ref_fp32_grad_rel=[float(x) for x in e32], near_tie_adjusted_grad_rel=[float(x) for x in ex],
+           vs_oracle_loss_rel=max(lo), flipped_decisions=len(margins), largest_flipped_margin=max(margins) if margins else 0.0)
+    # batched vs looped: identical arithmetic per task (measured 1e-7)
     assert max(el) < 1e-5 and e_sum < 1e-4
-    assert max(lo) < 1e-4 and min(eo) < 2e-3 and max(eo) < 2e-2
+    assert max(lo) < 1e-4 and e64.max() < RAW_MAX and e32.max() < RAW_MAX and np.median(np.minimum(e64, e32)) < 1e-4
+    assert ex.max() < ADJ_G and all(m < TF.TAU for m in margins), sorted(ex)[-4:]
+    assert all(float(acc[r['t']]) == r['acc64'] for r in res)
 
 
 def test_hessian_vector_sweep_properties_at_cfg2_size():
