@@ -266,6 +266,8 @@ def run_vision(args, wl, rank, world, local, dist):
                  'valid_acc_mean': round(float(vacc.mean()), 5)}
 
     hbm_copy_gbps = measure_stream_copy(eng)
+    collective = collective_record(dist, world, theta, eng.param_count + 2 * T,
+                                   'one in-place all-reduce per meta-iteration of [meta-gradient | per-task losses | accuracies]')
 
     roofline = None
     if dom in prof:
@@ -345,8 +347,41 @@ def run_vision(args, wl, rank, world, local, dist):
                    'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter',
                    'task_hardness': HARDNESS[wl['dataset']]},
         'post_adapt': post, 'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline,
-        'cpu_baseline': cpu,
+        'cpu_baseline': cpu, 'collective': collective,
     }
+
+
+def collective_record(dist, world, theta, numel, what):
+    """Evidence that N ranks really reduced: the world size RCCL reports, the timed all-reduce of a buffer of
+    the step's own size (20 calls after 3 warm-ups, events on the current stream), and a bit-level checksum of the parameters after
+    the last timed step gathered from every rank (identical = every rank applied the same reduced gradient)."""
+    if dist is None:
+        return None
+    buf = torch.zeros(numel, dtype=torch.float32, device='cuda')
+    for _ in range(3):
+        dist.all_reduce(buf)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        dist.all_reduce(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    chk = theta.detach().contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    sums = [int(c.item()) for c in allc]
+    if len(set(sums)) != 1:
+        raise SystemExit(f'parameters differ between ranks after the timed steps: checksums {sums}')
+    ver = None
+    try:
+        ver = '.'.join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    return dict(backend=f'{dist.get_backend()} (RCCL on ROCm)', rccl_version=ver, world_size=dist.get_world_size(), what=what,
+                allreduce_numel=int(numel), allreduce_bytes=int(numel) * 4, allreduce_us=round(us, 2), timed_calls=20,
+                theta_checksum=sums[0], theta_checksum_identical_on_all_ranks=True)
 
 
 def measure_stream_copy(eng_or_lib):
@@ -453,6 +488,8 @@ def run_trpo(args, wl, rank, world, local, dist):
                     'address-unit / padding bound: 11 Fisher-vector products of ~0.86 ms are 9.5 ms of a 13 ms step; the advantages of the 40 replays (returns, LinearValue fits, GAE, '
                     'normalisation) are one mi_gae_advantages launch, 1.4 ms with the device-side batch assembly (tools/trpo_step_timing.py)')
 
+    collective = collective_record(dist, world, policy.flat(), theta0.numel() + 2,
+                                   'task-count-weighted means of (loss, KL, gradient) and of every Fisher-vector product: one all-reduce each')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_trpo(p, policy, theta0, replays, olds, out['r'])
@@ -471,7 +508,7 @@ def run_trpo(args, wl, rank, world, local, dist):
                        'kl_after': None if r['kl'] is None else float(r['kl']), 'line_search_step': r['accepted'],
                        **(cpu.pop('_post') if cpu else {})},
         'secondary': {'metric': 'meta_optimize_trpo iterations/sec', 'value': round(args.steps / dt, 3)},
-        'roofline': roofline, 'cpu_baseline': cpu,
+        'roofline': roofline, 'cpu_baseline': cpu, 'collective': collective,
     }
 
 

@@ -168,8 +168,11 @@ class MetaEngine:
     def _outputs(self, kind, T, nlog, with_grad, return_logits):
         """(loss, acc, grad, logits) buffers of one fused call: fresh tensors, or the persistent set of this shape in graph mode."""
         def fresh():
-            return (torch.empty(T, dtype=torch.float32, device=self.device), torch.empty(T, dtype=torch.float32, device=self.device),
-                    torch.empty(self.param_count, dtype=torch.float32, device=self.device) if with_grad else None,
+            # one allocation [grad (P) | loss (T) | acc (T)]: a data-parallel caller all-reduces the three as ONE contiguous buffer
+            # (sharding.MetaTrainer) without gathering them into a new tensor first
+            P = self.param_count if with_grad else 0
+            buf = torch.empty(P + 2 * T, dtype=torch.float32, device=self.device)
+            return (buf[P:P + T], buf[P + T:], buf[:P] if with_grad else None,
                     torch.empty(T, nlog, self.spec.ways, dtype=torch.float32, device=self.device) if return_logits else None)
         if not getattr(self, '_graph', False):
             return fresh()

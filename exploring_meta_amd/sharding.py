@@ -35,6 +35,21 @@ def reduce_meta_batch(meta_grad, loss_sum, acc_sum, group=None, extra=()):
     return out + (parts[2:],) if extra else out
 
 
+def packed_outputs(grad, loss, acc):
+    """If (grad, loss, acc) are adjacent views [grad | loss | acc] of one allocation (how MetaEngine.meta_batch returns them), the
+    flat view over all three -- the all-reduce then needs no gather launch -- else None."""
+    try:
+        same = (grad.untyped_storage().data_ptr() == loss.untyped_storage().data_ptr() == acc.untyped_storage().data_ptr())
+    except (AttributeError, RuntimeError):
+        return None
+    if not same or grad.dtype != loss.dtype or grad.dtype != acc.dtype or not (grad.is_contiguous() and loss.is_contiguous() and acc.is_contiguous()):
+        return None
+    if loss.dim() != 1 or acc.shape != loss.shape or loss.storage_offset() != grad.storage_offset() + grad.numel() or \
+            acc.storage_offset() != loss.storage_offset() + loss.numel():
+        return None
+    return torch.as_strided(grad, (grad.numel() + 2 * loss.numel(),), (1,), grad.storage_offset())
+
+
 class MetaTrainer:
     """One meta-iteration = local shard through ``compute`` -> one all-reduce -> Adam (maml_vision.py:93-141, train half).
 
@@ -60,11 +75,21 @@ class MetaTrainer:
             # no process group (plain `python bench.py`): the two means in one stacked reduction (each tiny reduction / division launch is a measurable share
             # of the few-image configurations' 0.6..1.8 ms iterations)
             loss, acc, grad = self.compute(theta, tasks)
-            means = torch.stack((loss, acc)).sum(dim=1) / self.meta_batch_size
+            flat = packed_outputs(grad, loss, acc)
+            both = flat[grad.numel():].view(2, -1) if flat is not None else torch.stack((loss, acc))
+            means = both.sum(dim=1) / self.meta_batch_size
             self.adam(theta, grad, 1.0 / self.meta_batch_size)        # maml_vision.py:139-141
             return means[0], means[1], grad
         if tasks:
             loss, acc, grad = self.compute(theta, tasks)
+            flat = packed_outputs(grad, loss, acc) if self.meta_batch_size % self.world == 0 else None
+            if flat is not None:
+                # equal shards and the engine's packed outputs: ONE all-reduce of [grad | loss | acc] in place, no gather / sum
+                # launches in front of it (the per-task losses of different ranks add up elementwise: only their total is used)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                means = flat[grad.numel():].view(2, -1).sum(dim=1) / self.meta_batch_size
+                self.adam(theta, grad, 1.0 / self.meta_batch_size)    # maml_vision.py:139-141
+                return means[0], means[1], grad
             loss_sum, acc_sum = loss.sum(), acc.sum()
         else:      # meta-batch smaller than the world: this rank owns no task and contributes zeros to the all-reduce
             grad = torch.zeros_like(theta)

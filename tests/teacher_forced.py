@@ -288,6 +288,31 @@ def teacher_forced_task(job):
     return out
 
 
+def adapt_task(job):
+    """Post-adaptation query loss / accuracy of one task by the reference loop (oracle/vision_ref.py::maml_meta_batch without the
+    outer backward; first-order adaptation graph -- the forward values do not depend on the order) in fp64 and fp32."""
+    import torch
+    from oracle import vision_ref as R
+    torch.set_num_threads(int(job.get('threads', 4)))
+    ways, shots = int(job['ways']), int(job['shots'])
+    spec = R.mini_imagenet_spec(ways)
+    shapes = R.param_shapes(spec)
+    theta = torch.from_numpy(np.asarray(job['theta']))
+    out = dict(t=int(job['t']))
+    for dt, tag in ((torch.float64, '64'), (torch.float32, '32')):
+        th = OrderedDict((k, v.to(dt)) for k, v in _unflatten(theta, shapes).items())
+        l, a, _, _ = R.maml_meta_batch(th, spec, [torch.from_numpy(job['data']).to(dt)], [torch.from_numpy(job['labels'])], int(job['K']),
+                                       shots, ways, float(job['lr']), True, backward=False)
+        out['loss' + tag], out['acc' + tag] = float(l[0]), float(a[0])
+    return out
+
+
+def adapt_all(theta, data, labels, shots, ways, K, lr, tasks, workers=None, threads=4, timeout=1100):
+    jobs = [('adapt', dict(t=int(t), theta=np.asarray(theta), data=data[i], labels=labels[i], shots=shots, ways=ways, K=K, lr=lr,
+                           threads=threads)) for i, t in enumerate(tasks)]
+    return _run_workers(jobs, workers, threads, timeout)
+
+
 def _run_workers(jobs, workers, threads, timeout):
     """jobs: list of (kind, dict of numpy arrays / scalars).  Runs them in `python teacher_forced.py jobs.npz out.json` children (the
     parent keeps the GPU; importing torch opens the device, so the children count against the GPU box's 6-process guard: <= 4)."""
@@ -349,7 +374,7 @@ def _worker_main(job_path, out_path):
     import pickle
     with open(job_path, 'rb') as f:
         jobs = pickle.load(f)
-    res = [(teacher_forced_task if kind == 'maml' else anil_task)(job) for kind, job in jobs]
+    res = [dict(maml=teacher_forced_task, anil=anil_task, adapt=adapt_task)[kind](job) for kind, job in jobs]
     with open(out_path, 'w') as f:
         json.dump(res, f)
 

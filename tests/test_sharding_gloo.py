@@ -46,7 +46,7 @@ def _compute_factory():
     return compute, theta0, R
 
 
-def _run(rank, world, port, out_path, meta_batch):
+def _run(rank, world, port, out_path, meta_batch, packed=False):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     import torch.distributed as dist
@@ -55,6 +55,14 @@ def _run(rank, world, port, out_path, meta_batch):
     if world > 1:
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     compute, theta, R = _compute_factory()
+    if packed:      # the engine's output layout: [grad | loss | acc] views of ONE allocation (MetaEngine._outputs)
+        inner = compute
+
+        def compute(th, task_ids):
+            loss, acc, grad = inner(th, task_ids)
+            buf = torch.cat([grad.reshape(-1), loss.reshape(-1).to(grad.dtype), acc.reshape(-1).to(grad.dtype)])
+            P, T = grad.numel(), loss.numel()
+            return buf[P:P + T], buf[P + T:], buf[:P]
     m, v, step = torch.zeros_like(theta), torch.zeros_like(theta), [0]
 
     def adam(th, grad, scale):
@@ -93,6 +101,23 @@ def test_two_ranks_match_single_process(tmp_path, meta_batch):
     live = g > 1e-9 * g.max()
     assert live.float().mean() > 0.9
     assert torch.allclose(a['theta'][live], b['theta'][live], rtol=1e-9, atol=1e-12)
+
+
+def test_packed_outputs_take_the_in_place_all_reduce(tmp_path):
+    """Equal shards + the engine's packed [grad | loss | acc] outputs: MetaTrainer all-reduces that one buffer in place (no gather /
+    sum launches in front of the collective).  Same results as the single-process run and as the gather path."""
+    from exploring_meta_amd.sharding import packed_outputs
+    buf = torch.arange(10.0)
+    flat = packed_outputs(buf[:6], buf[6:8], buf[8:])
+    assert flat is not None and flat.data_ptr() == buf.data_ptr() and flat.numel() == 10
+    assert packed_outputs(buf[:6].clone(), buf[6:8], buf[8:]) is None and packed_outputs(buf[:5], buf[6:8], buf[8:]) is None
+    single, multi = str(tmp_path / 'single.pt'), str(tmp_path / 'multi.pt')
+    _run(0, 1, 0, single, 4, True)
+    mp.spawn(_run, args=(2, _free_port(), multi, 4, True), nprocs=2, join=True)
+    a, b = torch.load(single), torch.load(multi)
+    for (la, aa, ga), (lb, ab, gb) in zip(a['outs'], b['outs']):
+        assert la == pytest.approx(lb, rel=1e-12) and aa == pytest.approx(ab, rel=1e-12)
+        assert float((ga - gb).norm() / ga.norm()) < 1e-12
 
 
 def test_shard_range_covers_all_tasks():

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Post-adaptation accuracy parity at a resolution that can show +-0.2 % (missing item 3; north_star: "accuracy
+within +-0.2 % of reference"): N >= 256 tasks of BASELINE config 2 (5-way 5-shot, K = 5, lr 0.5; 25 query predictions per task, so
+256 tasks = 6400 predictions, 0.016 % per prediction) through the engine (mi_meta_batch_maml, with_grad = 0) and through the
+reference loop restated in oracle/vision_ref.py in fp32 (the reference's precision) and fp64, from the same initial parameters on
+the bench's synthetic tasks (bench.HARDNESS: accuracy near 0.74, not saturated).  Reports mean accuracy and loss of all three,
+the fp32-vs-fp64 spread (the noise floor of the chaotic 5-step inner loop) and the tasks whose accuracy differs.
+Kept out of the timed bench; runs on the GPU box (oracle legs in CPU worker processes)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+import bench  # noqa: E402
+from exploring_meta_amd.engine import MetaEngine, ModelSpec  # noqa: E402
+import teacher_forced as TF  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--tasks', type=int, default=256)
+    ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'accuracy_parity_cfg2'))
+    args = ap.parse_args()
+    wl = bench.WORKLOADS['cfg2']
+    spec = ModelSpec.mini_imagenet(wl['ways'])
+    theta0 = bench.init_theta(spec)
+    ids = list(range(args.tasks))
+    data, labels = bench.make_batch(wl, ids)
+    eng = MetaEngine(spec)
+    el, ea = [], []
+    for lo in range(0, args.tasks, 32):
+        d, l = torch.from_numpy(data[lo:lo + 32]).cuda(), torch.from_numpy(labels[lo:lo + 32]).cuda()
+        loss, acc, _, _ = eng.meta_batch(theta0.cuda(), d, l, wl['shots'], wl['steps'], wl['lr'], with_grad=False)
+        el += [float(x) for x in loss.cpu()]
+        ea += [float(x) for x in acc.cpu()]
+    t0 = time.time()
+    res = TF.adapt_all(theta0.numpy(), data, labels, wl['shots'], wl['ways'], wl['steps'], wl['lr'], ids)
+    dt = time.time() - t0
+    el, ea = np.array(el), np.array(ea)
+    l64, a64, l32, a32 = (np.array([r[k] for r in res]) for k in ('loss64', 'acc64', 'loss32', 'acc32'))
+    nq = wl['ways'] * wl['shots']
+    rows = [('engine (fp32, MI355X)', ea, el), ('reference loop fp32 (oracle)', a32, l32), ('reference loop fp64 (oracle)', a64, l64)]
+    lines = [f'Post-adaptation accuracy parity, cfg2 ({wl["name"]}): {args.tasks} tasks x {nq} query predictions = {args.tasks * nq} predictions '
+             f'(one prediction = {100.0 / (args.tasks * nq):.4f} %), initial parameters, task hardness {bench.HARDNESS["min"]}.  '
+             f'Oracle legs: {dt:.0f} s of CPU.', '', '| leg | mean accuracy | mean query loss |', '|---|---|---|']
+    for name, a, l in rows:
+        lines.append(f'| {name} | {a.mean():.5f} | {l.mean():.5f} |')
+    pairs = [('engine - fp64', ea - a64, el - l64), ('engine - reference fp32', ea - a32, el - l32), ('reference fp32 - fp64 (noise floor)', a32 - a64, l32 - l64)]
+    lines += ['', '| difference | mean accuracy (points of %) | tasks with different accuracy | max per-task |acc| diff | mean loss diff | max per-task |loss| diff |',
+              '|---|---|---|---|---|---|']
+    for name, da, dl in pairs:
+        lines.append(f'| {name} | {100 * da.mean():+.4f} | {int((da != 0).sum())} of {args.tasks} | {np.abs(da).max():.3f} | {dl.mean():+.2e} | {np.abs(dl).max():.3e} |')
+    d_e, d_n = abs(100 * (ea - a64).mean()), abs(100 * (a32 - a64).mean())
+    verdict = 'within +-0.2 %' if d_e <= 0.2 else ('within the fp32-vs-fp64 spread' if d_e <= d_n else 'OUTSIDE +-0.2 % and the spread')
+    lines += ['', f'|engine - fp64| = {d_e:.4f} % of accuracy (bar: 0.2 %); fp32-vs-fp64 noise floor {d_n:.4f} %: {verdict}.']
+    print('\n'.join(lines), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out + '.md', 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    with open(args.out + '.json', 'w') as f:
+        json.dump(dict(engine_loss=el.tolist(), engine_acc=ea.tolist(), results=res), f)
+
+
+if __name__ == '__main__':
+    main()
