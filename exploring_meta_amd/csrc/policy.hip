@@ -21,6 +21,8 @@
 #define LOG_EPS (-13.815510557964274f)   // log(1e-6), policies.py:14,51
 #define HALF_LOG_2PI 0.9189385332046727f
 
+#include "policy_sweep.h"
+
 #define MI_DENSE_TERMS 4   // products summed into one output (2 for first tangents, up to 4 for second tangents)
 struct DenseArgs {
   const float* x[MI_DENSE_TERMS];     // [T][B][I]
@@ -509,9 +511,21 @@ struct TrpoPlan {
   float *rdmu, *r2, *r1;                // tangent scratch
   float *g, *thetap, *q, *hv, *u, *w, *tmpP;   // [T][P]
   float *loss_t, *kl_t;
-  // cached call arguments
+  float* partial;                       // fused sweeps (policy_sweep.h): [T][slots][P] per-workgroup gradient partials
+  int spt, spw, slots, sweep_grid;
   size_t bytes;
 };
+// geometry of the fused sweeps: slabs of 32 rows, a contiguous run of slabs per workgroup, one round of workgroups on 256 CUs
+static void sweep_geometry(int T, int B, int& spt, int& spw, int& slots, int& grid) {
+  spt = ceil_div(B, 32);
+  const int total = T * spt;
+  spw = ceil_div(total, 256);
+  grid = ceil_div(total, spw);
+  slots = ceil_div(spt, spw) + 1;
+}
+static bool sweep_supported(const mi_policy* p) {
+  return p->act == ACT_RELU && p->H1 == 100 && p->H2 == 100 && p->S <= SW_MAX_S && p->A <= SW_MAX_A;
+}
 static void trpo_plan(const mi_policy* p, void* ws, int T, int B, TrpoPlan& pl) {
   PBump b{reinterpret_cast<char*>(ws), 0};
   const size_t TB = (size_t)T * B, TP = (size_t)T * p->P;
@@ -523,6 +537,8 @@ static void trpo_plan(const mi_policy* p, void* ws, int T, int B, TrpoPlan& pl) 
   pl.rdmu = b.f(TB * p->A); pl.r2 = b.f(TB * p->H2); pl.r1 = b.f(TB * p->H1);
   pl.g = b.f(TP); pl.thetap = b.f(TP); pl.q = b.f(TP); pl.hv = b.f(TP); pl.u = b.f(TP); pl.w = b.f(TP); pl.tmpP = b.f(TP);
   pl.loss_t = b.f(T); pl.kl_t = b.f(T);
+  sweep_geometry(T, B, pl.spt, pl.spw, pl.slots, pl.sweep_grid);
+  pl.partial = sweep_supported(p) ? b.f((size_t)T * pl.slots * p->P) : nullptr;
   pl.bytes = align_up(b.off, 256);
 }
 extern "C" int mi_trpo_workspace_bytes(const mi_policy* p, int tasks, int batch, size_t* bytes) {
@@ -690,6 +706,63 @@ extern "C" int mi_cg_update(void* stream, double* x, double* r, double* p, const
   return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
 }
 
+static int g_policy_fused_fvp = 1;
+// 1 (default): the Fisher-vector product of a supported policy runs as three fused sweeps + three folds (policy_sweep.h);
+// 0: the per-layer path (ablation / tests).
+extern "C" int mi_policy_set_fused_fvp(int on) { g_policy_fused_fvp = on ? 1 : 0; return MI_OK; }
+
+template <bool HVP>
+static hipError_t launch_sweep(hipStream_t st, const SweepArgs& a, int grid) {
+  static bool attr_set = false;
+  const size_t lds = policy_sweep_lds_bytes<100>();
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_sweep_kernel<100, HVP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((policy_sweep_kernel<100, HVP>), dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+static SweepArgs sweep_base(const mi_policy* p, const TrpoPlan& pl, int T, int B) {
+  SweepArgs a{};
+  a.T = T; a.B = B; a.S = p->S; a.A = p->A; a.spt = pl.spt; a.spw = pl.spw; a.slots = pl.slots; a.partial = pl.partial;
+  a.o_sigma = (int)p->o_sigma; a.o_w1 = (int)p->o_w1; a.o_b1 = (int)p->o_b1; a.o_w2 = (int)p->o_w2; a.o_b2 = (int)p->o_b2;
+  a.o_w3 = (int)p->o_w3; a.o_b3 = (int)p->o_b3; a.P = (int)p->P;
+  return a;
+}
+
+static int fused_fvp(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B, const float* theta, const float* s_states,
+                     const float* s_actions, const int32_t* s_count, const float* q_states, const int32_t* q_count, float inner_lr,
+                     float damping, const float* v, float* out) {
+  const int P = (int)p->P;
+  SweepArgs hs = sweep_base(p, pl, T, B);              // H_t over the support pass at theta
+  hs.x = s_states; hs.act = s_actions; hs.h1 = pl.sa.h1; hs.h2 = pl.sa.h2; hs.mu = pl.sa.mu; hs.coef = pl.s_coef; hs.dmu = pl.s_dmu;
+  hs.d2 = pl.s_d2; hs.count = s_count; hs.theta = theta; hs.tstride = 0;
+  FoldArgs f{};
+  f.partial = pl.partial; f.slots = pl.slots; f.spt = pl.spt; f.spw = pl.spw; f.T = T; f.P = P; f.v = v; f.lr = inner_lr;
+  f.damping = damping; f.o_sigma = (int)p->o_sigma; f.A = p->A;
+  const dim3 fg(ceil_div(P, 256), T), fb(256);
+  // A: u_t = v - lr H_t v
+  hs.dir = v; hs.dstride = 0;
+  PCHK(p, launch_sweep<true>(st, hs, pl.sweep_grid));
+  f.mode = 0; f.out = pl.u;
+  hipLaunchKernelGGL(policy_sweep_fold_kernel, fg, fb, 0, st, f);
+  // B: w_t = F_t u_t over the query pass at theta'_t
+  SweepArgs fs = sweep_base(p, pl, T, B);
+  fs.x = q_states; fs.h1 = pl.qa.h1; fs.h2 = pl.qa.h2; fs.count = q_count; fs.theta = pl.thetap; fs.tstride = P; fs.dir = pl.u; fs.dstride = P;
+  PCHK(p, launch_sweep<false>(st, fs, pl.sweep_grid));
+  f.mode = 1; f.out = pl.w; f.thetap = pl.thetap; f.u = pl.u;
+  hipLaunchKernelGGL(policy_sweep_fold_kernel, fg, fb, 0, st, f);
+  // C: out = mean_t (w_t - lr H_t w_t) + damping v
+  hs.dir = pl.w; hs.dstride = P;
+  PCHK(p, launch_sweep<true>(st, hs, pl.sweep_grid));
+  f.mode = 2; f.out = out; f.w = pl.w;
+  hipLaunchKernelGGL(policy_sweep_fold_kernel, dim3(ceil_div(P, 256)), fb, 0, st, f);
+  PCHK(p, hipGetLastError());
+  return MI_OK;
+}
+
 extern "C" int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
                            const int32_t* s_count, const float* q_states, const int32_t* q_count, int tasks, int batch,
                            float inner_lr, float damping, const float* v, float* out, void* workspace, size_t workspace_bytes) {
@@ -700,6 +773,8 @@ extern "C" int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const
   TrpoPlan pl;
   trpo_plan(p, workspace, T, B, pl);
   if (pl.bytes > workspace_bytes) return pfail(p, MI_ERR_WORKSPACE, "workspace too small");
+  if (g_policy_fused_fvp && sweep_supported(p) && pl.partial)
+    return fused_fvp(p, st, pl, T, B, theta, s_states, s_actions, s_count, q_states, q_count, inner_lr, damping, v, out);
   // u_t = v - lr H_t v   (v broadcast to every task)
   hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, v, (size_t)0, pl.tmpP, 0.f, (int)P, pl.u);
   PCHK(p, hipGetLastError());

@@ -366,6 +366,10 @@ int mi_trpo_surrogate(mi_policy* p, void* stream, const float* theta, const floa
 int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
                 const int32_t* s_count, const float* q_states, const int32_t* q_count, int tasks, int batch, float inner_lr,
                 float damping, const float* v, float* out, void* workspace, size_t workspace_bytes);
+/* 1 (default): mi_trpo_fvp of a supported policy (ReLU, 100-wide hidden layers: the reference's DiagNormalPolicy defaults,
+ * policies.py:30-37) runs as three fused sweeps over the stored passes + three folds (csrc/policy_sweep.h) instead of ~34 per-layer
+ * launches; 0: the per-layer path.  Process-wide ablation / test switch; results agree to fp32 rounding. */
+int mi_policy_set_fused_fvp(int on);
 
 /* ANIL-TRPO (rl/anil_trpo.py:104-129, core_functions/rl.py:409-473 with anil=True): the stored old policies were adapted with
  * the body under no_grad (rl.py:381-382) while meta_surrogate_loss re-adapts clone_module(policy) with every parameter

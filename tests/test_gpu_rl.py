@@ -628,3 +628,54 @@ def test_fused_conjugate_gradient_matches_the_plain_loop():
     A2d = A2.cuda()
     got2 = prl.conjugate_gradient(lambda v: (calls.append(1), A2d @ v)[1], b.cuda(), num_iterations=10)
     assert len(calls) == 1 and torch.allclose(got2.cpu(), b / 2.0, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('case', ['small_T4_B150', 'ragged_counts', 'cfg5_T20_B2000'])
+def test_fused_fvp_sweeps_match_the_per_layer_path_and_the_oracle(case):
+    """mi_trpo_fvp as three fused sweeps + folds (csrc/policy_sweep.h, the default for the reference's 2-100-100-2 ReLU policy)
+    against the per-layer launch sequence it replaces (mi_policy_set_fused_fvp(0)) on the same stored passes: a batch that is not
+    a multiple of the 32-row slab, tasks with fewer valid rows than the padded batch (count < B: padding rows must contribute
+    nothing), and BASELINE config 5's size (20 tasks x 2000 rows: five slabs per workgroup, workgroups that straddle two tasks).
+    Same mathematics in another summation order: agreement to fp32 rounding; and (small case) against the fp64 oracle's
+    hessian_vector_product of the mean KL."""
+    from exploring_meta_amd import _lib
+    from exploring_meta_amd.core_functions.rl import _SurrogateContext
+    lib = _lib.load()
+    params = PARAMS_CFG5 if case.startswith('cfg5') else PARAMS
+    theta, replays, olds = _replays(params)
+    pol = _policy(theta)
+    ctx = _SurrogateContext(replays, [_policy(o) for o in olds], pol, cf.LinearValue(2, 2), params)
+    if case == 'ragged_counts':          # shorten some tasks' valid rows: the rows behind count are padding to every kernel
+        for d in (ctx.sup, ctx.qry):
+            c = d['count'].clone()
+            c[0], c[2] = 97, 33
+            d['count'] = c.contiguous()
+    th = pol.flat()
+    ctx.evaluate(th, want_grad=True)
+    g = torch.Generator(device='cuda').manual_seed(11)
+    outs = {}
+    try:
+        for fused in (0, 1):
+            lib.mi_policy_set_fused_fvp(fused)
+            res = []
+            for k in range(3):
+                v = torch.randn(th.numel(), device='cuda', generator=torch.Generator(device='cuda').manual_seed(20 + k))
+                res.append(ctx.fvp(th, v).clone())
+            torch.cuda.synchronize()
+            outs[fused] = res
+    finally:
+        lib.mi_policy_set_fused_fvp(1)
+    errs = [rel_err(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(outs[1], outs[0])]
+    rep = dict(fused_vs_per_layer_rel=errs)
+    assert all(torch.isfinite(x).all() for x in outs[1]) and max(errs) < 2e-5, errs
+    # deterministic: a repeated fused product is bit-identical (fixed-order folds, no atomics)
+    v = torch.randn(th.numel(), device='cuda', generator=torch.Generator(device='cuda').manual_seed(20))
+    assert torch.equal(ctx.fvp(th, v), outs[1][0])
+    if case == 'small_T4_B150':
+        p64 = OrderedDict((k, x.clone().requires_grad_(True)) for k, x in theta.items())
+        _, kl = RL.meta_surrogate_loss(replays, olds, p64, RL.LinearValue(2, 2), params)
+        Fvp = RL.hessian_vector_product(kl, list(p64.values()))
+        v64 = torch.randn(th.numel(), device='cuda', generator=torch.Generator(device='cuda').manual_seed(20)).double().cpu()
+        rep['fused_vs_oracle_rel'] = rel_err(outs[1][0].cpu().numpy(), Fvp(v64).detach().numpy())
+        assert rep['fused_vs_oracle_rel'] < 1e-3
+    report(f'fused_fvp[{case}]', **rep)
