@@ -18,7 +18,6 @@
 #include "mi_common.h"
 #include "../../include/mi_maml.h"
 
-#define LOG_EPS (-13.815510557964274f)   // log(1e-6), policies.py:14,51
 #define HALF_LOG_2PI 0.9189385332046727f
 
 #include "policy_sweep.h"
@@ -524,7 +523,7 @@ static void sweep_geometry(int T, int B, int& spt, int& spw, int& slots, int& gr
   slots = ceil_div(spt, spw) + 1;
 }
 static bool sweep_supported(const mi_policy* p) {
-  return p->act == ACT_RELU && p->H1 == 100 && p->H2 == 100 && p->S <= SW_MAX_S && p->A <= SW_MAX_A;
+  return policy_sweep_supported(p->act == ACT_RELU, p->H1, p->H2, p->S, p->A);
 }
 static void trpo_plan(const mi_policy* p, void* ws, int T, int B, TrpoPlan& pl) {
   PBump b{reinterpret_cast<char*>(ws), 0};
@@ -707,28 +706,18 @@ extern "C" int mi_cg_update(void* stream, double* x, double* r, double* p, const
 }
 
 static int g_policy_fused_fvp = 1;
+static unsigned long long* g_sweep_stamps = nullptr;
+extern "C" int mi_debug_policy_sweep_stamps(void* buf) { g_sweep_stamps = reinterpret_cast<unsigned long long*>(buf); return MI_OK; }
 // 1 (default): the Fisher-vector product of a supported policy runs as three fused sweeps + three folds (policy_sweep.h);
 // 0: the per-layer path (ablation / tests).
 extern "C" int mi_policy_set_fused_fvp(int on) { g_policy_fused_fvp = on ? 1 : 0; return MI_OK; }
-
-template <bool HVP>
-static hipError_t launch_sweep(hipStream_t st, const SweepArgs& a, int grid) {
-  static bool attr_set = false;
-  const size_t lds = policy_sweep_lds_bytes<100>();
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_sweep_kernel<100, HVP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((policy_sweep_kernel<100, HVP>), dim3(grid), dim3(256), lds, st, a);
-  return hipGetLastError();
-}
 
 static SweepArgs sweep_base(const mi_policy* p, const TrpoPlan& pl, int T, int B) {
   SweepArgs a{};
   a.T = T; a.B = B; a.S = p->S; a.A = p->A; a.spt = pl.spt; a.spw = pl.spw; a.slots = pl.slots; a.partial = pl.partial;
   a.o_sigma = (int)p->o_sigma; a.o_w1 = (int)p->o_w1; a.o_b1 = (int)p->o_b1; a.o_w2 = (int)p->o_w2; a.o_b2 = (int)p->o_b2;
   a.o_w3 = (int)p->o_w3; a.o_b3 = (int)p->o_b3; a.P = (int)p->P;
+  a.stamps = g_sweep_stamps;
   return a;
 }
 
@@ -742,23 +731,23 @@ static int fused_fvp(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B, c
   FoldArgs f{};
   f.partial = pl.partial; f.slots = pl.slots; f.spt = pl.spt; f.spw = pl.spw; f.T = T; f.P = P; f.v = v; f.lr = inner_lr;
   f.damping = damping; f.o_sigma = (int)p->o_sigma; f.A = p->A;
-  const dim3 fg(ceil_div(P, 256), T), fb(256);
   // A: u_t = v - lr H_t v
   hs.dir = v; hs.dstride = 0;
-  PCHK(p, launch_sweep<true>(st, hs, pl.sweep_grid));
+  PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, true));
   f.mode = 0; f.out = pl.u;
-  hipLaunchKernelGGL(policy_sweep_fold_kernel, fg, fb, 0, st, f);
+  PCHK(p, launch_policy_sweep_fold(st, f, T));
   // B: w_t = F_t u_t over the query pass at theta'_t
   SweepArgs fs = sweep_base(p, pl, T, B);
   fs.x = q_states; fs.h1 = pl.qa.h1; fs.h2 = pl.qa.h2; fs.count = q_count; fs.theta = pl.thetap; fs.tstride = P; fs.dir = pl.u; fs.dstride = P;
-  PCHK(p, launch_sweep<false>(st, fs, pl.sweep_grid));
+  PCHK(p, launch_policy_sweep(st, fs, pl.sweep_grid, false));
   f.mode = 1; f.out = pl.w; f.thetap = pl.thetap; f.u = pl.u;
-  hipLaunchKernelGGL(policy_sweep_fold_kernel, fg, fb, 0, st, f);
+  PCHK(p, launch_policy_sweep_fold(st, f, T));
   // C: out = mean_t (w_t - lr H_t w_t) + damping v
   hs.dir = pl.w; hs.dstride = P;
-  PCHK(p, launch_sweep<true>(st, hs, pl.sweep_grid));
-  f.mode = 2; f.out = out; f.w = pl.w;
-  hipLaunchKernelGGL(policy_sweep_fold_kernel, dim3(ceil_div(P, 256)), fb, 0, st, f);
+  PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, true));
+  f.mode = 2; f.out = pl.tmpP; f.w = pl.w;
+  PCHK(p, launch_policy_sweep_fold(st, f, T));
+  hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, pl.tmpP, T, P, 1.f / (float)T, v, damping, out);
   PCHK(p, hipGetLastError());
   return MI_OK;
 }

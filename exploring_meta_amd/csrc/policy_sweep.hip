@@ -1,0 +1,481 @@
+// Kernels of the fused Fisher-vector-product sweeps: see policy_sweep.h for the design.
+#include "policy_sweep.h"
+
+#define SW_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[nstamp++] = ((unsigned long long)(k) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); } while (0)
+__device__ __forceinline__ floatx4 lds4(const float* p) { return *reinterpret_cast<const floatx4*>(p); }
+
+// NG groups of 4 reduction steps: operands of the next chunk of 4 groups are issued BEFORE the 16 MFMAs of the current chunk, and the
+// scheduling fences keep hipcc from sinking each LDS read next to its use (it otherwise emits read / s_waitcnt / two MFMAs, and the
+// matrix pipe idles for one LDS latency in every pair: measured 129 cycles per MFMA instead of 64)
+template <int NG, class LA, class LB>
+__device__ __forceinline__ void mfma_groups(floatx16& acc, LA la, LB lb) {
+  constexpr int CH = 4, NC = (NG + CH - 1) / CH;
+  floatx4 av[2][CH], bv[2][CH];
+#pragma unroll
+  for (int g = 0; g < CH; ++g)
+    if (g < NG) { av[0][g] = la(g); bv[0][g] = lb(g); }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int cur = c & 1, nxt = cur ^ 1;
+#pragma unroll
+    for (int g = 0; g < CH; ++g) {
+      const int j = (c + 1) * CH + g;
+      if (j < NG) { av[nxt][g] = la(j); bv[nxt][g] = lb(j); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < CH; ++g) {
+      const int j = c * CH + g;
+      if (j < NG) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][g][k], bv[cur][g][k], acc, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int H, bool HVP>
+__global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
+  static_assert(H % 4 == 0 && H <= 128 && (H % 8 == 0 || H % 8 == 4), "hidden width");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HH = H * H, SL = 32 * H, KH0 = ((H + 7) / 8) * 4, NG = KH0 / 4, MT = (H + 31) / 32;
+  const int S = a.S, A = a.A;
+  float* W2s = lds;                     // the pass's W2 [o][k]
+  float* W2d = W2s + HH;                // the direction's W2
+  float* h1s = W2d + HH;                // slab arrays [32][H]
+  float* h1d = h1s + SL;
+  float* h2s = h1d + SL;
+  float* h2d = h2s + SL;                // tangent of h2; later r2 (the tangent-backward cotangent of z2)
+  float* d2s = h2d + SL;                // primal dz2 (HVP)
+  float* sm = d2s + SL + 32;            // 32 floats of slack: the last M / N tile of the dW2 product reads past a slab array
+  float* xs = sm;            sm += 32 * SW_MAX_S;
+  float* acts = sm;          sm += 32 * SW_MAX_A;
+  float* mus = sm;           sm += 32 * SW_MAX_A;
+  float* dmus = sm;          sm += 32 * SW_MAX_A;
+  float* rdmus = sm;         sm += 32 * SW_MAX_A;
+  float* muds = sm;          sm += 32 * SW_MAX_A;
+  float* coefs = sm;         sm += 32;
+  float* red = sm;           sm += SW_MAX_A * 8 * 32;
+  float* W1d = sm;           sm += H * SW_MAX_S;
+  float* b1d = sm;           sm += H;
+  float* b2d = sm;           sm += H;
+  float* W3s = sm;           sm += SW_MAX_A * H;
+  float* W3d = sm;           sm += SW_MAX_A * H;
+  float* b3d = sm;           sm += 8;
+  float* rho = sm;           sm += 8;
+  float* rhod = sm;          sm += 8;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hh = lane >> 5;
+  const int B = a.B, spt = a.spt;
+  const int slab0 = blockIdx.x * a.spw, slab1 = min(slab0 + a.spw, a.T * spt);
+
+  // ---- accumulators that live across the slabs of one task
+  floatx16 accW2[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW2[m][r] = 0.f;
+  // vector-stage mapping: thread = (column col of the hidden layer, half of the slab's rows)
+  const int col = tid & 127, rb = (tid >> 7) * 16;
+  float accW3[SW_MAX_A], accb3 = 0.f, accb2 = 0.f, accb1 = 0.f, accW1[SW_MAX_S], accrho[SW_MAX_A];
+#pragma unroll
+  for (int d = 0; d < SW_MAX_A; ++d) accW3[d] = 0.f;
+#pragma unroll
+  for (int s = 0; s < SW_MAX_S; ++s) accW1[s] = 0.f;
+#pragma unroll
+  for (int d = 0; d < SW_MAX_A; ++d) accrho[d] = 0.f;
+
+  for (int e = tid; e < 32 * SW_MAX_S; e += 256) xs[e] = 0.f;
+  for (int e = tid; e < H * SW_MAX_S; e += 256) W1d[e] = 0.f;
+  for (int e = tid; e < SW_MAX_A * H; e += 256) { W3s[e] = 0.f; W3d[e] = 0.f; }
+  for (int e = tid; e < 32 * SW_MAX_A; e += 256) { dmus[e] = 0.f; rdmus[e] = 0.f; }
+  __syncthreads();
+  auto load_weights = [&](int t) {
+    const float* th = a.theta + (size_t)t * a.tstride;
+    const float* dv = a.dir + (size_t)t * a.dstride;
+#pragma unroll 16
+    for (int e = tid; e < HH; e += 256) { W2s[e] = th[a.o_w2 + e]; W2d[e] = dv[a.o_w2 + e]; }
+    for (int e = tid; e < H * S; e += 256) W1d[(e / S) * SW_MAX_S + e % S] = dv[a.o_w1 + e];
+    for (int e = tid; e < H; e += 256) { b1d[e] = dv[a.o_b1 + e]; b2d[e] = dv[a.o_b2 + e]; }
+    for (int e = tid; e < A * H; e += 256) { W3s[e] = th[a.o_w3 + e]; W3d[e] = dv[a.o_w3 + e]; }
+    if (tid < A) { b3d[tid] = dv[a.o_b3 + tid]; rho[tid] = th[a.o_sigma + tid]; rhod[tid] = dv[a.o_sigma + tid]; }
+  };
+
+  // one partial [P] per (workgroup, task): slot = this workgroup's position among the workgroups that touch the task
+  auto flush = [&](int t) {
+    const int slot = blockIdx.x - (t * spt) / a.spw;
+    float* pv = a.partial + ((size_t)t * a.slots + slot) * a.P;
+    const int icol = 32 * wave + n;
+    // the 64 store addresses hang off ONE lane offset that the compiler cannot see through: otherwise it hoists 64 loop-invariant
+    // 64-bit offsets out of the slab loop and the kernel spills (measured: 261 spilled registers)
+    int wbase = a.o_w2 + 4 * hh * H + icol;
+    asm volatile("" : "+v"(wbase));
+    float* pw = pv + wbase;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orel = 32 * m + (r & 3) + 8 * (r >> 2);      // o = orel + 4 hh
+        if (orel + 4 * hh < H && icol < H) pw[orel * H] = accW2[m][r];
+        accW2[m][r] = 0.f;
+      }
+    if (tid < A) pv[a.o_b3 + tid] = accb3;
+    accb3 = 0.f;
+    // W1 / b1 partials sit per lane half (16 rows each), rho partials per row-thread: fold through LDS (the slab arrays are free)
+    float* t1 = h1s;                                   // [2][H][S + 1]
+    if (icol < H) {
+#pragma unroll
+      for (int s = 0; s < SW_MAX_S; ++s) if (s < S) t1[(hh * H + icol) * (SW_MAX_S + 1) + s] = accW1[s];
+      t1[(hh * H + icol) * (SW_MAX_S + 1) + SW_MAX_S] = accb1;
+    }
+    float* t3 = h2s;                                   // [2][SW_MAX_A + 1][128]: W3 / b2 partials per (row half, column)
+    if (col < H) {
+#pragma unroll
+      for (int d = 0; d < SW_MAX_A; ++d) t3[((tid >> 7) * (SW_MAX_A + 1) + d) * 128 + col] = accW3[d];
+      t3[((tid >> 7) * (SW_MAX_A + 1) + SW_MAX_A) * 128 + col] = accb2;
+    }
+    float* t2 = h1d;                                   // [32][A]
+    if (tid < 32) {
+#pragma unroll
+      for (int d = 0; d < SW_MAX_A; ++d) if (d < A) t2[tid * SW_MAX_A + d] = accrho[d];
+    }
+    __syncthreads();
+    if (tid < H) {
+      for (int s = 0; s < S; ++s) pv[a.o_w1 + tid * S + s] = t1[tid * (SW_MAX_S + 1) + s] + t1[(H + tid) * (SW_MAX_S + 1) + s];
+      pv[a.o_b1 + tid] = t1[tid * (SW_MAX_S + 1) + SW_MAX_S] + t1[(H + tid) * (SW_MAX_S + 1) + SW_MAX_S];
+    }
+    if (tid < A) {
+      float s = 0.f;
+      for (int r = 0; r < 32; ++r) s += t2[r * SW_MAX_A + tid];
+      pv[a.o_sigma + tid] = s;
+    }
+    for (int idx = tid; idx < A * H; idx += 256) {
+      const int d = idx / H, k = idx - d * H;
+      pv[a.o_w3 + idx] = t3[d * 128 + k] + t3[((SW_MAX_A + 1) + d) * 128 + k];
+    }
+    if (tid < H) pv[a.o_b2 + tid] = t3[SW_MAX_A * 128 + tid] + t3[((SW_MAX_A + 1) + SW_MAX_A) * 128 + tid];
+    __syncthreads();
+    accb1 = 0.f; accb2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < SW_MAX_A; ++d) accW3[d] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SW_MAX_S; ++s) accW1[s] = 0.f;
+#pragma unroll
+    for (int d = 0; d < SW_MAX_A; ++d) accrho[d] = 0.f;
+  };
+
+  // the NEXT slab's global data travels in registers under this slab's last two matrix stages
+  constexpr int NPF = (SL + 1023) / 1024;
+  struct Prefetch { floatx4 v1[NPF], v2[NPF], v3[NPF]; float x, act, mu, dmu, coef; } pf;
+  auto fetch = [&](int slab, Prefetch& f) {
+    const int t = slab / spt, row0 = (slab - t * spt) * 32;
+    const int nv = min(32, B - row0);
+    const size_t rbase = (size_t)t * B + row0;
+    const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const float* g1 = a.h1 + rbase * H;
+    const float* g2 = a.h2 + rbase * H;
+    const float* g3 = HVP ? a.d2 + rbase * H : nullptr;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = tid * 4 + 1024 * i;
+      const bool ok = e < nv * H;
+      f.v1[i] = ok ? *reinterpret_cast<const floatx4*>(g1 + e) : z4;
+      f.v2[i] = ok ? *reinterpret_cast<const floatx4*>(g2 + e) : z4;
+      if (HVP) f.v3[i] = ok ? *reinterpret_cast<const floatx4*>(g3 + e) : z4;
+    }
+    f.x = (tid < nv * S) ? a.x[rbase * S + tid] : 0.f;
+    f.act = f.mu = f.dmu = f.coef = 0.f;
+    if (HVP) {
+      if (tid < nv * A) { f.act = a.act[rbase * A + tid]; f.mu = a.mu[rbase * A + tid]; f.dmu = a.dmu[rbase * A + tid]; }
+      if (tid < nv) f.coef = a.coef[rbase + tid];           // rows past count[t] are masked at staging (no wait on count here)
+    }
+  };
+
+  int cur = -1;
+  int nstamp = 0;
+  SW_STAMP(0);
+  for (int slab = slab0; slab < slab1; ++slab) {
+    const int t = slab / spt, row0 = (slab - t * spt) * 32;
+    if (t != cur) {
+      if (cur >= 0) flush(cur);
+      if (cur < 0 || a.tstride != 0 || a.dstride != 0) load_weights(t);
+      cur = t;
+    }
+    SW_STAMP(1);
+    const int cnt = a.count ? a.count[t] : B;
+    // ---- stage the slab from the registers its data was fetched into (16-byte coalesced copies of the stored activations; rows past
+    // the batch are zero; the per-row scalars)
+    if (slab == slab0) fetch(slab, pf);
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = tid * 4 + 1024 * i;
+      if (e < SL) {
+        *reinterpret_cast<floatx4*>(h1s + e) = pf.v1[i];
+        *reinterpret_cast<floatx4*>(h2s + e) = pf.v2[i];
+        if (HVP) *reinterpret_cast<floatx4*>(d2s + e) = pf.v3[i];
+      }
+    }
+    if (tid < 32 * S) xs[(tid / S) * SW_MAX_S + tid % S] = pf.x;
+    if (HVP) {
+      if (tid < 32 * A) { const int q = (tid / A) * SW_MAX_A + tid % A; acts[q] = pf.act; mus[q] = pf.mu; dmus[q] = pf.dmu; }
+      if (tid < 32) coefs[tid] = (row0 + tid < cnt) ? pf.coef : 0.f;
+    }
+    const int nv = min(32, B - row0);                 // rows of this slab inside the padded batch
+    __syncthreads();
+    SW_STAMP(2);
+    // ---- tangent of the first hidden layer (S-wide: vector work): h1d = [h1 > 0] (x W1d^T + b1d)
+    if (col < H) {
+      const floatx4 w1 = lds4(W1d + col * SW_MAX_S);   // rows past S are zero
+      const float bb = b1d[col];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r = rb + j;
+        const floatx4 xv = lds4(xs + r * SW_MAX_S);
+        const float z = fmaf(xv[3], w1[3], fmaf(xv[2], w1[2], fmaf(xv[1], w1[1], fmaf(xv[0], w1[0], bb))));
+        h1d[r * H + col] = h1s[r * H + col] > 0.f ? z : 0.f;
+      }
+    }
+    __syncthreads();
+    SW_STAMP(3);
+    // ---- tangent of the second hidden layer on the matrix pipe: z2d = h1 W2d^T + h1d W2^T + b2d, h2d = [h2 > 0] z2d
+    {
+      floatx16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int ocol = min(32 * wave + n, H - 1);
+#pragma unroll 1
+      for (int term = 0; term < 2; ++term) {
+        const float* arow = (term == 0 ? h1s : h1d) + n * H + hh * KH0;
+        const float* brow = (term == 0 ? W2d : W2s) + ocol * H + hh * KH0;
+        const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
+        mfma_groups<NG>(acc,
+                        [&](int j) { return (KH0 + 4 * j >= H && hh) ? z4 : lds4(arow + 4 * j); },     // upper half's k past the end
+                        [&](int j) { return (KH0 + 4 * j >= H && hh) ? z4 : lds4(brow + 4 * j); });
+      }
+      const int o = 32 * wave + n;
+      if (o < H) {
+        const float bb = b2d[o];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          h2d[row * H + o] = h2s[row * H + o] > 0.f ? acc[r] + bb : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    SW_STAMP(4);
+    // ---- head tangent (A-wide): mud = h2 W3d^T + h2d W3^T + b3d; partial dot products per (row, eighth of the columns)
+    {
+      const int r = tid & 31, q = tid >> 5;
+      float sacc[SW_MAX_A];
+#pragma unroll
+      for (int d = 0; d < SW_MAX_A; ++d) sacc[d] = 0.f;
+#pragma unroll
+      for (int j = 0; j < (H / 4 + 7) / 8; ++j) {
+        const int kq = q + 8 * j;
+        if (kq < H / 4) {
+          const floatx4 hv = lds4(h2s + r * H + 4 * kq), hd = lds4(h2d + r * H + 4 * kq);
+#pragma unroll
+          for (int d = 0; d < SW_MAX_A; ++d) {
+            if (d >= A) break;
+            const floatx4 wd = lds4(W3d + d * H + 4 * kq), ws = lds4(W3s + d * H + 4 * kq);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sacc[d] = fmaf(hv[c], wd[c], fmaf(hd[c], ws[c], sacc[d]));
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < SW_MAX_A; ++d) if (d < A) red[(d * 8 + q) * 32 + r] = sacc[d];
+    }
+    __syncthreads();
+    if (tid < 32 * A) {
+      const int r = tid & 31, d = tid >> 5;
+      float m = b3d[d];
+      for (int q = 0; q < 8; ++q) m += red[(d * 8 + q) * 32 + r];
+      muds[r * SW_MAX_A + d] = m;
+    }
+    __syncthreads();
+    SW_STAMP(5);
+    // ---- Gaussian part, one thread per row: the cotangent of mu that the tangent backward starts from (and the sigma slots)
+    if (tid < 32) {
+      const bool valid = tid < nv && row0 + tid < cnt;
+      const float invD = 1.f / (float)A;
+      if (HVP) {
+        const float c = coefs[tid];                    // 0 on padding rows
+#pragma unroll
+        for (int d = 0; d < SW_MAX_A; ++d) {
+          if (d >= A) break;
+          const float rp = rho[d];
+          const bool live = rp > LOG_EPS;
+          const float rr = fmaxf(rp, LOG_EPS), sg = expf(rr), iv = 1.f / (sg * sg);
+          const float rd = live ? rhod[d] : 0.f;
+          const float df = acts[tid * SW_MAX_A + d] - mus[tid * SW_MAX_A + d];
+          const float md = muds[tid * SW_MAX_A + d];
+          rdmus[tid * SW_MAX_A + d] = c * invD * (-md * iv - 2.f * df * rd * iv);
+          if (live) accrho[d] += c * invD * (-2.f * df * md * iv - 2.f * df * df * rd * iv);
+        }
+      } else {
+        const float invB = 1.f / (float)cnt;
+        for (int d = 0; d < A; ++d) {
+          const float rr = fmaxf(rho[d], LOG_EPS), sg = expf(rr);
+          rdmus[tid * SW_MAX_A + d] = valid ? muds[tid * SW_MAX_A + d] * invB * invD / (sg * sg) : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    SW_STAMP(6);
+    // ---- head weight gradient, then r2 = [h2 > 0] (rdmu W3 + dmu W3d) in place of h2d: a thread owns one column and 16 rows, reads
+    // its own h2d element before overwriting it (no barrier in between), and sums its rows of r2 for the bias gradient
+    if (tid < A) {
+      float s = 0.f;
+      for (int r = 0; r < 32; ++r) s += rdmus[r * SW_MAX_A + tid];
+      accb3 += s;
+    }
+    if (col < H) {
+      float w3[SW_MAX_A], w3d[SW_MAX_A];
+#pragma unroll
+      for (int d = 0; d < SW_MAX_A; ++d) { w3[d] = W3s[d * H + col]; w3d[d] = W3d[d * H + col]; }     // rows past A are zero
+#pragma unroll 4
+      for (int j = 0; j < 16; ++j) {
+        const int r = rb + j;
+        const float h2v = h2s[r * H + col], h2dv = h2d[r * H + col];
+        float v = 0.f;
+#pragma unroll
+        for (int d = 0; d < SW_MAX_A; ++d) {
+          if (d >= A) break;
+          const float rm = rdmus[r * SW_MAX_A + d], dm = HVP ? dmus[r * SW_MAX_A + d] : 0.f;
+          accW3[d] = fmaf(rm, h2v, accW3[d]);
+          v = fmaf(rm, w3[d], v);
+          if (HVP) { accW3[d] = fmaf(dm, h2dv, accW3[d]); v = fmaf(dm, w3d[d], v); }
+        }
+        v = h2v > 0.f ? v : 0.f;
+        h2d[r * H + col] = v;
+        accb2 += v;
+      }
+    }
+    __syncthreads();
+    SW_STAMP(8);
+    if (slab + 1 < slab1) fetch(slab + 1, pf);       // the next slab's data flies under the two matrix stages below
+    const float* r2 = h2d;
+    // ---- r1 = [h1 > 0] (r2 W2 + d2 W2d) on the matrix pipe; its products with the states (W1, b1 gradients) from the accumulators
+    {
+      floatx16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int icol = min(32 * wave + n, H - 1);
+#pragma unroll 1
+      for (int term = 0; term < (HVP ? 2 : 1); ++term) {
+        const float* arow = (term == 0 ? r2 : d2s) + n * H + hh * KH0;
+        const float* bcol = (term == 0 ? W2s : W2d) + icol + hh * KH0 * H;
+        const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
+        mfma_groups<NG>(acc,
+                        [&](int j) { return (KH0 + 4 * j >= H && hh) ? z4 : lds4(arow + 4 * j); },
+                        [&](int j) {                                  // the upper half's last group does not exist: stay in bounds
+                          const float* bp = (KH0 + 4 * j >= H && hh) ? bcol : bcol + (4 * j) * H;
+                          floatx4 b;
+#pragma unroll
+                          for (int c = 0; c < 4; ++c) b[c] = bp[c * H];
+                          return b;
+                        });
+      }
+      const int i = 32 * wave + n;
+      if (i < H) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const float v = h1s[row * H + i] > 0.f ? acc[r] : 0.f;
+          accb1 += v;
+#pragma unroll
+          for (int s = 0; s < SW_MAX_S; ++s) if (s < S) accW1[s] = fmaf(v, xs[row * SW_MAX_S + s], accW1[s]);
+        }
+      }
+    }
+    SW_STAMP(9);
+    // ---- dW2[o][i] += sum_rows r2[row][o] h1[row][i] + d2[row][o] h1d[row][i]: M = o (MT tiles), N = this wave's columns, K = rows
+    {
+      const int icol = 32 * wave + n;                  // columns past H read the next row: finite, never stored
+#pragma unroll 1
+      for (int term = 0; term < (HVP ? 2 : 1); ++term) {
+        const float* am = (term == 0 ? r2 : d2s) + (16 * hh) * H + n;
+        const float* bm = (term == 0 ? h1s : h1d) + (16 * hh) * H + icol;
+#pragma unroll 8
+        for (int s = 0; s < 16; ++s) {
+          const float bv = bm[s * H];
+          float avv[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) avv[m] = am[s * H + 32 * m];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) accW2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[m], bv, accW2[m], 0, 0, 0);
+        }
+      }
+    }
+    SW_STAMP(10);
+    __syncthreads();                                   // the next slab's staging overwrites the slab arrays
+  }
+  SW_STAMP(11);
+  if (cur >= 0) flush(cur);
+  SW_STAMP(12);
+}
+
+__device__ __forceinline__ float sweep_fold_sum(const FoldArgs& f, int t, int p) {
+  const int first = (t * f.spt) / f.spw, last = (t * f.spt + f.spt - 1) / f.spw;
+  const float* pp = f.partial + (size_t)t * f.slots * f.P + p;
+  float s = 0.f;
+  const int ns = last - first + 1;
+  int k = 0;
+  for (; k + 4 <= ns; k += 4) {                       // four slots in flight, summed in slot order
+    const float v0 = pp[(size_t)k * f.P], v1 = pp[(size_t)(k + 1) * f.P], v2 = pp[(size_t)(k + 2) * f.P], v3 = pp[(size_t)(k + 3) * f.P];
+    s += v0; s += v1; s += v2; s += v3;
+  }
+  for (; k < ns; ++k) s += pp[(size_t)k * f.P];
+  return s;
+}
+__global__ __launch_bounds__(256) void policy_sweep_fold_kernel(FoldArgs f) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= f.P) return;
+  const int t = blockIdx.y;
+  const float s = sweep_fold_sum(f, t, p);
+  if (f.mode == 0) {
+    f.out[(size_t)t * f.P + p] = f.v[p] - f.lr * s;
+  } else if (f.mode == 2) {
+    f.out[(size_t)t * f.P + p] = f.w[(size_t)t * f.P + p] - f.lr * s;
+  } else {
+    float o = s;
+    if (p >= f.o_sigma && p < f.o_sigma + f.A)
+      o = f.thetap[(size_t)t * f.P + p] > LOG_EPS ? 2.f * f.u[(size_t)t * f.P + p] / (float)f.A : 0.f;
+    f.out[(size_t)t * f.P + p] = o;
+  }
+}
+
+template <int H>
+static size_t policy_sweep_lds_bytes() {
+  return ((size_t)2 * H * H + 5 * 32 * H + 32 + 32 * SW_MAX_S + 5 * 32 * SW_MAX_A + 32 + SW_MAX_A * 8 * 32 + H * SW_MAX_S + 2 * H +
+          2 * SW_MAX_A * H + 24) * sizeof(float);
+}
+
+bool policy_sweep_supported(int act_relu, int h1, int h2, int s, int a) {
+  return act_relu && h1 == 100 && h2 == 100 && s <= SW_MAX_S && a <= SW_MAX_A;
+}
+
+template <bool HVP>
+static hipError_t launch_sweep_t(hipStream_t st, const SweepArgs& a, int grid) {
+  static bool attr_set = false;
+  const size_t lds = policy_sweep_lds_bytes<100>();
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_sweep_kernel<100, HVP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((policy_sweep_kernel<100, HVP>), dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_policy_sweep(hipStream_t st, const SweepArgs& a, int grid, bool hvp) {
+  return hvp ? launch_sweep_t<true>(st, a, grid) : launch_sweep_t<false>(st, a, grid);
+}
+hipError_t launch_policy_sweep_fold(hipStream_t st, const FoldArgs& f, int tasks) {
+  hipLaunchKernelGGL(policy_sweep_fold_kernel, dim3(ceil_div(f.P, 256), tasks), dim3(256), 0, st, f);
+  return hipGetLastError();
+}

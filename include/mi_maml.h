@@ -370,6 +370,9 @@ int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const float* s_s
  * policies.py:30-37) runs as three fused sweeps over the stored passes + three folds (csrc/policy_sweep.h) instead of ~34 per-layer
  * launches; 0: the per-layer path.  Process-wide ablation / test switch; results agree to fp32 rounding. */
 int mi_policy_set_fused_fvp(int on);
+/* Debug aid: shader-clock stamps (stage id << 56 | s_memtime) of workgroup 0 of every fused sweep into buf (>= 256 u64; the three sweeps of a
+ * product overwrite each other: read after the call, last sweep wins); NULL switches it off. */
+int mi_debug_policy_sweep_stamps(void* buf);
 
 /* ANIL-TRPO (rl/anil_trpo.py:104-129, core_functions/rl.py:409-473 with anil=True): the stored old policies were adapted with
  * the body under no_grad (rl.py:381-382) while meta_surrogate_loss re-adapts clone_module(policy) with every parameter
