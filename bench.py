@@ -480,13 +480,14 @@ def run_trpo(args, wl, rank, world, local, dist):
     fwd = 2.0 * B * (2 * 100 + 100 * 100 + 100 * 2)                   # one dense forward over a task's padded batch
     flops = 16.0 * fwd * (hi - lo)                                       # (I - aH) F (I - aH) v: two 6-pass Hessian products + JVP/VJP through the query forward
     achieved = flops / (fvp_ms * 1e-3) / 1e12
-    roofline = dict(kernel='mi_trpo_fvp (dense_fwd / dense_bwd_x / dense_bwd_w / gauss kernels of policy.hip, one call = about 20 launches)',
+    roofline = dict(kernel='mi_trpo_fvp = 3 fused sweeps (policy_sweep_kernel: H_t v over the support pass, F_t u over the query pass, H_t w over the '
+                           'support pass) + 3 folds + the mean over tasks: 7 launches',
                     op='fisher_vector_product', bound='mfma', achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
                     frac=round(achieved / FP32_MFMA_PEAK_TF, 5), traffic=None, launches=nf, avg_launch_ms=round(fvp_ms, 4),
-                    flops_per_launch=flops, note='2x100 MLP on 2000-row batches: about 35 launches of 0.4..1.6 GFLOP per product (dense '
-                    'products on the fp32 matrix pipe, one wave per 32x32 tile, 16-byte operand loads straight from global memory): '
-                    'address-unit / padding bound: 11 Fisher-vector products of ~0.86 ms are 9.5 ms of a 13 ms step; the advantages of the 40 replays (returns, LinearValue fits, GAE, '
-                    'normalisation) are one mi_gae_advantages launch, 1.4 ms with the device-side batch assembly (tools/trpo_step_timing.py)')
+                    flops_per_launch=flops, note='2x100 MLP on 2000-row batches; algorithmic FLOPs = 16 dense forward passes of a task batch per product '
+                    '(two 6-pass Hessian-vector sweeps + tangent forward / backward through the query pass); a sweep takes 32-row slabs through the whole '
+                    'chain inside one workgroup with both 100x100 weight matrices resident in LDS (csrc/policy_sweep.h); round 2 ran one product as ~34 '
+                    'per-layer launches in 0.86 ms')
 
     collective = collective_record(dist, world, policy.flat(), theta0.numel() + 2,
                                    'task-count-weighted means of (loss, KL, gradient) and of every Fisher-vector product: one all-reduce each')

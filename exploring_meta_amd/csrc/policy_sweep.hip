@@ -96,8 +96,17 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
   auto load_weights = [&](int t) {
     const float* th = a.theta + (size_t)t * a.tstride;
     const float* dv = a.dir + (size_t)t * a.dstride;
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    if ((((size_t)(th + a.o_w2) | (size_t)(dv + a.o_w2)) & 7) == 0) {      // 8-byte loads where both matrices are 8-byte aligned
+#pragma unroll 10
+      for (int e = 2 * tid; e < HH; e += 512) {
+        *reinterpret_cast<floatx2*>(W2s + e) = *reinterpret_cast<const floatx2*>(th + a.o_w2 + e);
+        *reinterpret_cast<floatx2*>(W2d + e) = *reinterpret_cast<const floatx2*>(dv + a.o_w2 + e);
+      }
+    } else {
 #pragma unroll 16
-    for (int e = tid; e < HH; e += 256) { W2s[e] = th[a.o_w2 + e]; W2d[e] = dv[a.o_w2 + e]; }
+      for (int e = tid; e < HH; e += 256) { W2s[e] = th[a.o_w2 + e]; W2d[e] = dv[a.o_w2 + e]; }
+    }
     for (int e = tid; e < H * S; e += 256) W1d[(e / S) * SW_MAX_S + e % S] = dv[a.o_w1 + e];
     for (int e = tid; e < H; e += 256) { b1d[e] = dv[a.o_b1 + e]; b2d[e] = dv[a.o_b2 + e]; }
     for (int e = tid; e < A * H; e += 256) { W3s[e] = th[a.o_w3 + e]; W3d[e] = dv[a.o_w3 + e]; }
@@ -259,9 +268,9 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       if (o < H) {
         const float bb = b2d[o];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 16; ++r) {                 // the ReLU gate [h2 > 0] is applied by the two readers of h2d (they hold h2 anyway)
           const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          h2d[row * H + o] = h2s[row * H + o] > 0.f ? acc[r] + bb : 0.f;
+          h2d[row * H + o] = acc[r] + bb;
         }
       }
     }
@@ -277,7 +286,10 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       for (int j = 0; j < (H / 4 + 7) / 8; ++j) {
         const int kq = q + 8 * j;
         if (kq < H / 4) {
-          const floatx4 hv = lds4(h2s + r * H + 4 * kq), hd = lds4(h2d + r * H + 4 * kq);
+          const floatx4 hv = lds4(h2s + r * H + 4 * kq);
+          floatx4 hd = lds4(h2d + r * H + 4 * kq);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) hd[c] = hv[c] > 0.f ? hd[c] : 0.f;
 #pragma unroll
           for (int d = 0; d < SW_MAX_A; ++d) {
             if (d >= A) break;
@@ -338,10 +350,11 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       float w3[SW_MAX_A], w3d[SW_MAX_A];
 #pragma unroll
       for (int d = 0; d < SW_MAX_A; ++d) { w3[d] = W3s[d * H + col]; w3d[d] = W3d[d * H + col]; }     // rows past A are zero
-#pragma unroll 4
+#pragma unroll 8
       for (int j = 0; j < 16; ++j) {
         const int r = rb + j;
-        const float h2v = h2s[r * H + col], h2dv = h2d[r * H + col];
+        const float h2v = h2s[r * H + col], h2raw = h2d[r * H + col];
+        const float h2dv = h2v > 0.f ? h2raw : 0.f;
         float v = 0.f;
 #pragma unroll
         for (int d = 0; d < SW_MAX_A; ++d) {
@@ -366,6 +379,9 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const int icol = min(32 * wave + n, H - 1);
+      float gate[16];                                  // [h1 > 0] of this lane's 16 output elements, in flight under the products
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gate[r] = h1s[((r & 3) + 8 * (r >> 2) + 4 * hh) * H + icol];
 #pragma unroll 1
       for (int term = 0; term < (HVP ? 2 : 1); ++term) {
         const float* arow = (term == 0 ? r2 : d2s) + n * H + hh * KH0;
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const float v = h1s[row * H + i] > 0.f ? acc[r] : 0.f;
+          const float v = gate[r] > 0.f ? acc[r] : 0.f;
           accb1 += v;
 #pragma unroll
           for (int s = 0; s < SW_MAX_S; ++s) if (s < S) accW1[s] = fmaf(v, xs[row * SW_MAX_S + s], accW1[s]);
