@@ -480,11 +480,16 @@ def run_trpo(args, wl, rank, world, local, dist):
     fwd = 2.0 * B * (2 * 100 + 100 * 100 + 100 * 2)                   # one dense forward over a task's padded batch
     flops = 16.0 * fwd * (hi - lo)                                       # (I - aH) F (I - aH) v: two 6-pass Hessian products + JVP/VJP through the query forward
     achieved = flops / (fvp_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):            # HBM bytes of ONE Hessian-vector sweep launch (the dominant kernel of a product: two of its three sweeps)
+        traffic = json.load(open(tpath)).get('cfg5,fisher_vector_product,0')
     roofline = dict(kernel='mi_trpo_fvp = 3 fused sweeps (policy_sweep_kernel: H_t v over the support pass, F_t u over the query pass, H_t w over the '
                            'support pass) + 3 folds + the mean over tasks: 7 launches',
                     op='fisher_vector_product', bound='mfma', achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
-                    frac=round(achieved / FP32_MFMA_PEAK_TF, 5), traffic=None, launches=nf, avg_launch_ms=round(fvp_ms, 4),
-                    flops_per_launch=flops, note='2x100 MLP on 2000-row batches; algorithmic FLOPs = 16 dense forward passes of a task batch per product '
+                    frac=round(achieved / FP32_MFMA_PEAK_TF, 5), traffic=traffic, launches=nf, avg_launch_ms=round(fvp_ms, 4),
+                    flops_per_launch=flops, traffic_note='counter bytes of one policy_sweep_kernel<HVP> launch (a product = 2 such sweeps + 1 Fisher sweep)',
+                    note='2x100 MLP on 2000-row batches; algorithmic FLOPs = 16 dense forward passes of a task batch per product '
                     '(two 6-pass Hessian-vector sweeps + tangent forward / backward through the query pass); a sweep takes 32-row slabs through the whole '
                     'chain inside one workgroup with both 100x100 weight matrices resident in LDS (csrc/policy_sweep.h); round 2 ran one product as ~34 '
                     'per-layer launches in 0.86 ms')

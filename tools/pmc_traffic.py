@@ -53,6 +53,8 @@ def main():
     ap.add_argument('--table', default='')
     ap.add_argument('--json', default='')
     ap.add_argument('--note', default='')
+    ap.add_argument('--pick', action='append', default=[], help="'<kernel regex>::<op>,<block index>': the launches of the matching kernel with the "
+                    "LARGEST grid (block 2 of the classifier / the only grid of a policy sweep) give roofline.traffic of that workload's (op, block)")
     args = ap.parse_args()
     fe, wr = read_pass(args.fetch_dir, 'FETCH_SIZE'), read_pass(args.write_dir, 'WRITE_SIZE')
     rows = []
@@ -86,6 +88,14 @@ def main():
         from exploring_meta_amd.engine import ModelSpec
         from exploring_meta_amd.utils.roofline import layer_geometry
         wl = bench.WORKLOADS[args.workload]
+        if wl.get('kind') == 'trpo':
+            for spec_ in args.pick:
+                rx, key = spec_.split('::')
+                cand = [(g, f + w) for k, g, nl, f, w in rows if re.search(rx, k) and nl > 0]
+                if cand:
+                    out[f'{args.workload},{key}'] = int(max(cand)[1] * 1e6)
+            json.dump(out, open(args.json, 'w'), indent=1)
+            return
         spec = ModelSpec.anil(wl['ways']) if wl.get('anil') else (
             ModelSpec.mini_imagenet(wl['ways']) if wl['dataset'] == 'min' else ModelSpec.omniglot(wl['ways']))
         T, n = wl['tasks'], wl['ways'] * wl['shots'] * (2 if wl.get('anil') else 1)
@@ -99,6 +109,11 @@ def main():
             nw = 8 if (nterms == 2 and ci == 32) else 4
             return -(-ntiles // (nw * tpw)) * T * cot * nw * 64
 
+        for spec_ in args.pick:
+            rx, key = spec_.split('::')
+            cand = [(g, f + w) for k, g, nl, f, w in rows if re.search(rx, k) and nl > 0]
+            if cand:
+                out[f'{args.workload},{key}'] = int(max(cand)[1] * 1e6)
         for k, g, nl, f, w in rows:
             m = re.match(r'conv3x3_s1_mfma_kernel<(\d+), (\d), (\d), (\d)>', k)
             if not (m and (m.group(2), m.group(3), m.group(4)) in CONV_OPS):
