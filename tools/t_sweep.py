@@ -22,11 +22,14 @@ def main():
     ap.add_argument('--tasks', default='1,2,4,8,16,32,64')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--out', default='')
+    ap.add_argument('--no-overlap', action='store_true', help='weight gradients on the main stream (isolated kernel durations in a trace)')
     args = ap.parse_args()
     wl = bench.WORKLOADS[args.workload]
     spec = ModelSpec.anil(wl['ways']) if wl.get('anil') else (
         ModelSpec.mini_imagenet(wl['ways']) if wl['dataset'] == 'min' else ModelSpec.omniglot(wl['ways']))
     eng = MetaEngine(spec)
+    if args.no_overlap:
+        eng.set_overlap(False)
     run = eng.meta_batch_anil if wl.get('anil') else eng.meta_batch
     theta = bench.init_theta(spec).cuda()
     rows = []
