@@ -297,9 +297,11 @@ class _SurrogateContext:
         else:
             self.sup = {k: torch.stack([d[k] for d in sups]).contiguous() for k in ('states', 'actions', 'adv', 'count')}
         self.engine = policy.engine()
-        thetas = torch.stack([p.flat() for p in iter_policies])
+        # the stored old policies' parameters as ONE gather ([tasks, P], engine order: sigma first) and their scales from its first columns
+        # (per-policy flat() / clamp / exp launches were ~80 of the ~100 launches of this constructor)
+        thetas = torch.cat([q.detach().reshape(-1).float() for p in iter_policies for q in p._engine_params()]).view(len(iter_policies), -1)
         self.old_loc = self.engine.forward(thetas, self.qry['states'])
-        self.old_scale = torch.stack([torch.exp(torch.clamp(p.sigma.detach(), min=np.log(1e-6))) for p in iter_policies]).float().contiguous()
+        self.old_scale = torch.exp(torch.clamp(thetas[:, :A], min=float(np.log(1e-6)))).contiguous()
         self.inner_lr = params['inner_lr']
 
     # Multi-GPU (TRPO): every rank holds a shard of the task list; the mean over tasks of (loss, kl, grad) and
