@@ -134,13 +134,27 @@ def _device_batch(replay_list, S, A, dev):
     lens = [int(r['states'].shape[0]) for r in replay_list]
     B = max(lens)
 
+    ragged = any(n != B for n in lens)
+    if ragged:          # one row index for all fields: replay r's rows, then the appended zero row for its padding
+        total = sum(lens)
+        idx = np.full((len(lens), B), total, dtype=np.int64)
+        off = 0
+        for i, n in enumerate(lens):
+            idx[i, :n] = np.arange(off, off + n)
+            off += n
+        idx = torch.from_numpy(idx.reshape(-1)).to(dev)
+
     def field(k, width):
         parts = []
         for r, n in zip(replay_list, lens):
             t = r[k] if torch.is_tensor(r[k]) else torch.as_tensor(np.asarray(r[k]))
-            t = t.detach().to(dev, torch.float32).reshape(n, width)
-            parts.append(t if n == B else torch.nn.functional.pad(t, (0, 0, 0, B - n)))
-        return torch.stack(parts).contiguous()
+            parts.append(t.detach().to(dev, torch.float32).reshape(n, width))
+        if not ragged:
+            return torch.stack(parts).contiguous()
+        # ragged replays (episodes that end early): concatenate, append a zero row, gather -- 3 launches per field instead of one
+        # pad per replay
+        flat = torch.nn.functional.pad(torch.cat(parts), (0, 0, 0, 1))
+        return flat.index_select(0, idx).view(len(lens), B, width)
 
     out = dict(states=field('states', S), actions=field('actions', A), next_states=field('next_states', S),
                rewards=field('rewards', 1).reshape(len(lens), B), dones=field('dones', 1).reshape(len(lens), B))
@@ -299,7 +313,10 @@ class _SurrogateContext:
         self.engine = policy.engine()
         # the stored old policies' parameters as ONE gather ([tasks, P], engine order: sigma first) and their scales from its first columns
         # (per-policy flat() / clamp / exp launches were ~80 of the ~100 launches of this constructor)
-        thetas = torch.cat([q.detach().reshape(-1).float() for p in iter_policies for q in p._engine_params()]).view(len(iter_policies), -1)
+        if all(hasattr(p, '_engine_params') for p in iter_policies):
+            thetas = torch.cat([q.detach().reshape(-1).float() for p in iter_policies for q in p._engine_params()]).view(len(iter_policies), -1)
+        else:                                                       # any object with the policy protocol (flat(), sigma first)
+            thetas = torch.stack([p.flat() for p in iter_policies])
         self.old_loc = self.engine.forward(thetas, self.qry['states'])
         self.old_scale = torch.exp(torch.clamp(thetas[:, :A], min=float(np.log(1e-6)))).contiguous()
         self.inner_lr = params['inner_lr']
@@ -387,14 +404,14 @@ def _conjugate_gradient_device(Ax, b, num_iterations, tol, eps):
     r = b.detach().to(torch.float64, copy=True).reshape(-1).contiguous()      # a copy: mi_cg_update overwrites r in place
     x, p = torch.zeros_like(r), r.clone()
     p32 = r.float()
-    rr = torch.zeros(2, dtype=torch.float64, device=dev)
+    rr = torch.zeros(3, dtype=torch.float64, device=dev)          # r.r, last step length, "converged" latch
     rr[0] = torch.dot(r, r)
     for _ in range(num_iterations):
+        # the reference's `if r_dot_new < tol: break` is taken on the device (mi_cg_update_checked): after the break every later
+        # recurrence is a no-op, so the loop needs no host synchronisation per iteration and x is exactly the x at the break
         ap = Ax(p32.to(b.dtype)).detach().float().reshape(-1).contiguous()
         with torch.cuda.device(dev):
-            _lib.check(lib.mi_cg_update(_stream(dev), _ptr(x), _ptr(r), _ptr(p), _ptr(ap), _ptr(rr), _ptr(p32), n, float(eps)))
-        if rr[0].item() < tol:
-            break
+            _lib.check(lib.mi_cg_update_checked(_stream(dev), _ptr(x), _ptr(r), _ptr(p), _ptr(ap), _ptr(rr), _ptr(p32), n, float(eps), float(tol)))
     return x.to(b.dtype).reshape(b.shape)
 
 

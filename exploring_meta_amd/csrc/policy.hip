@@ -661,7 +661,10 @@ extern "C" int mi_trpo_surrogate(mi_policy* p, void* stream, const float* theta,
 // hold the policy's ~10^4 parameters; both dot products are block reductions in a fixed order.
 __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
                                                          const float* __restrict__ ap, double* __restrict__ rr, float* __restrict__ p32,
-                                                         size_t n, double eps) {
+                                                         size_t n, double eps, double tol) {
+  // tol >= 0: the reference's `if r_dot_new < tol: break` is taken ON THE DEVICE -- rr[2] latches "converged" and every later
+  // recurrence of this solve is a no-op, so the host loop needs no synchronisation per iteration (x is exactly the x of the break)
+  if (tol >= 0.0 && rr[2] != 0.0) return;
   __shared__ double red[16];
   __shared__ double bcast;
   const int tid = threadIdx.x;
@@ -696,12 +699,18 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x,
     p[i] = pi;
     p32[i] = (float)pi;
   }
-  if (tid == 0) { rr[0] = rr_new; rr[1] = alpha; }
+  if (tid == 0) { rr[0] = rr_new; rr[1] = alpha; if (tol >= 0.0 && rr_new < tol) rr[2] = 1.0; }
 }
 
 extern "C" int mi_cg_update(void* stream, double* x, double* r, double* p, const float* ap, double* rr, float* p32, size_t n, double eps) {
   if (!x || !r || !p || !ap || !rr || !p32 || n == 0) return MI_ERR_ARG;
-  hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), x, r, p, ap, rr, p32, n, eps);
+  hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), x, r, p, ap, rr, p32, n, eps, -1.0);
+  return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
+}
+extern "C" int mi_cg_update_checked(void* stream, double* x, double* r, double* p, const float* ap, double* rr, float* p32, size_t n, double eps,
+                                    double tol) {
+  if (!x || !r || !p || !ap || !rr || !p32 || n == 0 || tol < 0.0) return MI_ERR_ARG;
+  hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), x, r, p, ap, rr, p32, n, eps, tol);
   return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
 }
 

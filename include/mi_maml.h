@@ -167,6 +167,11 @@ int mi_learner_hvp(mi_engine* e, void* stream, const float* theta, int theta_tas
  *   alpha = rr[0] / (p . ap + eps);  x += alpha p;  r -= alpha ap;  rr_new = r . r;  p = r + (rr_new / rr[0]) p;  rr[0] = rr_new, rr[1] = alpha.
  * x, r, p: fp64 [n];  ap: fp32 [n] (the Fisher-vector product of p32);  p32: fp32 [n], the new p for the next product. */
 int mi_cg_update(void* stream, double* x, double* r, double* p, const float* ap, double* rr, float* p32, size_t n, double eps);
+/* The same with the reference's convergence test `if r_dot_new < tol: break` (cherry conjugate_gradient, rl.py:418) taken on the device:
+ * rr is [3] (rr[2] = 0 on entry of a solve); once rr_new < tol, rr[2] latches to 1 and every later call of the solve leaves x, r, p, p32
+ * untouched -- the host loop runs its fixed number of iterations without synchronising, x is exactly the x at the break. */
+int mi_cg_update_checked(void* stream, double* x, double* r, double* p, const float* ap, double* rr, float* p32, size_t n, double eps,
+                         double tol);
 
 /* Generalised advantage estimation with cherry's LinearValue baseline for a list of replays, one launch (reference
  * core_functions/rl.py:95-110 compute_advantages: ch.td.discount, LinearValue.fit / __call__ (features [s, s^2, t, t^2, t^3, 1],

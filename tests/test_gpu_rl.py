@@ -605,7 +605,7 @@ def test_per_task_losses_on_device_match_host_walk(monkeypatch):
 
 def test_fused_conjugate_gradient_matches_the_plain_loop():
     """mi_cg_update (the recurrences of cherry's conjugate_gradient as one launch per iteration) against the same loop written with
-    torch operations, on a random symmetric positive definite system: same iterates, same early exit."""
+    torch operations, on a random symmetric positive definite system: same iterates, same result at the early exit."""
     from exploring_meta_amd.core_functions import rl as prl
     g = torch.Generator().manual_seed(9)
     n = 700
@@ -622,12 +622,15 @@ def test_fused_conjugate_gradient_matches_the_plain_loop():
 
     got = prl.conjugate_gradient(Ax, b.cuda(), num_iterations=10)
     assert len(calls) == 10 and rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5                 # (fp32 products on two devices)
-    # early exit: a well conditioned system converges below tol before the iteration cap on both paths
+    # early exit: a well conditioned system converges below tol before the iteration cap.  The plain loop breaks; the device loop takes
+    # the break on the device (mi_cg_update_checked latches "converged", later recurrences are no-ops: no host synchronisation per
+    # iteration) -- the iterate returned is the iterate AT the break, whatever the products computed afterwards
     A2 = (torch.eye(n, dtype=torch.float64) * 2.0).float()
+    ref2 = prl.conjugate_gradient(lambda v: A2 @ v, b, num_iterations=10)
     calls.clear()
     A2d = A2.cuda()
-    got2 = prl.conjugate_gradient(lambda v: (calls.append(1), A2d @ v)[1], b.cuda(), num_iterations=10)
-    assert len(calls) == 1 and torch.allclose(got2.cpu(), b / 2.0, rtol=1e-6, atol=1e-7)
+    got2 = prl.conjugate_gradient(lambda v: (calls.append(1), A2d @ v * (1.0 if len(calls) == 1 else 7.0))[1], b.cuda(), num_iterations=10)
+    assert torch.allclose(got2.cpu(), b / 2.0, rtol=1e-6, atol=1e-7) and torch.allclose(got2.cpu(), ref2, rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize('case', ['small_T4_B150', 'ragged_counts', 'cfg5_T20_B2000'])
