@@ -17,7 +17,7 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ x, const flo
 
 // The head runs as two launches so that a 32-task meta-batch fills the chip:
 //   rows kernel   grid (T, ceil(N/4)): one wave per sample row -> `ways` dot products, softmax, prob / dlogits, row loss, row hit
-//   grads kernel  grid (T, ceil(F/256)): one thread per feature column -> dWl[:, i], df[:, i]; chunk 0 also reduces loss, acc, dbl
+//   grads kernel  grid (T, ceil(F/64)): 64 feature columns x 4 row groups per workgroup -> dWl[:, i], df[:, i]; chunk 0 also reduces loss, acc, dbl
 // TANGENT = the R-operator version: rows compute ld = fd wl^T + f wld^T + bld and R{dl}; grads add the second products.
 template <bool TANGENT>
 __global__ __launch_bounds__(256) void head_rows_kernel(HeadArgs a) {
@@ -153,37 +153,53 @@ __global__ __launch_bounds__(256) void head_grads_kernel(HeadArgs a) {
   const float* wl_t = a.wl + (size_t)task * a.pstride;
   const float* wld_t = TANGENT ? a.wld + (size_t)task * a.vstride : nullptr;
   float* dwl_t = a.dwl + (size_t)task * a.gstride;
-  const int i = blockIdx.y * 256 + tid;
-  if (i < F && WY <= 8) {
-    // dwl[w][i] = sum_n a[n][w] f[n][i] (+ b[n][w] fd[n][i]): one pass over the rows, every row's feature loaded once for all ways
+  // 64 feature columns per workgroup, the N rows dealt to 4 thread groups (rows rg, rg+4, ...): every thread has at most
+  // ceil(N/4) rows' features in flight at once (one round trip to memory instead of N/8), partial column sums fold through LDS
+  // in group order, and each group writes df for its own rows.  (One thread per column walking all N rows took 18-24 us whatever
+  // the task count: 4 sequential rounds of loads and N sequential stores.)
+  const int rg = tid >> 6;
+  const int i = blockIdx.y * 64 + (tid & 63);
+  float* s_red = sm + (TANGENT ? 2 : 1) * N * WY;   // [3][8][64] partial sums of groups 1..3
+  if (WY <= 8) {
     float dw[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w) dw[w] = 0.f;
-    for (int n0 = 0; n0 < N; n0 += 8) {              // 8 rows' features in flight per round; same accumulation order
-      float fv[8], fdv[8];
+    constexpr int RMAX = 8;                           // rows per thread and round
+    if (i < F) {
+      for (int n0 = rg; n0 < N; n0 += 4 * RMAX) {
+        float fv[RMAX], fdv[RMAX];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool ok = n0 + u < N;
-        fv[u] = ok ? f_t[(size_t)(n0 + u) * F + i] : 0.f;
-        fdv[u] = (TANGENT && fd_t && ok) ? fd_t[(size_t)(n0 + u) * F + i] : 0.f;
-      }
+        for (int u = 0; u < RMAX; ++u) {
+          const int n = n0 + 4 * u;
+          const bool ok = n < N;
+          fv[u] = ok ? f_t[(size_t)n * F + i] : 0.f;
+          fdv[u] = (TANGENT && fd_t && ok) ? fd_t[(size_t)n * F + i] : 0.f;
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int n = n0 + u;
-        if (n >= N) break;
+        for (int u = 0; u < RMAX; ++u) {
+          const int n = n0 + 4 * u;
+          if (n >= N) break;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
-          if (w < WY) {
-            dw[w] = fmaf(s_a[n * WY + w], fv[u], dw[w]);
-            if (TANGENT && fd_t) dw[w] = fmaf(s_b[n * WY + w], fdv[u], dw[w]);
+          for (int w = 0; w < 8; ++w) {
+            if (w < WY) {
+              dw[w] = fmaf(s_a[n * WY + w], fv[u], dw[w]);
+              if (TANGENT && fd_t) dw[w] = fmaf(s_b[n * WY + w], fdv[u], dw[w]);
+            }
           }
         }
       }
     }
+    if (rg > 0) {
 #pragma unroll
-    for (int w = 0; w < 8; ++w)
-      if (w < WY) dwl_t[(size_t)w * F + i] = dw[w];
-    if (a.df) {                                    // df[n][i] = sum_w a[n][w] wl[w][i] (+ b[n][w] wld[w][i]): weights in registers
+      for (int w = 0; w < 8; ++w) s_red[((rg - 1) * 8 + w) * 64 + (tid & 63)] = dw[w];
+    }
+    __syncthreads();
+    if (rg == 0 && i < F) {
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+        if (w < WY) dwl_t[(size_t)w * F + i] = ((dw[w] + s_red[(0 * 8 + w) * 64 + tid]) + s_red[(1 * 8 + w) * 64 + tid]) + s_red[(2 * 8 + w) * 64 + tid];
+    }
+    if (a.df && i < F) {                              // df[n][i] = sum_w a[n][w] wl[w][i] (+ b[n][w] wld[w][i]): weights in registers
       float wv[8], wdv[8];
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256) void head_grads_kernel(HeadArgs a) {
         wdv[w] = (TANGENT && w < WY) ? wld_t[(size_t)w * F + i] : 0.f;
       }
       float* df_t = a.df + (size_t)task * N * F;
-      for (int n = 0; n < N; ++n) {
+      for (int n = rg; n < N; n += 4) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(256) void head_grads_kernel(HeadArgs a) {
         df_t[(size_t)n * F + i] = s;
       }
     }
-  } else if (i < F) {
+  } else if (i < F && rg == 0) {
     for (int w = 0; w < WY; ++w) {                 // dwl[w][i] = sum_n a[n][w] f[n][i] (+ b[n][w] fd[n][i])
       float s = 0.f;
       for (int n = 0; n < N; ++n) {
@@ -274,8 +290,8 @@ hipError_t launch_head_fwd_bwd(hipStream_t st, const HeadArgs& a, int tasks, int
   if (a.ways > 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(head_rows_kernel<false>, dim3(tasks, ceil_div(a.n, 4)), dim3(256), 0, st, a);
   if (with_grad) {     // the gradient launch also folds the row losses / hits into loss[t], acc[t]
-    const size_t sm = (size_t)(a.n * a.ways) * sizeof(float);
-    hipLaunchKernelGGL(head_grads_kernel<false>, dim3(tasks, ceil_div(a.feat, 256)), dim3(256), sm, st, a);
+    const size_t sm = (size_t)(a.n * a.ways + 3 * 8 * 64) * sizeof(float);
+    hipLaunchKernelGGL(head_grads_kernel<false>, dim3(tasks, ceil_div(a.feat, 64)), dim3(256), sm, st, a);
   } else {
     hipLaunchKernelGGL(head_reduce_kernel, dim3(ceil_div(tasks, 64)), dim3(64), 0, st, a.rowloss, a.rowhit, tasks, a.n, a.loss, a.acc);
   }
@@ -284,15 +300,15 @@ hipError_t launch_head_fwd_bwd(hipStream_t st, const HeadArgs& a, int tasks, int
 hipError_t launch_head_tangent(hipStream_t st, const HeadArgs& a, int tasks) {
   if (a.ways > 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(head_rows_kernel<true>, dim3(tasks, ceil_div(a.n, 4)), dim3(256), 0, st, a);
-  const size_t sm = (size_t)(2 * a.n * a.ways) * sizeof(float);
-  hipLaunchKernelGGL(head_grads_kernel<true>, dim3(tasks, ceil_div(a.feat, 256)), dim3(256), sm, st, a);
+  const size_t sm = (size_t)(2 * a.n * a.ways + 3 * 8 * 64) * sizeof(float);
+  hipLaunchKernelGGL(head_grads_kernel<true>, dim3(tasks, ceil_div(a.feat, 64)), dim3(256), sm, st, a);
   return hipGetLastError();
 }
 // Backward of the linear head from caller-supplied dlogits (a.dl): dWl, dbl, df.  Used by the step-wise learner whose loss
 // is computed outside the engine (rc_vision.py:68-70 scales it, cl_vision.py:58-59 does not).
 hipError_t launch_head_grads(hipStream_t st, const HeadArgs& a, int tasks) {
-  const size_t sm = (size_t)(a.n * a.ways) * sizeof(float);
-  hipLaunchKernelGGL(head_grads_kernel<false>, dim3(tasks, ceil_div(a.feat, 256)), dim3(256), sm, st, a);
+  const size_t sm = (size_t)(a.n * a.ways + 3 * 8 * 64) * sizeof(float);
+  hipLaunchKernelGGL(head_grads_kernel<false>, dim3(tasks, ceil_div(a.feat, 64)), dim3(256), sm, st, a);
   return hipGetLastError();
 }
 hipError_t launch_spatial_mean(hipStream_t st, const float* p, float* f, int rows, int hw, int c) {
