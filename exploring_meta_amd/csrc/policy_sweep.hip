@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     const float* dv = a.dir + (size_t)t * a.dstride;
     typedef float floatx2 __attribute__((ext_vector_type(2)));
     if ((((size_t)(th + a.o_w2) | (size_t)(dv + a.o_w2)) & 7) == 0) {      // 8-byte loads where both matrices are 8-byte aligned
-#pragma unroll 10
-      for (int e = 2 * tid; e < HH; e += 512) {
+#pragma unroll 20
+      for (int e = 2 * tid; e < HH; e += 512) {       // H = 100: all 20 + 20 loads of a thread in flight at once
         *reinterpret_cast<floatx2*>(W2s + e) = *reinterpret_cast<const floatx2*>(th + a.o_w2 + e);
         *reinterpret_cast<floatx2*>(W2d + e) = *reinterpret_cast<const floatx2*>(dv + a.o_w2 + e);
       }
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     const int t = slab / spt, row0 = (slab - t * spt) * 32;
     if (t != cur) {
       if (cur >= 0) flush(cur);
+      if (cur < 0) fetch(slab, pf);                 // the first slab's rows fly under the weight load
       if (cur < 0 || a.tstride != 0 || a.dstride != 0) load_weights(t);
       cur = t;
     }
@@ -217,7 +218,6 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     const int cnt = a.count ? a.count[t] : B;
     // ---- stage the slab from the registers its data was fetched into (16-byte coalesced copies of the stored activations; rows past
     // the batch are zero; the per-row scalars)
-    if (slab == slab0) fetch(slab, pf);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int e = tid * 4 + 1024 * i;
