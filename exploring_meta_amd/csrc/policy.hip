@@ -559,6 +559,22 @@ extern "C" int mi_policy_forward(mi_policy* p, void* stream, const float* theta,
   return mlp_forward(p, reinterpret_cast<hipStream_t>(stream), tasks, batch, states, theta, tstride, a);
 }
 
+static int g_policy_fused_fvp = 1;
+static unsigned long long* g_sweep_stamps = nullptr;
+extern "C" int mi_debug_policy_sweep_stamps(void* buf) { g_sweep_stamps = reinterpret_cast<unsigned long long*>(buf); return MI_OK; }
+// 1 (default): the Fisher-vector product of a supported policy runs as three fused sweeps + three folds (policy_sweep.h);
+// 0: the per-layer path (ablation / tests).
+extern "C" int mi_policy_set_fused_fvp(int on) { g_policy_fused_fvp = on ? 1 : 0; return MI_OK; }
+
+static SweepArgs sweep_base(const mi_policy* p, const TrpoPlan& pl, int T, int B) {
+  SweepArgs a{};
+  a.T = T; a.B = B; a.S = p->S; a.A = p->A; a.spt = pl.spt; a.spw = pl.spw; a.slots = pl.slots; a.partial = pl.partial;
+  a.o_sigma = (int)p->o_sigma; a.o_w1 = (int)p->o_w1; a.o_b1 = (int)p->o_b1; a.o_w2 = (int)p->o_w2; a.o_b2 = (int)p->o_b2;
+  a.o_w3 = (int)p->o_w3; a.o_b3 = (int)p->o_b3; a.P = (int)p->P;
+  a.stamps = g_sweep_stamps;
+  return a;
+}
+
 // inner-loss HVP on the cached support pass: hv = H_t v for every task (v, hv: [T][P])
 static int support_hvp(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B, const float* theta, const float* s_states,
                        const float* s_actions, const int32_t* s_count, const float* v, float* hv) {
@@ -644,9 +660,21 @@ extern "C" int mi_trpo_surrogate(mi_policy* p, void* stream, const float* theta,
   if (!grad_out) return MI_OK;
   rc = mlp_backward(p, st, T, B, q_states, pl.thetap, P, pl.qa, pl.q_dmu, pl.q_d2, pl.q_d1, pl.q);   // q_t = grad S_t(theta'_t)
   if (rc) return rc;
-  rc = support_hvp(p, st, pl, T, B, theta, s_states, s_actions, s_count, pl.q, pl.hv);
-  if (rc) return rc;
-  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.q, P, pl.hv, inner_lr, (int)P, pl.tmpP);
+  if (g_policy_fused_fvp && sweep_supported(p) && pl.partial) {
+    // (I - lr H_t) q_t as ONE fused sweep over the support pass (direction q_t per task) + fold, instead of ~10 per-layer launches
+    SweepArgs hs = sweep_base(p, pl, T, B);
+    hs.x = s_states; hs.act = s_actions; hs.h1 = pl.sa.h1; hs.h2 = pl.sa.h2; hs.mu = pl.sa.mu; hs.coef = pl.s_coef; hs.dmu = pl.s_dmu;
+    hs.d2 = pl.s_d2; hs.count = s_count; hs.theta = theta; hs.tstride = 0; hs.dir = pl.q; hs.dstride = P;
+    PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, true));
+    FoldArgs f{};
+    f.partial = pl.partial; f.slots = pl.slots; f.spt = pl.spt; f.spw = pl.spw; f.T = T; f.P = (int)P; f.lr = inner_lr;
+    f.o_sigma = (int)p->o_sigma; f.A = p->A; f.mode = 2; f.out = pl.tmpP; f.w = pl.q;
+    PCHK(p, launch_policy_sweep_fold(st, f, T));
+  } else {
+    rc = support_hvp(p, st, pl, T, B, theta, s_states, s_actions, s_count, pl.q, pl.hv);
+    if (rc) return rc;
+    hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, pl.q, P, pl.hv, inner_lr, (int)P, pl.tmpP);
+  }
   hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div((int)P, 256)), dim3(256), 0, st, pl.tmpP, T, (int)P, 1.f / (float)T,
                      (const float*)nullptr, 0.f, grad_out);
   PCHK(p, hipGetLastError());
@@ -712,22 +740,6 @@ extern "C" int mi_cg_update_checked(void* stream, double* x, double* r, double* 
   if (!x || !r || !p || !ap || !rr || !p32 || n == 0 || tol < 0.0) return MI_ERR_ARG;
   hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), x, r, p, ap, rr, p32, n, eps, tol);
   return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
-}
-
-static int g_policy_fused_fvp = 1;
-static unsigned long long* g_sweep_stamps = nullptr;
-extern "C" int mi_debug_policy_sweep_stamps(void* buf) { g_sweep_stamps = reinterpret_cast<unsigned long long*>(buf); return MI_OK; }
-// 1 (default): the Fisher-vector product of a supported policy runs as three fused sweeps + three folds (policy_sweep.h);
-// 0: the per-layer path (ablation / tests).
-extern "C" int mi_policy_set_fused_fvp(int on) { g_policy_fused_fvp = on ? 1 : 0; return MI_OK; }
-
-static SweepArgs sweep_base(const mi_policy* p, const TrpoPlan& pl, int T, int B) {
-  SweepArgs a{};
-  a.T = T; a.B = B; a.S = p->S; a.A = p->A; a.spt = pl.spt; a.spw = pl.spw; a.slots = pl.slots; a.partial = pl.partial;
-  a.o_sigma = (int)p->o_sigma; a.o_w1 = (int)p->o_w1; a.o_b1 = (int)p->o_b1; a.o_w2 = (int)p->o_w2; a.o_b2 = (int)p->o_b2;
-  a.o_w3 = (int)p->o_w3; a.o_b3 = (int)p->o_b3; a.P = (int)p->P;
-  a.stamps = g_sweep_stamps;
-  return a;
 }
 
 static int fused_fvp(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B, const float* theta, const float* s_states,
