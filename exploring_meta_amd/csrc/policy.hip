@@ -537,7 +537,7 @@ static void trpo_plan(const mi_policy* p, void* ws, int T, int B, TrpoPlan& pl) 
   pl.g = b.f(TP); pl.thetap = b.f(TP); pl.q = b.f(TP); pl.hv = b.f(TP); pl.u = b.f(TP); pl.w = b.f(TP); pl.tmpP = b.f(TP);
   pl.loss_t = b.f(T); pl.kl_t = b.f(T);
   sweep_geometry(T, B, pl.spt, pl.spw, pl.slots, pl.sweep_grid);
-  pl.partial = sweep_supported(p) ? b.f((size_t)T * pl.slots * p->P) : nullptr;
+  pl.partial = sweep_supported(p) ? b.f((size_t)T * pl.slots * (p->P + 2)) : nullptr;
   pl.bytes = align_up(b.off, 256);
 }
 extern "C" int mi_trpo_workspace_bytes(const mi_policy* p, int tasks, int batch, size_t* bytes) {
@@ -569,6 +569,7 @@ extern "C" int mi_policy_set_fused_fvp(int on) { g_policy_fused_fvp = on ? 1 : 0
 static SweepArgs sweep_base(const mi_policy* p, const TrpoPlan& pl, int T, int B) {
   SweepArgs a{};
   a.T = T; a.B = B; a.S = p->S; a.A = p->A; a.spt = pl.spt; a.spw = pl.spw; a.slots = pl.slots; a.partial = pl.partial;
+  a.pitch = (int)p->P + 2;
   a.o_sigma = (int)p->o_sigma; a.o_w1 = (int)p->o_w1; a.o_b1 = (int)p->o_b1; a.o_w2 = (int)p->o_w2; a.o_b2 = (int)p->o_b2;
   a.o_w3 = (int)p->o_w3; a.o_b3 = (int)p->o_b3; a.P = (int)p->P;
   a.stamps = g_sweep_stamps;
@@ -631,43 +632,70 @@ extern "C" int mi_trpo_surrogate(mi_policy* p, void* stream, const float* theta,
   TrpoPlan pl;
   trpo_plan(p, workspace, T, B, pl);
   if (pl.bytes > workspace_bytes) return pfail(p, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes));
-  // inner step on support at theta (shared)
-  int rc = mlp_forward(p, st, T, B, s_states, theta, 0, pl.sa);
-  if (rc) return rc;
-  PCHK(p, hipMemsetAsync(pl.g, 0, (size_t)T * P * sizeof(float), st));
-  GaussArgs ga{};
-  ga.mu = pl.sa.mu; ga.rho = theta + p->o_sigma; ga.rstride = 0; ga.act = s_actions; ga.adv = s_adv; ga.count = s_count;
-  ga.coef = pl.s_coef; ga.dmu = pl.s_dmu; ga.drho = pl.g + p->o_sigma; ga.gstride = P; ga.loss = pl.loss_t;
-  ga.B = B; ga.A = p->A; ga.mode = G_A2C;
-  PCHK(p, gauss(st, T, ga));
-  rc = mlp_backward(p, st, T, B, s_states, theta, 0, pl.sa, pl.s_dmu, pl.s_d2, pl.s_d1, pl.g, pl.s_pre2, pl.s_pre1);
-  if (rc) return rc;
-  hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, theta, (size_t)0, pl.g, inner_lr, (int)P,
-                     pl.thetap);
-  PCHK(p, hipGetLastError());
-  // query at theta'
-  rc = mlp_forward(p, st, T, B, q_states, pl.thetap, P, pl.qa);
-  if (rc) return rc;
-  PCHK(p, hipMemsetAsync(pl.q, 0, (size_t)T * P * sizeof(float), st));
-  GaussArgs gq{};
-  gq.mu = pl.qa.mu; gq.rho = pl.thetap + p->o_sigma; gq.rstride = P; gq.act = q_actions; gq.adv = q_adv; gq.count = q_count;
-  gq.old_loc = old_loc; gq.old_scale = old_scale; gq.coef = pl.q_coef; gq.dmu = pl.q_dmu; gq.drho = pl.q + p->o_sigma;
-  gq.gstride = P; gq.loss = pl.loss_t; gq.kl = pl.kl_t; gq.B = B; gq.A = p->A; gq.mode = G_SURROGATE;
-  PCHK(p, gauss(st, T, gq));
-  hipLaunchKernelGGL(mean_tasks_kernel, dim3(1), dim3(64), 0, st, pl.loss_t, T, 1, 1.f / (float)T, (const float*)nullptr, 0.f, loss_out);
-  hipLaunchKernelGGL(mean_tasks_kernel, dim3(1), dim3(64), 0, st, pl.kl_t, T, 1, 1.f / (float)T, (const float*)nullptr, 0.f, kl_out);
-  PCHK(p, hipGetLastError());
-  if (!grad_out) return MI_OK;
-  rc = mlp_backward(p, st, T, B, q_states, pl.thetap, P, pl.qa, pl.q_dmu, pl.q_d2, pl.q_d1, pl.q);   // q_t = grad S_t(theta'_t)
-  if (rc) return rc;
+  int rc = MI_OK;
+  const bool fused = g_policy_fused_fvp && sweep_supported(p) && pl.partial;
+  if (fused) {
+    // inner step and query pass as two PRIMAL sweeps (forward + loss + backward of a pass in one launch, leaving the activations and
+    // cotangents the Hessian-vector / Fisher sweeps read) instead of ~22 per-layer launches
+    SweepArgs sp = sweep_base(p, pl, T, B);
+    sp.x = s_states; sp.act = s_actions; sp.adv = s_adv; sp.count = s_count; sp.theta = theta; sp.tstride = 0; sp.surrogate = 0;
+    sp.h1_out = pl.sa.h1; sp.h2_out = pl.sa.h2; sp.mu_out = pl.sa.mu; sp.dmu_out = pl.s_dmu; sp.d2_out = pl.s_d2; sp.coef_out = pl.s_coef;
+    PCHK(p, launch_policy_sweep(st, sp, pl.sweep_grid, SW_PRIMAL));
+    FoldArgs f{};
+    f.partial = pl.partial; f.slots = pl.slots; f.spt = pl.spt; f.spw = pl.spw; f.T = T; f.P = (int)P; f.pitch = (int)P + 2; f.lr = inner_lr;
+    f.o_sigma = (int)p->o_sigma; f.A = p->A;
+    f.mode = 0; f.v = theta; f.out = pl.thetap;                     // theta'_t = theta - lr g_t
+    PCHK(p, launch_policy_sweep_fold(st, f, T));
+    SweepArgs sq = sweep_base(p, pl, T, B);
+    sq.x = q_states; sq.act = q_actions; sq.adv = q_adv; sq.count = q_count; sq.theta = pl.thetap; sq.tstride = P; sq.surrogate = 1;
+    sq.old_loc = old_loc; sq.old_scale = old_scale; sq.fwd_only = grad_out ? 0 : 1;
+    sq.h1_out = pl.qa.h1; sq.h2_out = pl.qa.h2; sq.mu_out = pl.qa.mu;
+    PCHK(p, launch_policy_sweep(st, sq, pl.sweep_grid, SW_PRIMAL));
+    f.mode = 3; f.out = grad_out ? pl.q : nullptr; f.loss_t = pl.loss_t; f.kl_t = pl.kl_t;      // q_t = grad S_t(theta'_t); per-task loss / KL
+    PCHK(p, launch_policy_sweep_fold(st, f, T));
+    hipLaunchKernelGGL(mean_tasks_kernel, dim3(1), dim3(64), 0, st, pl.loss_t, T, 1, 1.f / (float)T, (const float*)nullptr, 0.f, loss_out);
+    hipLaunchKernelGGL(mean_tasks_kernel, dim3(1), dim3(64), 0, st, pl.kl_t, T, 1, 1.f / (float)T, (const float*)nullptr, 0.f, kl_out);
+    PCHK(p, hipGetLastError());
+    if (!grad_out) return MI_OK;
+  } else {
+    // inner step on support at theta (shared)
+    rc = mlp_forward(p, st, T, B, s_states, theta, 0, pl.sa);
+    if (rc) return rc;
+    PCHK(p, hipMemsetAsync(pl.g, 0, (size_t)T * P * sizeof(float), st));
+    GaussArgs ga{};
+    ga.mu = pl.sa.mu; ga.rho = theta + p->o_sigma; ga.rstride = 0; ga.act = s_actions; ga.adv = s_adv; ga.count = s_count;
+    ga.coef = pl.s_coef; ga.dmu = pl.s_dmu; ga.drho = pl.g + p->o_sigma; ga.gstride = P; ga.loss = pl.loss_t;
+    ga.B = B; ga.A = p->A; ga.mode = G_A2C;
+    PCHK(p, gauss(st, T, ga));
+    rc = mlp_backward(p, st, T, B, s_states, theta, 0, pl.sa, pl.s_dmu, pl.s_d2, pl.s_d1, pl.g, pl.s_pre2, pl.s_pre1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(axpy_bcast_kernel, dim3(ceil_div((int)P, 256), T), dim3(256), 0, st, theta, (size_t)0, pl.g, inner_lr, (int)P,
+                       pl.thetap);
+    PCHK(p, hipGetLastError());
+    // query at theta'
+    rc = mlp_forward(p, st, T, B, q_states, pl.thetap, P, pl.qa);
+    if (rc) return rc;
+    PCHK(p, hipMemsetAsync(pl.q, 0, (size_t)T * P * sizeof(float), st));
+    GaussArgs gq{};
+    gq.mu = pl.qa.mu; gq.rho = pl.thetap + p->o_sigma; gq.rstride = P; gq.act = q_actions; gq.adv = q_adv; gq.count = q_count;
+    gq.old_loc = old_loc; gq.old_scale = old_scale; gq.coef = pl.q_coef; gq.dmu = pl.q_dmu; gq.drho = pl.q + p->o_sigma;
+    gq.gstride = P; gq.loss = pl.loss_t; gq.kl = pl.kl_t; gq.B = B; gq.A = p->A; gq.mode = G_SURROGATE;
+    PCHK(p, gauss(st, T, gq));
+    hipLaunchKernelGGL(mean_tasks_kernel, dim3(1), dim3(64), 0, st, pl.loss_t, T, 1, 1.f / (float)T, (const float*)nullptr, 0.f, loss_out);
+    hipLaunchKernelGGL(mean_tasks_kernel, dim3(1), dim3(64), 0, st, pl.kl_t, T, 1, 1.f / (float)T, (const float*)nullptr, 0.f, kl_out);
+    PCHK(p, hipGetLastError());
+    if (!grad_out) return MI_OK;
+    rc = mlp_backward(p, st, T, B, q_states, pl.thetap, P, pl.qa, pl.q_dmu, pl.q_d2, pl.q_d1, pl.q);   // q_t = grad S_t(theta'_t)
+    if (rc) return rc;
+  }
   if (g_policy_fused_fvp && sweep_supported(p) && pl.partial) {
     // (I - lr H_t) q_t as ONE fused sweep over the support pass (direction q_t per task) + fold, instead of ~10 per-layer launches
     SweepArgs hs = sweep_base(p, pl, T, B);
     hs.x = s_states; hs.act = s_actions; hs.h1 = pl.sa.h1; hs.h2 = pl.sa.h2; hs.mu = pl.sa.mu; hs.coef = pl.s_coef; hs.dmu = pl.s_dmu;
     hs.d2 = pl.s_d2; hs.count = s_count; hs.theta = theta; hs.tstride = 0; hs.dir = pl.q; hs.dstride = P;
-    PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, true));
+    PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, SW_HVP));
     FoldArgs f{};
-    f.partial = pl.partial; f.slots = pl.slots; f.spt = pl.spt; f.spw = pl.spw; f.T = T; f.P = (int)P; f.lr = inner_lr;
+    f.partial = pl.partial; f.slots = pl.slots; f.spt = pl.spt; f.spw = pl.spw; f.T = T; f.P = (int)P; f.pitch = (int)P + 2; f.lr = inner_lr;
     f.o_sigma = (int)p->o_sigma; f.A = p->A; f.mode = 2; f.out = pl.tmpP; f.w = pl.q;
     PCHK(p, launch_policy_sweep_fold(st, f, T));
   } else {
@@ -750,22 +778,22 @@ static int fused_fvp(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B, c
   hs.x = s_states; hs.act = s_actions; hs.h1 = pl.sa.h1; hs.h2 = pl.sa.h2; hs.mu = pl.sa.mu; hs.coef = pl.s_coef; hs.dmu = pl.s_dmu;
   hs.d2 = pl.s_d2; hs.count = s_count; hs.theta = theta; hs.tstride = 0;
   FoldArgs f{};
-  f.partial = pl.partial; f.slots = pl.slots; f.spt = pl.spt; f.spw = pl.spw; f.T = T; f.P = P; f.v = v; f.lr = inner_lr;
+  f.partial = pl.partial; f.slots = pl.slots; f.spt = pl.spt; f.spw = pl.spw; f.T = T; f.P = P; f.pitch = P + 2; f.v = v; f.lr = inner_lr;
   f.damping = damping; f.o_sigma = (int)p->o_sigma; f.A = p->A;
   // A: u_t = v - lr H_t v
   hs.dir = v; hs.dstride = 0;
-  PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, true));
+  PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, SW_HVP));
   f.mode = 0; f.out = pl.u;
   PCHK(p, launch_policy_sweep_fold(st, f, T));
   // B: w_t = F_t u_t over the query pass at theta'_t
   SweepArgs fs = sweep_base(p, pl, T, B);
   fs.x = q_states; fs.h1 = pl.qa.h1; fs.h2 = pl.qa.h2; fs.count = q_count; fs.theta = pl.thetap; fs.tstride = P; fs.dir = pl.u; fs.dstride = P;
-  PCHK(p, launch_policy_sweep(st, fs, pl.sweep_grid, false));
+  PCHK(p, launch_policy_sweep(st, fs, pl.sweep_grid, SW_FISHER));
   f.mode = 1; f.out = pl.w; f.thetap = pl.thetap; f.u = pl.u;
   PCHK(p, launch_policy_sweep_fold(st, f, T));
   // C: out = mean_t (w_t - lr H_t w_t) + damping v
   hs.dir = pl.w; hs.dstride = P;
-  PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, true));
+  PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, SW_HVP));
   f.mode = 2; f.out = pl.tmpP; f.w = pl.w;
   PCHK(p, launch_policy_sweep_fold(st, f, T));
   hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, pl.tmpP, T, P, 1.f / (float)T, v, damping, out);

@@ -20,6 +20,8 @@
 #include "mi_common.h"
 
 #define LOG_EPS (-13.815510557964274f)   // log(1e-6), policies.py:14,51
+#define HALF_LOG_2PI 0.9189385332046727f
+enum { SW_HVP = 0, SW_FISHER = 1, SW_PRIMAL = 2 };
 
 #define SW_MAX_S 4
 #define SW_MAX_A 6
@@ -36,7 +38,15 @@ struct SweepArgs {
   const int32_t* count;  // [T] valid rows (null: B)
   const float* theta; size_t tstride;   // parameters of the pass (stride 0 = shared by all tasks)
   const float* dir; size_t dstride;     // direction of the product
-  float* partial;        // [T][slots][P]
+  float* partial;        // [T][slots][pitch], pitch = P + 2 (the primal sweep's loss / KL partial sums ride behind the gradient)
+  int pitch;
+  // primal sweep (SW_PRIMAL): forward + loss + backward of the pass in one go, leaving what the later sweeps read
+  const float* adv;      // [T][B]
+  const float* old_loc;  // [T][B][A]   surrogate only
+  const float* old_scale;   // [T][A]   surrogate only
+  int surrogate;         // 0: L = -mean(logp adv) (rl.py:358); 1: L = -mean(exp(logp - logp_old) adv), KL(new || old) (rl.py:459-469)
+  int fwd_only;          // loss / KL only (line-search evaluations of the query pass): no backward, gradient partials are zero
+  float *h1_out, *h2_out, *mu_out, *dmu_out, *d2_out, *coef_out;     // [T][B][.] stores of the pass (null: not kept)
   int T, B, S, A, spt, spw, slots;      // spt = slabs per task, spw = slabs per workgroup
   int o_sigma, o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, P;
   unsigned long long* stamps;   // debug: shader-clock stamps of workgroup 0's stages (null in production)
@@ -46,8 +56,10 @@ struct SweepArgs {
 //   mode 0 (after A): out[t][p] = v[p] - lr sum                          (u_t)
 //   mode 1 (after B): out[t][p] = sum; sigma slots: the Gaussian Fisher's 2 u / D where sigma is not clamped   (w_t)
 //   mode 2 (after C): out[t][p] = w[t][p] - lr sum    (the caller takes the mean over tasks and adds damping v)
+//   mode 3 (primal)  : out[t][p] = sum (the pass's gradient); loss_t[t], kl_t[t] = the two extra slots
 struct FoldArgs {
-  const float* partial; int slots, spt, spw, T, P;
+  const float* partial; int slots, spt, spw, T, P, pitch;
+  float *loss_t, *kl_t;    // mode 3: per-task loss / KL sums of a primal sweep
   const float* v;          // [P]
   const float* w;          // [T][P]   (mode 2)
   const float* thetap;     // [T][P]   (mode 1: rho of theta')
@@ -60,5 +72,5 @@ struct FoldArgs {
 // launchers (policy_sweep.hip, built WITHOUT -amdgpu-mfma-vgpr-form: the sweep keeps its 80 accumulator registers in the AGPR half
 // of the register file, where only MFMAs reach them, and all 256 architectural VGPRs for operands, prefetch and vector work)
 bool policy_sweep_supported(int act_relu, int h1, int h2, int s, int a);
-hipError_t launch_policy_sweep(hipStream_t st, const SweepArgs& a, int grid, bool hvp);
+hipError_t launch_policy_sweep(hipStream_t st, const SweepArgs& a, int grid, int mode);      // mode = SW_*
 hipError_t launch_policy_sweep_fold(hipStream_t st, const FoldArgs& f, int tasks);

@@ -35,8 +35,9 @@ __device__ __forceinline__ void mfma_groups(floatx16& acc, LA la, LB lb) {
   }
 }
 
-template <int H, bool HVP>
+template <int H, int MODE>
 __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
+  constexpr bool HVP = MODE == SW_HVP, PRIMAL = MODE == SW_PRIMAL;
   static_assert(H % 4 == 0 && H <= 128 && (H % 8 == 0 || H % 8 == 4), "hidden width");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HH = H * H, SL = 32 * H, KH0 = ((H + 7) / 8) * 4, NG = KH0 / 4, MT = (H + 31) / 32;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     for (int r = 0; r < 16; ++r) accW2[m][r] = 0.f;
   // vector-stage mapping: thread = (column col of the hidden layer, half of the slab's rows)
   const int col = tid & 127, rb = (tid >> 7) * 16;
-  float accW3[SW_MAX_A], accb3 = 0.f, accb2 = 0.f, accb1 = 0.f, accW1[SW_MAX_S], accrho[SW_MAX_A];
+  float accW3[SW_MAX_A], accb3 = 0.f, accb2 = 0.f, accb1 = 0.f, accW1[SW_MAX_S], accrho[SW_MAX_A], accloss = 0.f, acckl = 0.f;
 #pragma unroll
   for (int d = 0; d < SW_MAX_A; ++d) accW3[d] = 0.f;
 #pragma unroll
@@ -95,9 +96,12 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
   __syncthreads();
   auto load_weights = [&](int t) {
     const float* th = a.theta + (size_t)t * a.tstride;
-    const float* dv = a.dir + (size_t)t * a.dstride;
+    const float* dv = PRIMAL ? th : a.dir + (size_t)t * a.dstride;      // primal sweep: the "direction" tables hold theta's own W1, b1, b2, b3
     typedef float floatx2 __attribute__((ext_vector_type(2)));
-    if ((((size_t)(th + a.o_w2) | (size_t)(dv + a.o_w2)) & 7) == 0) {      // 8-byte loads where both matrices are 8-byte aligned
+    if (PRIMAL) {
+#pragma unroll 20
+      for (int e = tid; e < HH; e += 256) W2s[e] = th[a.o_w2 + e];
+    } else if ((((size_t)(th + a.o_w2) | (size_t)(dv + a.o_w2)) & 7) == 0) {      // 8-byte loads where both matrices are 8-byte aligned
 #pragma unroll 20
       for (int e = 2 * tid; e < HH; e += 512) {       // H = 100: all 20 + 20 loads of a thread in flight at once
         *reinterpret_cast<floatx2*>(W2s + e) = *reinterpret_cast<const floatx2*>(th + a.o_w2 + e);
@@ -110,13 +114,16 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     for (int e = tid; e < H * S; e += 256) W1d[(e / S) * SW_MAX_S + e % S] = dv[a.o_w1 + e];
     for (int e = tid; e < H; e += 256) { b1d[e] = dv[a.o_b1 + e]; b2d[e] = dv[a.o_b2 + e]; }
     for (int e = tid; e < A * H; e += 256) { W3s[e] = th[a.o_w3 + e]; W3d[e] = dv[a.o_w3 + e]; }
-    if (tid < A) { b3d[tid] = dv[a.o_b3 + tid]; rho[tid] = th[a.o_sigma + tid]; rhod[tid] = dv[a.o_sigma + tid]; }
+    if (tid < A) {
+      b3d[tid] = dv[a.o_b3 + tid]; rho[tid] = th[a.o_sigma + tid];
+      rhod[tid] = PRIMAL ? (a.surrogate ? a.old_scale[(size_t)t * A + tid] : 1.f) : dv[a.o_sigma + tid];      // primal: the OLD policy's scale
+    }
   };
 
   // one partial [P] per (workgroup, task): slot = this workgroup's position among the workgroups that touch the task
   auto flush = [&](int t) {
     const int slot = blockIdx.x - (t * spt) / a.spw;
-    float* pv = a.partial + ((size_t)t * a.slots + slot) * a.P;
+    float* pv = a.partial + ((size_t)t * a.slots + slot) * a.pitch;
     const int icol = 32 * wave + n;
     // the 64 store addresses hang off ONE lane offset that the compiler cannot see through: otherwise it hoists 64 loop-invariant
     // 64-bit offsets out of the slab loop and the kernel spills (measured: 261 spilled registers)
@@ -146,10 +153,11 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       for (int d = 0; d < SW_MAX_A; ++d) t3[((tid >> 7) * (SW_MAX_A + 1) + d) * 128 + col] = accW3[d];
       t3[((tid >> 7) * (SW_MAX_A + 1) + SW_MAX_A) * 128 + col] = accb2;
     }
-    float* t2 = h1d;                                   // [32][A]
+    float* t2 = h1d;                                   // [32][A], then [32][2] loss / KL partials of the primal sweep
     if (tid < 32) {
 #pragma unroll
       for (int d = 0; d < SW_MAX_A; ++d) if (d < A) t2[tid * SW_MAX_A + d] = accrho[d];
+      if (PRIMAL) { t2[32 * SW_MAX_A + 2 * tid] = accloss; t2[32 * SW_MAX_A + 2 * tid + 1] = acckl; }
     }
     __syncthreads();
     if (tid < H) {
@@ -161,13 +169,18 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       for (int r = 0; r < 32; ++r) s += t2[r * SW_MAX_A + tid];
       pv[a.o_sigma + tid] = s;
     }
+    if (PRIMAL && tid >= 64 && tid < 66) {
+      float s = 0.f;
+      for (int r = 0; r < 32; ++r) s += t2[32 * SW_MAX_A + 2 * r + (tid - 64)];
+      pv[a.P + (tid - 64)] = s;
+    }
     for (int idx = tid; idx < A * H; idx += 256) {
       const int d = idx / H, k = idx - d * H;
       pv[a.o_w3 + idx] = t3[d * 128 + k] + t3[((SW_MAX_A + 1) + d) * 128 + k];
     }
     if (tid < H) pv[a.o_b2 + tid] = t3[SW_MAX_A * 128 + tid] + t3[((SW_MAX_A + 1) + SW_MAX_A) * 128 + tid];
     __syncthreads();
-    accb1 = 0.f; accb2 = 0.f;
+    accb1 = 0.f; accb2 = 0.f; accloss = 0.f; acckl = 0.f;
 #pragma unroll
     for (int d = 0; d < SW_MAX_A; ++d) accW3[d] = 0.f;
 #pragma unroll
@@ -184,22 +197,28 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     const int nv = min(32, B - row0);
     const size_t rbase = (size_t)t * B + row0;
     const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const float* g1 = a.h1 + rbase * H;
-    const float* g2 = a.h2 + rbase * H;
-    const float* g3 = HVP ? a.d2 + rbase * H : nullptr;
+    if (!PRIMAL) {
+      const float* g1 = a.h1 + rbase * H;
+      const float* g2 = a.h2 + rbase * H;
+      const float* g3 = HVP ? a.d2 + rbase * H : nullptr;
 #pragma unroll
-    for (int i = 0; i < NPF; ++i) {
-      const int e = tid * 4 + 1024 * i;
-      const bool ok = e < nv * H;
-      f.v1[i] = ok ? *reinterpret_cast<const floatx4*>(g1 + e) : z4;
-      f.v2[i] = ok ? *reinterpret_cast<const floatx4*>(g2 + e) : z4;
-      if (HVP) f.v3[i] = ok ? *reinterpret_cast<const floatx4*>(g3 + e) : z4;
+      for (int i = 0; i < NPF; ++i) {
+        const int e = tid * 4 + 1024 * i;
+        const bool ok = e < nv * H;
+        f.v1[i] = ok ? *reinterpret_cast<const floatx4*>(g1 + e) : z4;
+        f.v2[i] = ok ? *reinterpret_cast<const floatx4*>(g2 + e) : z4;
+        if (HVP) f.v3[i] = ok ? *reinterpret_cast<const floatx4*>(g3 + e) : z4;
+      }
     }
     f.x = (tid < nv * S) ? a.x[rbase * S + tid] : 0.f;
     f.act = f.mu = f.dmu = f.coef = 0.f;
     if (HVP) {
       if (tid < nv * A) { f.act = a.act[rbase * A + tid]; f.mu = a.mu[rbase * A + tid]; f.dmu = a.dmu[rbase * A + tid]; }
       if (tid < nv) f.coef = a.coef[rbase + tid];           // rows past count[t] are masked at staging (no wait on count here)
+    }
+    if (PRIMAL) {                                           // actions, advantages, the old policy's mean
+      if (tid < nv * A) { f.act = a.act[rbase * A + tid]; if (a.surrogate) f.mu = a.old_loc[rbase * A + tid]; }
+      if (tid < nv) f.coef = a.adv[rbase + tid];
     }
   };
 
@@ -218,20 +237,23 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     const int cnt = a.count ? a.count[t] : B;
     // ---- stage the slab from the registers its data was fetched into (16-byte coalesced copies of the stored activations; rows past
     // the batch are zero; the per-row scalars)
+    if (!PRIMAL) {
 #pragma unroll
-    for (int i = 0; i < NPF; ++i) {
-      const int e = tid * 4 + 1024 * i;
-      if (e < SL) {
-        *reinterpret_cast<floatx4*>(h1s + e) = pf.v1[i];
-        *reinterpret_cast<floatx4*>(h2s + e) = pf.v2[i];
-        if (HVP) *reinterpret_cast<floatx4*>(d2s + e) = pf.v3[i];
+      for (int i = 0; i < NPF; ++i) {
+        const int e = tid * 4 + 1024 * i;
+        if (e < SL) {
+          *reinterpret_cast<floatx4*>(h1s + e) = pf.v1[i];
+          *reinterpret_cast<floatx4*>(h2s + e) = pf.v2[i];
+          if (HVP) *reinterpret_cast<floatx4*>(d2s + e) = pf.v3[i];
+        }
       }
     }
     if (tid < 32 * S) xs[(tid / S) * SW_MAX_S + tid % S] = pf.x;
-    if (HVP) {
-      if (tid < 32 * A) { const int q = (tid / A) * SW_MAX_A + tid % A; acts[q] = pf.act; mus[q] = pf.mu; dmus[q] = pf.dmu; }
+    if (HVP || PRIMAL) {
+      if (tid < 32 * A) { const int q = (tid / A) * SW_MAX_A + tid % A; acts[q] = pf.act; mus[q] = pf.mu; if (HVP) dmus[q] = pf.dmu; }
       if (tid < 32) coefs[tid] = (row0 + tid < cnt) ? pf.coef : 0.f;
     }
+    const size_t rbase = (size_t)t * B + row0;
     const int nv = min(32, B - row0);                 // rows of this slab inside the padded batch
     __syncthreads();
     SW_STAMP(2);
@@ -244,7 +266,13 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
         const int r = rb + j;
         const floatx4 xv = lds4(xs + r * SW_MAX_S);
         const float z = fmaf(xv[3], w1[3], fmaf(xv[2], w1[2], fmaf(xv[1], w1[1], fmaf(xv[0], w1[0], bb))));
-        h1d[r * H + col] = h1s[r * H + col] > 0.f ? z : 0.f;
+        if (PRIMAL) {                                  // the layer itself: h1 = relu(x W1^T + b1), kept for the later sweeps
+          const float hv = fmaxf(z, 0.f);
+          h1s[r * H + col] = hv;
+          if (r < nv) a.h1_out[(rbase + r) * H + col] = hv;
+        } else {
+          h1d[r * H + col] = h1s[r * H + col] > 0.f ? z : 0.f;
+        }
       }
     }
     __syncthreads();
@@ -256,9 +284,9 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const int ocol = min(32 * wave + n, H - 1);
 #pragma unroll 1
-      for (int term = 0; term < 2; ++term) {
+      for (int term = 0; term < (PRIMAL ? 1 : 2); ++term) {
         const float* arow = (term == 0 ? h1s : h1d) + n * H + hh * KH0;
-        const float* brow = (term == 0 ? W2d : W2s) + ocol * H + hh * KH0;
+        const float* brow = ((term == 0 && !PRIMAL) ? W2d : W2s) + ocol * H + hh * KH0;
         const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
         mfma_groups<NG>(acc,
                         [&](int j) { return (KH0 + 4 * j >= H && hh) ? z4 : lds4(arow + 4 * j); },     // upper half's k past the end
@@ -270,7 +298,13 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {                 // the ReLU gate [h2 > 0] is applied by the two readers of h2d (they hold h2 anyway)
           const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          h2d[row * H + o] = acc[r] + bb;
+          if (PRIMAL) {                                // h2 = relu(h1 W2^T + b2)
+            const float hv = fmaxf(acc[r] + bb, 0.f);
+            h2s[row * H + o] = hv;
+            if (row < nv) a.h2_out[(rbase + row) * H + o] = hv;
+          } else {
+            h2d[row * H + o] = acc[r] + bb;
+          }
         }
       }
     }
@@ -287,6 +321,16 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
         const int kq = q + 8 * j;
         if (kq < H / 4) {
           const floatx4 hv = lds4(h2s + r * H + 4 * kq);
+          if (PRIMAL) {                                // mu = h2 W3^T + b3
+#pragma unroll
+            for (int d = 0; d < SW_MAX_A; ++d) {
+              if (d >= A) break;
+              const floatx4 ws = lds4(W3s + d * H + 4 * kq);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) sacc[d] = fmaf(hv[c], ws[c], sacc[d]);
+            }
+            continue;
+          }
           floatx4 hd = lds4(h2d + r * H + 4 * kq);
 #pragma unroll
           for (int c = 0; c < 4; ++c) hd[c] = hv[c] > 0.f ? hd[c] : 0.f;
@@ -308,6 +352,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       float m = b3d[d];
       for (int q = 0; q < 8; ++q) m += red[(d * 8 + q) * 32 + r];
       muds[r * SW_MAX_A + d] = m;
+      if (PRIMAL && a.mu_out && r < nv) a.mu_out[(rbase + r) * A + d] = m;
     }
     __syncthreads();
     SW_STAMP(5);
@@ -315,7 +360,46 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     if (tid < 32) {
       const bool valid = tid < nv && row0 + tid < cnt;
       const float invD = 1.f / (float)A;
-      if (HVP) {
+      if (PRIMAL) {
+        // the loss of the pass per row (reference rl.py:358 / 459-469): its value, dL/dlogp (kept for the Hessian-vector sweeps), the
+        // cotangent of mu the backward starts from, and the sigma gradient
+        const float invB = 1.f / (float)cnt;
+        float lp = 0.f, lpo = 0.f, klb = 0.f;
+#pragma unroll
+        for (int d = 0; d < SW_MAX_A; ++d) {
+          if (d >= A) break;
+          const float rr = fmaxf(rho[d], LOG_EPS), sg = expf(rr);
+          const float df = acts[tid * SW_MAX_A + d] - muds[tid * SW_MAX_A + d];
+          lp += -(df * df) / (2.f * sg * sg) - rr - HALF_LOG_2PI;
+          if (a.surrogate) {
+            const float so = rhod[d], lo = mus[tid * SW_MAX_A + d];
+            const float dfo = acts[tid * SW_MAX_A + d] - lo;
+            lpo += -(dfo * dfo) / (2.f * so * so) - logf(so) - HALF_LOG_2PI;
+            const float vr = (sg / so) * (sg / so), t1 = (muds[tid * SW_MAX_A + d] - lo) / so;
+            klb += 0.5f * (vr + t1 * t1 - 1.f - logf(vr));
+          }
+        }
+        lp *= invD;
+        lpo *= invD;
+        float c = 0.f;
+        if (valid) {
+          const float ad = coefs[tid];
+          if (!a.surrogate) { c = -ad * invB; accloss += c * lp; }
+          else { const float ratio = expf(lp - lpo); c = -ratio * ad * invB; accloss += c; acckl += klb * invB * invD; }
+        }
+        if (a.coef_out && tid < nv) a.coef_out[rbase + tid] = c;
+#pragma unroll
+        for (int d = 0; d < SW_MAX_A; ++d) {
+          if (d >= A) break;
+          const float rp = rho[d];
+          const float rr = fmaxf(rp, LOG_EPS), sg = expf(rr), iv = 1.f / (sg * sg);
+          const float df = acts[tid * SW_MAX_A + d] - muds[tid * SW_MAX_A + d];
+          const float dm = c * invD * df * iv;
+          rdmus[tid * SW_MAX_A + d] = dm;
+          if (a.dmu_out && tid < nv) a.dmu_out[(rbase + tid) * A + d] = dm;
+          if (rp > LOG_EPS) accrho[d] += c * invD * (df * df * iv - 1.f);
+        }
+      } else if (HVP) {
         const float c = coefs[tid];                    // 0 on padding rows
 #pragma unroll
         for (int d = 0; d < SW_MAX_A; ++d) {
@@ -341,12 +425,13 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     SW_STAMP(6);
     // ---- head weight gradient, then r2 = [h2 > 0] (rdmu W3 + dmu W3d) in place of h2d: a thread owns one column and 16 rows, reads
     // its own h2d element before overwriting it (no barrier in between), and sums its rows of r2 for the bias gradient
-    if (tid < A) {
+    const bool bwd = !(PRIMAL && a.fwd_only);        // uniform: a forward-only primal sweep stops after the loss
+    if (bwd && tid < A) {
       float s = 0.f;
       for (int r = 0; r < 32; ++r) s += rdmus[r * SW_MAX_A + tid];
       accb3 += s;
     }
-    if (col < H) {
+    if (bwd && col < H) {
       float w3[SW_MAX_A], w3d[SW_MAX_A];
 #pragma unroll
       for (int d = 0; d < SW_MAX_A; ++d) { w3[d] = W3s[d * H + col]; w3d[d] = W3d[d * H + col]; }     // rows past A are zero
@@ -366,6 +451,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
         }
         v = h2v > 0.f ? v : 0.f;
         h2d[r * H + col] = v;
+        if (PRIMAL && a.d2_out && r < nv) a.d2_out[(rbase + r) * H + col] = v;      // dz2 of the pass, for its Hessian-vector sweeps
         accb2 += v;
       }
     }
@@ -374,7 +460,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     if (slab + 1 < slab1) fetch(slab + 1, pf);       // the next slab's data flies under the two matrix stages below
     const float* r2 = h2d;
     // ---- r1 = [h1 > 0] (r2 W2 + d2 W2d) on the matrix pipe; its products with the states (W1, b1 gradients) from the accumulators
-    {
+    if (bwd) {
       floatx16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -411,7 +497,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     }
     SW_STAMP(9);
     // ---- dW2[o][i] += sum_rows r2[row][o] h1[row][i] + d2[row][o] h1d[row][i]: M = o (MT tiles), N = this wave's columns, K = rows
-    {
+    if (bwd) {
       const int icol = 32 * wave + n;                  // columns past H read the next row: finite, never stored
 #pragma unroll 1
       for (int term = 0; term < (HVP ? 2 : 1); ++term) {
@@ -438,26 +524,35 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 
 __device__ __forceinline__ float sweep_fold_sum(const FoldArgs& f, int t, int p) {
   const int first = (t * f.spt) / f.spw, last = (t * f.spt + f.spt - 1) / f.spw;
-  const float* pp = f.partial + (size_t)t * f.slots * f.P + p;
+  const float* pp = f.partial + (size_t)t * f.slots * f.pitch + p;
   float s = 0.f;
   const int ns = last - first + 1;
   int k = 0;
   for (; k + 4 <= ns; k += 4) {                       // four slots in flight, summed in slot order
-    const float v0 = pp[(size_t)k * f.P], v1 = pp[(size_t)(k + 1) * f.P], v2 = pp[(size_t)(k + 2) * f.P], v3 = pp[(size_t)(k + 3) * f.P];
+    const float v0 = pp[(size_t)k * f.pitch], v1 = pp[(size_t)(k + 1) * f.pitch], v2 = pp[(size_t)(k + 2) * f.pitch], v3 = pp[(size_t)(k + 3) * f.pitch];
     s += v0; s += v1; s += v2; s += v3;
   }
-  for (; k < ns; ++k) s += pp[(size_t)k * f.P];
+  for (; k < ns; ++k) s += pp[(size_t)k * f.pitch];
   return s;
 }
 __global__ __launch_bounds__(256) void policy_sweep_fold_kernel(FoldArgs f) {
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= f.P) return;
+  if (p >= f.P) {
+    if (f.mode == 3 && p < f.P + 2) {                  // the primal sweep's loss / KL slots
+      const float s = sweep_fold_sum(f, blockIdx.y, p);
+      if (p == f.P && f.loss_t) f.loss_t[blockIdx.y] = s;
+      if (p == f.P + 1 && f.kl_t) f.kl_t[blockIdx.y] = s;
+    }
+    return;
+  }
   const int t = blockIdx.y;
   const float s = sweep_fold_sum(f, t, p);
   if (f.mode == 0) {
     f.out[(size_t)t * f.P + p] = f.v[p] - f.lr * s;
   } else if (f.mode == 2) {
     f.out[(size_t)t * f.P + p] = f.w[(size_t)t * f.P + p] - f.lr * s;
+  } else if (f.mode == 3) {
+    if (f.out) f.out[(size_t)t * f.P + p] = s;
   } else {
     float o = s;
     if (p >= f.o_sigma && p < f.o_sigma + f.A)
@@ -476,22 +571,25 @@ bool policy_sweep_supported(int act_relu, int h1, int h2, int s, int a) {
   return act_relu && h1 == 100 && h2 == 100 && s <= SW_MAX_S && a <= SW_MAX_A;
 }
 
-template <bool HVP>
+template <int MODE>
 static hipError_t launch_sweep_t(hipStream_t st, const SweepArgs& a, int grid) {
   static bool attr_set = false;
   const size_t lds = policy_sweep_lds_bytes<100>();
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_sweep_kernel<100, HVP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_sweep_kernel<100, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((policy_sweep_kernel<100, HVP>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((policy_sweep_kernel<100, MODE>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
-hipError_t launch_policy_sweep(hipStream_t st, const SweepArgs& a, int grid, bool hvp) {
-  return hvp ? launch_sweep_t<true>(st, a, grid) : launch_sweep_t<false>(st, a, grid);
+hipError_t launch_policy_sweep(hipStream_t st, const SweepArgs& a, int grid, int mode) {
+  if (mode == SW_HVP) return launch_sweep_t<SW_HVP>(st, a, grid);
+  if (mode == SW_FISHER) return launch_sweep_t<SW_FISHER>(st, a, grid);
+  if (mode == SW_PRIMAL) return launch_sweep_t<SW_PRIMAL>(st, a, grid);
+  return hipErrorInvalidValue;
 }
 hipError_t launch_policy_sweep_fold(hipStream_t st, const FoldArgs& f, int tasks) {
-  hipLaunchKernelGGL(policy_sweep_fold_kernel, dim3(ceil_div(f.P, 256), tasks), dim3(256), 0, st, f);
+  hipLaunchKernelGGL(policy_sweep_fold_kernel, dim3(ceil_div(f.P + 2, 256), tasks), dim3(256), 0, st, f);
   return hipGetLastError();
 }

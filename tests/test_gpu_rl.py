@@ -654,12 +654,18 @@ def test_fused_fvp_sweeps_match_the_per_layer_path_and_the_oracle(case):
             c[0], c[2] = 97, 33
             d['count'] = c.contiguous()
     th = pol.flat()
-    ctx.evaluate(th, want_grad=True)
     g = torch.Generator(device='cuda').manual_seed(11)
-    outs = {}
+    outs, evals = {}, {}
+    cand = th + 0.01 * torch.sin(torch.arange(th.numel(), device='cuda', dtype=torch.float32))      # a displaced line-search candidate
     try:
         for fused in (0, 1):
             lib.mi_policy_set_fused_fvp(fused)
+            # the surrogate itself: inner step + query pass as two primal sweeps (fused) vs the per-layer launches; then a forward-only
+            # evaluation at a displaced candidate (the line search's call), then back to theta so that the products below see its passes
+            l1, k1, g1 = ctx.evaluate(th, want_grad=True)
+            l2, k2, _ = ctx.evaluate(cand)
+            evals[fused] = (float(l1), float(k1), g1.clone(), float(l2), float(k2))
+            ctx.evaluate(th, want_grad=True)
             res = []
             for k in range(3):
                 v = torch.randn(th.numel(), device='cuda', generator=torch.Generator(device='cuda').manual_seed(20 + k))
@@ -670,6 +676,13 @@ def test_fused_fvp_sweeps_match_the_per_layer_path_and_the_oracle(case):
         lib.mi_policy_set_fused_fvp(1)
     errs = [rel_err(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(outs[1], outs[0])]
     rep = dict(fused_vs_per_layer_rel=errs)
+    (l1a, k1a, g1a, l2a, k2a), (l1b, k1b, g1b, l2b, k2b) = evals[0], evals[1]
+    rep['surrogate_grad_fused_vs_per_layer_rel'] = rel_err(g1b.cpu().numpy(), g1a.cpu().numpy())
+    rep['surrogate_loss_abs_diff'] = [abs(l1a - l1b), abs(l2a - l2b)]
+    rep['kl_abs_diff'] = [abs(k1a - k1b), abs(k2a - k2b)]
+    assert rep['surrogate_grad_fused_vs_per_layer_rel'] < 2e-5
+    assert abs(l1a - l1b) < 1e-6 * max(1.0, abs(l1a)) and abs(l2a - l2b) < 2e-6 * max(1.0, abs(l2a))
+    assert abs(k1a - k1b) < 1e-7 and abs(k2a - k2b) < 1e-6 * max(k2a, 1e-3)
     assert all(torch.isfinite(x).all() for x in outs[1]) and max(errs) < 2e-5, errs
     # deterministic: a repeated fused product is bit-identical (fixed-order folds, no atomics)
     v = torch.randn(th.numel(), device='cuda', generator=torch.Generator(device='cuda').manual_seed(20))
