@@ -196,18 +196,19 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     const int t = slab / spt, row0 = (slab - t * spt) * 32;
     const int nv = min(32, B - row0);
     const size_t rbase = (size_t)t * B + row0;
-    const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
     if (!PRIMAL) {
-      const float* g1 = a.h1 + rbase * H;
-      const float* g2 = a.h2 + rbase * H;
-      const float* g3 = HVP ? a.d2 + rbase * H : nullptr;
+      // raw buffer loads: one descriptor per tensor and slab whose record count is the slab's valid bytes -- rows past the batch read 0
+      // from the hardware range check, no predication (a predicated global load is an exec-mask branch region each)
+      const unsigned bytes = (unsigned)(nv * H * 4);
+      const mi_rsrc r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.h1 + rbase * H), 0, bytes, 0x00020000);
+      const mi_rsrc r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.h2 + rbase * H), 0, bytes, 0x00020000);
+      const mi_rsrc r3 = __builtin_amdgcn_make_buffer_rsrc((void*)((HVP ? a.d2 : a.h2) + rbase * H), 0, bytes, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NPF; ++i) {
-        const int e = tid * 4 + 1024 * i;
-        const bool ok = e < nv * H;
-        f.v1[i] = ok ? *reinterpret_cast<const floatx4*>(g1 + e) : z4;
-        f.v2[i] = ok ? *reinterpret_cast<const floatx4*>(g2 + e) : z4;
-        if (HVP) f.v3[i] = ok ? *reinterpret_cast<const floatx4*>(g3 + e) : z4;
+        const unsigned off = (unsigned)(tid * 16 + 4096 * i);
+        f.v1[i] = buf_ld16(r1, off);
+        f.v2[i] = buf_ld16(r2, off);
+        if (HVP) f.v3[i] = buf_ld16(r3, off);
       }
     }
     f.x = (tid < nv * S) ? a.x[rbase * S + tid] : 0.f;
@@ -486,12 +487,22 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       const int i = 32 * wave + n;
       if (i < H) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const float v = gate[r] > 0.f ? acc[r] : 0.f;
-          accb1 += v;
+        for (int rb8 = 0; rb8 < 16; rb8 += 8) {        // the states of 8 rows in flight (one 16-byte broadcast read per row), then the FMAs
+          floatx4 xv[8];
 #pragma unroll
-          for (int s = 0; s < SW_MAX_S; ++s) if (s < S) accW1[s] = fmaf(v, xs[row * SW_MAX_S + s], accW1[s]);
+          for (int q = 0; q < 8; ++q) {
+            const int r = rb8 + q;
+            xv[q] = lds4(xs + ((r & 3) + 8 * (r >> 2) + 4 * hh) * SW_MAX_S);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = rb8 + q;
+            const float v = gate[r] > 0.f ? acc[r] : 0.f;
+            accb1 += v;
+#pragma unroll
+            for (int s = 0; s < SW_MAX_S; ++s) accW1[s] = fmaf(v, xv[q][s], accW1[s]);       // states past S are zero
+          }
         }
       }
     }
