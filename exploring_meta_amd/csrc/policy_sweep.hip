@@ -442,13 +442,19 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
         const float h2v = h2s[r * H + col], h2raw = h2d[r * H + col];
         const float h2dv = h2v > 0.f ? h2raw : 0.f;
         float v = 0.f;
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int d = 0; d < SW_MAX_A; ++d) {
-          if (d >= A) break;
-          const float rm = rdmus[r * SW_MAX_A + d], dm = HVP ? dmus[r * SW_MAX_A + d] : 0.f;
-          accW3[d] = fmaf(rm, h2v, accW3[d]);
-          v = fmaf(rm, w3[d], v);
-          if (HVP) { accW3[d] = fmaf(dm, h2dv, accW3[d]); v = fmaf(dm, w3d[d], v); }
+        for (int dp = 0; dp < SW_MAX_A / 2; ++dp) {    // action dimensions in pairs: one 8-byte broadcast read per table and pair
+          if (2 * dp >= A) break;
+          const floatx2 rm = *reinterpret_cast<const floatx2*>(rdmus + r * SW_MAX_A + 2 * dp);
+          floatx2 dm = {0.f, 0.f};
+          if (HVP) dm = *reinterpret_cast<const floatx2*>(dmus + r * SW_MAX_A + 2 * dp);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {                // a dimension past A has zero table entries and zero weights: contributes 0
+            accW3[2 * dp + e] = fmaf(rm[e], h2v, accW3[2 * dp + e]);
+            v = fmaf(rm[e], w3[2 * dp + e], v);
+            if (HVP) { accW3[2 * dp + e] = fmaf(dm[e], h2dv, accW3[2 * dp + e]); v = fmaf(dm[e], w3d[2 * dp + e], v); }
+          }
         }
         v = h2v > 0.f ? v : 0.f;
         h2d[r * H + col] = v;
