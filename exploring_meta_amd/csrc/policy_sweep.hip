@@ -263,17 +263,28 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       const floatx4 w1 = lds4(W1d + col * SW_MAX_S);   // rows past S are zero
       const float bb = b1d[col];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int r = rb + j;
-        const floatx4 xv = lds4(xs + r * SW_MAX_S);
-        const float z = fmaf(xv[3], w1[3], fmaf(xv[2], w1[2], fmaf(xv[1], w1[1], fmaf(xv[0], w1[0], bb))));
-        if (PRIMAL) {                                  // the layer itself: h1 = relu(x W1^T + b1), kept for the later sweeps
-          const float hv = fmaxf(z, 0.f);
-          h1s[r * H + col] = hv;
-          if (r < nv) a.h1_out[(rbase + r) * H + col] = hv;
-        } else {
-          h1d[r * H + col] = h1s[r * H + col] > 0.f ? z : 0.f;
+      for (int jb = 0; jb < 16; jb += 8) {             // 8 rows' operands in flight, then the arithmetic
+        floatx4 xv[8];
+        float hv0[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xv[j] = lds4(xs + (rb + jb + j) * SW_MAX_S);
+          if (!PRIMAL) hv0[j] = h1s[(rb + jb + j) * H + col];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = rb + jb + j;
+          const float z = fmaf(xv[j][3], w1[3], fmaf(xv[j][2], w1[2], fmaf(xv[j][1], w1[1], fmaf(xv[j][0], w1[0], bb))));
+          if (PRIMAL) {                                // the layer itself: h1 = relu(x W1^T + b1), kept for the later sweeps
+            const float hv = fmaxf(z, 0.f);
+            h1s[r * H + col] = hv;
+            if (r < nv) a.h1_out[(rbase + r) * H + col] = hv;
+          } else {
+            h1d[r * H + col] = hv0[j] > 0.f ? z : 0.f;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
