@@ -330,26 +330,27 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       for (int d = 0; d < SW_MAX_A; ++d) sacc[d] = 0.f;
 #pragma unroll
       for (int j = 0; j < (H / 4 + 7) / 8; ++j) {
+        // no branch on the chunk index (it differs between the lane halves): a chunk past the row reads the row's last chunk and is
+        // zeroed -- unconditional loads can all be in flight together
         const int kq = q + 8 * j;
-        if (kq < H / 4) {
-          const floatx4 hv = lds4(h2s + r * H + 4 * kq);
+        const bool okq = kq < H / 4;
+        const int kc = okq ? kq : H / 4 - 1;
+        floatx4 hv = lds4(h2s + r * H + 4 * kc);
+        floatx4 hd = PRIMAL ? hv : lds4(h2d + r * H + 4 * kc);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          hd[c] = (okq && hv[c] > 0.f) ? hd[c] : 0.f;
+          hv[c] = okq ? hv[c] : 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < SW_MAX_A; ++d) {
+          if (d >= A) break;
+          const floatx4 ws = lds4(W3s + d * H + 4 * kc);
           if (PRIMAL) {                                // mu = h2 W3^T + b3
 #pragma unroll
-            for (int d = 0; d < SW_MAX_A; ++d) {
-              if (d >= A) break;
-              const floatx4 ws = lds4(W3s + d * H + 4 * kq);
-#pragma unroll
-              for (int c = 0; c < 4; ++c) sacc[d] = fmaf(hv[c], ws[c], sacc[d]);
-            }
-            continue;
-          }
-          floatx4 hd = lds4(h2d + r * H + 4 * kq);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) hd[c] = hv[c] > 0.f ? hd[c] : 0.f;
-#pragma unroll
-          for (int d = 0; d < SW_MAX_A; ++d) {
-            if (d >= A) break;
-            const floatx4 wd = lds4(W3d + d * H + 4 * kq), ws = lds4(W3s + d * H + 4 * kq);
+            for (int c = 0; c < 4; ++c) sacc[d] = fmaf(hv[c], ws[c], sacc[d]);
+          } else {
+            const floatx4 wd = lds4(W3d + d * H + 4 * kc);
 #pragma unroll
             for (int c = 0; c < 4; ++c) sacc[d] = fmaf(hv[c], wd[c], fmaf(hd[c], ws[c], sacc[d]));
           }
