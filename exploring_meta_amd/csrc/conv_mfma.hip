@@ -241,6 +241,10 @@ __device__ __forceinline__ void divmod24(unsigned x, unsigned d, float rd, unsig
   r = (unsigned)rr;
 }
 
+// debug aid: shader-clock stamps of workgroup (0, 0, 0)'s wave 0 (mi_debug_conv_stamps; null in production)
+__device__ unsigned long long* g_conv_stamps = nullptr;
+#define CV_STAMP(k) do { if (cstamp && tid == 0) cstamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+
 template <int CI, int NTERMS, int EPI, int MODE>
 __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s1_mfma_kernel(ConvArgs a) {
   constexpr int NW = ConvWaves<CI, NTERMS>::value, NT = NW * 64, CO = CI;
@@ -264,6 +268,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   }
   const int H = a.g.h, W = a.g.w;
   const int cbase = ct * 32;
+  unsigned long long* cstamp = (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) ? g_conv_stamps : nullptr;
+  CV_STAMP(0);
 
   // ---- stage this task's weights (same layout as the generic kernel): lds[((term*9+tap)*CI + k)*32 + nl]
   constexpr int NQ = NTERMS * 9 * CI * 32 / 4;
@@ -364,8 +370,12 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
 #pragma unroll
   for (int st = 0; st < DEPTH; ++st) issue(cur, st, ring[st % RING]);
   __syncthreads();                                            // weights staged (the first operand loads are already in flight)
+  CV_STAMP(1);
+  int ntile_done = 0;
 
   for (; tile < tile_end; tile += NW) {
+    if (ntile_done == 1) CV_STAMP(2);
+    ++ntile_done;
     const TileSt nxt = decode(tile + NW);
     floatx16 acc;
 #pragma unroll
@@ -467,10 +477,12 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
       }
     }
   }
+  CV_STAMP(3);
   if (EPI != EPI_NONE) {
     double* pb = a.partial + (size_t)task * gridDim.x * 2 * CO;
     stats_block_reduce(s, q, reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase, a.fin, task, bx);
   }
+  CV_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1025,4 +1037,9 @@ hipError_t launch_wgrad_reduce(hipStream_t st, const float* partial, int nchunks
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nelem, 256), tasks), dim3(256), 0, st, partial, nchunks, nelem, out,
                      ostride);
   return hipGetLastError();
+}
+
+extern "C" int mi_debug_conv_stamps(void* buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -2;
 }

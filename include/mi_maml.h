@@ -378,6 +378,9 @@ int mi_policy_set_fused_fvp(int on);
 /* Debug aid: shader-clock stamps (stage id << 56 | s_memtime) of workgroup 0 of every fused sweep into buf (>= 256 u64; the three sweeps of a
  * product overwrite each other: read after the call, last sweep wins); NULL switches it off. */
 int mi_debug_policy_sweep_stamps(void* buf);
+/* Debug aid: s_memtime stamps {start, weights staged, first tile done, tiles done, epilogue done} of workgroup (0,0,0) of every stride-1
+ * conv launch (csrc/conv_mfma.hip) into buf (>= 8 u64, the last launch wins); NULL switches it off. */
+int mi_debug_conv_stamps(void* buf);
 
 /* ANIL-TRPO (rl/anil_trpo.py:104-129, core_functions/rl.py:409-473 with anil=True): the stored old policies were adapted with
  * the body under no_grad (rl.py:381-382) while meta_surrogate_loss re-adapts clone_module(policy) with every parameter
