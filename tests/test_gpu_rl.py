@@ -695,3 +695,53 @@ def test_fused_fvp_sweeps_match_the_per_layer_path_and_the_oracle(case):
         rep['fused_vs_oracle_rel'] = rel_err(outs[1][0].cpu().numpy(), Fvp(v64).detach().numpy())
         assert rep['fused_vs_oracle_rel'] < 1e-3
     report(f'fused_fvp[{case}]', **rep)
+
+
+@pytest.mark.parametrize('S,A,T,B', [(3, 3, 3, 70), (4, 6, 2, 33), (1, 1, 5, 64), (2, 4, 7, 129)])
+def test_fused_policy_sweeps_other_state_and_action_widths(S, A, T, B):
+    """The fused sweeps keep their per-row tables at compile-time pitches (4 states, 6 actions) and walk the action dimensions in
+    pairs: policies with other state / action widths (odd action counts, the maxima, width 1) on synthetic replays, surrogate loss /
+    KL / gradient and three Fisher-vector products against the per-layer path (mi_policy_set_fused_fvp(0)) on the same inputs."""
+    from exploring_meta_amd import _lib
+    from exploring_meta_amd.engine import PolicyEngine
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(100 * S + A)
+    eng = PolicyEngine(S, A, (100, 100), activation='relu')
+    P = eng.param_count
+    rnd = lambda *shape: torch.randn(*shape, device='cuda', generator=g)
+    theta = 0.1 * rnd(P)
+    theta[:A] = torch.linspace(-0.4, 0.3, A, device='cuda')                      # sigma
+    count = torch.randint(B // 2, B + 1, (T,), device='cuda', generator=g, dtype=torch.int32)
+    count[0] = B
+
+    def replay():
+        d = dict(states=rnd(T, B, S).contiguous(), actions=rnd(T, B, A).contiguous(), adv=rnd(T, B).contiguous(), count=count)
+        rows = torch.arange(B, device='cuda')[None, :] >= count[:, None]                  # padding rows are zeros, as the drivers pad
+        for k in ('states', 'actions'):
+            d[k][rows] = 0.0
+        d['adv'][rows] = 0.0
+        return d
+
+    sup, qry = replay(), replay()
+    old_loc = (0.3 * rnd(T, B, A)).contiguous()
+    old_scale = (0.5 + torch.rand(T, A, device='cuda', generator=g)).contiguous()
+    v = [rnd(P) for _ in range(3)]
+    out = {}
+    try:
+        for fused in (0, 1):
+            lib.mi_policy_set_fused_fvp(fused)
+            loss, kl, grad = eng.surrogate(theta, sup, qry, old_loc, old_scale, 0.1, True)
+            fv = [eng.fvp(theta, sup, qry, 0.1, 1e-5, x).clone() for x in v]
+            l2, k2, _ = eng.surrogate(theta + 0.01, sup, qry, old_loc, old_scale, 0.1, False)
+            torch.cuda.synchronize()
+            out[fused] = (float(loss), float(kl), grad.clone(), fv, float(l2), float(k2))
+    finally:
+        lib.mi_policy_set_fused_fvp(1)
+    a, b = out[0], out[1]
+    eg = rel_err(b[2].cpu().numpy(), a[2].cpu().numpy())
+    ef = [rel_err(y.cpu().numpy(), x.cpu().numpy()) for x, y in zip(a[3], b[3])]
+    report(f'fused_sweeps_widths[S{S},A{A},T{T},B{B}]', loss=[a[0], b[0]], kl=[a[1], b[1]], grad_rel=eg, fvp_rel=ef)
+    assert all(torch.isfinite(x).all() for x in [b[2]] + b[3])
+    assert abs(a[0] - b[0]) < 2e-6 * max(1.0, abs(a[0])) and abs(a[1] - b[1]) < 2e-6 * max(1.0, abs(a[1]))
+    assert abs(a[4] - b[4]) < 2e-6 * max(1.0, abs(a[4])) and abs(a[5] - b[5]) < 2e-6 * max(1.0, abs(a[5]))
+    assert eg < 2e-5 and max(ef) < 2e-5, (eg, ef)
