@@ -395,8 +395,7 @@ def conjugate_gradient(Ax, b, num_iterations=10, tol=1e-10, eps=1e-8):
 
 
 def _conjugate_gradient_device(Ax, b, num_iterations, tol, eps):
-    """The same recurrences with the whole loop body after `Ap = Ax(p)` as one launch (mi_cg_update)."""
-    import ctypes as C
+    """The same recurrences with the whole loop body after `Ap = Ax(p)` as one launch (mi_cg_update_checked)."""
     from .. import _lib
     from ..engine import _ptr, _stream
     lib = _lib.load()

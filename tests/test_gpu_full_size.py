@@ -27,7 +27,6 @@ from collections import OrderedDict
 import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
 
 from exploring_meta_amd.engine import MetaEngine, ModelSpec
 from exploring_meta_amd.utils import synthetic

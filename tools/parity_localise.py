@@ -27,7 +27,6 @@ from exploring_meta_amd import _lib  # noqa: E402
 from exploring_meta_amd.engine import MetaEngine, ModelSpec  # noqa: E402
 from exploring_meta_amd.utils import synthetic  # noqa: E402
 from oracle import vision_ref as R  # noqa: E402
-from oracle import kernels_ref as KR  # noqa: E402
 
 
 def rel(a, b):
