@@ -32,7 +32,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from exploring_meta_amd.engine import MetaEngine, ModelSpec  # noqa: E402
-from exploring_meta_amd.sharding import MetaTrainer, shard_range  # noqa: E402
+from exploring_meta_amd.sharding import MetaTrainer, init_process_group, shard_range  # noqa: E402
 from exploring_meta_amd.utils import roofline as RF  # noqa: E402
 from exploring_meta_amd.utils import synthetic  # noqa: E402
 
@@ -575,7 +575,7 @@ def main():
     dist = None
     if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run always go through RCCL (also exercised at N=1)
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        init_process_group(local)               # RCCL; MI_DIST_BACKEND=gloo only to rehearse ranks that share a card
     runner = run_trpo if wl.get('kind') == 'trpo' else run_vision
     line = runner(args, wl, rank, world, local, dist)
     if rank == 0:

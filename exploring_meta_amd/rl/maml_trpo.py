@@ -19,7 +19,7 @@ import torch
 
 from ..core_functions import (DiagNormalPolicy, DiagNormalPolicyANIL, LinearValue, Particles2DRunner, fast_adapt_trpo, meta_optimize_trpo,
                               set_device)
-from ..sharding import shard_range
+from ..sharding import init_process_group, shard_range
 
 params = {
     'inner_lr': 0.1, 'max_path_length': 100, 'adapt_steps': 1, 'adapt_batch_size': 20, 'meta_batch_size': 20,
@@ -32,7 +32,7 @@ def run(p, log=print, anil=False):
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
     torch.cuda.set_device(local)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        init_process_group(local)
     dev = torch.device('cuda', local)
     set_device(dev)
     random.seed(p['seed']); np.random.seed(p['seed']); torch.manual_seed(p['seed'])

@@ -8,6 +8,18 @@ import torch
 import torch.distributed as dist
 
 
+def init_process_group(local_rank):
+    """Join the job `torchrun` described in the environment.  Backend "nccl" (= RCCL) with the rank's device bound up front;
+    ``MI_DIST_BACKEND=gloo`` is for rehearsing N > 1 where ranks must share a card (RCCL refuses two ranks on one GPU): the
+    engine path is the same, only the all-reduce is staged through the host."""
+    import os
+    backend = os.environ.get('MI_DIST_BACKEND', 'nccl')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        dist.init_process_group(backend)
+
+
 def shard_range(num_tasks, rank, world):
     """Contiguous block of the global task list owned by ``rank`` (sizes differ by at most one)."""
     base, rem = divmod(num_tasks, world)

@@ -20,7 +20,7 @@ import torch
 from ..core_functions import MAML, ConvBase
 from ..core_functions.anil import anil_engine, meta_batch_adapt_anil
 from ..core_functions.vision_models import RunningStatsFold
-from ..sharding import reduce_meta_batch, shard_range
+from ..sharding import init_process_group, reduce_meta_batch, shard_range
 from .maml_vision import SyntheticTasks
 
 params = {
@@ -59,7 +59,7 @@ def run(dataset, p, log=print):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        init_process_group(local)
     random.seed(p['seed']); np.random.seed(p['seed']); torch.manual_seed(p['seed']); torch.cuda.manual_seed(p['seed'])
     device = torch.device('cuda', local)
     features, head = build(dataset, p['ways'], p['inner_lr'], device)

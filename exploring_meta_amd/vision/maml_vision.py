@@ -19,7 +19,7 @@ import torch
 
 from ..core_functions import MAML, MiniImagenetCNN, OmniglotCNN, evaluate, meta_batch_adapt
 from ..core_functions.vision_models import RunningStatsFold
-from ..sharding import reduce_meta_batch, shard_range
+from ..sharding import init_process_group, reduce_meta_batch, shard_range
 from ..utils import synthetic
 
 params = {
@@ -50,7 +50,7 @@ def run(dataset, p, first_order=False, log=print):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        init_process_group(local)
     random.seed(p['seed']); np.random.seed(p['seed']); torch.manual_seed(p['seed']); torch.cuda.manual_seed(p['seed'])
     device = torch.device('cuda', local)
     model = (OmniglotCNN(p['ways']) if dataset == 'omni' else MiniImagenetCNN(p['ways'])).to(device)
