@@ -241,13 +241,54 @@ __device__ __forceinline__ void divmod24(unsigned x, unsigned d, float rd, unsig
   r = (unsigned)rr;
 }
 
+// ---- split-bf16 operands (BF variants of the stride-1 kernel) ----------------------------------------------------------------------
+// An fp32 value is the exact sum of three bf16 pieces, x = h + m + l (round-to-nearest pieces of x, x - h, x - h - m; 8 mantissa bits
+// each), so an fp32 product is  ah bh + ah bm + am bh + am bm + ah bl + al bh  up to the three dropped terms (am bl, al bm, al bl:
+// <= 2^-24 |a b| together -- the size of ONE fp32 rounding), each partial product exact in the fp32 accumulator of
+// v_mfma_f32_32x32x16_bf16.  Six 8-pass bf16 MFMAs cover K = 16 where the fp32 pipe needs eight 16-pass ones: 2.7x the matrix rate,
+// provided the 4.5 VALU instructions per split value issue in the MFMAs' shadow (tools/mfma_valu_overlap_probe.hip: they do).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bf16_split2(floatx2 v, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));                    // v_cvt_pk_bf16_f32 (RNE)
+  const floatx2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  const floatx2 r = v - hf;                                                                // exact (v_pk_add_f32)
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  const floatx2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  const floatx2 q = r - mf;                                                                // exact
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
+}
+// A store the compiler's wait-count bookkeeping does not see.  gfx9 counts loads and stores in ONE counter and lets them complete out of
+// order with respect to each other, so with a visible store pending hipcc turns every wait for an operand load into vmcnt(0) -- which also
+// drains the prefetched loads of the next two half-groups, at every tile boundary.  Hidden, the stores only ever make a counted wait
+// longer (loads still complete in issue order among themselves), never shorter; nothing in the kernel reads what they write.
+__device__ __forceinline__ void buf_st_untracked(mi_u32x4 rsrc, unsigned off, float v) {
+  asm volatile("buffer_store_dword %0, %1, %2, 0 offen" : : "v"(v), "v"(off), "s"(rsrc) : "memory");
+}
+struct Bf16Planes { unsigned h[4], m[4], l[4]; };              // 8 values: three bf16x8 operands
+template <int P>
+__device__ __forceinline__ void bf16_split_pair(const floatx4& x, Bf16Planes& p) {       // values 2P, 2P + 1 of the eight (x = their float4)
+  bf16_split2(floatx2{x[(P & 1) * 2], x[(P & 1) * 2 + 1]}, p.h[P], p.m[P], p.l[P]);
+  asm volatile("" : "+v"(p.h[P]), "+v"(p.m[P]), "+v"(p.l[P]));     // computed HERE (instruction selection otherwise sinks the split to its use)
+}
+__device__ __forceinline__ void bf16_split8(const floatx4& x0, const floatx4& x1, Bf16Planes& p) {
+  bf16_split_pair<0>(x0, p); bf16_split_pair<1>(x0, p); bf16_split_pair<2>(x1, p); bf16_split_pair<3>(x1, p);
+}
+#define MI_BF8(q) __builtin_bit_cast(bf16x8, (mi_u32x4{(q)[0], (q)[1], (q)[2], (q)[3]}))
+#define MI_BF_MFMA(x, y, acc) __builtin_amdgcn_mfma_f32_32x32x16_bf16(MI_BF8(x), MI_BF8(y), acc, 0, 0, 0)
+
 // debug aid: shader-clock stamps of workgroup (0, 0, 0)'s wave 0 (mi_debug_conv_stamps; null in production)
 __device__ unsigned long long* g_conv_stamps = nullptr;
+#ifndef MI_CONV_STAMP_TILES
+#define MI_CONV_STAMP_TILES 0
+#endif
 #define CV_STAMP(k) do { if (cstamp && tid == 0) cstamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <int CI, int NTERMS, int EPI, int MODE>
+template <int CI, int NTERMS, int EPI, int MODE, bool BF = false>
 __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s1_mfma_kernel(ConvArgs a) {
   constexpr int NW = ConvWaves<CI, NTERMS>::value, NT = NW * 64, CO = CI;
+  constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -272,7 +313,35 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   CV_STAMP(0);
 
   // ---- stage this task's weights (same layout as the generic kernel): lds[((term*9+tap)*CI + k)*32 + nl]
-  constexpr int NQ = NTERMS * 9 * CI * 32 / 4;
+  // BF: three bf16 planes per weight, in MFMA operand order: 16-B unit ((step*2 + kb)*3 + plane)*64 + lane holds, for lane (h, j),
+  // the 8 values k = cc*32 + h*16 + kb*8 + 0..7 of output channel cbase + j  (step = (term*9 + tap)*NCC + cc)
+  constexpr int NQ = BF ? 0 : NTERMS * 9 * CI * 32 / 4;
+  if constexpr (BF) {
+    mi_u32x4* l4 = reinterpret_cast<mi_u32x4*>(lds);
+    constexpr int NIT = NSTEP * 2 * 64;
+    for (int it = tid; it < NIT; it += NT) {
+      const int ln = it & 63, grp = it >> 6;
+      const int jj = ln & 31, hb = ln >> 5, kb = grp & 1, stp = grp >> 1;
+      const int cc = stp % NCC, tt = stp / NCC, term = tt / 9, tap = tt - term * 9;
+      const int k0 = cc * 32 + hb * 16 + kb * 8;
+      const float* wsrc = a.wt[term] + (size_t)task * a.wstride;
+      floatx4 w0, w1;
+      if (MODE == 0) {
+        const float* src = wsrc + ((size_t)tap * CI + k0) * CO + cbase + jj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { w0[i] = src[(size_t)i * CO]; w1[i] = src[(size_t)(i + 4) * CO]; }
+      } else {
+        const float* src = wsrc + ((size_t)tap * CO + cbase + jj) * CI + k0;
+        w0 = *reinterpret_cast<const floatx4*>(src);
+        w1 = *reinterpret_cast<const floatx4*>(src + 4);
+      }
+      Bf16Planes pw;
+      bf16_split8(w0, w1, pw);
+      l4[(grp * 3 + 0) * 64 + ln] = mi_u32x4{pw.h[0], pw.h[1], pw.h[2], pw.h[3]};
+      l4[(grp * 3 + 1) * 64 + ln] = mi_u32x4{pw.m[0], pw.m[1], pw.m[2], pw.m[3]};
+      l4[(grp * 3 + 2) * 64 + ln] = mi_u32x4{pw.l[0], pw.l[1], pw.l[2], pw.l[3]};
+    }
+  }
 #pragma unroll 3
   for (int qd = tid; qd < NQ; qd += NT) {
     if (MODE == 0) {
@@ -307,6 +376,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   for (int term = 0; term < NTERMS; ++term)
     rin[term] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in[term] + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
   const mi_rsrc rout = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+  const unsigned long long out_addr = (unsigned long long)(a.out + (size_t)task * t_elems);
+  const mi_u32x4 rout_raw = {(unsigned)out_addr, (unsigned)(out_addr >> 32) & 0xffffu, t_bytes, 0x00020000u};   // = rout, as plain words
   mi_rsrc rz = rout;
   float mu_c = 0.f, r_c = 0.f;
   if (EPI == EPI_TSTATS) {
@@ -329,7 +400,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   const unsigned lane_in = (unsigned)(h * 64);
   const unsigned lane_out = (unsigned)(((4 * h) * CO + cbase + j) * 4);
 
-  constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC, DEPTH = 2, RING = DEPTH + 1;
+  constexpr int DEPTH = 2, RING = DEPTH + 1;
   static_assert(NSTEP % RING == 0, "the operand ring must be in phase at every tile boundary");
   const int tile_base = bx * NW * a.tiles_per_wave;
   const int tile_end = min(tile_base + NW * a.tiles_per_wave, a.ntiles);
@@ -339,7 +410,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
 #ifndef MI_CONV_XTILE
 #define MI_CONV_XTILE 1
 #endif
-  struct TileSt { unsigned base; bool rowok[3], colok[3]; };
+  struct TileSt { unsigned base; bool rowok[3], colok[3]; unsigned keep_m, keep_p, offc[3], offe[3]; bool conf_m, conf_p; };
   auto decode = [&](int tl) {
     TileSt t;
     const unsigned pix = (unsigned)(tl * 32 + j);
@@ -351,6 +422,25 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
     t.rowok[0] = valid && oy >= 1u; t.rowok[1] = valid; t.rowok[2] = valid && oy + 1u < (unsigned)H;
     t.colok[0] = ox >= 1u; t.colok[1] = true; t.colok[2] = ox + 1u < (unsigned)W;
     t.base = pix * (unsigned)(CI * 4) + lane_in;
+    if constexpr (BF) {
+      // operands of the horizontal displacements -1 / +1 come from the centre operand one lane over (DPP wave shift); the lanes that take
+      // them from the edge load instead: the tile's first / last pixel, and every pixel in the image's first / last column (the edge
+      // registers are zero there) -- unless that pixel sits in the OTHER edge lane, whose register holds the opposite neighbour (conf_*)
+      // (as bit masks for v_bfi_b32: a v_cndmask_b32 costs four times a plain VALU instruction here, tools/valu_rate_probe.hip)
+      t.keep_m = (!t.colok[0] || j == 0) ? 0u : 0xffffffffu;
+      t.keep_p = (!t.colok[2] || j == 31) ? 0u : 0xffffffffu;
+      asm volatile("" : "+v"(t.keep_m), "+v"(t.keep_p));        // opaque: (x & keep) | (e & ~keep) must stay one v_bfi_b32, not turn back into a select
+      t.conf_m = __builtin_amdgcn_readlane((int)!t.colok[0], 31) != 0;
+      t.conf_p = __builtin_amdgcn_readlane((int)!t.colok[2], 0) != 0;
+      // byte offsets of the centre / edge loads of the three displaced rows (out of range where the row, or the neighbour, is padding)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const bool rok = t.rowok[d];
+        const unsigned row = t.base + (unsigned)((d - 1) * wci);
+        t.offc[d] = rok ? row : MI_OOB;
+        t.offe[d] = (j == 0 && rok && t.colok[0]) ? row - (unsigned)(CI * 4) : ((j == 31 && rok && t.colok[2]) ? row + (unsigned)(CI * 4) : MI_OOB);
+      }
+    }
     return t;
   };
   auto issue = [&](const TileSt& t, int step, floatx4* dst) {
@@ -364,17 +454,56 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
     dst[2] = buf_ld16(rin[term], off + cc * 128 + 32);
     dst[3] = buf_ld16(rin[term], off + cc * 128 + 48);
   };
-  floatx4 ring[RING][4];
+  floatx4 ring[BF ? 1 : RING][4];
   int tile = tile_base + wave;
   TileSt cur = decode(tile);
+  // ---- BF pipeline.  Half-group i of a tile = (term, row displacement, 32-channel chunk cc, k half kb): the lane's 8 values
+  // k = cc*32 + 16h + 8kb + 0..7 of its pixel in the displaced row (centre load, 2 x 16 B) and of the tile's two outside neighbours in
+  // that row (edge load: lanes j = 0 / j = 31 only, everyone else out of range -> zeros, no cache access).  Three MFMA units per half-group
+  // (horizontal displacement 0, -1, +1), six bf16 MFMAs each.  A row is fetched ONCE and shifted across lanes for the two other taps:
+  // a third of the fp32 kernel's per-lane 16-B cache accesses (its L1 runs at 0.77 accesses per clock and CU, tools/conv_l1_probe.py).
+  constexpr int NH = NSTEP / 3 * 2, HRING = 3;               // loads run two half-groups ahead of the split, three ahead of the MFMAs
+  static_assert(NH % HRING == 0 && NH % 2 == 0, "raw ring and plane double buffer must be in phase at every tile boundary");
+  floatx4 rawc[BF ? HRING : 1][2], rawe[BF ? HRING : 1][2];
+  auto hg_term = [](int i) { return i / (6 * NCC); };
+  auto hg_ddy = [](int i) { return (i % (6 * NCC)) / (2 * NCC) - 1; };
+  auto hg_cc = [](int i) { return (i / 2) % NCC; };
+  auto hg_unit = [&](int i, int ddx) {                          // index of the unit's weights in LDS: ((term*9 + tap)*NCC + cc)*2 + kb
+    const int ddy = hg_ddy(i);
+    const int tap = (MODE == 0) ? (ddy + 1) * 3 + (ddx + 1) : (1 - ddy) * 3 + (1 - ddx);
+    return ((hg_term(i) * 9 + tap) * NCC + hg_cc(i)) * 2 + (i & 1);
+  };
+  auto issue_hg = [&](const TileSt& t, int i) {
+    const int ddy = hg_ddy(i), term = hg_term(i);
+    const unsigned offc = t.offc[ddy + 1] + (unsigned)(hg_cc(i) * 128 + (i & 1) * 32);
+    const unsigned offe = t.offe[ddy + 1] + (unsigned)(hg_cc(i) * 128 + (i & 1) * 32);
+    rawc[i % HRING][0] = buf_ld16(rin[term], offc);
+    rawc[i % HRING][1] = buf_ld16(rin[term], offc + 16);
+    rawe[i % HRING][0] = buf_ld16(rin[term], offe);
+    rawe[i % HRING][1] = buf_ld16(rin[term], offe + 16);
+  };
+  if constexpr (BF) {
 #pragma unroll
-  for (int st = 0; st < DEPTH; ++st) issue(cur, st, ring[st % RING]);
+    for (int i = 0; i < HRING; ++i) issue_hg(cur, i);
+  } else {
+#pragma unroll
+    for (int st = 0; st < DEPTH; ++st) issue(cur, st, ring[st % RING]);
+  }
   __syncthreads();                                            // weights staged (the first operand loads are already in flight)
   CV_STAMP(1);
   int ntile_done = 0;
+  Bf16Planes pc[2], pe[2], opm, opp;                           // centre / edge planes (double-buffered over half-groups), shifted operands
+  mi_u32x4 pb[2][3];
+  const mi_u32x4* l4 = reinterpret_cast<const mi_u32x4*>(lds) + lane;
+  if constexpr (BF) {
+    bf16_split8(rawc[0][0], rawc[0][1], pc[0]);
+    bf16_split8(rawe[0][0], rawe[0][1], pe[0]);
+    const int u0 = hg_unit(0, 0);
+    pb[0][0] = l4[(u0 * 3 + 0) * 64]; pb[0][1] = l4[(u0 * 3 + 1) * 64]; pb[0][2] = l4[(u0 * 3 + 2) * 64];
+  }
 
   for (; tile < tile_end; tile += NW) {
-    if (ntile_done == 1) CV_STAMP(2);
+    if (MI_CONV_STAMP_TILES && ntile_done == 1) CV_STAMP(2);   // a (flat) store inside the tile loop makes every operand wait of the first half-groups a vmcnt(0)
     ++ntile_done;
     const TileSt nxt = decode(tile + NW);
     floatx16 acc;
@@ -390,8 +519,81 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
         zpre[r] = buf_ld(rz, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro);
       }
     }
+    if constexpr (BF) {
+      // shifted operand: lane <- the centre planes one lane over, edge / padding lanes <- the edge planes (zero unless lane j = 0 / 31)
+#define MI_SHIFT(dst, P, R, CTRL, SEL)                                                                  \
+      { const unsigned sh_ = (unsigned)__builtin_amdgcn_mov_dpp((int)pc_.P[R], CTRL, 0xf, 0xf, true); \
+        dst.P[R] = (sh_ & SEL) | (pe_.P[R] & ~SEL); }
+#define MI_SHIFT6(dst, A0, A1, CTRL, SEL)                                                               \
+      { MI_SHIFT(dst, A0, 0, CTRL, SEL) MI_SHIFT(dst, A0, 1, CTRL, SEL) MI_SHIFT(dst, A0, 2, CTRL, SEL) MI_SHIFT(dst, A0, 3, CTRL, SEL) \
+        MI_SHIFT(dst, A1, 0, CTRL, SEL) MI_SHIFT(dst, A1, 1, CTRL, SEL)                                  \
+        asm volatile("" : "+v"(dst.A0[0]), "+v"(dst.A0[1]), "+v"(dst.A0[2]), "+v"(dst.A0[3]), "+v"(dst.A1[0]), "+v"(dst.A1[1])); }
+#define MI_SHIFT6B(dst, A1, A2, CTRL, SEL)                                                              \
+      { MI_SHIFT(dst, A1, 2, CTRL, SEL) MI_SHIFT(dst, A1, 3, CTRL, SEL)                                  \
+        MI_SHIFT(dst, A2, 0, CTRL, SEL) MI_SHIFT(dst, A2, 1, CTRL, SEL) MI_SHIFT(dst, A2, 2, CTRL, SEL) MI_SHIFT(dst, A2, 3, CTRL, SEL) \
+        asm volatile("" : "+v"(dst.A1[2]), "+v"(dst.A1[3]), "+v"(dst.A2[0]), "+v"(dst.A2[1]), "+v"(dst.A2[2]), "+v"(dst.A2[3])); }
+#define MI_UNIT(ca, cb, V1, V2, V3, V4)                           \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      acc = MI_BF_MFMA(ca.l, cb[0], acc);                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      V1;                                                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      acc = MI_BF_MFMA(ca.h, cb[2], acc);                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      V2;                                                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      acc = MI_BF_MFMA(ca.m, cb[1], acc);                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      V3;                                                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      acc = MI_BF_MFMA(ca.m, cb[0], acc);                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      V4;                                                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      acc = MI_BF_MFMA(ca.h, cb[1], acc);                         \
+      acc = MI_BF_MFMA(ca.h, cb[0], acc);                         \
+      __builtin_amdgcn_sched_barrier(0);
+#define MI_READB(dst, U) { dst[0] = l4[((U) * 3 + 0) * 64]; dst[1] = l4[((U) * 3 + 1) * 64]; dst[2] = l4[((U) * 3 + 2) * 64]; }
 #pragma unroll
-    for (int step = 0; step < NSTEP; ++step) {
+      for (int i = 0; i < NH; ++i) {
+        // the loads of half-group i + 3 (the raw slot of half-group i was split during half-group i - 1)
+        if (i + HRING < NH) issue_hg(cur, i + HRING); else issue_hg(nxt, i + HRING - NH);
+        const Bf16Planes& pc_ = pc[i & 1];
+        const Bf16Planes& pe_ = pe[i & 1];
+        Bf16Planes& nc = pc[(i + 1) & 1];
+        Bf16Planes& ne = pe[(i + 1) & 1];
+        const floatx4* rc = rawc[(i + 1) % HRING];
+        const floatx4* re = rawe[(i + 1) % HRING];
+        const unsigned selm = cur.keep_m, selp = cur.keep_p;
+        // unit 0: centre tap; meanwhile the -1 operand and the first half of the next half-group's centre split
+        MI_READB(pb[(3 * i + 1) & 1], hg_unit(i, -1));
+        MI_UNIT(pc_, pb[(3 * i) & 1], MI_SHIFT6(opm, h, m, 0x138, selm), MI_SHIFT6B(opm, m, l, 0x138, selm), bf16_split_pair<0>(rc[0], nc),
+                bf16_split_pair<1>(rc[0], nc))
+        if (cur.conf_m) {                                          // rare: the tile's last pixel starts an image row
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { opm.h[r] = j == 31 ? 0u : opm.h[r]; opm.m[r] = j == 31 ? 0u : opm.m[r]; opm.l[r] = j == 31 ? 0u : opm.l[r]; }
+        }
+        // unit 1: tap -1; meanwhile the +1 operand and the second half of the centre split
+        MI_READB(pb[(3 * i + 2) & 1], hg_unit(i, 1));
+        MI_UNIT(opm, pb[(3 * i + 1) & 1], MI_SHIFT6(opp, h, m, 0x130, selp), MI_SHIFT6B(opp, m, l, 0x130, selp), bf16_split_pair<2>(rc[1], nc),
+                bf16_split_pair<3>(rc[1], nc))
+        if (cur.conf_p) {                                          // rare: the tile's first pixel ends an image row
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { opp.h[r] = j == 0 ? 0u : opp.h[r]; opp.m[r] = j == 0 ? 0u : opp.m[r]; opp.l[r] = j == 0 ? 0u : opp.l[r]; }
+        }
+        // unit 2: tap +1; meanwhile the next half-group's edge split
+        MI_READB(pb[(3 * i + 3) & 1], hg_unit((i + 1) % NH, 0));
+        MI_UNIT(opp, pb[(3 * i + 2) & 1], bf16_split_pair<0>(re[0], ne), bf16_split_pair<1>(re[0], ne), bf16_split_pair<2>(re[1], ne),
+                bf16_split_pair<3>(re[1], ne))
+      }
+#undef MI_READB
+#undef MI_UNIT
+#undef MI_SHIFT6B
+#undef MI_SHIFT6
+#undef MI_SHIFT
+    }
+#pragma unroll
+    for (int step = 0; step < (BF ? 0 : NSTEP); ++step) {
       if (step + DEPTH < NSTEP) issue(cur, step + DEPTH, ring[(step + DEPTH) % RING]);
       else if (MI_CONV_XTILE) issue(nxt, step + DEPTH - NSTEP, ring[(step + DEPTH) % RING]);
       __builtin_amdgcn_sched_barrier(0);
@@ -408,6 +610,10 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
       __builtin_amdgcn_sched_barrier(0);
     }
     cur = nxt;
+    // The epilogue's stores are inline assembly (buf_st_untracked): the hazard recogniser does not see that they read the accumulators, and
+    // the hardware does not interlock a matrix result against a following memory instruction's data read (up to 19 wait states after a
+    // 16-pass MFMA).  Spend them here, once per tile, tied to the accumulators so that no MFMA can be scheduled behind the fence.
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
     if (!MI_CONV_XTILE) {
 #pragma unroll
       for (int st = 0; st < DEPTH; ++st) issue(cur, st, ring[st % RING]);
@@ -437,7 +643,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
         for (int rr = 0; rr < GR; ++rr) {
           const int r = grp * GR + rr;
           const float v = acc[r];
-          buf_st(rout, row_off(r), v);
+          buf_st_untracked(rout_raw, row_off(r), v);
           const bool on = gq.pp[rr] > 0.f;
           const float vv = on ? v : 0.f;
           if (NTERMS == 1) {
@@ -465,7 +671,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
     for (int r = 0; r < 16; ++r) {
       const unsigned ro = (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
       const float v = acc[r];
-      buf_st(rout, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro, v);
+      buf_st_untracked(rout_raw, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro, v);
       if (EPI == EPI_STATS) {
         const double dv = (double)v;
         s += dv;
@@ -810,13 +1016,31 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host launchers
+// Split-bf16 operands for the 32-channel stride-1 kernels (default on; MI_CONV_BF16X3=0 / mi_conv_set_split_bf16(0) = the fp32 pipe everywhere)
+static int g_conv_split_bf16 = -1;
+static bool conv_split_bf16() {
+  if (g_conv_split_bf16 < 0) {
+    const char* e = getenv("MI_CONV_BF16X3");
+    g_conv_split_bf16 = e ? (atoi(e) != 0) : 1;
+  }
+  return g_conv_split_bf16 != 0;
+}
+static unsigned g_conv_split_mask = 0xffffu;                   // debug: which variants ((terms-1)*2 + mode)*4 + epi take the split form
+extern "C" int mi_conv_set_split_bf16(int on) {
+  const int was = conv_split_bf16() ? 1 : 0;
+  g_conv_split_bf16 = on ? 1 : 0;
+  g_conv_split_mask = on > 1 ? ((unsigned)on >> 8) : 0xffffu;  // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
+  return was;
+}
+
 static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int nterms, int& ntiles, int& tpw, dim3& grid) {
   ntiles = ceil_div(mpix, 32);
   // One balanced round: give every resident wave ceil(tiles / slots) tiles -- more, shorter waves would run as 2.x rounds whose last
   // round is mostly idle.  Resident waves: 4 per SIMD by registers (<= 128 VGPRs in every variant), limited by the LDS copy of the
   // weights (160 KB per CU): 36 KB per 32-channel term and workgroup -> 4096 waves on the chip; the 64-channel kernels stage 74 KB
   // (one term, two workgroups of 4 waves per CU) or 147 KB (two terms, one workgroup) -> 2048 / 1024 waves.
-  const long slots = ci >= 64 ? (nterms == 2 ? 1024 : 2048) : 4096;
+  // Split-bf16 32-channel kernels: 54 KB (one term, two 4-wave workgroups per CU) / 108 KB (two terms, one 8-wave workgroup) -> 2048.
+  const long slots = ci >= 64 ? (nterms == 2 ? 1024 : 2048) : (conv_split_bf16() ? 2048 : 4096);
   long total = (long)ntiles * tasks * cot;
   tpw = (int)((total + slots - 1) / slots);
   if (tpw < 1) tpw = 1;
@@ -849,7 +1073,24 @@ static hipError_t launch_conv_t(hipStream_t st, ConvArgs& a, dim3 grid) {
   return hipGetLastError();
 }
 template <int CI, int NTERMS, int EPI, int MODE>
+static hipError_t launch_conv_s1_bf(hipStream_t st, ConvArgs& a, dim3 grid) {
+  const size_t lds = (size_t)NTERMS * 9 * CI * 32 * 6;       // three bf16 planes
+  auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE, true>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS>::value * 64), lds, st, a);
+  return hipGetLastError();
+}
+template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
+  if constexpr (CI == 32) {
+    if (conv_split_bf16() && ((g_conv_split_mask >> (((NTERMS - 1) * 2 + MODE) * 4 + EPI)) & 1u))
+      return launch_conv_s1_bf<CI, NTERMS, EPI, MODE>(st, a, grid);
+  }
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);
   auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE>;
   static bool attr_done = false;

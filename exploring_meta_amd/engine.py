@@ -291,6 +291,8 @@ class MetaEngine:
         for t in (theta, x):
             if t.dtype != torch.float32 or not t.is_cuda:
                 raise ValueError('theta / x must be fp32 CUDA tensors')
+        if x.dim() != 5 or tuple(x.shape[2:]) != (self.spec.in_channels, self.spec.in_h, self.spec.in_w):
+            raise ValueError(f'x must be [tasks, n, {self.spec.in_channels}, {self.spec.in_h}, {self.spec.in_w}], got {tuple(x.shape)}')
         T, n = x.shape[0], x.shape[1]
         b = C.c_size_t()
         _lib.check(self.lib.mi_forward_workspace_bytes(self._h, T, n, C.byref(b)), self._h)

@@ -51,14 +51,28 @@ CASES = [
     ('cfg2_min_5w5s_K2_so_lr01', 'min', 5, 5, 2, 0.1, False, [0], 1e-4, 2e-3),
     # K=5, lr=0.5 on raw 0..255 inputs is chaotic in fp32: the reference's OWN fp32 run deviates from fp64 by 6e-4..6e-2 in
     # loss and 0.17..0.37 in the meta-gradient (first- and second-order alike; BASELINE.md section 3, and the fp32 leg
-    # measured below), and a single task's deviation is a random draw.  Floors are set a factor >3 below that envelope.
-    ('cfg2_min_5w5s_K5_fo', 'min', 5, 5, 5, 0.5, True, [0], 1e-3, 5e-2),
-    ('cfg2_min_5w5s_K5_so', 'min', 5, 5, 5, 0.5, False, [0, 1], 1e-3, 5e-2),
+    # measured below), and a single task's deviation is a random draw: which way a near-tied pooling / ReLU decision falls depends
+    # on the last bits of the convolution, so the two operand forms of the hidden convs (fp32 pipe / split bf16, both run below) draw
+    # differently -- task 0: 4e-5 / 2.1e-3 in loss.  Floors sit a factor >= 3 below the top of that envelope; the decision-aware
+    # bound for this configuration is the teacher-forced test at the benched size (test_gpu_full_size.py: every step <= 2e-5 of
+    # the fp64 arithmetic once decisions with margin < 1e-5 may fall either way).
+    ('cfg2_min_5w5s_K5_fo', 'min', 5, 5, 5, 0.5, True, [0], 1e-2, 5e-2),
+    ('cfg2_min_5w5s_K5_so', 'min', 5, 5, 5, 0.5, False, [0, 1], 1e-2, 5e-2),
 ]
 
 
+@pytest.fixture(params=['split_bf16', 'fp32_pipe'])
+def conv_form(request):
+    """Operand form of the 32-channel stride-1 convolutions (mi_conv_set_split_bf16) for the duration of one test."""
+    from exploring_meta_amd import _lib
+    lb = _lib.load()
+    was = lb.mi_conv_set_split_bf16(1 if request.param == 'split_bf16' else 0)
+    yield request.param
+    lb.mi_conv_set_split_bf16(was)
+
+
 @pytest.mark.parametrize('tag,dataset,ways,shots,K,lr,fo,tasks,loss_floor,grad_floor', CASES)
-def test_meta_batch_vs_oracle_and_golden(golden_fa, tag, dataset, ways, shots, K, lr, fo, tasks, loss_floor, grad_floor):
+def test_meta_batch_vs_oracle_and_golden(golden_fa, conv_form, tag, dataset, ways, shots, K, lr, fo, tasks, loss_floor, grad_floor):
     spec, mspec = _spec(dataset, ways)
     theta = model_params(spec, 11)
     loss, acc, grad, logits = _run_engine(mspec, theta, dataset, tasks, ways, shots, K, lr, fo)
@@ -74,7 +88,7 @@ def test_meta_batch_vs_oracle_and_golden(golden_fa, tag, dataset, ways, shots, K
     loss_err = np.abs(loss - l64) / np.abs(l64)
     grad_err = rel_err(grad, g64)
     # conv.bias gradients are exactly zero in the engine (inert under batch-stat BN); noise-level in any autograd run
-    report(f'meta_batch[{tag}]', loss_rel_err=float(loss_err.max()), ref_fp32_loss_rel_err=float(ref_loss_err.max()),
+    report(f'meta_batch[{tag}][{conv_form}]', loss_rel_err=float(loss_err.max()), ref_fp32_loss_rel_err=float(ref_loss_err.max()),
            grad_rel_err=grad_err, ref_fp32_grad_rel_err=ref_grad_err, loss=[float(x) for x in loss],
            loss_fp64=[float(x) for x in l64], acc=[float(x) for x in acc])
     assert np.all(loss_err <= np.maximum(loss_floor, 2 * ref_loss_err))
@@ -320,24 +334,46 @@ def test_edge_shapes_vs_oracle(dataset, ways, shots, K, fo, tasks):
 
 def test_two_second_order_steps_on_plateau_free_inputs():
     """K = 2 second-order steps on 5-image tasks whose pixels are i.i.d. uniform in [0, 255] (no clipped plateaus, hence no
-    exact pooling ties): every task must agree with the fp64 oracle.  This is the strict check of the multi-step path (Gram
-    statistics, pooled-resolution reductions, sparse weight gradient, all tangent kernels) that the plateau data cannot give."""
+    exact pooling ties): the strict check of the multi-step path (Gram statistics, pooled-resolution reductions, sparse weight
+    gradient, all tangent kernels) that the plateau data cannot give.  NEAR ties still happen by chance -- six tasks hold 2.2 M
+    pooling windows per pass and the smallest fp64 margin among them is ~1e-7 of the activations' scale, the size of one fp32
+    rounding -- and which way such a window falls depends on the convolution's last bits (task 5's support pass has one at 7e-7 in
+    block 3: the fp32 pipe falls with fp64, the split-bf16 form the other way, moving the task's loss by 1.3e-2).  So: per step,
+    against the fp64 arithmetic with the near-tied decisions (margin < 1e-5) allowed to fall either way, EVERY task within
+    2e-5 / 2e-4 (tests/teacher_forced.py); end to end, every task without such a decision within 1e-4 / 2e-3 of the fp64 oracle, and
+    at least four of the six are of that kind."""
+    import teacher_forced as TF
     spec, mspec = _spec('min', 5)
     theta = model_params(spec, 5)
-    ways, shots, K, lr = 5, 1, 2, 0.05
+    ways, shots, K, lr, T = 5, 1, 2, 0.05, 6
     eng = MetaEngine(mspec)
     th32 = R.flatten_params(theta).float().cuda().contiguous()
-    labels = torch.from_numpy(synthetic.task_labels(ways, shots))
-    lerr, gerr = [], []
-    for t in range(6):
-        data = torch.from_numpy(synthetic.hash_uniform(700 + t, (2 * ways * shots, 3, 84, 84)) * 255.0)
-        loss, acc, grad, _ = eng.meta_batch(th32, data.float().cuda().unsqueeze(0).contiguous(), labels.cuda().unsqueeze(0).contiguous(),
-                                            shots, K, lr, first_order=False, return_logits=True)
-        l64, a64, g64, _ = R.maml_meta_batch(theta, spec, [data], [labels], K, shots, ways, lr, False)
-        lerr.append(abs(float(loss[0]) - float(l64[0])) / abs(float(l64[0])))
-        gerr.append(rel_err(grad.cpu().numpy(), R.flatten_params(g64).double().numpy()))
-    report('plateau_free_K2_so', loss_rel=lerr, grad_rel=gerr)
-    assert max(lerr) < 1e-4 and np.median(gerr) < 1e-4 and max(gerr) < 2e-3
+    lab = synthetic.task_labels(ways, shots)
+    data = np.stack([(synthetic.hash_uniform(700 + t, (2 * ways * shots, 3, 84, 84)) * 255.0).astype(np.float32) for t in range(T)])
+    labels = np.stack([lab for _ in range(T)])
+    trace = eng.set_trace(T, K)
+    loss, acc, grad, _ = eng.meta_batch(th32, torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda(), shots, K, lr, first_order=False)
+    torch.cuda.synchronize()
+    per_task = (trace['lam_in'][0].double() - lr * trace['hv'][0].double()).cpu().numpy()
+    trace_all = {k: v.clone() for k, v in trace.items()}
+    eng.set_trace(0)
+    res = TF.teacher_forced_all(trace_all, data, labels, shots, ways, list(range(T)))
+    lerr, gerr, nflip = [], [], []
+    for t in range(T):
+        l64, a64, g64, _ = R.maml_meta_batch(theta, spec, [torch.from_numpy(data[t]).double()], [torch.from_numpy(labels[t])], K, shots, ways, lr, False)
+        lerr.append(abs(float(loss[t]) - float(l64[0])) / abs(float(l64[0])))
+        gerr.append(rel_err(per_task[t], R.flatten_params(g64).double().numpy()))
+        nflip.append(sum(len(step) for step in res[t]['flips']))
+    adj_g = [max(max(r['gx']), r['qx']) for r in res]
+    adj_h = [max(r['hx']) for r in res]
+    margins = [abs(fl['margin']) for r in res for step in r['flips'] for fl in step]
+    report('plateau_free_K2_so', loss_rel=lerr, grad_rel=gerr, near_tied_decisions=nflip, adjusted_grad=adj_g, adjusted_hvp=adj_h,
+           largest_flipped_margin=max(margins) if margins else 0.0)
+    assert max(adj_g) < 2e-5 and max(adj_h) < 2e-4 and all(m < TF.TAU for m in margins)
+    clean = [t for t in range(T) if nflip[t] == 0]
+    assert len(clean) >= 4
+    assert all(lerr[t] < 1e-4 and gerr[t] < 2e-3 for t in clean) and np.median([gerr[t] for t in clean]) < 1e-4
+    assert max(lerr) < 5e-2          # a flipped decision moves a task, it does not break it
 
 
 def test_fused_block1_single_channel_inputs():

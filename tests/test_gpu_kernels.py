@@ -15,9 +15,13 @@ from gpu_utils import dev, ptr, stream, rel_err, max_err, report
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def lib():
-    return _lib.load()
+@pytest.fixture(scope='module', params=['split_bf16', 'fp32_pipe'])
+def lib(request):
+    """Every case runs with both operand forms of the 32-channel stride-1 convolutions (mi_conv_set_split_bf16): same bars."""
+    lb = _lib.load()
+    was = lb.mi_conv_set_split_bf16(1 if request.param == 'split_bf16' else 0)
+    yield lb
+    lb.mi_conv_set_split_bf16(was)
 
 
 def _rand(seed, shape, lo=-1.0, hi=1.0):

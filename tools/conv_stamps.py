@@ -14,6 +14,7 @@ from exploring_meta_amd import _lib  # noqa: E402
 lib = _lib.load()
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+BF_MODES = (0, 1) if '--bf' in sys.argv else (None,)
 for T in (1, 4, 32):
     n, h, w, c = 25, 42, 42, 32
     x0 = torch.randn(T, n, h, w, c, device='cuda')
@@ -27,7 +28,10 @@ for T in (1, 4, 32):
     sb = lib.mi_kernel_scratch_bytes(T, n, h, w, c)
     scr = torch.empty(sb, dtype=torch.uint8, device='cuda')
     buf = torch.zeros(8, dtype=torch.int64, device='cuda')
-    for terms in (1, 2):
+    for terms, bf in [(t, b) for t in (1, 2) for b in BF_MODES]:
+        if bf is not None:
+            lib.mi_conv_set_split_bf16(bf)
+
         def run():
             _lib.check(lib.mi_conv3x3_tangent(st(), vp(x0), vp(w0), vp(x1) if terms == 2 else None, vp(w1) if terms == 2 else None, w0.shape[1],
                                               vp(z), vp(mu), vp(rs), T, n, h, w, c, c, 1, vp(zd), vp(m1), vp(m2), vp(scr), sb))
@@ -45,5 +49,5 @@ for T in (1, 4, 32):
         lib.mi_debug_conv_stamps(None)
         s = buf.cpu().numpy().astype(np.int64)
         d = [int(s[i + 1] - s[i]) for i in range(4)]
-        print(f'T={T} terms={terms}: conv + finalize launches {e0.elapsed_time(e1) / 10 * 1e3:.1f} us | wg0 cycles: weights {d[0]}, first tile {d[1]}, '
+        print(f'T={T} terms={terms} split_bf16={bf}: conv + finalize launches {e0.elapsed_time(e1) / 10 * 1e3:.1f} us | wg0 cycles: weights {d[0]}, first tile {d[1]}, '
               f'remaining tiles {d[2]}, epilogue {d[3]}, total {int(s[4] - s[0])}', flush=True)
