@@ -273,11 +273,14 @@ def run_vision(args, wl, rank, world, local, dist):
     if dom in prof:
         ms, cnt = prof[dom]
         flops, nbytes = RF.op_costs(spec, dom[0], dom[1], n_img)
-        bound = RF.bound_of(flops, nbytes)
+        split = bool(eng.lib.mi_conv_set_split_bf16(1))         # read the operand form of the hidden convolutions ...
+        eng.lib.mi_conv_set_split_bf16(int(split))              # ... and leave it as it was
+        pipe_peak, pipe = RF.mfma_peak(spec, dom[0], dom[1], split)
+        bound = RF.bound_of(flops, nbytes, pipe_peak)
         h, w, ci, co, ho, wo, _, _ = RF.layer_geometry(spec)[dom[1]]
         sec = ms / cnt * 1e-3
         if bound == 'mfma':
-            achieved, peak, unit = flops / sec / 1e12, FP32_MFMA_PEAK_TF, 'TFLOP/s'
+            achieved, peak, unit = flops / sec / 1e12, round(pipe_peak, 1), 'TFLOP/s'
         else:
             achieved, peak, unit = nbytes / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
         traffic = None
@@ -291,19 +294,25 @@ def run_vision(args, wl, rank, world, local, dist):
             if c is None or len(iso) >= 12:
                 continue
             fl, by = c
-            b1 = RF.bound_of(fl, by)
+            pk1, pipe1 = RF.mfma_peak(spec, op, layer, split)
+            b1 = RF.bound_of(fl, by, pk1)
             sec1 = ms1 / cnt1 * 1e-3
-            a1, p1 = (fl / sec1 / 1e12, FP32_MFMA_PEAK_TF) if b1 == 'mfma' else (by / sec1 / 1e9, HBM_PEAK_GBS)
-            iso.append(dict(op=op, block=layer + 1, launches=int(cnt1), avg_launch_ms=round(ms1 / cnt1, 4), bound=b1,
-                            achieved=round(a1, 1), frac=round(a1 / p1, 3)))
+            a1, p1 = (fl / sec1 / 1e12, pk1) if b1 == 'mfma' else (by / sec1 / 1e9, HBM_PEAK_GBS)
+            iso.append(dict(op=op, block=layer + 1, launches=int(cnt1), avg_launch_ms=round(ms1 / cnt1, 4), bound=b1, pipe=pipe1,
+                            achieved=round(a1, 1), frac=round(a1 / p1, 3), tflops=round(fl / sec1 / 1e12, 1) if fl else None))
         roofline = dict(kernel=f'{RF.kernel_name(spec, dom[0], dom[1])}, block {dom[1] + 1} ({h}x{w}, {ci}->{co} filters)', op=dom[0],
                         bound=bound, achieved=round(achieved, 2), peak=peak, unit=unit, frac=round(achieved / peak, 4), traffic=traffic,
                         launches=int(cnt), avg_launch_ms=round(ms / cnt, 4), flops_per_launch=flops,
                         algorithmic_bytes_per_launch=nbytes, images_per_launch=n_img,
-                        hbm_stream_copy_measured_GBps=round(hbm_copy_gbps, 1), single_stream_step=iso,
+                        hbm_stream_copy_measured_GBps=round(hbm_copy_gbps, 1), pipe=pipe,
+                        algorithmic_tflops=round(flops / sec / 1e12, 2), vs_fp32_mfma_peak=round(flops / sec / 1e12 / FP32_MFMA_PEAK_TF, 4),
+                        single_stream_step=iso,
                         note='dominant kernel among those that run alone on the chip (dgrad / wgrad of blocks >= 2 share it with each '
                              'other in the timed region); single_stream_step: per-kernel figures of one untimed step with the side '
-                             'stream off, HIP events around every launch')
+                             'stream off, HIP events around every launch.  FLOPs are ALGORITHMIC fp32 FLOPs throughout; a kernel on '
+                             'the split-bf16 operand form executes six bf16 products per fp32 multiply-add, so its peak is the dense '
+                             'bf16 MFMA rate / 6 = 416.7 TFLOP/s (pipe: "bf16 x6"), and vs_fp32_mfma_peak says what the same launch is '
+                             'against the fp32 matrix pipe it no longer uses')
 
     if args.breakdown:                          # every rank runs the extra step (it contains the all-reduce); rank 0 writes
         eng.set_overlap(False)                  # one stream: the per-kernel times add up to the iteration

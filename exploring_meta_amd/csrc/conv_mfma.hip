@@ -16,6 +16,7 @@
 // reduced wave -> workgroup in LDS and written as one deterministic partial per workgroup (no atomics).
 #include "mi_common.h"
 #include "kernels.h"
+#include "bf16_split.h"
 
 #define EPI_NONE 0
 #define EPI_STATS 1
@@ -241,24 +242,7 @@ __device__ __forceinline__ void divmod24(unsigned x, unsigned d, float rd, unsig
   r = (unsigned)rr;
 }
 
-// ---- split-bf16 operands (BF variants of the stride-1 kernel) ----------------------------------------------------------------------
-// An fp32 value is the exact sum of three bf16 pieces, x = h + m + l (round-to-nearest pieces of x, x - h, x - h - m; 8 mantissa bits
-// each), so an fp32 product is  ah bh + ah bm + am bh + am bm + ah bl + al bh  up to the three dropped terms (am bl, al bm, al bl:
-// <= 2^-24 |a b| together -- the size of ONE fp32 rounding), each partial product exact in the fp32 accumulator of
-// v_mfma_f32_32x32x16_bf16.  Six 8-pass bf16 MFMAs cover K = 16 where the fp32 pipe needs eight 16-pass ones: 2.7x the matrix rate,
-// provided the 4.5 VALU instructions per split value issue in the MFMAs' shadow (tools/mfma_valu_overlap_probe.hip: they do).
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float floatx2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void bf16_split2(floatx2 v, unsigned& h, unsigned& m, unsigned& l) {
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));                    // v_cvt_pk_bf16_f32 (RNE)
-  const floatx2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
-  const floatx2 r = v - hf;                                                                // exact (v_pk_add_f32)
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-  const floatx2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
-  const floatx2 q = r - mf;                                                                // exact
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
-}
+// ---- split-bf16 operands (BF variants of the stride-1 kernel): bf16_split.h
 // A store the compiler's wait-count bookkeeping does not see.  gfx9 counts loads and stores in ONE counter and lets them complete out of
 // order with respect to each other, so with a visible store pending hipcc turns every wait for an operand load into vmcnt(0) -- which also
 // drains the prefetched loads of the next two half-groups, at every tile boundary.  Hidden, the stores only ever make a counted wait
@@ -275,8 +259,6 @@ __device__ __forceinline__ void bf16_split_pair(const floatx4& x, Bf16Planes& p)
 __device__ __forceinline__ void bf16_split8(const floatx4& x0, const floatx4& x1, Bf16Planes& p) {
   bf16_split_pair<0>(x0, p); bf16_split_pair<1>(x0, p); bf16_split_pair<2>(x1, p); bf16_split_pair<3>(x1, p);
 }
-#define MI_BF8(q) __builtin_bit_cast(bf16x8, (mi_u32x4{(q)[0], (q)[1], (q)[2], (q)[3]}))
-#define MI_BF_MFMA(x, y, acc) __builtin_amdgcn_mfma_f32_32x32x16_bf16(MI_BF8(x), MI_BF8(y), acc, 0, 0, 0)
 
 // debug aid: shader-clock stamps of workgroup (0, 0, 0)'s wave 0 (mi_debug_conv_stamps; null in production)
 __device__ unsigned long long* g_conv_stamps = nullptr;
@@ -1025,11 +1007,13 @@ static bool conv_split_bf16() {
   }
   return g_conv_split_bf16 != 0;
 }
-static unsigned g_conv_split_mask = 0xffffu;                   // debug: which variants ((terms-1)*2 + mode)*4 + epi take the split form
+int g_wgrad_bf16_dbg = 0;                                      // timing experiments (bits 19..20 of the mask): see wgrad_bf16.hip
+static unsigned g_conv_split_mask = 0x3ffffu;                   // debug: which variants take the split form: conv bit ((terms-1)*2 + mode)*4 + epi, weight gradient bit 16 + (terms-1)
 extern "C" int mi_conv_set_split_bf16(int on) {
   const int was = conv_split_bf16() ? 1 : 0;
   g_conv_split_bf16 = on ? 1 : 0;
-  g_conv_split_mask = on > 1 ? ((unsigned)on >> 8) : 0xffffu;  // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
+  g_conv_split_mask = on > 1 ? ((unsigned)on >> 8) : 0x3ffffu;
+  g_wgrad_bf16_dbg = (int)((g_conv_split_mask >> 19) & 3u);  // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
   return was;
 }
 
@@ -1214,10 +1198,35 @@ static void rows_split(const ConvGeom& g, int tasks, int& rh, int& nunits, int& 
   blocks = ceil_div(nunits, upb);
 }
 
+// split-bf16 weight gradient (wgrad_bf16.hip): units of 2 rows x 8 columns, ONE workgroup per CU (144 accumulator AGPRs per lane)
+bool wgrad_bf16_ok(const ConvGeom& g);
+int wgrad_bf16_units(const ConvGeom& g);
+hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid, bool interleave_loads);
+static void rows_split_bf16(const ConvGeom& g, int tasks, int& nunits, int& upb, int& blocks) {
+  nunits = wgrad_bf16_units(g);
+  int max_bpt = ceil_div(nunits, 16);                       // never fewer than 4 units per wave
+  if (max_bpt > 128) max_bpt = 128;
+  if (max_bpt < 1) max_bpt = 1;
+  int best = 1;
+  long best_cost = -1;
+  for (int bpt = 1; bpt <= max_bpt; ++bpt) {                // rounds of 256 resident workgroups x (units per workgroup + the reduction epilogue, ~24 units)
+    const long rounds = ((long)tasks * bpt + 255) / 256;
+    const long cost = rounds * (ceil_div(nunits, bpt) + 24);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bpt; }
+  }
+  upb = ceil_div(ceil_div(nunits, best), 24) * 24;          // whole six-unit trips for each of the four waves (wgrad_bf16.hip)
+  blocks = ceil_div(nunits, upb);
+}
+
 size_t wgrad_partial_floats(const ConvGeom& g, int tasks) {
   if (use_rows_kernel(g)) {
     int rh, nunits, upb, blocks;
     rows_split(g, tasks, rh, nunits, upb, blocks);
+    if (wgrad_bf16_ok(g)) {                                 // either operand form may be selected at launch time: size for the larger split
+      int nu, ub, bl;
+      rows_split_bf16(g, tasks, nu, ub, bl);
+      if (bl > blocks) blocks = bl;
+    }
     return (size_t)tasks * blocks * 9 * g.ci * g.co;
   }
   const int mpix = g.n * g.ho * g.wo;
@@ -1242,6 +1251,15 @@ static void launch_rows(hipStream_t st, const WgradArgs& a, dim3 grid, int rh) {
 
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out) {
   const int s = a.g.stride;
+  if (use_rows_kernel(a.g) && conv_split_bf16() && wgrad_bf16_ok(a.g) && (g_conv_split_mask & (1u << (16 + (nterms - 1))))) {
+    int nunits, upb, blocks;
+    rows_split_bf16(a.g, tasks, nunits, upb, blocks);
+    a.nterms = nterms;
+    a.chunk_pix = upb * nterms;                            // the unit stream is nterms x nunits long, same workgroup count
+    a.nchunks = blocks;
+    *nchunks_out = blocks;
+    return launch_wgrad_rows_bf16(st, a, dim3(blocks, tasks, 1), (g_conv_split_mask >> 18) & 1u);   // bit 18: debug variant
+  }
   if (use_rows_kernel(a.g)) {
     int rh, nunits, upb, blocks;
     rows_split(a.g, tasks, rh, nunits, upb, blocks);

@@ -1,0 +1,234 @@
+// Stride-1 3x3 weight gradient of a 32 -> 32 channel block on the split-bf16 operand form (bf16_split.h): the counterpart of
+// wgrad3x3_rows_mfma_kernel (conv_mfma.hip) for the implicit ATen conv2d-backward-weight launches behind ConvBlock.conv
+// (reference core_functions/vision_models.py:177-185,189), every task of the meta-batch in one launch.
+//
+// dW[tap][ci][co] = sum over pixels of x[pixel + tap][ci] * dz[pixel][co]: M = ci, N = co, K = pixels.  v_mfma_f32_32x32x16_bf16
+// takes K = 16 pixels per instruction: lane half h owns image row y = 2*yp + h, both halves the same 8 columns [8s, 8s + 8) -- a work
+// unit is (image, row pair yp, column segment s).  Per unit a lane loads the 8 dz values of its output channel (B operand) and a
+// 3 x 10 halo patch of x of its input channel (A operand): 38 coalesced dword loads (32 lanes = the 32 channels of one pixel) feed
+// 54 MFMAs (9 taps x 6 plane products).  Every loaded value is split into its three bf16 planes ONCE (4.5 VALU instructions per
+// value) and re-used by up to nine taps from registers: the horizontal displacement -1 / +1 is a choice of four of the row's five
+// packed register pairs, 0 a v_alignbit_b32 of neighbouring pairs.  The VALU work of a row (57 instructions) is placed between the
+// 18 MFMAs of the previous row, the next unit's loads fly under the current unit (two register sets).
+// Accumulators (9 x 16) live in AGPRs (this file is built without -amdgpu-mfma-vgpr-form): one workgroup of four waves per CU.
+// The four waves of a workgroup interleave units, reduce their accumulators through LDS tap by tap and leave ONE partial per
+// workgroup; reduce_partials_kernel folds workgroups in a fixed order (deterministic, no atomics) -- as the fp32 kernel does.
+#include "mi_common.h"
+#include "kernels.h"
+#include "bf16_split.h"
+
+namespace {
+
+struct WRaw { float xa[3][10]; float b[8]; };                   // one unit's loads: x rows y-1, y, y+1 x columns c0-1 .. c0+8; dz row y
+struct RowPl { unsigned h[5], m[5], l[5]; };                    // a row's pairs (v0,v1) .. (v8,v9), three planes
+struct OddPl { unsigned h[4], m[4], l[4]; };                    // the odd packing (v1,v2) .. (v7,v8): displacement 0
+struct DzPl { unsigned h[4], m[4], l[4]; };
+
+// The loads of a unit in four pieces (piece 0: its 8 dz values, pieces 1..3: the 10 x values of halo row piece - 1), so that they can
+// be placed between the MFMAs of an earlier unit.  unit, and everything decoded from it, is wave-uniform (scalar unit); rows are per
+// lane half (h).  unit < 0: every load out of range (zeros).
+struct WUnitPos { int n, y0, c0; bool ok; };
+__device__ __forceinline__ WUnitPos unit_pos(int unit, int hp2, int nseg) {
+  WUnitPos p;
+  p.ok = unit >= 0;
+  const int uu = p.ok ? unit : 0;
+  p.n = uu / (hp2 * nseg);
+  const int rem = uu - p.n * hp2 * nseg;
+  const int yp = rem / nseg;
+  p.y0 = 2 * yp;
+  p.c0 = (rem - yp * nseg) * 8;
+  return p;
+}
+template <int PIECE>
+__device__ __forceinline__ void load_piece(WRaw& u, const WUnitPos& p, mi_rsrc rx, mi_rsrc rdz, unsigned lane_ch, int H, int W, int h) {
+  const int y = p.y0 + h;
+  if (PIECE == 0) {
+    const bool rowok = p.ok && y < H;
+    const unsigned mask = rowok ? 0u : MI_OOB;                                               // out of range as an OR: no select, no branch
+    const unsigned dzoff = (lane_ch + (unsigned)(((p.n * H + y) * W + p.c0) * 128)) | mask;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned col = (p.c0 + i) < W ? (unsigned)(i * 128) : MI_OOB;                    // scalar select
+      u.b[i] = buf_ld(rdz, dzoff + col);
+    }
+  } else {
+    const int r = PIECE - 1;
+    const int iy = y + r - 1;
+    const bool rok = p.ok && y < H && (unsigned)iy < (unsigned)H;
+    const unsigned mask = rok ? 0u : MI_OOB;
+    const unsigned xoff = (lane_ch + (unsigned)(((p.n * H + iy) * W + p.c0) * 128)) | mask;   // pixel c0 of the row (offsets < 2^30: launcher)
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      const unsigned col = (unsigned)(p.c0 + c - 1) < (unsigned)W ? (unsigned)((c - 1) * 128) : MI_OOB;   // scalar select (c = 0: -128, only where c0 >= 1)
+      u.xa[r][c] = buf_ld(rx, xoff + col);
+    }
+  }
+}
+
+template <int P>
+__device__ __forceinline__ void split_x_pair(const float* v, RowPl& p) {
+  bf16_split2(floatx2{v[2 * P], v[2 * P + 1]}, p.h[P], p.m[P], p.l[P]);
+  asm volatile("" : "+v"(p.h[P]), "+v"(p.m[P]), "+v"(p.l[P]));       // computed HERE (instruction selection otherwise sinks the split to its use)
+}
+template <int P>
+__device__ __forceinline__ void split_dz_pair(const float* v, DzPl& p) {
+  bf16_split2(floatx2{v[2 * P], v[2 * P + 1]}, p.h[P], p.m[P], p.l[P]);
+  asm volatile("" : "+v"(p.h[P]), "+v"(p.m[P]), "+v"(p.l[P]));
+}
+__device__ __forceinline__ void odd_plane(const unsigned* e, unsigned* o) {   // (v1,v2) = high half of (v0,v1) | low half of (v2,v3) ...
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbit(e[i + 1], e[i], 16);
+  asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+}
+
+}  // namespace
+
+template <bool ILV, int DBG = 0>   // DBG (timing experiments only): 1 = no MFMAs, 2 = no operand preparation, 3 = no loads; ILV: the loads of the unit two ahead between this unit's MFMAs (rows 0 and 1) instead of in front of them
+__global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
+  __shared__ float red[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: unit decode runs on the scalar unit
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y;
+  const int H = a.g.h, W = a.g.w;                              // stride 1, 32 -> 32 channels: conv output is H x W as well
+  const int hp2 = (H + 1) >> 1, nseg = (W + 7) >> 3;
+  const int nunits = a.g.n * hp2 * nseg;                       // per term; the unit stream is [term][unit]
+  const int total = nunits * a.nterms;
+  const int ub0 = blockIdx.x * a.chunk_pix;                    // chunk_pix = units per workgroup here
+  const int ub1 = min(ub0 + a.chunk_pix, total);
+  const size_t t_elems = (size_t)a.g.n * H * W * 32;
+  const unsigned tb = (unsigned)(t_elems * 4);
+  const mi_rsrc rx0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x[0] + (size_t)task * t_elems), 0, tb, 0x00020000);
+  const mi_rsrc rd0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dz[0] + (size_t)task * t_elems), 0, tb, 0x00020000);
+  const float* x1p = a.nterms > 1 ? a.x[1] : a.x[0];
+  const float* d1p = a.nterms > 1 ? a.dz[1] : a.dz[0];
+  const mi_rsrc rx1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1p + (size_t)task * t_elems), 0, tb, 0x00020000);
+  const mi_rsrc rd1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d1p + (size_t)task * t_elems), 0, tb, 0x00020000);
+  const unsigned lane_ch = (unsigned)j * 4u;
+
+  floatx16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // unit v of this wave's stream: second term of the stream from nunits on (scalar selects, no branch); v >= ub1: nothing left (zeros)
+  auto pos_of = [&](int v) { return unit_pos(v >= ub1 ? -1 : (v >= nunits ? v - nunits : v), hp2, nseg); };
+#define WG_LOAD(PIECE, RAW, V, POS) load_piece<PIECE>(RAW, POS, (V) >= nunits ? rx1 : rx0, (V) >= nunits ? rd1 : rd0, lane_ch, H, W, h)
+
+  WRaw raw[3];                                                  // loads run two units ahead
+  RowPl pe[2];
+  OddPl po[2];
+  DzPl pb[2];
+  // six plane products of one tap, the next row's (or unit's) operand preparation spread between them
+#define WG_MFMA(T, X, Y) if (DBG != 1) acc[T] = MI_BF_MFMA(X, Y, acc[T])
+#define WG_TAP(T, AH, AM, AL, B, V0, V1, V2, V3)                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  WG_MFMA(T, AL, B.h);                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  if (DBG != 2) { V0; }                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  WG_MFMA(T, AH, B.l);                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  if (DBG != 2) { V1; }                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  WG_MFMA(T, AM, B.m);                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  if (DBG != 2) { V2; }                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  WG_MFMA(T, AM, B.h);                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  if (DBG != 2) { V3; }                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  WG_MFMA(T, AH, B.m);                                                            \
+  WG_MFMA(T, AH, B.h);                                                            \
+  __builtin_amdgcn_sched_barrier(0);
+  // one row of taps (3r, 3r + 1, 3r + 2) from planes (E, O) against B; meanwhile row NR of raw set NRAW is prepared into (NE, NO) and,
+  // where NR == 0 (the next unit), its dz into NB
+#define WG_ROW(R, E, O, B, NRAW, NR, NE, NO, NB, FRAW)                                                                         \
+  WG_TAP(3 * (R) + 0, (E.h), (E.m), (E.l), B, split_x_pair<0>(NRAW.xa[NR], NE), split_x_pair<1>(NRAW.xa[NR], NE),        \
+         split_x_pair<2>(NRAW.xa[NR], NE), split_x_pair<3>(NRAW.xa[NR], NE))                                             \
+  WG_TAP(3 * (R) + 1, (O.h), (O.m), (O.l), B, split_x_pair<4>(NRAW.xa[NR], NE), odd_plane(NE.h, NO.h), odd_plane(NE.m, NO.m), \
+         odd_plane(NE.l, NO.l))                                                                                          \
+  WG_TAP(3 * (R) + 2, (E.h + 1), (E.m + 1), (E.l + 1), B,                                                                \
+         if (NR == 0) split_dz_pair<0>(NRAW.b, NB); else if (ILV && NR == 1) WG_LOAD(0, FRAW, fv, fpos); else if (ILV) WG_LOAD(2, FRAW, fv, fpos),   \
+         if (NR == 0) split_dz_pair<1>(NRAW.b, NB); else if (ILV && NR == 1) WG_LOAD(1, FRAW, fv, fpos); else if (ILV) WG_LOAD(3, FRAW, fv, fpos),   \
+         if (NR == 0) split_dz_pair<2>(NRAW.b, NB), if (NR == 0) split_dz_pair<3>(NRAW.b, NB))
+  // one unit: raw set K % 3 (its row 0 and dz are already in planes, buffers K & 1), the next unit in raw set (K + 1) % 3
+#define WG_UNIT(K)                                                                              \
+  WG_ROW(0, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[(K) % 3], 1, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[(K) & 1], raw[((K) + 2) % 3])       \
+  WG_ROW(1, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[(K) & 1], raw[(K) % 3], 2, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[((K) + 2) % 3])       \
+  WG_ROW(2, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[((K) + 1) % 3], 0, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[((K) + 1) & 1], raw[((K) + 2) % 3])
+
+  int u = ub0 + wave;
+  {
+    const WUnitPos p0 = pos_of(u), p1 = pos_of(u + 4);
+    WG_LOAD(0, raw[0], u, p0); WG_LOAD(1, raw[0], u, p0); WG_LOAD(2, raw[0], u, p0); WG_LOAD(3, raw[0], u, p0);
+    WG_LOAD(0, raw[1], u + 4, p1); WG_LOAD(1, raw[1], u + 4, p1); WG_LOAD(2, raw[1], u + 4, p1); WG_LOAD(3, raw[1], u + 4, p1);
+  }
+  // prologue: row 0 and dz of the first unit
+  split_x_pair<0>(raw[0].xa[0], pe[0]); split_x_pair<1>(raw[0].xa[0], pe[0]); split_x_pair<2>(raw[0].xa[0], pe[0]);
+  split_x_pair<3>(raw[0].xa[0], pe[0]); split_x_pair<4>(raw[0].xa[0], pe[0]);
+  odd_plane(pe[0].h, po[0].h); odd_plane(pe[0].m, po[0].m); odd_plane(pe[0].l, po[0].l);
+  split_dz_pair<0>(raw[0].b, pb[0]); split_dz_pair<1>(raw[0].b, pb[0]); split_dz_pair<2>(raw[0].b, pb[0]); split_dz_pair<3>(raw[0].b, pb[0]);
+  // Six units per trip: the raw sets rotate with period three, the plane buffers with period two (a unit has three rows, so the row
+  // planes of unit K start in buffer K & 1 and end there, the next unit's row 0 lands in (K + 1) & 1).  No exit and no skip inside
+  // a trip (either makes the compiler keep a second copy of the 144 accumulator registers and move between them): a unit past the
+  // wave's last one runs on zeros, and the launcher deals units to workgroups in multiples of 24 so that only a task's last
+  // workgroup has any.
+#define WG_STEP(K)                                                          \
+  {                                                                         \
+    const int fv = u + 4 * ((K) + 2);      /* the unit two ahead: its loads go out before this unit's MFMAs (between them they were slower) */ \
+    const WUnitPos fpos = pos_of(fv);                                       \
+    if (!ILV && DBG != 3) {                                                 \
+      WG_LOAD(0, raw[((K) + 2) % 3], fv, fpos); WG_LOAD(1, raw[((K) + 2) % 3], fv, fpos);   \
+      WG_LOAD(2, raw[((K) + 2) % 3], fv, fpos); WG_LOAD(3, raw[((K) + 2) % 3], fv, fpos);   \
+    }                                                                       \
+    WG_UNIT(K)                                                              \
+  }
+  for (; u < ub1; u += 24) {
+    WG_STEP(0) WG_STEP(1) WG_STEP(2) WG_STEP(3) WG_STEP(4) WG_STEP(5)
+  }
+#undef WG_STEP
+#undef WG_LOAD
+#undef WG_UNIT
+#undef WG_ROW
+#undef WG_TAP
+#undef WG_MFMA
+
+  // cross-wave reduction, one tap at a time: red[wave][r*64 + lane]
+  float* pt = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 9 * 32 * 32;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[tap][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      const int r = e >> 6, l = e & 63;
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+      pt[((size_t)tap * 32 + row) * 32 + col] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// units per task for geometry g (per term) and whether this kernel takes it (32 -> 32 channels, stride 1, tensors addressable in 30 bits)
+bool wgrad_bf16_ok(const ConvGeom& g) {
+  // (w >= 16: on 10 x 10 maps -- two column segments, 20 % of them padding -- the fp32 kernel with its exact segments is faster, 27 vs 30 us)
+  return g.stride == 1 && g.ci == 32 && g.co == 32 && g.h == g.ho && g.w == g.wo && g.w >= 16 &&
+         (size_t)g.n * g.h * g.w * 32 * 4 < (size_t)MI_OOB - 4096;
+}
+int wgrad_bf16_units(const ConvGeom& g) { return g.n * ((g.h + 1) / 2) * ((g.w + 7) / 8); }
+
+hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid, bool interleave_loads) {
+  extern int g_wgrad_bf16_dbg;
+  if (g_wgrad_bf16_dbg == 1) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 1>), grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg == 2) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 2>), grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg == 3) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 3>), grid, dim3(256), 0, st, a);
+  else if (interleave_loads) hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}

@@ -9,6 +9,19 @@ gradients are the sparse matrix pass over pooling windows (algorithmic weight-gr
 
 PEAK_TFLOPS = 157.3      # fp32-input MFMA == fp32 vector peak (MI355X_MICROARCH.md)
 PEAK_GBPS = 8000.0       # HBM3E spec (about 6300 GB/s is achievable with a streaming copy)
+BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
+# The 32-channel stride-1 forward / dgrad convolutions run in the split-bf16 operand form (csrc/conv_mfma.hip): SIX bf16 products per
+# algorithmic fp32 multiply-add, so the matrix pipe bounds them at a sixth of its dense bf16 rate, in algorithmic (fp32) FLOPs:
+SPLIT_BF16_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6.0
+SPLIT_BF16_OPS = ('conv_fwd_stats', 'dgrad', 'tangent_conv_fwd', 'tangent_dgrad')
+
+
+def mfma_peak(spec, op, layer, split_bf16=True):
+    """(peak TFLOP/s in algorithmic fp32 FLOPs, pipe) of the matrix pipe `op` on block `layer` runs on."""
+    h, w, ci, co, ho, wo, _, _ = layer_geometry(spec)[layer]
+    if split_bf16 and op in SPLIT_BF16_OPS and ci == 32 and co == 32 and (h, w) == (ho, wo):
+        return SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)'
+    return PEAK_TFLOPS, 'fp32'
 
 
 def layer_geometry(spec):
@@ -59,11 +72,11 @@ def op_costs(spec, op, layer, images):
     return fl * images, by * images
 
 
-def bound_of(flops, nbytes):
-    """Which roofline bounds an op with this arithmetic intensity."""
+def bound_of(flops, nbytes, peak_tflops=PEAK_TFLOPS):
+    """Which roofline bounds an op with this arithmetic intensity (peak_tflops: the matrix pipe it runs on, mfma_peak)."""
     if not flops:
         return 'hbm'
-    return 'mfma' if flops / nbytes > PEAK_TFLOPS * 1e12 / (PEAK_GBPS * 1e9) else 'hbm'
+    return 'mfma' if flops / nbytes > peak_tflops * 1e12 / (PEAK_GBPS * 1e9) else 'hbm'
 
 
 KERNEL_NAMES = {

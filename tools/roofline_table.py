@@ -16,7 +16,7 @@ import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from exploring_meta_amd.engine import ModelSpec  # noqa: E402
-from exploring_meta_amd.utils.roofline import PEAK_TFLOPS, PEAK_GBPS, op_costs  # noqa: E402
+from exploring_meta_amd.utils.roofline import PEAK_GBPS, mfma_peak, op_costs  # noqa: E402
 
 SPEC = ModelSpec.mini_imagenet(5)
 
@@ -26,13 +26,17 @@ def costs(op, l, images):
 
 
 def main():
-    path = sys.argv[1]
-    images = int(sys.argv[2]) if len(sys.argv) > 2 else 32 * 25
+    args = [a for a in sys.argv[1:] if a != '--fp32-pipe']
+    split = '--fp32-pipe' not in sys.argv[1:]          # the hidden forward / dgrad convolutions ran in the split-bf16 form (default)
+    path = args[0]
+    images = int(args[1]) if len(args) > 1 else 32 * 25
     rows = [r for r in csv.reader(open(path)) if r and not r[0].startswith('#')]
     hdr, rows = rows[0], rows[1:]
     total = sum(float(r[3]) for r in rows)
     print(f'Per-kernel roofline, {path} ({images} images per launch, one meta-iteration = {total:.2f} ms of kernel time)\n')
-    print('| op | block | launches | avg ms | share | GFLOP/launch | MB/launch | TFLOP/s (% of 157.3) | GB/s (% of 8000) | bound |')
+    print('FLOPs are algorithmic fp32 FLOPs.  Matrix peak per kernel: 157.3 TFLOP/s on the fp32 pipe; 416.7 (= dense bf16 2500 / 6 products per '
+          'multiply-add) for the kernels on the split-bf16 operand form (marked bf16x6).\n')
+    print('| op | block | launches | avg ms | share | GFLOP/launch | MB/launch | TFLOP/s (% of its matrix peak) | GB/s (% of 8000) | bound |')
     print('|---|---|---|---|---|---|---|---|---|---|')
     for r in rows:
         op, l, n, tot, avg, share = r[0], int(r[1]), int(r[2]), float(r[3]), float(r[4]), float(r[5])
@@ -43,11 +47,14 @@ def main():
         fl, by = c
         tf = fl / (avg * 1e-3) / 1e12
         gb = by / (avg * 1e-3) / 1e9
+        peak, pipe = mfma_peak(SPEC, op, l, split)
         if l == 0:
             bound = 'hbm' if not fl else ('mfma (sparse)' if 'wgrad' in op else 'valu/latency')
         else:
-            bound = 'mfma' if fl and (fl / by) > PEAK_TFLOPS * 1e12 / (PEAK_GBPS * 1e9) else 'hbm'
-        tfs = f'{tf:.1f} ({tf / PEAK_TFLOPS * 100:.0f} %)' if fl else '-'
+            bound = 'mfma' if fl and (fl / by) > peak * 1e12 / (PEAK_GBPS * 1e9) else 'hbm'
+        if pipe != 'fp32':
+            bound += ' bf16x6'
+        tfs = f'{tf:.1f} ({tf / peak * 100:.0f} %)' if fl else '-'
         print(f'| {op} | {l + 1} | {n} | {avg:.4f} | {share * 100:.1f} % | {fl / 1e9:.2f} | {by / 1e6:.1f} | '
               f'{tfs} | {gb:.0f} ({gb / PEAK_GBPS * 100:.0f} %) | {bound} |')
 
