@@ -29,14 +29,23 @@ def read_pass(path, counter):
     files = glob.glob(os.path.join(path, '**', '*counter_collection.csv'), recursive=True)
     if not files:
         sys.exit(f'no *counter_collection.csv under {path}')
-    acc = defaultdict(lambda: [0, 0.0])            # (kernel, grid) -> [launches, sum of counter]
+    vals = defaultdict(list)                       # (kernel, grid) -> counter value of every launch
     for f in files:
         for r in csv.DictReader(open(f)):
             if r.get('Counter_Name') != counter:
                 continue
-            k = (short_name(r['Kernel_Name']), int(r['Grid_Size']))
-            acc[k][0] += 1
-            acc[k][1] += float(r['Counter_Value'])
+            vals[(short_name(r['Kernel_Name']), int(r['Grid_Size']))].append(float(r['Counter_Value']))
+    # Two blocks of the classifier can be launched with the SAME grid (one balanced round of resident waves: block 2 with 22 tiles per
+    # wave, block 3 with 6): their launches differ 4x in bytes, so a (kernel, grid) group is cut wherever consecutive sorted values
+    # differ by more than 1.8x; cluster 0 = the largest.
+    acc = {}                                       # (kernel, grid, cluster) -> [launches, sum of counter]
+    for (k, g), v in vals.items():
+        v = sorted(v, reverse=True)
+        c, start = 0, 0
+        for i in range(1, len(v) + 1):
+            if i == len(v) or (v[i] > 0 and v[i - 1] / v[i] > 1.8) or (v[i] == 0 and v[i - 1] > 0):
+                acc[(k, g, c)] = [i - start, sum(v[start:i])]
+                c, start = c + 1, i
     return acc
 
 
@@ -64,12 +73,13 @@ def main():
         n = max(nf, nw)
         fetch_mb = 2.0 * sf * 1024 / max(nf, 1) / 1e6        # KB -> bytes, x2 (gfx950 wide-stream correction)
         write_mb = sw * 1024 / max(nw, 1) / 1e6
-        rows.append((k[0], k[1], n, fetch_mb, write_mb))
+        rows.append((k[0], k[1], n, fetch_mb, write_mb, k[2]))
     lines = [f'# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --workload {args.workload} --steps 1 --warmup 1 '
              f'--no-cpu-baseline{"; " + args.note if args.note else ""}',
              '# FETCH_SIZE is KB and counts HALF of wide (16 B/lane) coalesced streams on gfx950 (MI355X_MICROARCH.md HBM): shown x2; WRITE_SIZE KB exact',
-             'kernel,grid_threads,launches,fetch_MB_per_launch_x2,write_MB_per_launch']
-    lines += [f'"{k}",{g},{n},{f:.1f},{w:.1f}' for k, g, n, f, w in rows if n > 0 and (f + w) > 0.5]
+             '# launches of one kernel with one grid whose byte counts differ by more than 1.8x are listed as separate size classes (0 = largest)',
+             'kernel,grid_threads,size_class,launches,fetch_MB_per_launch_x2,write_MB_per_launch']
+    lines += [f'"{k}",{g},{c},{n},{f:.1f},{w:.1f}' for k, g, n, f, w, c in rows if n > 0 and (f + w) > 0.5]
     text = '\n'.join(lines) + '\n'
     if args.table:
         open(args.table, 'w').write(text)
@@ -91,7 +101,7 @@ def main():
         if wl.get('kind') == 'trpo':
             for spec_ in args.pick:
                 rx, key = spec_.split('::')
-                cand = [(g, f + w) for k, g, nl, f, w in rows if re.search(rx, k) and nl > 0]
+                cand = [(g, f + w) for k, g, nl, f, w, c in rows if re.search(rx, k) and nl > 0]
                 if cand:
                     out[f'{args.workload},{key}'] = int(max(cand)[1] * 1e6)
             json.dump(out, open(args.json, 'w'), indent=1)
@@ -101,27 +111,29 @@ def main():
         T, n = wl['tasks'], wl['ways'] * wl['shots'] * (2 if wl.get('anil') else 1)
         geo = layer_geometry(spec)
 
-        def grid_threads(layer, nterms):
+        def grid_threads(layer, nterms, split_bf16):
             h, w, ci, co, ho, wo = geo[layer][:6]
             ntiles = -(-(n * ho * wo) // 32)
             cot = co // 32
-            tpw = min(32, max(1, -(-(ntiles * T * cot) // 4096)))
+            slots = (1024 if nterms == 2 else 2048) if ci >= 64 else (2048 if split_bf16 else 4096)     # conv_grid (csrc/conv_mfma.hip)
+            tpw = min(128, max(1, -(-(ntiles * T * cot) // slots)))
             nw = 8 if (nterms == 2 and ci == 32) else 4
             return -(-ntiles // (nw * tpw)) * T * cot * nw * 64
 
         for spec_ in args.pick:
             rx, key = spec_.split('::')
-            cand = [(g, f + w) for k, g, nl, f, w in rows if re.search(rx, k) and nl > 0]
+            cand = [(g, -c, f + w) for k, g, nl, f, w, c in rows if re.search(rx, k) and nl > 0]
             if cand:
-                out[f'{args.workload},{key}'] = int(max(cand)[1] * 1e6)
-        for k, g, nl, f, w in rows:
-            m = re.match(r'conv3x3_s1_mfma_kernel<(\d+), (\d), (\d), (\d)>', k)
+                out[f'{args.workload},{key}'] = int(max(cand)[2] * 1e6)
+        for k, g, nl, f, w, c in rows:
+            m = re.match(r'conv3x3_s1_mfma_kernel<(\d+), (\d), (\d), (\d)(?:, (true|false))?>', k)
             if not (m and (m.group(2), m.group(3), m.group(4)) in CONV_OPS):
                 continue
             op = CONV_OPS[(m.group(2), m.group(3), m.group(4))]
-            for layer in range(1, len(geo)):
-                if geo[layer][2] == int(m.group(1)) and grid_threads(layer, int(m.group(2))) == g:
-                    out[f'{args.workload},{op},{layer}'] = int((f + w) * 1e6)
+            same_grid = [layer for layer in range(1, len(geo))       # blocks launched with this grid, largest maps first
+                         if geo[layer][2] == int(m.group(1)) and grid_threads(layer, int(m.group(2)), m.group(5) == 'true') == g]
+            if c < len(same_grid):
+                out[f'{args.workload},{op},{same_grid[c]}'] = int((f + w) * 1e6)
         json.dump(out, open(args.json, 'w'), indent=1)
 
 
