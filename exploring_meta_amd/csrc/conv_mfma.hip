@@ -392,10 +392,14 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
 #ifndef MI_CONV_XTILE
 #define MI_CONV_XTILE 1
 #endif
-  struct TileSt { unsigned base; bool rowok[3], colok[3]; unsigned keep_m, keep_p, offc[3], offe[3]; bool conf_m, conf_p; };
+  // BF: a tile is 30 output pixels; lanes j = 0 / 31 carry the pixel before / behind them -- operands for their neighbours' horizontal
+  // taps, their own accumulator rows are dropped -- so no tap needs anything from outside the wave (7 % more MFMAs instead of an
+  // "edge" load, its split and a merge per shifted register: half the vector instructions per row).
+  constexpr int TP = BF ? 30 : 32, PO = BF ? 1 : 0;
+  struct TileSt { unsigned base; bool rowok[3], colok[3]; unsigned keep_m, keep_p, offc[3]; };
   auto decode = [&](int tl) {
     TileSt t;
-    const unsigned pix = (unsigned)(tl * 32 + j);
+    const unsigned pix = (unsigned)(tl * TP + j - PO);              // tile 0, lane 0 of the BF form: "-1" wraps to an invalid pixel
     unsigned nimg, rem, oy, ox;
     divmod24(pix, hw, rhw, nimg, rem);
     divmod24(rem, (unsigned)W, rw, oy, ox);
@@ -405,23 +409,15 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
     t.colok[0] = ox >= 1u; t.colok[1] = true; t.colok[2] = ox + 1u < (unsigned)W;
     t.base = pix * (unsigned)(CI * 4) + lane_in;
     if constexpr (BF) {
-      // operands of the horizontal displacements -1 / +1 come from the centre operand one lane over (DPP wave shift); the lanes that take
-      // them from the edge load instead: the tile's first / last pixel, and every pixel in the image's first / last column (the edge
-      // registers are zero there) -- unless that pixel sits in the OTHER edge lane, whose register holds the opposite neighbour (conf_*)
-      // (as bit masks for v_bfi_b32: a v_cndmask_b32 costs four times a plain VALU instruction here, tools/valu_rate_probe.hip)
-      t.keep_m = (!t.colok[0] || j == 0) ? 0u : 0xffffffffu;
-      t.keep_p = (!t.colok[2] || j == 31) ? 0u : 0xffffffffu;
-      asm volatile("" : "+v"(t.keep_m), "+v"(t.keep_p));        // opaque: (x & keep) | (e & ~keep) must stay one v_bfi_b32, not turn back into a select
-      t.conf_m = __builtin_amdgcn_readlane((int)!t.colok[0], 31) != 0;
-      t.conf_p = __builtin_amdgcn_readlane((int)!t.colok[2], 0) != 0;
-      // byte offsets of the centre / edge loads of the three displaced rows (out of range where the row, or the neighbour, is padding)
+      // operands of the horizontal displacements -1 / +1 are the centre operand one lane over (DPP wave shift), zero where the pixel sits
+      // in the image's first / last column (as bit masks fused into the shift: a v_cndmask_b32 costs four plain VALU instructions here,
+      // tools/valu_rate_probe.hip); opaque, so that the optimiser cannot turn the AND back into a select
+      t.keep_m = t.colok[0] ? 0xffffffffu : 0u;
+      t.keep_p = t.colok[2] ? 0xffffffffu : 0u;
+      asm volatile("" : "+v"(t.keep_m), "+v"(t.keep_p));
+      // byte offsets of the centre loads of the three displaced rows (out of range where the row is padding)
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const bool rok = t.rowok[d];
-        const unsigned row = t.base + (unsigned)((d - 1) * wci);
-        t.offc[d] = rok ? row : MI_OOB;
-        t.offe[d] = (j == 0 && rok && t.colok[0]) ? row - (unsigned)(CI * 4) : ((j == 31 && rok && t.colok[2]) ? row + (unsigned)(CI * 4) : MI_OOB);
-      }
+      for (int d = 0; d < 3; ++d) t.offc[d] = t.rowok[d] ? t.base + (unsigned)((d - 1) * wci) : MI_OOB;
     }
     return t;
   };
@@ -440,13 +436,12 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   int tile = tile_base + wave;
   TileSt cur = decode(tile);
   // ---- BF pipeline.  Half-group i of a tile = (term, row displacement, 32-channel chunk cc, k half kb): the lane's 8 values
-  // k = cc*32 + 16h + 8kb + 0..7 of its pixel in the displaced row (centre load, 2 x 16 B) and of the tile's two outside neighbours in
-  // that row (edge load: lanes j = 0 / j = 31 only, everyone else out of range -> zeros, no cache access).  Three MFMA units per half-group
-  // (horizontal displacement 0, -1, +1), six bf16 MFMAs each.  A row is fetched ONCE and shifted across lanes for the two other taps:
+  // k = cc*32 + 16h + 8kb + 0..7 of its pixel in the displaced row (2 x 16 B).  Three MFMA units per half-group (horizontal
+  // displacement 0, -1, +1), six bf16 MFMAs each.  A row is fetched ONCE and shifted across lanes for the two other taps:
   // a third of the fp32 kernel's per-lane 16-B cache accesses (its L1 runs at 0.77 accesses per clock and CU, tools/conv_l1_probe.py).
   constexpr int NH = NSTEP / 3 * 2, HRING = 3;               // loads run two half-groups ahead of the split, three ahead of the MFMAs
   static_assert(NH % HRING == 0 && NH % 2 == 0, "raw ring and plane double buffer must be in phase at every tile boundary");
-  floatx4 rawc[BF ? HRING : 1][2], rawe[BF ? HRING : 1][2];
+  floatx4 rawc[BF ? HRING : 1][2];
   auto hg_term = [](int i) { return i / (6 * NCC); };
   auto hg_ddy = [](int i) { return (i % (6 * NCC)) / (2 * NCC) - 1; };
   auto hg_cc = [](int i) { return (i / 2) % NCC; };
@@ -458,11 +453,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   auto issue_hg = [&](const TileSt& t, int i) {
     const int ddy = hg_ddy(i), term = hg_term(i);
     const unsigned offc = t.offc[ddy + 1] + (unsigned)(hg_cc(i) * 128 + (i & 1) * 32);
-    const unsigned offe = t.offe[ddy + 1] + (unsigned)(hg_cc(i) * 128 + (i & 1) * 32);
     rawc[i % HRING][0] = buf_ld16(rin[term], offc);
     rawc[i % HRING][1] = buf_ld16(rin[term], offc + 16);
-    rawe[i % HRING][0] = buf_ld16(rin[term], offe);
-    rawe[i % HRING][1] = buf_ld16(rin[term], offe + 16);
   };
   if constexpr (BF) {
 #pragma unroll
@@ -474,12 +466,11 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
   __syncthreads();                                            // weights staged (the first operand loads are already in flight)
   CV_STAMP(1);
   int ntile_done = 0;
-  Bf16Planes pc[2], pe[2], opm, opp;                           // centre / edge planes (double-buffered over half-groups), shifted operands
+  Bf16Planes pc[2], opm, opp;                                  // centre planes (double-buffered over half-groups), shifted operands
   mi_u32x4 pb[2][3];
   const mi_u32x4* l4 = reinterpret_cast<const mi_u32x4*>(lds) + lane;
   if constexpr (BF) {
     bf16_split8(rawc[0][0], rawc[0][1], pc[0]);
-    bf16_split8(rawe[0][0], rawe[0][1], pe[0]);
     const int u0 = hg_unit(0, 0);
     pb[0][0] = l4[(u0 * 3 + 0) * 64]; pb[0][1] = l4[(u0 * 3 + 1) * 64]; pb[0][2] = l4[(u0 * 3 + 2) * 64];
   }
@@ -492,7 +483,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    const unsigned obase = lane_out + (unsigned)tile * (unsigned)(32 * CO * 4);
+    const unsigned obase = lane_out + (unsigned)(tile * TP - PO) * (unsigned)(CO * 4);      // (BF tile 0: "-1 pixel" wraps; row 0 is dropped anyway)
     float zpre[16];
     if (EPI == EPI_TSTATS) {
 #pragma unroll
@@ -502,10 +493,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
       }
     }
     if constexpr (BF) {
-      // shifted operand: lane <- the centre planes one lane over, edge / padding lanes <- the edge planes (zero unless lane j = 0 / 31)
-#define MI_SHIFT(dst, P, R, CTRL, SEL)                                                                  \
-      { const unsigned sh_ = (unsigned)__builtin_amdgcn_mov_dpp((int)pc_.P[R], CTRL, 0xf, 0xf, true); \
-        dst.P[R] = (sh_ & SEL) | (pe_.P[R] & ~SEL); }
+      // shifted operand: lane <- the centre planes one lane over, zero in the image's first / last column (one v_and_b32_dpp per register)
+#define MI_SHIFT(dst, P, R, CTRL, SEL) dst.P[R] = (unsigned)__builtin_amdgcn_mov_dpp((int)pc_.P[R], CTRL, 0xf, 0xf, true) & SEL;
 #define MI_SHIFT6(dst, A0, A1, CTRL, SEL)                                                               \
       { MI_SHIFT(dst, A0, 0, CTRL, SEL) MI_SHIFT(dst, A0, 1, CTRL, SEL) MI_SHIFT(dst, A0, 2, CTRL, SEL) MI_SHIFT(dst, A0, 3, CTRL, SEL) \
         MI_SHIFT(dst, A1, 0, CTRL, SEL) MI_SHIFT(dst, A1, 1, CTRL, SEL)                                  \
@@ -541,32 +530,20 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
         // the loads of half-group i + 3 (the raw slot of half-group i was split during half-group i - 1)
         if (i + HRING < NH) issue_hg(cur, i + HRING); else issue_hg(nxt, i + HRING - NH);
         const Bf16Planes& pc_ = pc[i & 1];
-        const Bf16Planes& pe_ = pe[i & 1];
         Bf16Planes& nc = pc[(i + 1) & 1];
-        Bf16Planes& ne = pe[(i + 1) & 1];
         const floatx4* rc = rawc[(i + 1) % HRING];
-        const floatx4* re = rawe[(i + 1) % HRING];
         const unsigned selm = cur.keep_m, selp = cur.keep_p;
-        // unit 0: centre tap; meanwhile the -1 operand and the first half of the next half-group's centre split
+        // unit 0: centre tap; meanwhile the -1 operand and the first half of the next half-group's split
         MI_READB(pb[(3 * i + 1) & 1], hg_unit(i, -1));
         MI_UNIT(pc_, pb[(3 * i) & 1], MI_SHIFT6(opm, h, m, 0x138, selm), MI_SHIFT6B(opm, m, l, 0x138, selm), bf16_split_pair<0>(rc[0], nc),
                 bf16_split_pair<1>(rc[0], nc))
-        if (cur.conf_m) {                                          // rare: the tile's last pixel starts an image row
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { opm.h[r] = j == 31 ? 0u : opm.h[r]; opm.m[r] = j == 31 ? 0u : opm.m[r]; opm.l[r] = j == 31 ? 0u : opm.l[r]; }
-        }
-        // unit 1: tap -1; meanwhile the +1 operand and the second half of the centre split
+        // unit 1: tap -1; meanwhile the +1 operand and the second half of the split
         MI_READB(pb[(3 * i + 2) & 1], hg_unit(i, 1));
         MI_UNIT(opm, pb[(3 * i + 1) & 1], MI_SHIFT6(opp, h, m, 0x130, selp), MI_SHIFT6B(opp, m, l, 0x130, selp), bf16_split_pair<2>(rc[1], nc),
                 bf16_split_pair<3>(rc[1], nc))
-        if (cur.conf_p) {                                          // rare: the tile's first pixel ends an image row
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { opp.h[r] = j == 0 ? 0u : opp.h[r]; opp.m[r] = j == 0 ? 0u : opp.m[r]; opp.l[r] = j == 0 ? 0u : opp.l[r]; }
-        }
-        // unit 2: tap +1; meanwhile the next half-group's edge split
+        // unit 2: tap +1
         MI_READB(pb[(3 * i + 3) & 1], hg_unit((i + 1) % NH, 0));
-        MI_UNIT(opp, pb[(3 * i + 2) & 1], bf16_split_pair<0>(re[0], ne), bf16_split_pair<1>(re[0], ne), bf16_split_pair<2>(re[1], ne),
-                bf16_split_pair<3>(re[1], ne))
+        MI_UNIT(opp, pb[(3 * i + 2) & 1], (void)0, (void)0, (void)0, (void)0)
       }
 #undef MI_READB
 #undef MI_UNIT
@@ -611,6 +588,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
       auto row_off = [&](int r) {
         return obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
       };
+      // BF: accumulator rows 0 (r = 0 of lane half 0) and 31 (r = 15 of lane half 1) belong to the halo lanes: not stored, not summed
+      auto dropped = [&](int r) { return BF && ((r == 0 && h == 0) || (r == 15 && h == 1)); };
       auto fetch = [&](int grp, Grp& gq) {
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) {
@@ -625,8 +604,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
         for (int rr = 0; rr < GR; ++rr) {
           const int r = grp * GR + rr;
           const float v = acc[r];
-          buf_st_untracked(rout_raw, row_off(r), v);
-          const bool on = gq.pp[rr] > 0.f;
+          buf_st_untracked(rout_raw, dropped(r) ? MI_OOB : row_off(r), v);
+          const bool on = gq.pp[rr] > 0.f && !dropped(r);
           const float vv = on ? v : 0.f;
           if (NTERMS == 1) {
             s = fma((double)vv, (double)gq.zz[rr], s);
@@ -652,8 +631,9 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned ro = (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
-      const float v = acc[r];
-      buf_st_untracked(rout_raw, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro, v);
+      const bool drop = BF && ((r == 0 && h == 0) || (r == 15 && h == 1));      // the halo lanes' accumulator rows (BF tiles: 30 pixels)
+      buf_st_untracked(rout_raw, drop ? MI_OOB : obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro, acc[r]);
+      const float v = drop ? 0.f : acc[r];
       if (EPI == EPI_STATS) {
         const double dv = (double)v;
         s += dv;
@@ -1017,14 +997,14 @@ extern "C" int mi_conv_set_split_bf16(int on) {
   return was;
 }
 
-static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int nterms, int& ntiles, int& tpw, dim3& grid) {
-  ntiles = ceil_div(mpix, 32);
+static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int nterms, int& ntiles, int& tpw, dim3& grid, int tile_pix = 32) {
+  ntiles = ceil_div(mpix, tile_pix);
   // One balanced round: give every resident wave ceil(tiles / slots) tiles -- more, shorter waves would run as 2.x rounds whose last
   // round is mostly idle.  Resident waves: 4 per SIMD by registers (<= 128 VGPRs in every variant), limited by the LDS copy of the
   // weights (160 KB per CU): 36 KB per 32-channel term and workgroup -> 4096 waves on the chip; the 64-channel kernels stage 74 KB
   // (one term, two workgroups of 4 waves per CU) or 147 KB (two terms, one workgroup) -> 2048 / 1024 waves.
   // Split-bf16 32-channel kernels: 54 KB (one term, two 4-wave workgroups per CU) / 108 KB (two terms, one 8-wave workgroup) -> 2048.
-  const long slots = ci >= 64 ? (nterms == 2 ? 1024 : 2048) : (conv_split_bf16() ? 2048 : 4096);
+  const long slots = ci >= 64 ? (nterms == 2 ? 1024 : 2048) : (tile_pix != 32 ? 2048 : 4096);
   long total = (long)ntiles * tasks * cot;
   tpw = (int)((total + slots - 1) / slots);
   if (tpw < 1) tpw = 1;
@@ -1035,12 +1015,12 @@ static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int n
 int conv_tiles_per_wave(int mpix, int tasks, int cot) {
   int ntiles, tpw;
   dim3 grid;
-  conv_grid(mpix, tasks, cot, 4, 32, 1, ntiles, tpw, grid);
+  conv_grid(mpix, tasks, cot, 4, 32, 1, ntiles, tpw, grid, conv_split_bf16() ? 30 : 32);   // (a 32-filter stride-1 block, as the tests ask)
   return tpw;
 }
 
-int conv_max_blocks_per_task(const ConvGeom& g) {  // tiles_per_wave == 1 is the finest split any launch uses
-  return ceil_div(ceil_div(g.n * g.ho * g.wo, 32), 4);
+int conv_max_blocks_per_task(const ConvGeom& g) {  // tiles_per_wave == 1 is the finest split any launch uses (30-pixel tiles: split-bf16 form)
+  return ceil_div(ceil_div(g.n * g.ho * g.wo, 30), 4);
 }
 
 template <int CI, int NTERMS, int EPI, int MODE, int STRIDE>
@@ -1072,8 +1052,7 @@ static hipError_t launch_conv_s1_bf(hipStream_t st, ConvArgs& a, dim3 grid) {
 template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
   if constexpr (CI == 32) {
-    if (conv_split_bf16() && ((g_conv_split_mask >> (((NTERMS - 1) * 2 + MODE) * 4 + EPI)) & 1u))
-      return launch_conv_s1_bf<CI, NTERMS, EPI, MODE>(st, a, grid);
+    if (a.split_bf16) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE>(st, a, grid);
   }
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);
   auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE>;
@@ -1120,7 +1099,10 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
   int ntiles, tpw;
   dim3 grid;
   const int nw = (nterms == 2 && a.g.ci == 32) ? 8 : 4;     // ConvWaves<CI, NTERMS>
-  conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid);
+  // the split-bf16 form of the stride-1 kernel (32 filters): tiles of 30 output pixels, 2048 resident waves
+  a.split_bf16 = a.g.ci == 32 && conv_s1_ok(a) && conv_split_bf16() && (epi == EPI_BRED ? mode == 1 : (mode == 0 || epi == EPI_NONE)) &&
+                 ((g_conv_split_mask >> (((nterms - 1) * 2 + mode) * 4 + epi)) & 1u);
+  conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid, a.split_bf16 ? 30 : 32);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   if (blocks_per_task) *blocks_per_task = grid.x;

@@ -21,6 +21,7 @@ struct ConvArgs {
   ConvGeom g;
   int mpix;             // n*ho*wo
   int ntiles, tiles_per_wave;
+  int split_bf16;       // set by launch_conv3x3: this launch takes the split-bf16 form (30-pixel tiles)
 };
 
 struct WgradArgs {

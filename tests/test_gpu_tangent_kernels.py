@@ -190,11 +190,11 @@ def test_conv_fwd_bwd_at_bench_sizes(lib, name, T, n, h, w, ci, co, check):
     tpw = lib.mi_debug_conv_tiles_per_wave(T, n, h, w, co)
     split = lib.mi_conv_set_split_bf16(1)
     lib.mi_conv_set_split_bf16(split)
-    # resident waves: 4096 with the fp32 operands' 36 KB of staged weights per workgroup, 2048 with the split-bf16 form's 54 KB
+    # resident waves: 4096 with the fp32 operands' 36 KB of staged weights per workgroup, 2048 with the split-bf16 form's 54 KB (and 30-pixel tiles)
     if name == 'bench_l2_T32':
-        assert tpw == (22 if split else 11)
+        assert tpw == (23 if split else 11)
     if name == 'cap32_T96':
-        assert tpw == (65 if split else 33)          # beyond the 32-tile cap of round 1 (the cap is 128 tiles per wave now)
+        assert tpw == (69 if split else 33)          # beyond the 32-tile cap of round 1 (the cap is 128 tiles per wave now)
     errs = dict(z=0.0, mu=0.0, rstd=0.0, dx=0.0, dw=0.0)
     for t in check:
         k = t % nd
