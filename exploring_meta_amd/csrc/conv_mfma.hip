@@ -987,13 +987,15 @@ static bool conv_split_bf16() {
   }
   return g_conv_split_bf16 != 0;
 }
+int g_wgrad_bf16_dbg4 = 0;
 int g_wgrad_bf16_dbg = 0;                                      // timing experiments (bits 19..20 of the mask): see wgrad_bf16.hip
 static unsigned g_conv_split_mask = 0x3ffffu;                   // debug: which variants take the split form: conv bit ((terms-1)*2 + mode)*4 + epi, weight gradient bit 16 + (terms-1)
 extern "C" int mi_conv_set_split_bf16(int on) {
   const int was = conv_split_bf16() ? 1 : 0;
   g_conv_split_bf16 = on ? 1 : 0;
   g_conv_split_mask = on > 1 ? ((unsigned)on >> 8) : 0x3ffffu;
-  g_wgrad_bf16_dbg = (int)((g_conv_split_mask >> 19) & 3u);  // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
+  g_wgrad_bf16_dbg = (int)((g_conv_split_mask >> 19) & 3u);
+  g_wgrad_bf16_dbg4 = (int)((g_conv_split_mask >> 22) & 1u);  // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
   return was;
 }
 
@@ -1184,6 +1186,24 @@ static void rows_split(const ConvGeom& g, int tasks, int& rh, int& nunits, int& 
 bool wgrad_bf16_ok(const ConvGeom& g);
 int wgrad_bf16_units(const ConvGeom& g);
 hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid, bool interleave_loads);
+bool wgrad_bf16_strips(const ConvGeom& g);
+int wgrad_bf16_strip_items(const ConvGeom& g);
+hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid);
+// strip form: items (a 16-column strip piece of ~24 rows) per workgroup; each of the four waves walks whole items
+static void strips_split_bf16(const ConvGeom& g, int tasks, int nterms, int& ipb, int& blocks) {
+  const int items = wgrad_bf16_strip_items(g);
+  int max_bpt = items < 128 ? items : 128;
+  if (max_bpt < 1) max_bpt = 1;
+  int best = 1;
+  long best_cost = -1;
+  for (int bpt = 1; bpt <= max_bpt; ++bpt) {                // rounds of 256 resident workgroups x (items per wave + the reduction epilogue, ~1/3 item)
+    const long rounds = ((long)tasks * bpt + 255) / 256;
+    const long cost = rounds * (3 * ceil_div(ceil_div(items, bpt) * nterms, 4) + 1);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bpt; }
+  }
+  ipb = ceil_div(items, best);
+  blocks = ceil_div(items, ipb);
+}
 static void rows_split_bf16(const ConvGeom& g, int tasks, int& nunits, int& upb, int& blocks) {
   nunits = wgrad_bf16_units(g);
   int max_bpt = ceil_div(nunits, 16);                       // never fewer than 4 units per wave
@@ -1208,6 +1228,12 @@ size_t wgrad_partial_floats(const ConvGeom& g, int tasks) {
       int nu, ub, bl;
       rows_split_bf16(g, tasks, nu, ub, bl);
       if (bl > blocks) blocks = bl;
+      if (wgrad_bf16_strips(g)) {
+        for (int nt = 1; nt <= 2; ++nt) {
+          strips_split_bf16(g, tasks, nt, ub, bl);
+          if (bl > blocks) blocks = bl;
+        }
+      }
     }
     return (size_t)tasks * blocks * 9 * g.ci * g.co;
   }
@@ -1233,6 +1259,16 @@ static void launch_rows(hipStream_t st, const WgradArgs& a, dim3 grid, int rh) {
 
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out) {
   const int s = a.g.stride;
+  if (use_rows_kernel(a.g) && conv_split_bf16() && wgrad_bf16_ok(a.g) && (g_conv_split_mask & (1u << (16 + (nterms - 1)))) &&
+      wgrad_bf16_strips(a.g) && !((g_conv_split_mask >> 21) & 1u)) {        // bit 21 (debug): the unit form on wide maps too
+    int ipb, blocks;
+    strips_split_bf16(a.g, tasks, nterms, ipb, blocks);
+    a.nterms = nterms;
+    a.chunk_pix = ipb * nterms;                            // the item stream is nterms x items long, same workgroup count
+    a.nchunks = blocks;
+    *nchunks_out = blocks;
+    return launch_wgrad_strips_bf16(st, a, dim3(blocks, tasks, 1));
+  }
   if (use_rows_kernel(a.g) && conv_split_bf16() && wgrad_bf16_ok(a.g) && (g_conv_split_mask & (1u << (16 + (nterms - 1))))) {
     int nunits, upb, blocks;
     rows_split_bf16(a.g, tasks, nunits, upb, blocks);

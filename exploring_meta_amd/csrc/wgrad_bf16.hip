@@ -215,6 +215,186 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Strip form (maps at least 32 wide): a work item is a vertical strip of one image -- 16 columns (lane half h = columns [8h, 8h + 8) of
+// it), a run of rows -- walked one output row per step with the x rows it needs RESIDENT as split planes: step y multiplies dz row y
+// against x rows y - 1, y, y + 1 (9 taps, 54 MFMAs) and meanwhile loads and splits only the NEW x row y + 2 and dz row y + 1: 18 loads and
+// 18 split values per 54 MFMAs where the unit form above needs 38 and 38.  Every row has its own buffer descriptor (base = the row's
+// first pixel, size = the row): columns outside the image are out of range (zeros) and all loads take immediates -- no address arithmetic
+// on the vector unit at all.  Row planes rotate through four register sets, raw rows through four (three steps of load lookahead): four
+// steps per loop trip, strips are dealt in runs of a multiple of four rows.
+struct StripItem { int n, c0, ya, yb; bool ok; };
+struct XRowPl { RowPl e; };                                     // (the odd packing is rebuilt per step: 12 instructions instead of 12 resident registers per row)
+
+template <int DBG>   // timing experiments only: 1 = no MFMAs, 2 = no operand preparation, 3 = no loads in the loop, 4 = loads only
+__global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
+  __shared__ float red[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.y;
+  const int H = a.g.h, W = a.g.w;
+  const int nseg = (W + 15) >> 4;
+  const int rp = a.mpix;                                       // rows per strip piece (multiple of 4; the launcher passes it here)
+  const int nh = (H + rp - 1) / rp;
+  const int nitems = a.g.n * nseg * nh;                        // per term; the item stream is [term][item]
+  const int total = nitems * a.nterms;
+  const int ub0 = blockIdx.x * a.chunk_pix;                    // chunk_pix = items per workgroup here
+  const int ub1 = min(ub0 + a.chunk_pix, total);
+  const size_t t_elems = (size_t)a.g.n * H * W * 32;
+  const unsigned rowb = (unsigned)(W * 128);                   // bytes of one image row (32 channels)
+
+  floatx16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  XRowPl xr[4];                                                // x row planes, slot = (row - first row + 1) & 3
+  OddPl ot;                                                    // odd packing of the row whose taps are running
+  DzPl dzp[2];
+  float rawx[4][10], rawd[4][8];
+
+  for (int item = ub0 + wave; item < ub1; item += 4) {
+    const int term = item >= nitems ? 1 : 0;
+    const int it = item - term * nitems;
+    const int n = it / (nseg * nh);
+    const int rem = it - n * nseg * nh;
+    const int s16 = rem / nh, half = rem - s16 * nh;
+    const int ya = half * rp, yb = min(H, ya + rp);
+    const int cb = s16 * 16 + 8 * h;                           // this lane half's first column
+    const float* xt = (term ? a.x[1] : a.x[0]) + (size_t)task * t_elems + (size_t)n * H * W * 32;
+    const float* dt = (term ? a.dz[1] : a.dz[0]) + (size_t)task * t_elems + (size_t)n * H * W * 32;
+    // per-lane offsets inside a row: column cb (x columns cb .. cb + 8 and all dz columns as immediates), and column cb - 1 on its own
+    const unsigned vo = (unsigned)((cb * 32 + j) * 4);
+    const unsigned vom = cb >= 1 ? vo - 128u : MI_OOB;
+    auto xrow = [&](int yy) {                                    // descriptor of x row yy (empty outside the image)
+      const bool ok = (unsigned)yy < (unsigned)H;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(xt + (size_t)(ok ? yy : 0) * W * 32), 0, ok ? rowb : 0u, 0x00020000);
+    };
+    auto drow = [&](int yy) {                                    // dz row yy; rows past the strip piece contribute nothing
+      const bool ok = yy < yb;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(dt + (size_t)(ok ? yy : 0) * W * 32), 0, ok ? rowb : 0u, 0x00020000);
+    };
+#define ST_LOADX(SET, YY) { const mi_rsrc rr_ = xrow(YY); rawx[SET][0] = buf_ld(rr_, vom);                                  \
+      _Pragma("unroll") for (int c = 1; c < 10; ++c) rawx[SET][c] = buf_ld(rr_, vo + (unsigned)((c - 1) * 128)); }
+#define ST_LOADD(SET, YY) { const mi_rsrc rr_ = drow(YY);                                                                  \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) rawd[SET][c] = buf_ld(rr_, vo + (unsigned)(c * 128)); }
+#define ST_SPLITX(SET, SLOT) { split_x_pair<0>(rawx[SET], xr[SLOT].e); split_x_pair<1>(rawx[SET], xr[SLOT].e); split_x_pair<2>(rawx[SET], xr[SLOT].e); \
+      split_x_pair<3>(rawx[SET], xr[SLOT].e); split_x_pair<4>(rawx[SET], xr[SLOT].e); }
+#define ST_SPLITD(SET, BUF) { split_dz_pair<0>(rawd[SET], dzp[BUF]); split_dz_pair<1>(rawd[SET], dzp[BUF]); split_dz_pair<2>(rawd[SET], dzp[BUF]); \
+      split_dz_pair<3>(rawd[SET], dzp[BUF]); }
+    // prologue: x rows ya - 1, ya, ya + 1 (slots 0, 1, 2) and dz row ya; then the ring: x rows ya + 2 .. ya + 4, dz rows ya + 1 .. ya + 3
+    ST_LOADX(0, ya - 1) ST_LOADX(1, ya) ST_LOADX(2, ya + 1) ST_LOADD(0, ya)
+    ST_SPLITX(0, 0) ST_SPLITX(1, 1) ST_SPLITX(2, 2) ST_SPLITD(0, 0)
+    // The ring.  hipcc turns the FIRST operand wait of every loop trip into vmcnt(0) whatever is in flight across the back edge (its
+    // wait-count pass does not carry exact counts around a loop), so the loads are timed such that everything in flight at a trip
+    // boundary is at least two steps old: a trip's steps 2 and 3 are loaded at its step 0, the NEXT trip's steps 0 and 1 at its step 2.
+    ST_LOADX(3, ya + 2) ST_LOADD(1, ya + 1) ST_LOADX(0, ya + 3) ST_LOADD(2, ya + 2)
+    // step T (output row y + T of the trip that starts at row y): x rows in slots T, T+1, T+2 (mod 4), dz planes T & 1; meanwhile x row
+    // y + T + 2 (raw set (T + 3) & 3) is split into slot (T + 3) & 3 and dz row y + T + 1 (raw set (T + 1) & 3) into planes (T + 1) & 1
+#define ST_MFMA(T, X, Y) if (DBG != 1 && DBG != 4) acc[T] = MI_BF_MFMA(X, Y, acc[T])
+#define ST_TAP(T, AH, AM, AL, B, V0, V1, V2, V3)                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    ST_MFMA(T, AL, B.h);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    V0;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    ST_MFMA(T, AH, B.l);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    V1;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    ST_MFMA(T, AM, B.m);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    V2;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    ST_MFMA(T, AM, B.h);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    V3;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    ST_MFMA(T, AH, B.m);                                                          \
+    ST_MFMA(T, AH, B.h);                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define ST_ROW(R, X, B, V3, V4, V5, V6, V7, V8, V9, V10, V11)                                                     \
+    ST_TAP(3 * (R) + 0, (X.e.h), (X.e.m), (X.e.l), B, ST_PREP(odd_plane(X.e.h, ot.h)), ST_PREP(odd_plane(X.e.m, ot.m)), ST_PREP(odd_plane(X.e.l, ot.l)), V3)   \
+    ST_TAP(3 * (R) + 1, (ot.h), (ot.m), (ot.l), B, V4, V5, V6, V7)                                                \
+    ST_TAP(3 * (R) + 2, (X.e.h + 1), (X.e.m + 1), (X.e.l + 1), B, V8, V9, V10, V11)
+#define ST_PREP(X) if (DBG != 2 && DBG != 4) { X; }
+#define ST_STEP(T)                                                                                                \
+    {                                                                                                             \
+      XRowPl& nx = xr[((T) + 3) & 3];                                                                             \
+      const float* rx_ = rawx[((T) + 3) & 3];                                                                     \
+      const float* rd_ = rawd[((T) + 1) & 3];                                                                     \
+      DzPl& nd = dzp[((T) + 1) & 1];                                                                              \
+      const DzPl& cd = dzp[(T) & 1];                                                                              \
+      ST_ROW(0, xr[(T) & 3], cd, ST_PREP(split_x_pair<0>(rx_, nx.e)), ST_PREP(split_x_pair<1>(rx_, nx.e)), ST_PREP(split_x_pair<2>(rx_, nx.e)),      \
+             ST_PREP(split_x_pair<3>(rx_, nx.e)), ST_PREP(split_x_pair<4>(rx_, nx.e)), ST_PREP(split_dz_pair<0>(rd_, nd)), ST_PREP(split_dz_pair<1>(rd_, nd)), \
+             ST_PREP(split_dz_pair<2>(rd_, nd)), ST_PREP(split_dz_pair<3>(rd_, nd)))                                \
+      ST_ROW(1, xr[((T) + 1) & 3], cd,                                                                            \
+             if (DBG == 3) {} else if ((T) == 0) ST_LOADX(1, y + 4) else if ((T) == 2) ST_LOADX(3, y + 6),          \
+             if (DBG == 3) {} else if ((T) == 0) ST_LOADD(3, y + 3) else if ((T) == 2) ST_LOADD(1, y + 5),          \
+             (void)0, (void)0,                                                                                    \
+             if (DBG == 3) {} else if ((T) == 0) ST_LOADX(2, y + 5) else if ((T) == 2) ST_LOADX(0, y + 7),          \
+             if (DBG == 3) {} else if ((T) == 0) ST_LOADD(0, y + 4) else if ((T) == 2) ST_LOADD(2, y + 6),          \
+             (void)0, (void)0, (void)0)                                                                           \
+      ST_ROW(2, xr[((T) + 2) & 3], cd, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0) \
+    }
+    for (int y = ya; y < yb; y += 4) {
+      ST_STEP(0) ST_STEP(1) ST_STEP(2) ST_STEP(3)
+    }
+#undef ST_STEP
+#undef ST_PREP
+#undef ST_ROW
+#undef ST_TAP
+#undef ST_MFMA
+#undef ST_SPLITD
+#undef ST_SPLITX
+#undef ST_LOADD
+#undef ST_LOADX
+  }
+
+  // cross-wave reduction, one tap at a time: red[wave][r*64 + lane]
+  float* pt = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 9 * 32 * 32;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[tap][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      const int r = e >> 6, l = e & 63;
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+      pt[((size_t)tap * 32 + row) * 32 + col] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// strip form: maps at least 32 wide whose width wastes at most 15 % of whole 16-column strips (42 -> 48)
+bool wgrad_bf16_strips(const ConvGeom& g) { return g.w >= 32 && ((g.w + 15) / 16) * 16 * 100 <= g.w * 115; }
+// rows per strip piece (a multiple of four, about 24) and items per task (per term)
+int wgrad_bf16_strip_rows(const ConvGeom& g) {
+  const int nh = (g.h + 23) / 24;
+  return (((g.h + nh - 1) / nh + 3) / 4) * 4;
+}
+int wgrad_bf16_strip_items(const ConvGeom& g) {
+  const int rp = wgrad_bf16_strip_rows(g);
+  return g.n * ((g.w + 15) / 16) * ((g.h + rp - 1) / rp);
+}
+hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid) {
+  a.mpix = wgrad_bf16_strip_rows(a.g);                         // (the kernel takes the rows per piece in this field)
+  extern int g_wgrad_bf16_dbg;
+  extern int g_wgrad_bf16_dbg4;
+  if (g_wgrad_bf16_dbg4) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<4>, grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg == 1) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<1>, grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg == 2) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<2>, grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg == 3) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<3>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<0>, grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 // units per task for geometry g (per term) and whether this kernel takes it (32 -> 32 channels, stride 1, tensors addressable in 30 bits)
 bool wgrad_bf16_ok(const ConvGeom& g) {
   // (w >= 16: on 10 x 10 maps -- two column segments, 20 % of them padding -- the fp32 kernel with its exact segments is faster, 27 vs 30 us)

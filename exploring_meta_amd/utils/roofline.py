@@ -14,12 +14,14 @@ BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 # algorithmic fp32 multiply-add, so the matrix pipe bounds them at a sixth of its dense bf16 rate, in algorithmic (fp32) FLOPs:
 SPLIT_BF16_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6.0
 SPLIT_BF16_OPS = ('conv_fwd_stats', 'dgrad', 'tangent_conv_fwd', 'tangent_dgrad')
+SPLIT_BF16_WGRAD_OPS = ('wgrad', 'tangent_wgrad')      # csrc/wgrad_bf16.hip: maps at least 16 wide (the 10 x 10 block keeps the fp32 kernel)
 
 
 def mfma_peak(spec, op, layer, split_bf16=True):
     """(peak TFLOP/s in algorithmic fp32 FLOPs, pipe) of the matrix pipe `op` on block `layer` runs on."""
     h, w, ci, co, ho, wo, _, _ = layer_geometry(spec)[layer]
-    if split_bf16 and op in SPLIT_BF16_OPS and ci == 32 and co == 32 and (h, w) == (ho, wo):
+    hidden32 = ci == 32 and co == 32 and (h, w) == (ho, wo)
+    if split_bf16 and hidden32 and (op in SPLIT_BF16_OPS or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
         return SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)'
     return PEAK_TFLOPS, 'fp32'
 

@@ -15,7 +15,7 @@ lib = _lib.load()
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 ALL = 0x3ffff
-for (T, n, h) in [(32, 25, 42), (32, 25, 21), (32, 75, 42), (32, 5, 42)]:
+for (T, n, h) in [(32, 25, 42), (32, 25, 21), (32, 75, 42), (32, 5, 42), (4, 25, 42)]:
     c, w = 32, h
     x = torch.randn(T, n, h, w, c, device='cuda')
     dz = torch.randn(T, n, h, w, c, device='cuda')
@@ -24,9 +24,10 @@ for (T, n, h) in [(32, 25, 42), (32, 25, 21), (32, 75, 42), (32, 5, 42)]:
     dw = torch.empty(T, ps, device='cuda')
     sb = lib.mi_kernel_scratch_bytes(T, n, h, w, c)
     scr = torch.empty(sb, dtype=torch.uint8, device='cuda')
-    out = []
-    for name, mode in (('fp32 rows', 0), ('bf16 loads-first', ((ALL & ~(1 << 18)) << 8) | 1), ('bf16 loads-between', (ALL << 8) | 1), ('bf16 no-MFMA', (((ALL & ~(1 << 18)) | (1 << 19)) << 8) | 1),
-                       ('bf16 no-prep', (((ALL & ~(1 << 18)) | (2 << 19)) << 8) | 1), ('bf16 no-loads', (((ALL & ~(1 << 18)) | (3 << 19)) << 8) | 1)):
+    out, ref = [], None
+    for name, mode in (('fp32 rows', 0), ('bf16 strips', ((ALL & ~(1 << 18)) << 8) | 1), ('bf16 units', (((ALL & ~(1 << 18)) | (1 << 21)) << 8) | 1),
+                       ('strips no-MFMA', (((ALL & ~(1 << 18)) | (1 << 19)) << 8) | 1), ('strips no-prep', (((ALL & ~(1 << 18)) | (2 << 19)) << 8) | 1),
+                       ('strips no-loads', (((ALL & ~(1 << 18)) | (3 << 19)) << 8) | 1), ('strips loads-only', (((ALL & ~(1 << 18)) | (1 << 22)) << 8) | 1)):
         lib.mi_conv_set_split_bf16(mode)
         run = lambda: _lib.check(lib.mi_conv3x3_bwd(st(), vp(x), vp(dz), vp(wt), ps, T, n, h, w, c, c, 1, None, vp(dw), ps, vp(scr), sb))
         for _ in range(3):
@@ -37,6 +38,7 @@ for (T, n, h) in [(32, 25, 42), (32, 25, 21), (32, 75, 42), (32, 5, 42)]:
             run()
         e1.record()
         torch.cuda.synchronize()
-        out.append(f'{name} {e0.elapsed_time(e1) / 20 * 1e3:.1f} us')
+        ref = dw.clone() if mode == 0 else ref
+        out.append(f'{name} {e0.elapsed_time(e1) / 20 * 1e3:.1f} us (vs fp32 rows {float((dw - ref).norm() / ref.norm()):.1e})')
     print(f'T={T} n={n} {h}x{w}: ' + ' | '.join(out), flush=True)
 lib.mi_conv_set_split_bf16(1)
