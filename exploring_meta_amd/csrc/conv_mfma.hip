@@ -91,7 +91,10 @@ __device__ __forceinline__ void conv_prefetch_z(float* zpre, const float* __rest
 // MODE 0: forward   out[o] = sum_tap in[o*S + d - 1] * W[tap]            weights [9][CI][CO]
 // MODE 1: dgrad     out[i] = sum_tap in[(i + 1 - d)/S] * W[tap]^T        weights [9][CO_op][CI_op] (the forward layout)
 // waves per workgroup: the 2-term variants stage 2 x 36 KB of weights, so 8 waves share one copy (2 workgroups = 4 waves/SIMD)
-template <int CI, int NTERMS> struct ConvWaves { static constexpr int value = (NTERMS == 2 && CI == 32) ? 8 : 4; };
+template <int CI, int NTERMS, bool BF = false> struct ConvWaves {
+  // (split-bf16 form at 64 filters: 108 KB of weight planes per workgroup -> one workgroup per CU, so eight waves share it)
+  static constexpr int value = ((NTERMS == 2 && CI == 32) || (BF && CI == 64)) ? 8 : 4;
+};
 // Measured (rocprofv3 SQ counters + hipOccupancy): the 2-term EPI_TSTATS variant takes 178 VGPRs, so one 8-wave workgroup is
 // resident per CU (1.8 waves/SIMD) while the 2-term dgrad (108 VGPRs, two workgroups, 2.9 waves/SIMD) reaches the same 74 % MFMA
 // busy fraction: occupancy is not the limiter.  Forcing <= 128 VGPRs (__launch_bounds__(512, 4)) spills 17 dwords into the
@@ -268,8 +271,8 @@ __device__ unsigned long long* g_conv_stamps = nullptr;
 #define CV_STAMP(k) do { if (cstamp && tid == 0) cstamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <int CI, int NTERMS, int EPI, int MODE, bool BF = false>
-__global__ __launch_bounds__((ConvWaves<CI, NTERMS>::value * 64)) void conv3x3_s1_mfma_kernel(ConvArgs a) {
-  constexpr int NW = ConvWaves<CI, NTERMS>::value, NT = NW * 64, CO = CI;
+__global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3x3_s1_mfma_kernel(ConvArgs a) {
+  constexpr int NW = ConvWaves<CI, NTERMS, BF>::value, NT = NW * 64, CO = CI;
   constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1006,7 +1009,7 @@ static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int n
   // weights (160 KB per CU): 36 KB per 32-channel term and workgroup -> 4096 waves on the chip; the 64-channel kernels stage 74 KB
   // (one term, two workgroups of 4 waves per CU) or 147 KB (two terms, one workgroup) -> 2048 / 1024 waves.
   // Split-bf16 32-channel kernels: 54 KB (one term, two 4-wave workgroups per CU) / 108 KB (two terms, one 8-wave workgroup) -> 2048.
-  const long slots = ci >= 64 ? (nterms == 2 ? 1024 : 2048) : (tile_pix != 32 ? 2048 : 4096);
+  const long slots = tile_pix != 32 ? 2048 : (ci >= 64 ? (nterms == 2 ? 1024 : 2048) : 4096);   // (split form: 2 waves per SIMD in every variant)
   long total = (long)ntiles * tasks * cot;
   tpw = (int)((total + slots - 1) / slots);
   if (tpw < 1) tpw = 1;
@@ -1048,12 +1051,12 @@ static hipError_t launch_conv_s1_bf(hipStream_t st, ConvArgs& a, dim3 grid) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS>::value * 64), lds, st, a);
+  hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS, true>::value * 64), lds, st, a);
   return hipGetLastError();
 }
 template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
-  if constexpr (CI == 32) {
+  if constexpr (CI == 32 || (CI == 64 && NTERMS == 1)) {
     if (a.split_bf16) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE>(st, a, grid);
   }
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);
@@ -1100,10 +1103,11 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
   const int cot = a.g.co / 32;
   int ntiles, tpw;
   dim3 grid;
-  const int nw = (nterms == 2 && a.g.ci == 32) ? 8 : 4;     // ConvWaves<CI, NTERMS>
-  // the split-bf16 form of the stride-1 kernel (32 filters): tiles of 30 output pixels, 2048 resident waves
-  a.split_bf16 = a.g.ci == 32 && conv_s1_ok(a) && conv_split_bf16() && (epi == EPI_BRED ? mode == 1 : (mode == 0 || epi == EPI_NONE)) &&
+  // the split-bf16 form of the stride-1 kernel (32 filters; 64 filters with one term): tiles of 30 output pixels, 2048 resident waves
+  a.split_bf16 = (a.g.ci == 32 || (a.g.ci == 64 && nterms == 1)) && conv_s1_ok(a) && conv_split_bf16() &&
+                 (epi == EPI_BRED ? mode == 1 : (mode == 0 || epi == EPI_NONE)) &&
                  ((g_conv_split_mask >> (((nterms - 1) * 2 + mode) * 4 + epi)) & 1u);
+  const int nw = ((nterms == 2 && a.g.ci == 32) || (a.split_bf16 && a.g.ci == 64)) ? 8 : 4;     // ConvWaves<CI, NTERMS, BF>
   conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid, a.split_bf16 ? 30 : 32);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;

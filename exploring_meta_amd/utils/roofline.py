@@ -20,8 +20,10 @@ SPLIT_BF16_WGRAD_OPS = ('wgrad', 'tangent_wgrad')      # csrc/wgrad_bf16.hip: ma
 def mfma_peak(spec, op, layer, split_bf16=True):
     """(peak TFLOP/s in algorithmic fp32 FLOPs, pipe) of the matrix pipe `op` on block `layer` runs on."""
     h, w, ci, co, ho, wo, _, _ = layer_geometry(spec)[layer]
-    hidden32 = ci == 32 and co == 32 and (h, w) == (ho, wo)
-    if split_bf16 and hidden32 and (op in SPLIT_BF16_OPS or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
+    same = ci == co and (h, w) == (ho, wo)                  # stride-1 hidden -> hidden block
+    if split_bf16 and same and ci == 32 and (op in SPLIT_BF16_OPS or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
+        return SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)'
+    if split_bf16 and same and ci == 64 and op in ('conv_fwd_stats', 'dgrad'):      # one-term kernels only (two terms: 216 KB of weight planes)
         return SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)'
     return PEAK_TFLOPS, 'fp32'
 
