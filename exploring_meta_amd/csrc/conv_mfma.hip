@@ -1200,8 +1200,9 @@ static void strips_split_bf16(const ConvGeom& g, int tasks, int nterms, int& ipb
   if (max_bpt < 1) max_bpt = 1;
   int best = 1;
   long best_cost = -1;
+  const int nz = (g.ci / 32) * (g.co / 32);
   for (int bpt = 1; bpt <= max_bpt; ++bpt) {                // rounds of 256 resident workgroups x (items per wave + the reduction epilogue, ~1/3 item)
-    const long rounds = ((long)tasks * bpt + 255) / 256;
+    const long rounds = ((long)tasks * bpt * nz + 255) / 256;
     const long cost = rounds * (3 * ceil_div(ceil_div(items, bpt) * nterms, 4) + 1);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bpt; }
   }
@@ -1228,15 +1229,15 @@ size_t wgrad_partial_floats(const ConvGeom& g, int tasks) {
   if (use_rows_kernel(g)) {
     int rh, nunits, upb, blocks;
     rows_split(g, tasks, rh, nunits, upb, blocks);
-    if (wgrad_bf16_ok(g)) {                                 // either operand form may be selected at launch time: size for the larger split
-      int nu, ub, bl;
+    int nu, ub, bl;                                         // either operand form may be selected at launch time: size for the larger split
+    if (wgrad_bf16_ok(g)) {
       rows_split_bf16(g, tasks, nu, ub, bl);
       if (bl > blocks) blocks = bl;
-      if (wgrad_bf16_strips(g)) {
-        for (int nt = 1; nt <= 2; ++nt) {
-          strips_split_bf16(g, tasks, nt, ub, bl);
-          if (bl > blocks) blocks = bl;
-        }
+    }
+    if (wgrad_bf16_strips(g)) {
+      for (int nt = 1; nt <= 2; ++nt) {
+        strips_split_bf16(g, tasks, nt, ub, bl);
+        if (bl > blocks) blocks = bl;
       }
     }
     return (size_t)tasks * blocks * 9 * g.ci * g.co;
@@ -1263,15 +1264,15 @@ static void launch_rows(hipStream_t st, const WgradArgs& a, dim3 grid, int rh) {
 
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out) {
   const int s = a.g.stride;
-  if (use_rows_kernel(a.g) && conv_split_bf16() && wgrad_bf16_ok(a.g) && (g_conv_split_mask & (1u << (16 + (nterms - 1)))) &&
-      wgrad_bf16_strips(a.g) && !((g_conv_split_mask >> 21) & 1u)) {        // bit 21 (debug): the unit form on wide maps too
+  if (use_rows_kernel(a.g) && conv_split_bf16() && (g_conv_split_mask & (1u << (16 + (nterms - 1)))) && wgrad_bf16_strips(a.g) &&
+      (size_t)a.g.n * a.g.h * a.g.w * a.g.ci * 4 < (size_t)MI_OOB && !((g_conv_split_mask >> 21) & 1u)) {   // bit 21 (debug): the unit form on wide maps too
     int ipb, blocks;
     strips_split_bf16(a.g, tasks, nterms, ipb, blocks);
     a.nterms = nterms;
     a.chunk_pix = ipb * nterms;                            // the item stream is nterms x items long, same workgroup count
     a.nchunks = blocks;
     *nchunks_out = blocks;
-    return launch_wgrad_strips_bf16(st, a, dim3(blocks, tasks, 1));
+    return launch_wgrad_strips_bf16(st, a, dim3(blocks, tasks, (a.g.ci / 32) * (a.g.co / 32)));
   }
   if (use_rows_kernel(a.g) && conv_split_bf16() && wgrad_bf16_ok(a.g) && (g_conv_split_mask & (1u << (16 + (nterms - 1))))) {
     int nunits, upb, blocks;

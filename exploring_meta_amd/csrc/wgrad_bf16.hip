@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
 struct StripItem { int n, c0, ya, yb; bool ok; };
 struct XRowPl { RowPl e; };                                     // (the odd packing is rebuilt per step: 12 instructions instead of 12 resident registers per row)
 
-template <int DBG>   // timing experiments only: 1 = no MFMAs, 2 = no operand preparation, 3 = no loads in the loop, 4 = loads only
+template <int C, int DBG>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile)); DBG, timing experiments only: 1 = no MFMAs, 2 = no operand preparation, 3 = no loads in the loop, 4 = loads only
 __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   __shared__ float red[4 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -241,8 +241,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   const int total = nitems * a.nterms;
   const int ub0 = blockIdx.x * a.chunk_pix;                    // chunk_pix = items per workgroup here
   const int ub1 = min(ub0 + a.chunk_pix, total);
-  const size_t t_elems = (size_t)a.g.n * H * W * 32;
-  const unsigned rowb = (unsigned)(W * 128);                   // bytes of one image row (32 channels)
+  const size_t t_elems = (size_t)a.g.n * H * W * C;
+  const unsigned rowb = (unsigned)(W * C * 4);                 // bytes of one image row
+  constexpr int NCT = C / 32;
+  const int cit = blockIdx.z / NCT, cot = blockIdx.z - cit * NCT;
 
   floatx16 acc[9];
 #pragma unroll
@@ -263,23 +265,23 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
     const int s16 = rem / nh, half = rem - s16 * nh;
     const int ya = half * rp, yb = min(H, ya + rp);
     const int cb = s16 * 16 + 8 * h;                           // this lane half's first column
-    const float* xt = (term ? a.x[1] : a.x[0]) + (size_t)task * t_elems + (size_t)n * H * W * 32;
-    const float* dt = (term ? a.dz[1] : a.dz[0]) + (size_t)task * t_elems + (size_t)n * H * W * 32;
+    const float* xt = (term ? a.x[1] : a.x[0]) + (size_t)task * t_elems + (size_t)n * H * W * C;
+    const float* dt = (term ? a.dz[1] : a.dz[0]) + (size_t)task * t_elems + (size_t)n * H * W * C;
     // per-lane offsets inside a row: column cb (x columns cb .. cb + 8 and all dz columns as immediates), and column cb - 1 on its own
-    const unsigned vo = (unsigned)((cb * 32 + j) * 4);
-    const unsigned vom = cb >= 1 ? vo - 128u : MI_OOB;
+    const unsigned vo = (unsigned)((cb * C + cit * 32 + j) * 4), vod = (unsigned)((cb * C + cot * 32 + j) * 4);
+    const unsigned vom = cb >= 1 ? vo - (unsigned)(C * 4) : MI_OOB;
     auto xrow = [&](int yy) {                                    // descriptor of x row yy (empty outside the image)
       const bool ok = (unsigned)yy < (unsigned)H;
-      return __builtin_amdgcn_make_buffer_rsrc((void*)(xt + (size_t)(ok ? yy : 0) * W * 32), 0, ok ? rowb : 0u, 0x00020000);
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(xt + (size_t)(ok ? yy : 0) * W * C), 0, ok ? rowb : 0u, 0x00020000);
     };
     auto drow = [&](int yy) {                                    // dz row yy; rows past the strip piece contribute nothing
       const bool ok = yy < yb;
-      return __builtin_amdgcn_make_buffer_rsrc((void*)(dt + (size_t)(ok ? yy : 0) * W * 32), 0, ok ? rowb : 0u, 0x00020000);
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(dt + (size_t)(ok ? yy : 0) * W * C), 0, ok ? rowb : 0u, 0x00020000);
     };
 #define ST_LOADX(SET, YY) { const mi_rsrc rr_ = xrow(YY); rawx[SET][0] = buf_ld(rr_, vom);                                  \
-      _Pragma("unroll") for (int c = 1; c < 10; ++c) rawx[SET][c] = buf_ld(rr_, vo + (unsigned)((c - 1) * 128)); }
+      _Pragma("unroll") for (int c = 1; c < 10; ++c) rawx[SET][c] = buf_ld(rr_, vo + (unsigned)((c - 1) * C * 4)); }
 #define ST_LOADD(SET, YY) { const mi_rsrc rr_ = drow(YY);                                                                  \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) rawd[SET][c] = buf_ld(rr_, vo + (unsigned)(c * 128)); }
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) rawd[SET][c] = buf_ld(rr_, vod + (unsigned)(c * C * 4)); }
 #define ST_SPLITX(SET, SLOT) { split_x_pair<0>(rawx[SET], xr[SLOT].e); split_x_pair<1>(rawx[SET], xr[SLOT].e); split_x_pair<2>(rawx[SET], xr[SLOT].e); \
       split_x_pair<3>(rawx[SET], xr[SLOT].e); split_x_pair<4>(rawx[SET], xr[SLOT].e); }
 #define ST_SPLITD(SET, BUF) { split_dz_pair<0>(rawd[SET], dzp[BUF]); split_dz_pair<1>(rawd[SET], dzp[BUF]); split_dz_pair<2>(rawd[SET], dzp[BUF]); \
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   }
 
   // cross-wave reduction, one tap at a time: red[wave][r*64 + lane]
-  float* pt = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 9 * 32 * 32;
+  float* pt = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 9 * C * C;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
@@ -366,14 +368,17 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
       const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
       const int r = e >> 6, l = e & 63;
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
-      pt[((size_t)tap * 32 + row) * 32 + col] = v;
+      pt[((size_t)tap * C + cit * 32 + row) * C + cot * 32 + col] = v;
     }
     __syncthreads();
   }
 }
 
-// strip form: maps at least 32 wide whose width wastes at most 15 % of whole 16-column strips (42 -> 48)
-bool wgrad_bf16_strips(const ConvGeom& g) { return g.w >= 32 && ((g.w + 15) / 16) * 16 * 100 <= g.w * 115; }
+// strip form: 32 or 64 filters, maps at least 32 wide whose width wastes at most 15 % of whole 16-column strips (42 -> 48)
+bool wgrad_bf16_strips(const ConvGeom& g) {
+  return g.stride == 1 && g.ci == g.co && (g.ci == 32 || g.ci == 64) && g.h == g.ho && g.w == g.wo && g.w >= 32 &&
+         ((g.w + 15) / 16) * 16 * 100 <= g.w * 115;
+}
 // rows per strip piece (a multiple of four, about 24) and items per task (per term)
 int wgrad_bf16_strip_rows(const ConvGeom& g) {
   const int nh = (g.h + 23) / 24;
@@ -387,11 +392,12 @@ hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid) {
   a.mpix = wgrad_bf16_strip_rows(a.g);                         // (the kernel takes the rows per piece in this field)
   extern int g_wgrad_bf16_dbg;
   extern int g_wgrad_bf16_dbg4;
-  if (g_wgrad_bf16_dbg4) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<4>, grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg == 1) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<1>, grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg == 2) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<2>, grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg == 3) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<3>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<0>, grid, dim3(256), 0, st, a);
+  if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<64, 0>), grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg4) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 4>), grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg == 1) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 1>), grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg == 2) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 2>), grid, dim3(256), 0, st, a);
+  else if (g_wgrad_bf16_dbg == 3) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 3>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 0>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -159,7 +159,8 @@ def test_conv_bwd_two_terms(lib, name, T, n, h, w, ci, co, stride, check):
 
 
 BIG_CONV = [('bench_l2_T32', 32, 25, 42, 42, 32, 32, [0, 31]), ('cap32_T96', 96, 25, 42, 42, 32, 32, [0, 95]),
-            ('bench_l4_T32', 32, 25, 10, 10, 32, 32, [5])]
+            ('bench_l4_T32', 32, 25, 10, 10, 32, 32, [5]),
+            ('anil_l2_T8', 8, 50, 42, 42, 64, 64, [1])]          # ANIL trunk block 2 (cfg3): the 64-filter split forms incl. the strip weight gradient
 
 
 @pytest.mark.parametrize('name,T,n,h,w,ci,co,check', BIG_CONV)
