@@ -9,7 +9,7 @@ mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
 declare -A PICK
 PICK[cfg1]='conv3x3_mfma_kernel<64, 1, 1, 0, 2>::conv_fwd_stats,1'
-PICK[cfg3]='conv3x3_s1_mfma_kernel<64, 1, 1, 0, false>::conv_fwd_stats,1'
+PICK[cfg3]='conv3x3_s1_mfma_kernel<64, 1, 1, 0, true>::conv_fwd_stats,1'
 PICK[cfg4]='conv3x3_s1_mfma_kernel<32, 2, 2, 0, true>::tangent_conv_fwd,1'
 PICK[cfg5]='policy_sweep_kernel<100, true>::fisher_vector_product,0'
 PICK[cfg2]='conv3x3_s1_mfma_kernel<32, 2, 2, 0, true>::tangent_conv_fwd,1'

@@ -113,11 +113,11 @@ def main():
 
         def grid_threads(layer, nterms, split_bf16):
             h, w, ci, co, ho, wo = geo[layer][:6]
-            ntiles = -(-(n * ho * wo) // 32)
+            ntiles = -(-(n * ho * wo) // (30 if split_bf16 else 32))                                      # conv_grid (csrc/conv_mfma.hip)
             cot = co // 32
-            slots = (1024 if nterms == 2 else 2048) if ci >= 64 else (2048 if split_bf16 else 4096)     # conv_grid (csrc/conv_mfma.hip)
+            slots = 2048 if split_bf16 else ((1024 if nterms == 2 else 2048) if ci >= 64 else 4096)
             tpw = min(128, max(1, -(-(ntiles * T * cot) // slots)))
-            nw = 8 if (nterms == 2 and ci == 32) else 4
+            nw = 8 if ((nterms == 2 and ci == 32) or (split_bf16 and ci == 64)) else 4
             return -(-ntiles // (nw * tpw)) * T * cot * nw * 64
 
         for spec_ in args.pick:
