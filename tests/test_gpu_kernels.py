@@ -57,6 +57,13 @@ CONV_CASES = [
     ('omni_l2', 2, 5, 14, 14, 64, 64, 2),
     ('omni_l3', 2, 5, 7, 7, 64, 64, 2),
     ('omni_l4', 2, 5, 4, 4, 64, 64, 2),
+    # maps narrower than a tile and rectangular ones: several image rows (and images) inside one 30- / 32-pixel tile, every lane next to a
+    # column boundary (the shifted operands of the split form), partial last tiles
+    ('tiny_7x7', 3, 4, 7, 7, 32, 32, 1),
+    ('tiny_3x3', 2, 5, 3, 3, 32, 32, 1),
+    ('row_1x5', 2, 3, 1, 5, 32, 32, 1),
+    ('rect_6x33', 2, 2, 6, 33, 32, 32, 1),
+    ('tiny_7x7_64', 2, 3, 7, 7, 64, 64, 1),
 ]
 
 

@@ -64,6 +64,8 @@ TAN_CONV_CASES = [
     ('min_l4', 2, 5, 10, 10, 32, 32, 1, None),
     ('anil_l2', 2, 2, 21, 21, 64, 64, 1, None),
     ('omni_l2', 2, 5, 14, 14, 64, 64, 2, None),
+    ('tiny_7x7', 3, 4, 7, 7, 32, 32, 1, None),                    # several rows and images inside one tile
+    ('rect_6x33', 2, 2, 6, 33, 32, 32, 1, None),
     ('bench_l2_T32', 32, 25, 42, 42, 32, 32, 1, [0, 17, 31]),     # cfg2 block 2 as timed: tiles_per_wave 11
     ('bench_l3_T32', 32, 25, 21, 21, 32, 32, 1, [0, 31]),         # tiles_per_wave 3
     ('anil_l2_T8', 8, 50, 42, 42, 64, 64, 1, [3]),                # ANIL trunk block 2, 50 images per task
