@@ -14,6 +14,10 @@
 // accumulate into the same MFMA accumulators in one launch.
 // Epilogues: per-(task,channel) fp64 partial sums for batch-stat BN (sum z, sum z^2) or its tangent (sum zd, sum zh*zd),
 // reduced wave -> workgroup in LDS and written as one deterministic partial per workgroup (no atomics).
+// Split-bf16 operand form (template flag BF of the stride-1 kernel, 32 filters and one-term 64 filters; default, see
+// mi_conv_set_split_bf16 and bf16_split.h): every fp32 operand as three exact bf16 planes, six v_mfma_f32_32x32x16_bf16 products per
+// K = 16, fp32 accumulation -- fp32-equivalent results on the 16x faster pipe.  Tiles of 30 output pixels (lanes 0 / 31 are halo lanes), a
+// displaced image row fetched once and shifted across lanes for the horizontal taps, splits and shifts placed between the MFMAs.
 #include "mi_common.h"
 #include "kernels.h"
 #include "bf16_split.h"
