@@ -356,8 +356,22 @@ def run_vision(args, wl, rank, world, local, dist):
                    'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter',
                    'task_hardness': HARDNESS[wl['dataset']]},
         'post_adapt': post, 'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline,
-        'cpu_baseline': cpu, 'collective': collective,
+        'cpu_baseline': cpu, 'collective': collective, 'arithmetic': arithmetic_note(eng),
     }
+
+
+def arithmetic_note(eng):
+    """What "f32" means for this line: inputs, outputs, accumulation and every stored tensor are fp32; with the split operand form
+    (the default) the hidden convolutions and weight gradients form each fp32 product from exact three-way bf16 splits of both operands."""
+    split = bool(eng.lib.mi_conv_set_split_bf16(1))
+    eng.lib.mi_conv_set_split_bf16(int(split))
+    if not split:
+        return {'split_bf16_operands': False, 'note': 'fp32 throughout (fp32-input MFMA = an fmaf chain; fp64 for statistics and reductions)'}
+    return {'split_bf16_operands': True,
+            'note': 'fp32 tensors and fp32 accumulation throughout (fp64 for statistics and reductions).  Hidden 3x3 convolutions and weight '
+                    'gradients: each fp32 operand as the EXACT sum of three bf16 pieces, six bf16 MFMA products per multiply-add, dropped '
+                    'cross terms <= 2^-24 of a product (one fp32 rounding): per-kernel errors against the fp64 oracle are the same or smaller '
+                    'than with the fp32 matrix pipe (tests run both forms against the same bars); MI_CONV_BF16X3=0 selects the fp32 pipe'}
 
 
 def collective_record(dist, world, theta, numel, what):

@@ -38,3 +38,5 @@ def test_bench_line_has_the_contract_fields():
     # the engine's post-adaptation figures sit beside the oracle's on the same tasks
     pa = d['post_adapt']
     assert pa['compared_tasks'] >= 1 and pa['max_abs_acc_diff_per_task'] == 0.0 and pa['max_abs_loss_diff_per_task'] < 1e-3
+    # what "f32" means on this build is spelled out next to it
+    assert d['arithmetic']['split_bf16_operands'] in (True, False) and 'fp32' in d['arithmetic']['note']
