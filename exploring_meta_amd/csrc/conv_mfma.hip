@@ -1220,8 +1220,9 @@ static void rows_split_bf16(const ConvGeom& g, int tasks, int& nunits, int& upb,
   if (max_bpt < 1) max_bpt = 1;
   int best = 1;
   long best_cost = -1;
+  const int nz = (g.ci / 32) * (g.co / 32);
   for (int bpt = 1; bpt <= max_bpt; ++bpt) {                // rounds of 256 resident workgroups x (units per workgroup + the reduction epilogue, ~24 units)
-    const long rounds = ((long)tasks * bpt + 255) / 256;
+    const long rounds = ((long)tasks * bpt * nz + 255) / 256;
     const long cost = rounds * (ceil_div(nunits, bpt) + 24);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bpt; }
   }
@@ -1285,7 +1286,7 @@ hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, i
     a.chunk_pix = upb * nterms;                            // the unit stream is nterms x nunits long, same workgroup count
     a.nchunks = blocks;
     *nchunks_out = blocks;
-    return launch_wgrad_rows_bf16(st, a, dim3(blocks, tasks, 1), (g_conv_split_mask >> 18) & 1u);   // bit 18: debug variant
+    return launch_wgrad_rows_bf16(st, a, dim3(blocks, tasks, (a.g.ci / 32) * (a.g.co / 32)), (g_conv_split_mask >> 18) & 1u);   // bit 18: debug variant
   }
   if (use_rows_kernel(a.g)) {
     int rh, nunits, upb, blocks;

@@ -39,16 +39,16 @@ __device__ __forceinline__ WUnitPos unit_pos(int unit, int hp2, int nseg) {
   p.c0 = (rem - yp * nseg) * 8;
   return p;
 }
-template <int PIECE>
-__device__ __forceinline__ void load_piece(WRaw& u, const WUnitPos& p, mi_rsrc rx, mi_rsrc rdz, unsigned lane_ch, int H, int W, int h) {
+template <int PIECE, int C>   // C = filters: a pixel is C * 4 bytes; lane_x / lane_dz = this lane's channel inside it
+__device__ __forceinline__ void load_piece(WRaw& u, const WUnitPos& p, mi_rsrc rx, mi_rsrc rdz, unsigned lane_x, unsigned lane_dz, int H, int W, int h) {
   const int y = p.y0 + h;
   if (PIECE == 0) {
     const bool rowok = p.ok && y < H;
     const unsigned mask = rowok ? 0u : MI_OOB;                                               // out of range as an OR: no select, no branch
-    const unsigned dzoff = (lane_ch + (unsigned)(((p.n * H + y) * W + p.c0) * 128)) | mask;
+    const unsigned dzoff = (lane_dz + (unsigned)(((p.n * H + y) * W + p.c0) * (C * 4))) | mask;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const unsigned col = (p.c0 + i) < W ? (unsigned)(i * 128) : MI_OOB;                    // scalar select
+      const unsigned col = (p.c0 + i) < W ? (unsigned)(i * C * 4) : MI_OOB;                  // scalar select
       u.b[i] = buf_ld(rdz, dzoff + col);
     }
   } else {
@@ -56,10 +56,10 @@ __device__ __forceinline__ void load_piece(WRaw& u, const WUnitPos& p, mi_rsrc r
     const int iy = y + r - 1;
     const bool rok = p.ok && y < H && (unsigned)iy < (unsigned)H;
     const unsigned mask = rok ? 0u : MI_OOB;
-    const unsigned xoff = (lane_ch + (unsigned)(((p.n * H + iy) * W + p.c0) * 128)) | mask;   // pixel c0 of the row (offsets < 2^30: launcher)
+    const unsigned xoff = (lane_x + (unsigned)(((p.n * H + iy) * W + p.c0) * (C * 4))) | mask;   // pixel c0 of the row (offsets < 2^30: launcher)
 #pragma unroll
     for (int c = 0; c < 10; ++c) {
-      const unsigned col = (unsigned)(p.c0 + c - 1) < (unsigned)W ? (unsigned)((c - 1) * 128) : MI_OOB;   // scalar select (c = 0: -128, only where c0 >= 1)
+      const unsigned col = (unsigned)(p.c0 + c - 1) < (unsigned)W ? (unsigned)((c - 1) * C * 4) : MI_OOB;   // scalar select (c = 0: one pixel back, only where c0 >= 1)
       u.xa[r][c] = buf_ld(rx, xoff + col);
     }
   }
@@ -83,7 +83,7 @@ __device__ __forceinline__ void odd_plane(const unsigned* e, unsigned* o) {   //
 
 }  // namespace
 
-template <bool ILV, int DBG = 0>   // DBG (timing experiments only): 1 = no MFMAs, 2 = no operand preparation, 3 = no loads; ILV: the loads of the unit two ahead between this unit's MFMAs (rows 0 and 1) instead of in front of them
+template <bool ILV, int DBG = 0, int C = 32>   // C = filters (blockIdx.z = (ci tile, co tile)); DBG (timing experiments only): 1 = no MFMAs, 2 = no operand preparation, 3 = no loads; ILV: the loads of the unit two ahead between this unit's MFMAs (rows 0 and 1) instead of in front of them
 __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   __shared__ float red[4 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   const int total = nunits * a.nterms;
   const int ub0 = blockIdx.x * a.chunk_pix;                    // chunk_pix = units per workgroup here
   const int ub1 = min(ub0 + a.chunk_pix, total);
-  const size_t t_elems = (size_t)a.g.n * H * W * 32;
+  const size_t t_elems = (size_t)a.g.n * H * W * C;
+  constexpr int NCT = C / 32;
+  const int cit = blockIdx.z / NCT, cot = blockIdx.z - cit * NCT;
   const unsigned tb = (unsigned)(t_elems * 4);
   const mi_rsrc rx0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x[0] + (size_t)task * t_elems), 0, tb, 0x00020000);
   const mi_rsrc rd0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dz[0] + (size_t)task * t_elems), 0, tb, 0x00020000);
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   const float* d1p = a.nterms > 1 ? a.dz[1] : a.dz[0];
   const mi_rsrc rx1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1p + (size_t)task * t_elems), 0, tb, 0x00020000);
   const mi_rsrc rd1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d1p + (size_t)task * t_elems), 0, tb, 0x00020000);
-  const unsigned lane_ch = (unsigned)j * 4u;
+  const unsigned lane_x = (unsigned)(cit * 32 + j) * 4u, lane_dz = (unsigned)(cot * 32 + j) * 4u;
 
   floatx16 acc[9];
 #pragma unroll
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
 
   // unit v of this wave's stream: second term of the stream from nunits on (scalar selects, no branch); v >= ub1: nothing left (zeros)
   auto pos_of = [&](int v) { return unit_pos(v >= ub1 ? -1 : (v >= nunits ? v - nunits : v), hp2, nseg); };
-#define WG_LOAD(PIECE, RAW, V, POS) load_piece<PIECE>(RAW, POS, (V) >= nunits ? rx1 : rx0, (V) >= nunits ? rd1 : rd0, lane_ch, H, W, h)
+#define WG_LOAD(PIECE, RAW, V, POS) load_piece<PIECE, C>(RAW, POS, (V) >= nunits ? rx1 : rx0, (V) >= nunits ? rd1 : rd0, lane_x, lane_dz, H, W, h)
 
   WRaw raw[3];                                                  // loads run two units ahead
   RowPl pe[2];
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
 #undef WG_MFMA
 
   // cross-wave reduction, one tap at a time: red[wave][r*64 + lane]
-  float* pt = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 9 * 32 * 32;
+  float* pt = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 9 * C * C;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
       const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
       const int r = e >> 6, l = e & 63;
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
-      pt[((size_t)tap * 32 + row) * 32 + col] = v;
+      pt[((size_t)tap * C + cit * 32 + row) * C + cot * 32 + col] = v;
     }
     __syncthreads();
   }
@@ -404,8 +406,8 @@ hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid) {
 // units per task for geometry g (per term) and whether this kernel takes it (32 -> 32 channels, stride 1, tensors addressable in 30 bits)
 bool wgrad_bf16_ok(const ConvGeom& g) {
   // (w >= 16: on 10 x 10 maps -- two column segments, 20 % of them padding -- the fp32 kernel with its exact segments is faster, 27 vs 30 us)
-  return g.stride == 1 && g.ci == 32 && g.co == 32 && g.h == g.ho && g.w == g.wo && g.w >= 16 &&
-         (size_t)g.n * g.h * g.w * 32 * 4 < (size_t)MI_OOB - 4096;
+  return g.stride == 1 && g.ci == g.co && (g.ci == 32 || g.ci == 64) && g.h == g.ho && g.w == g.wo && g.w >= 16 &&
+         (size_t)g.n * g.h * g.w * g.ci * 4 < (size_t)MI_OOB - 4096;
 }
 int wgrad_bf16_units(const ConvGeom& g) { return g.n * ((g.h + 1) / 2) * ((g.w + 7) / 8); }
 
@@ -414,6 +416,7 @@ hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid,
   if (g_wgrad_bf16_dbg == 1) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 1>), grid, dim3(256), 0, st, a);
   else if (g_wgrad_bf16_dbg == 2) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 2>), grid, dim3(256), 0, st, a);
   else if (g_wgrad_bf16_dbg == 3) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 3>), grid, dim3(256), 0, st, a);
+  else if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 0, 64>), grid, dim3(256), 0, st, a);
   else if (interleave_loads) hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<false>, grid, dim3(256), 0, st, a);
   return hipGetLastError();

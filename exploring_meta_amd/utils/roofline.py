@@ -23,8 +23,8 @@ def mfma_peak(spec, op, layer, split_bf16=True):
     same = ci == co and (h, w) == (ho, wo)                  # stride-1 hidden -> hidden block
     if split_bf16 and same and ci == 32 and (op in SPLIT_BF16_OPS or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
         return SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)'
-    if split_bf16 and same and ci == 64 and (op in ('conv_fwd_stats', 'dgrad') or (op in SPLIT_BF16_WGRAD_OPS and w >= 32)):
-        # one-term forward / dgrad (two terms would need 216 KB of weight planes); weight gradient: the strip form (maps >= 32 wide)
+    if split_bf16 and same and ci == 64 and (op in ('conv_fwd_stats', 'dgrad') or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
+        # one-term forward / dgrad (two terms would need 216 KB of weight planes); weight gradients as at 32 filters
         return SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)'
     return PEAK_TFLOPS, 'fp32'
 

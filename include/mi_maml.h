@@ -382,7 +382,7 @@ int mi_debug_policy_sweep_stamps(void* buf);
  * conv launch (csrc/conv_mfma.hip) into buf (>= 8 u64, the last launch wins); NULL switches it off. */
 int mi_debug_conv_stamps(void* buf);
 /* Operand form of the stride-1 hidden -> hidden 3x3 convolutions with 32 filters (forward, dgrad, their two-term tangent forms and the
- * weight gradient on maps at least 16 wide) and with 64 filters (one-term forward and dgrad, weight gradient on maps at least 32 wide) --
+ * weight gradient on maps at least 16 wide) and with 64 filters (one-term forward and dgrad, weight gradient on maps at least 16 wide) --
  * the implicit ATen conv2d launches behind
  * ConvBlock.conv, reference core_functions/vision_models.py:177-185,189.  1: split-bf16 -- every fp32 operand as the
  * exact sum of three bf16 pieces, six v_mfma_f32_32x32x16_bf16 products per K = 16 accumulated in fp32 (the three dropped cross terms
