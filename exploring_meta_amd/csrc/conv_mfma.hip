@@ -1195,23 +1195,30 @@ bool wgrad_bf16_ok(const ConvGeom& g);
 int wgrad_bf16_units(const ConvGeom& g);
 hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid, bool interleave_loads);
 bool wgrad_bf16_strips(const ConvGeom& g);
-int wgrad_bf16_strip_items(const ConvGeom& g);
-hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid);
-// strip form: items (a 16-column strip piece of ~24 rows) per workgroup; each of the four waves walks whole items
-static void strips_split_bf16(const ConvGeom& g, int tasks, int nterms, int& ipb, int& blocks) {
-  const int items = wgrad_bf16_strip_items(g);
-  int max_bpt = items < 128 ? items : 128;
-  if (max_bpt < 1) max_bpt = 1;
-  int best = 1;
-  long best_cost = -1;
+int wgrad_bf16_strip_rows(const ConvGeom& g, int rows);
+int wgrad_bf16_strip_items(const ConvGeom& g, int rows);
+hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid, int rows);
+// strip form: rows per piece and items (a 16-column strip piece) per workgroup; each of the four waves walks whole items.  Cost of a
+// split in steps (one output row = 54 MFMAs): rounds of 256 resident workgroups x (items per wave x (rows + 3 for the item's prologue)
+// + ~8 for the reduction epilogue).
+static void strips_split_bf16(const ConvGeom& g, int tasks, int nterms, int& rows, int& ipb, int& blocks) {
+  const int cand[4] = {24, 16, 12, 8};
   const int nz = (g.ci / 32) * (g.co / 32);
-  for (int bpt = 1; bpt <= max_bpt; ++bpt) {                // rounds of 256 resident workgroups x (items per wave + the reduction epilogue, ~1/3 item)
-    const long rounds = ((long)tasks * bpt * nz + 255) / 256;
-    const long cost = rounds * (3 * ceil_div(ceil_div(items, bpt) * nterms, 4) + 1);
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bpt; }
+  long best_cost = -1;
+  rows = 24; ipb = 1; blocks = 1;
+  for (int c = 0; c < 4; ++c) {
+    const int rp = wgrad_bf16_strip_rows(g, cand[c]);
+    const int items = wgrad_bf16_strip_items(g, cand[c]);
+    int max_bpt = items < 128 ? items : 128;
+    if (max_bpt < 1) max_bpt = 1;
+    for (int bpt = 1; bpt <= max_bpt; ++bpt) {
+      const long rounds = ((long)tasks * bpt * nz + 255) / 256;
+      const long cost = rounds * ((long)ceil_div(ceil_div(items, bpt) * nterms, 4) * (rp + 3) + 8);
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost; rows = cand[c]; ipb = ceil_div(items, bpt); blocks = ceil_div(items, ipb);
+      }
+    }
   }
-  ipb = ceil_div(items, best);
-  blocks = ceil_div(items, ipb);
 }
 static void rows_split_bf16(const ConvGeom& g, int tasks, int& nunits, int& upb, int& blocks) {
   nunits = wgrad_bf16_units(g);
@@ -1241,7 +1248,8 @@ size_t wgrad_partial_floats(const ConvGeom& g, int tasks) {
     }
     if (wgrad_bf16_strips(g)) {
       for (int nt = 1; nt <= 2; ++nt) {
-        strips_split_bf16(g, tasks, nt, ub, bl);
+        int rw;
+        strips_split_bf16(g, tasks, nt, rw, ub, bl);
         if (bl > blocks) blocks = bl;
       }
     }
@@ -1271,13 +1279,13 @@ hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, i
   const int s = a.g.stride;
   if (use_rows_kernel(a.g) && conv_split_bf16() && (g_conv_split_mask & (1u << (16 + (nterms - 1)))) && wgrad_bf16_strips(a.g) &&
       (size_t)a.g.n * a.g.h * a.g.w * a.g.ci * 4 < (size_t)MI_OOB && !((g_conv_split_mask >> 21) & 1u)) {   // bit 21 (debug): the unit form on wide maps too
-    int ipb, blocks;
-    strips_split_bf16(a.g, tasks, nterms, ipb, blocks);
+    int rows, ipb, blocks;
+    strips_split_bf16(a.g, tasks, nterms, rows, ipb, blocks);
     a.nterms = nterms;
     a.chunk_pix = ipb * nterms;                            // the item stream is nterms x items long, same workgroup count
     a.nchunks = blocks;
     *nchunks_out = blocks;
-    return launch_wgrad_strips_bf16(st, a, dim3(blocks, tasks, (a.g.ci / 32) * (a.g.co / 32)));
+    return launch_wgrad_strips_bf16(st, a, dim3(blocks, tasks, (a.g.ci / 32) * (a.g.co / 32)), rows);
   }
   if (use_rows_kernel(a.g) && conv_split_bf16() && wgrad_bf16_ok(a.g) && (g_conv_split_mask & (1u << (16 + (nterms - 1))))) {
     int nunits, upb, blocks;

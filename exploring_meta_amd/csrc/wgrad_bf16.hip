@@ -381,17 +381,19 @@ bool wgrad_bf16_strips(const ConvGeom& g) {
   return g.stride == 1 && g.ci == g.co && (g.ci == 32 || g.ci == 64) && g.h == g.ho && g.w == g.wo && g.w >= 32 &&
          ((g.w + 15) / 16) * 16 * 100 <= g.w * 115;
 }
-// rows per strip piece (a multiple of four, about 24) and items per task (per term)
-int wgrad_bf16_strip_rows(const ConvGeom& g) {
-  const int nh = (g.h + 23) / 24;
+// Items per task (per term) with pieces of `rows` rows (a multiple of four; the launcher picks it: 24 where the launch has items for every
+// wave of the chip, shorter pieces for few-image launches, whose time is otherwise that of ONE 24-row item per wave however little work
+// there is).  Pieces are evened out (42 rows as 24 + 18, not 24 + 24).
+int wgrad_bf16_strip_rows(const ConvGeom& g, int rows) {
+  const int nh = (g.h + rows - 1) / rows;
   return (((g.h + nh - 1) / nh + 3) / 4) * 4;
 }
-int wgrad_bf16_strip_items(const ConvGeom& g) {
-  const int rp = wgrad_bf16_strip_rows(g);
+int wgrad_bf16_strip_items(const ConvGeom& g, int rows) {
+  const int rp = wgrad_bf16_strip_rows(g, rows);
   return g.n * ((g.w + 15) / 16) * ((g.h + rp - 1) / rp);
 }
-hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid) {
-  a.mpix = wgrad_bf16_strip_rows(a.g);                         // (the kernel takes the rows per piece in this field)
+hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid, int rows) {
+  a.mpix = wgrad_bf16_strip_rows(a.g, rows);                   // (the kernel takes the rows per piece in this field)
   extern int g_wgrad_bf16_dbg;
   extern int g_wgrad_bf16_dbg4;
   if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<64, 0>), grid, dim3(256), 0, st, a);
