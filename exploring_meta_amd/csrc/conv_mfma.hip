@@ -994,15 +994,12 @@ static bool conv_split_bf16() {
   }
   return g_conv_split_bf16 != 0;
 }
-int g_wgrad_bf16_dbg4 = 0;
-int g_wgrad_bf16_dbg = 0;                                      // timing experiments (bits 19..20 of the mask): see wgrad_bf16.hip
 static unsigned g_conv_split_mask = 0x3ffffu;                   // debug: which variants take the split form: conv bit ((terms-1)*2 + mode)*4 + epi, weight gradient bit 16 + (terms-1)
 extern "C" int mi_conv_set_split_bf16(int on) {
   const int was = conv_split_bf16() ? 1 : 0;
   g_conv_split_bf16 = on ? 1 : 0;
   g_conv_split_mask = on > 1 ? ((unsigned)on >> 8) : 0x3ffffu;
-  g_wgrad_bf16_dbg = (int)((g_conv_split_mask >> 19) & 3u);
-  g_wgrad_bf16_dbg4 = (int)((g_conv_split_mask >> 22) & 1u);  // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
+  // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
   return was;
 }
 
@@ -1193,7 +1190,7 @@ static void rows_split(const ConvGeom& g, int tasks, int& rh, int& nunits, int& 
 // split-bf16 weight gradient (wgrad_bf16.hip): units of 2 rows x 8 columns, ONE workgroup per CU (144 accumulator AGPRs per lane)
 bool wgrad_bf16_ok(const ConvGeom& g);
 int wgrad_bf16_units(const ConvGeom& g);
-hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid, bool interleave_loads);
+hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid);
 bool wgrad_bf16_strips(const ConvGeom& g);
 int wgrad_bf16_strip_rows(const ConvGeom& g, int rows);
 int wgrad_bf16_strip_items(const ConvGeom& g, int rows);
@@ -1294,7 +1291,7 @@ hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, i
     a.chunk_pix = upb * nterms;                            // the unit stream is nterms x nunits long, same workgroup count
     a.nchunks = blocks;
     *nchunks_out = blocks;
-    return launch_wgrad_rows_bf16(st, a, dim3(blocks, tasks, (a.g.ci / 32) * (a.g.co / 32)), (g_conv_split_mask >> 18) & 1u);   // bit 18: debug variant
+    return launch_wgrad_rows_bf16(st, a, dim3(blocks, tasks, (a.g.ci / 32) * (a.g.co / 32)));
   }
   if (use_rows_kernel(a.g)) {
     int rh, nunits, upb, blocks;

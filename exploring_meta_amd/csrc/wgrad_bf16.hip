@@ -17,6 +17,12 @@
 #include "kernels.h"
 #include "bf16_split.h"
 
+// Ablation builds (timing experiments, not shipped): -DMI_WGRAD_DBG=1 no MFMAs, 2 no operand preparation, 3 no loads in the loop, 4 loads
+// only; build to another file name and select it with MI_MAML_LIB (tools/wgrad_probe.py runs in one process either way).
+#ifndef MI_WGRAD_DBG
+#define MI_WGRAD_DBG 0
+#endif
+
 namespace {
 
 struct WRaw { float xa[3][10]; float b[8]; };                   // one unit's loads: x rows y-1, y, y+1 x columns c0-1 .. c0+8; dz row y
@@ -83,7 +89,7 @@ __device__ __forceinline__ void odd_plane(const unsigned* e, unsigned* o) {   //
 
 }  // namespace
 
-template <bool ILV, int DBG = 0, int C = 32>   // C = filters (blockIdx.z = (ci tile, co tile)); DBG (timing experiments only): 1 = no MFMAs, 2 = no operand preparation, 3 = no loads; ILV: the loads of the unit two ahead between this unit's MFMAs (rows 0 and 1) instead of in front of them
+template <int C>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile))
 __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   __shared__ float red[4 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -123,24 +129,24 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   OddPl po[2];
   DzPl pb[2];
   // six plane products of one tap, the next row's (or unit's) operand preparation spread between them
-#define WG_MFMA(T, X, Y) if (DBG != 1) acc[T] = MI_BF_MFMA(X, Y, acc[T])
+#define WG_MFMA(T, X, Y) if (MI_WGRAD_DBG != 1 && MI_WGRAD_DBG != 4) acc[T] = MI_BF_MFMA(X, Y, acc[T])
 #define WG_TAP(T, AH, AM, AL, B, V0, V1, V2, V3)                                       \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   WG_MFMA(T, AL, B.h);                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                   \
-  if (DBG != 2) { V0; }                                                                \
+  if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { V0; }                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   WG_MFMA(T, AH, B.l);                                                            \
   __builtin_amdgcn_sched_barrier(0);                                                   \
-  if (DBG != 2) { V1; }                                                                \
+  if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { V1; }                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   WG_MFMA(T, AM, B.m);                                                            \
   __builtin_amdgcn_sched_barrier(0);                                                   \
-  if (DBG != 2) { V2; }                                                                \
+  if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { V2; }                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   WG_MFMA(T, AM, B.h);                                                            \
   __builtin_amdgcn_sched_barrier(0);                                                   \
-  if (DBG != 2) { V3; }                                                                \
+  if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { V3; }                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   WG_MFMA(T, AH, B.m);                                                            \
   WG_MFMA(T, AH, B.h);                                                            \
@@ -153,8 +159,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   WG_TAP(3 * (R) + 1, (O.h), (O.m), (O.l), B, split_x_pair<4>(NRAW.xa[NR], NE), odd_plane(NE.h, NO.h), odd_plane(NE.m, NO.m), \
          odd_plane(NE.l, NO.l))                                                                                          \
   WG_TAP(3 * (R) + 2, (E.h + 1), (E.m + 1), (E.l + 1), B,                                                                \
-         if (NR == 0) split_dz_pair<0>(NRAW.b, NB); else if (ILV && NR == 1) WG_LOAD(0, FRAW, fv, fpos); else if (ILV) WG_LOAD(2, FRAW, fv, fpos),   \
-         if (NR == 0) split_dz_pair<1>(NRAW.b, NB); else if (ILV && NR == 1) WG_LOAD(1, FRAW, fv, fpos); else if (ILV) WG_LOAD(3, FRAW, fv, fpos),   \
+         if (NR == 0) split_dz_pair<0>(NRAW.b, NB), if (NR == 0) split_dz_pair<1>(NRAW.b, NB),                           \
          if (NR == 0) split_dz_pair<2>(NRAW.b, NB), if (NR == 0) split_dz_pair<3>(NRAW.b, NB))
   // one unit: raw set K % 3 (its row 0 and dz are already in planes, buffers K & 1), the next unit in raw set (K + 1) % 3
 #define WG_UNIT(K)                                                                              \
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   {                                                                         \
     const int fv = u + 4 * ((K) + 2);      /* the unit two ahead: its loads go out before this unit's MFMAs (between them they were slower) */ \
     const WUnitPos fpos = pos_of(fv);                                       \
-    if (!ILV && DBG != 3) {                                                 \
+    if (MI_WGRAD_DBG != 3) {                                                \
       WG_LOAD(0, raw[((K) + 2) % 3], fv, fpos); WG_LOAD(1, raw[((K) + 2) % 3], fv, fpos);   \
       WG_LOAD(2, raw[((K) + 2) % 3], fv, fpos); WG_LOAD(3, raw[((K) + 2) % 3], fv, fpos);   \
     }                                                                       \
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
 struct StripItem { int n, c0, ya, yb; bool ok; };
 struct XRowPl { RowPl e; };                                     // (the odd packing is rebuilt per step: 12 instructions instead of 12 resident registers per row)
 
-template <int C, int DBG>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile)); DBG, timing experiments only: 1 = no MFMAs, 2 = no operand preparation, 3 = no loads in the loop, 4 = loads only
+template <int C>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile))
 __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   __shared__ float red[4 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
     ST_LOADX(3, ya + 2) ST_LOADD(1, ya + 1) ST_LOADX(0, ya + 3) ST_LOADD(2, ya + 2)
     // step T (output row y + T of the trip that starts at row y): x rows in slots T, T+1, T+2 (mod 4), dz planes T & 1; meanwhile x row
     // y + T + 2 (raw set (T + 3) & 3) is split into slot (T + 3) & 3 and dz row y + T + 1 (raw set (T + 1) & 3) into planes (T + 1) & 1
-#define ST_MFMA(T, X, Y) if (DBG != 1 && DBG != 4) acc[T] = MI_BF_MFMA(X, Y, acc[T])
+#define ST_MFMA(T, X, Y) if (MI_WGRAD_DBG != 1 && MI_WGRAD_DBG != 4) acc[T] = MI_BF_MFMA(X, Y, acc[T])
 #define ST_TAP(T, AH, AM, AL, B, V0, V1, V2, V3)                                       \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     ST_MFMA(T, AL, B.h);                                                          \
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
     ST_TAP(3 * (R) + 0, (X.e.h), (X.e.m), (X.e.l), B, ST_PREP(odd_plane(X.e.h, ot.h)), ST_PREP(odd_plane(X.e.m, ot.m)), ST_PREP(odd_plane(X.e.l, ot.l)), V3)   \
     ST_TAP(3 * (R) + 1, (ot.h), (ot.m), (ot.l), B, V4, V5, V6, V7)                                                \
     ST_TAP(3 * (R) + 2, (X.e.h + 1), (X.e.m + 1), (X.e.l + 1), B, V8, V9, V10, V11)
-#define ST_PREP(X) if (DBG != 2 && DBG != 4) { X; }
+#define ST_PREP(X) if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { X; }
 #define ST_STEP(T)                                                                                                \
     {                                                                                                             \
       XRowPl& nx = xr[((T) + 3) & 3];                                                                             \
@@ -335,11 +340,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
              ST_PREP(split_x_pair<3>(rx_, nx.e)), ST_PREP(split_x_pair<4>(rx_, nx.e)), ST_PREP(split_dz_pair<0>(rd_, nd)), ST_PREP(split_dz_pair<1>(rd_, nd)), \
              ST_PREP(split_dz_pair<2>(rd_, nd)), ST_PREP(split_dz_pair<3>(rd_, nd)))                                \
       ST_ROW(1, xr[((T) + 1) & 3], cd,                                                                            \
-             if (DBG == 3) {} else if ((T) == 0) ST_LOADX(1, y + 4) else if ((T) == 2) ST_LOADX(3, y + 6),          \
-             if (DBG == 3) {} else if ((T) == 0) ST_LOADD(3, y + 3) else if ((T) == 2) ST_LOADD(1, y + 5),          \
+             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADX(1, y + 4) else if ((T) == 2) ST_LOADX(3, y + 6),          \
+             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADD(3, y + 3) else if ((T) == 2) ST_LOADD(1, y + 5),          \
              (void)0, (void)0,                                                                                    \
-             if (DBG == 3) {} else if ((T) == 0) ST_LOADX(2, y + 5) else if ((T) == 2) ST_LOADX(0, y + 7),          \
-             if (DBG == 3) {} else if ((T) == 0) ST_LOADD(0, y + 4) else if ((T) == 2) ST_LOADD(2, y + 6),          \
+             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADX(2, y + 5) else if ((T) == 2) ST_LOADX(0, y + 7),          \
+             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADD(0, y + 4) else if ((T) == 2) ST_LOADD(2, y + 6),          \
              (void)0, (void)0, (void)0)                                                                           \
       ST_ROW(2, xr[((T) + 2) & 3], cd, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0) \
     }
@@ -394,14 +399,8 @@ int wgrad_bf16_strip_items(const ConvGeom& g, int rows) {
 }
 hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid, int rows) {
   a.mpix = wgrad_bf16_strip_rows(a.g, rows);                   // (the kernel takes the rows per piece in this field)
-  extern int g_wgrad_bf16_dbg;
-  extern int g_wgrad_bf16_dbg4;
-  if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<64, 0>), grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg4) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 4>), grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg == 1) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 1>), grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg == 2) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 2>), grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg == 3) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 3>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, 0>), grid, dim3(256), 0, st, a);
+  if (a.g.ci == 64) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<64>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<32>, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -413,13 +412,8 @@ bool wgrad_bf16_ok(const ConvGeom& g) {
 }
 int wgrad_bf16_units(const ConvGeom& g) { return g.n * ((g.h + 1) / 2) * ((g.w + 7) / 8); }
 
-hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid, bool interleave_loads) {
-  extern int g_wgrad_bf16_dbg;
-  if (g_wgrad_bf16_dbg == 1) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 1>), grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg == 2) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 2>), grid, dim3(256), 0, st, a);
-  else if (g_wgrad_bf16_dbg == 3) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 3>), grid, dim3(256), 0, st, a);
-  else if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<false, 0, 64>), grid, dim3(256), 0, st, a);
-  else if (interleave_loads) hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<true>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid) {
+  if (a.g.ci == 64) hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<64>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<32>, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }

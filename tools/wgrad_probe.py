@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""In-process A/B of the stride-1 weight-gradient kernels (launch + partial fold, HIP events): fp32 rows kernel vs the split-bf16 kernel
-(loads in front of / between the MFMAs), at the block geometries of the 4-conv-32 classifier.  Box-to-box variance is +-10 %: compare
-within one run only."""
+"""In-process A/B of the stride-1 weight-gradient kernels (launch + partial fold, HIP events): the fp32 rows kernel vs the split-bf16 strip
+and unit forms (mi_conv_set_split_bf16 with a variant mask), at block geometries of the 4-conv-32 classifier, with the relative
+difference of each result from the fp32 kernel's.  Box-to-box variance is +-10 %: compare within one run only.  Ablations (no MFMAs /
+no operand preparation / no loads) are separate builds: csrc/wgrad_bf16.hip, MI_WGRAD_DBG, selected with MI_MAML_LIB."""
 import ctypes as C
 import os
 import sys
@@ -15,7 +16,7 @@ lib = _lib.load()
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 ALL = 0x3ffff
-for (T, n, h) in [(32, 25, 42), (32, 5, 42), (4, 25, 42), (4, 75, 42), (1, 25, 42), (4, 5, 42)]:
+for (T, n, h) in [(32, 25, 42), (32, 25, 21), (32, 75, 42), (32, 5, 42), (4, 25, 42), (1, 25, 42)]:
     c, w = 32, h
     x = torch.randn(T, n, h, w, c, device='cuda')
     dz = torch.randn(T, n, h, w, c, device='cuda')
@@ -25,9 +26,7 @@ for (T, n, h) in [(32, 25, 42), (32, 5, 42), (4, 25, 42), (4, 75, 42), (1, 25, 4
     sb = lib.mi_kernel_scratch_bytes(T, n, h, w, c)
     scr = torch.empty(sb, dtype=torch.uint8, device='cuda')
     out, ref = [], None
-    for name, mode in (('fp32 rows', 0), ('bf16 strips', ((ALL & ~(1 << 18)) << 8) | 1), ('bf16 units', (((ALL & ~(1 << 18)) | (1 << 21)) << 8) | 1),
-                       ('strips no-MFMA', (((ALL & ~(1 << 18)) | (1 << 19)) << 8) | 1), ('strips no-prep', (((ALL & ~(1 << 18)) | (2 << 19)) << 8) | 1),
-                       ('strips no-loads', (((ALL & ~(1 << 18)) | (3 << 19)) << 8) | 1), ('strips loads-only', (((ALL & ~(1 << 18)) | (1 << 22)) << 8) | 1)):
+    for name, mode in (('fp32 rows', 0), ('bf16 strips', (ALL << 8) | 1), ('bf16 units', ((ALL | (1 << 21)) << 8) | 1)):
         lib.mi_conv_set_split_bf16(mode)
         run = lambda: _lib.check(lib.mi_conv3x3_bwd(st(), vp(x), vp(dz), vp(wt), ps, T, n, h, w, c, c, 1, None, vp(dw), ps, vp(scr), sb))
         for _ in range(3):
