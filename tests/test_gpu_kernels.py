@@ -265,3 +265,28 @@ def test_input_gram_and_stats(lib, name, T, n, h, w, ci, co, lo, hi):
             worst[k] = max(worst.get(k, 0.0), float(np.max(np.abs(got - want) / scale)))
     report(f'gram_stats[{name}]', **worst)
     assert worst['mu'] < 1e-6 and worst['rstd'] < 1e-6 and worst['m1'] < 1e-6 and worst['m2'] < 1e-6
+
+
+@pytest.mark.parametrize('sx,sw,spread', [(1.0, 1.0, True), (1e15, 1e15, False), (1e-18, 1e-18, False), (1e18, 1e-18, False)])
+def test_conv_operand_forms_keep_fp32_accuracy_across_magnitudes(lib, sx, sw, spread):
+    """The hidden convolution on inputs and weights from 1e-18 to 1e18 (and, `spread`, element magnitudes spread over twelve decades
+    inside one tensor): both operand forms stay at fp32 rounding of the fp64 result -- the three-way bf16 split is exact at every exponent
+    (bf16 has fp32's exponent range), the dropped cross terms stay 2^-24 of a product."""
+    T, n, h, w, c = 2, 3, 21, 21, 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, n, h, w, c, generator=g) * sx
+    if spread:
+        x = x * torch.pow(10.0, torch.randint(-6, 7, x.shape, generator=g).float())
+    ps = 9 * c * c + 64
+    wb = torch.randn(T, ps, generator=g) * sw
+    xd, wd = x.cuda(), wb.cuda()
+    z = torch.full((T, n, h, w, c), float('nan'), device='cuda')
+    mu, rstd = torch.empty(T, c, device='cuda'), torch.empty(T, c, device='cuda')
+    sb = lib.mi_kernel_scratch_bytes(T, n, h, w, c)
+    scratch = torch.empty(sb, dtype=torch.uint8, device='cuda')
+    _lib.check(lib.mi_conv3x3_bn_stats(stream(), ptr(xd), ptr(wd), ps, T, n, h, w, c, c, 1, ptr(z), ptr(mu), ptr(rstd), ptr(scratch), sb))
+    torch.cuda.synchronize()
+    for t in range(T):
+        ref = KR.conv3x3(x[t].double(), wb[t, :9 * c * c].reshape(9, c, c).double())
+        assert torch.isfinite(z[t]).all()
+        assert rel_err(z[t].cpu().numpy(), ref.numpy()) < 1e-6
