@@ -307,28 +307,39 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
   constexpr int NQ = BF ? 0 : NTERMS * 9 * CI * 32 / 4;
   if constexpr (BF) {
     mi_u32x4* l4 = reinterpret_cast<mi_u32x4*>(lds);
-    constexpr int NIT = NSTEP * 2 * 64;
-    for (int it = tid; it < NIT; it += NT) {
+    constexpr int NIT = NSTEP * 2 * 64, IPT = (NIT + NT - 1) / NT;   // items (8 weights of one output channel) per thread
+    // all of a thread's loads first, then the splits: one memory latency per workgroup instead of one per item
+    floatx4 w0[IPT], w1[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const int it = tid + q * NT;
       const int ln = it & 63, grp = it >> 6;
       const int jj = ln & 31, hb = ln >> 5, kb = grp & 1, stp = grp >> 1;
       const int cc = stp % NCC, tt = stp / NCC, term = tt / 9, tap = tt - term * 9;
       const int k0 = cc * 32 + hb * 16 + kb * 8;
-      const float* wsrc = a.wt[term] + (size_t)task * a.wstride;
-      floatx4 w0, w1;
+      const bool live = it < NIT;
+      const float* wsrc = a.wt[live ? term : 0] + (size_t)task * a.wstride;
       if (MODE == 0) {
-        const float* src = wsrc + ((size_t)tap * CI + k0) * CO + cbase + jj;
+        const float* src = wsrc + ((size_t)(live ? tap : 0) * CI + k0) * CO + cbase + jj;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { w0[i] = src[(size_t)i * CO]; w1[i] = src[(size_t)(i + 4) * CO]; }
+        for (int i = 0; i < 4; ++i) { w0[q][i] = src[(size_t)i * CO]; w1[q][i] = src[(size_t)(i + 4) * CO]; }
       } else {
-        const float* src = wsrc + ((size_t)tap * CO + cbase + jj) * CI + k0;
-        w0 = *reinterpret_cast<const floatx4*>(src);
-        w1 = *reinterpret_cast<const floatx4*>(src + 4);
+        const float* src = wsrc + ((size_t)(live ? tap : 0) * CO + cbase + jj) * CI + k0;
+        w0[q] = *reinterpret_cast<const floatx4*>(src);
+        w1[q] = *reinterpret_cast<const floatx4*>(src + 4);
       }
-      Bf16Planes pw;
-      bf16_split8(w0, w1, pw);
-      l4[(grp * 3 + 0) * 64 + ln] = mi_u32x4{pw.h[0], pw.h[1], pw.h[2], pw.h[3]};
-      l4[(grp * 3 + 1) * 64 + ln] = mi_u32x4{pw.m[0], pw.m[1], pw.m[2], pw.m[3]};
-      l4[(grp * 3 + 2) * 64 + ln] = mi_u32x4{pw.l[0], pw.l[1], pw.l[2], pw.l[3]};
+    }
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const int it = tid + q * NT;
+      if (it < NIT) {
+        const int ln = it & 63, grp = it >> 6;
+        Bf16Planes pw;
+        bf16_split8(w0[q], w1[q], pw);
+        l4[(grp * 3 + 0) * 64 + ln] = mi_u32x4{pw.h[0], pw.h[1], pw.h[2], pw.h[3]};
+        l4[(grp * 3 + 1) * 64 + ln] = mi_u32x4{pw.m[0], pw.m[1], pw.m[2], pw.m[3]};
+        l4[(grp * 3 + 2) * 64 + ln] = mi_u32x4{pw.l[0], pw.l[1], pw.l[2], pw.l[3]};
+      }
     }
   }
 #pragma unroll 3
