@@ -440,18 +440,18 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
       const unsigned go32 = o32 + (unsigned)(2 * g * CO * 4), go8 = o8 + (unsigned)(2 * g * CO);
       if (ARG) {
         // z holds zd (the conv ran with the direction's weights): pd = [on] (gammad zh + gamma zhd + betad), zhd = r (zd - m1 - zh m2)
+        // the stored argmax byte (0..3, 4 = the window's ReLU is off) picks the position through its bits (mi_common.h lane_select)
         const unsigned agv = o.ag[g];
-        float zd_at = z[4 * g];
-        zd_at = agv == 1u ? z[4 * g + 1] : zd_at;
-        zd_at = agv == 2u ? z[4 * g + 2] : zd_at;
-        zd_at = agv == 3u ? z[4 * g + 3] : zd_at;
+        const int b0 = lane_mask_bit<0>(agv), b1 = lane_mask_bit<1>(agv), off = lane_mask_bit<2>(agv);
+        const float zd_at = lane_select(b1, lane_select(b0, z[4 * g + 3], z[4 * g + 2]), lane_select(b0, z[4 * g + 1], z[4 * g]));
         const float zhd_s = rs * (zd_at - m1 - o.zh[g] * m2);
-        const bool on = agv < 4u;
-        buf_st(rout, go32, on ? gmd * o.zh[g] + gm * zhd_s + btd : 0.f);
-        buf_st(rzho, go32, on ? zhd_s : 0.f);
+        buf_st(rout, go32, lane_zero_where(off, gmd * o.zh[g] + gm * zhd_s + btd));
+        buf_st(rzho, go32, lane_zero_where(off, zhd_s));
       } else {
         // the reference's rule exactly (MaxPool2d after BN + ReLU, vision_models.py:188-193): FIRST maximum of u itself, so two
-        // positions whose u round to the same float resolve by position even when their z differ
+        // positions whose u round to the same float resolve by position even when their z differ.  "uq > u" is taken as the sign
+        // of u - uq (the difference of two finite floats is exact near a tie, so it is negative exactly when uq > u) and the three
+        // selects are v_bfi_b32 on that lane mask (mi_common.h lane_select)
         float zh_at = bn_zh(z[4 * g], mu, rs);
         float u = bn_u(zh_at, gm, bt);
         unsigned arg = 0u;
@@ -459,15 +459,16 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
         for (int q = 1; q < 4; ++q) {
           const float zq = bn_zh(z[4 * g + q], mu, rs);
           const float uq = bn_u(zq, gm, bt);
-          const bool gt = uq > u;
-          u = gt ? uq : u;
-          zh_at = gt ? zq : zh_at;
-          arg = gt ? (unsigned)q : arg;
+          const int gt = lane_mask_negative(u - uq);
+          u = lane_select(gt, uq, u);
+          zh_at = lane_select(gt, zq, zh_at);
+          arg = lane_select(gt, (unsigned)q, arg);
         }
-        const bool on = u > 0.f;
-        buf_st(rout, go32, on ? u : 0.f);
+        const float p = fmaxf(u, 0.f);                               // +0 (all bits clear) exactly when the ReLU is off
+        const int offm = (__builtin_bit_cast(int, p) - 1) >> 31;
+        buf_st(rout, go32, p);
         buf_st(rzho, go32, zh_at);
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(on ? arg : 4u), rago, go8, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lane_select(offm, 4u, arg), rago, go8, 0, 0);
       }
     }
   };

@@ -283,12 +283,12 @@ __global__ __launch_bounds__(256) void sparse_wgrad_kernel(SparseWgArgs a) {
     for (int i = 0; i < CH; ++i) {
       if (CH == 7 || s0 + i < nsteps) {            // chunks of 7 are launched only when they tile the row exactly
         const float a0 = ac[4 * i * CI0], a1 = ac[4 * i * CI0 + CI0], a2 = ac1[4 * i * CI0], a3 = ac1[4 * i * CI0 + CI0];
-        const unsigned ag = cur.ag[i];
+        const unsigned hot = 1u << cur.ag[i];       // one-hot of the argmax byte: bit q -> lane mask of position q (mi_common.h)
         const float cot = TAN ? fmaf(sB, cur.qd[i], sA * cur.q[i]) : cur.q[i];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ag == 0u ? cot : 0.f, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ag == 1u ? cot : 0.f, acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, ag == 2u ? cot : 0.f, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, ag == 3u ? cot : 0.f, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, lane_keep_where(lane_mask_bit<0>(hot), cot), acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, lane_keep_where(lane_mask_bit<1>(hot), cot), acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, lane_keep_where(lane_mask_bit<2>(hot), cot), acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, lane_keep_where(lane_mask_bit<3>(hot), cot), acc2, 0, 0, 0);
       }
     }
     tile = ntile; s0 = ns0; set = nset;
@@ -398,12 +398,14 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
     for (int i = 0; i < CH; ++i) {
       const int o = 4 * (c * CH + i) * CI0;
       const float a0 = ac[o], a1 = ac[o + CI0], a2 = ac1[o], a3 = ac1[o + CI0];
-      const unsigned ag = b.ag[i];
+      // B of position q is the cotangent where the stored argmax byte is q: one-hot of the byte, its bit q smeared into a lane
+      // mask, one AND (mi_common.h: a compare + v_cndmask pair per position costs more than twice as much issue time)
+      const unsigned hot = 1u << b.ag[i];
       const float cot = TAN ? fmaf(sB, b.qd[i], sA * b.q[i]) : b.q[i];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ag == 0u ? cot : 0.f, acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ag == 1u ? cot : 0.f, acc2, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, ag == 2u ? cot : 0.f, acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, ag == 3u ? cot : 0.f, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, lane_keep_where(lane_mask_bit<0>(hot), cot), acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, lane_keep_where(lane_mask_bit<1>(hot), cot), acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, lane_keep_where(lane_mask_bit<2>(hot), cot), acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, lane_keep_where(lane_mask_bit<3>(hot), cot), acc2, 0, 0, 0);
     }
   };
   int tile = tile_base + ((wave + blockIdx.x) & 3);   // this wave's tiles: tile, tile + 4, ... (start rotated per workgroup); pairs per iteration

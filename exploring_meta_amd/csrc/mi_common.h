@@ -35,6 +35,41 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ float bn_zh(float z, float mu, float r) { return (z - mu) * r; }
 __device__ __forceinline__ float bn_u(float zh, float g, float b) { return fmaf(g, zh, b); }
 
+// Per-lane selects as bit-field operations.  v_cndmask_b32 issues at a QUARTER of the plain VALU rate on gfx950 (16 cycles, and a
+// v_cmp in front of it: tools/valu_rate_probe.hip, profiles/r3/valu_rate_probe.txt), and on the fp32 matrix pipe VALU time adds
+// to MFMA time; a lane mask kept in a VGPR (0 / -1) and v_bfi_b32 do the same select at full rate.  Inline asm because instruction
+// selection folds the C form (mask & a | ~mask & b with mask = x >> 31) back into compare + v_cndmask.
+__device__ __forceinline__ int lane_mask_negative(float d) {            // -1 where d's sign bit is set
+  int r;
+  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(d));
+  return r;
+}
+template <int BIT> __device__ __forceinline__ int lane_mask_bit(unsigned v) {   // -1 where bit BIT of v is set
+  int r;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(v), "n"(BIT));
+  return r;
+}
+__device__ __forceinline__ float lane_select(int mask, float a, float b) {     // mask ? a : b
+  float r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned lane_select(int mask, unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float lane_zero_where(int mask, float b) {          // mask ? 0 : b
+  float r;
+  asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(mask), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float lane_keep_where(int mask, float b) {          // mask ? b : 0
+  float r;
+  asm("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(mask), "v"(b));
+  return r;
+}
+
 // Out-of-image operands are fetched from this zero word by selecting the ADDRESS (never the loaded value): a predicated load
 // costs an exec-mask branch region, and a select on the loaded value makes the wave wait for the load before it can issue
 // the MFMAs of the previous, already loaded, tile.
