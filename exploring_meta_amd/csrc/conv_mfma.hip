@@ -608,6 +608,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
       };
       // BF: accumulator rows 0 (r = 0 of lane half 0) and 31 (r = 15 of lane half 1) belong to the halo lanes: not stored, not summed
       auto dropped = [&](int r) { return BF && ((r == 0 && h == 0) || (r == 15 && h == 1)); };
+      const int keep_lo = h == 0 ? 0 : -1, keep_hi = h == 1 ? 0 : -1;
       auto fetch = [&](int grp, Grp& gq) {
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) {
@@ -623,12 +624,16 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
           const int r = grp * GR + rr;
           const float v = acc[r];
           buf_st_untracked(rout_raw, dropped(r) ? MI_OOB : row_off(r), v);
-          const bool on = gq.pp[rr] > 0.f && !dropped(r);
-          const float vv = on ? v : 0.f;
+          // "ReLU on" as a lane mask: p is a ReLU output (>= +0), so 0 - p carries a sign bit exactly where p > 0.  The masked
+          // values are ANDs on the floats (mi_common.h): a select after the fp64 conversion is two quarter-rate v_cndmask per row
+          int on = lane_mask_negative(0.f - gq.pp[rr]);
+          if (BF && r == 0) on &= keep_lo;
+          if (BF && r == 15) on &= keep_hi;
+          const float vv = lane_keep_where(on, v);
           if (NTERMS == 1) {
             s = fma((double)vv, (double)gq.zz[rr], s);
           } else {
-            const float dv = on ? gq.dq[rr] : 0.f;
+            const float dv = lane_keep_where(on, gq.dq[rr]);
             s += (double)vv * (double)gq.zz[rr] + (double)dv * (double)gq.zd[rr];
           }
           q += (double)vv;
