@@ -436,18 +436,20 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+  // (lane index and column base re-derived here rather than kept live across the loop: the kernel sits at its 128-register budget)
+  const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) lds[wave * 1024 + r * 64 + lane] = acc[r];
+  for (int r = 0; r < 16; ++r) lds[wave * 1024 + r * 64 + ln] = acc[r];
   __syncthreads();
-  float* pt = a.wpartial + ((size_t)task * gridDim.x + blockIdx.x) * K * CO;
+  float* pt = a.wpartial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * K * CO + blockIdx.z * 32;
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
-    const int e = tid + 256 * qq;
+    const int e = wave * 64 + ln + 256 * qq;
     const float v = lds[e] + lds[1024 + e] + lds[2048 + e] + lds[3072 + e];
-    const int r = e >> 6, l = e & 63;
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
-    if (row < K) pt[(size_t)row * CO + cbase + col] = v;
+    const int r = e >> 6;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = ln & 31;
+    if (row < K) pt[(size_t)row * CO + col] = v;
   }
 }
 
