@@ -1003,14 +1003,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // host launchers
 // Split-bf16 operands for the 32-channel stride-1 kernels (default on; MI_CONV_BF16X3=0 / mi_conv_set_split_bf16(0) = the fp32 pipe everywhere)
 static int g_conv_split_bf16 = -1;
+static unsigned g_conv_split_mask = 0x3ffffu;                   // debug: which variants take the split form: conv bit ((terms-1)*2 + mode)*4 + epi, weight gradient bit 16 + (terms-1)
 static bool conv_split_bf16() {
   if (g_conv_split_bf16 < 0) {
     const char* e = getenv("MI_CONV_BF16X3");
     g_conv_split_bf16 = e ? (atoi(e) != 0) : 1;
+    const char* m = getenv("MI_CONV_BF16X3_MASK");              // bisecting aid (hex): the variant mask of mi_conv_set_split_bf16
+    if (m) g_conv_split_mask = (unsigned)strtoul(m, nullptr, 16);
   }
   return g_conv_split_bf16 != 0;
 }
-static unsigned g_conv_split_mask = 0x3ffffu;                   // debug: which variants take the split form: conv bit ((terms-1)*2 + mode)*4 + epi, weight gradient bit 16 + (terms-1)
 extern "C" int mi_conv_set_split_bf16(int on) {
   const int was = conv_split_bf16() ? 1 : 0;
   g_conv_split_bf16 = on ? 1 : 0;

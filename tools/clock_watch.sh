@@ -4,11 +4,14 @@
 LABEL=$1; shift
 python bench.py "$@" > /tmp/cw_$LABEL.json 2>/dev/null &
 PID=$!
-sleep 25                                   # import, task batch, warmup
+sleep 18                                   # import, task batch, warmup
+N=0
 while kill -0 $PID 2>/dev/null; do
   S=$(rocm-smi -c -P 2>/dev/null)
+  N=$((N+1)); [ $N -eq 5 ] && echo "$S" > /tmp/cw_raw_$LABEL.txt
   echo "$LABEL $(echo "$S" | grep -i 'sclk' | head -n 1 | sed 's/  */ /g') | $(echo "$S" | grep -i 'power' | head -n 1 | sed 's/  */ /g')"
   sleep 1
 done
 wait $PID
+cat /tmp/cw_raw_$LABEL.txt 2>/dev/null | grep -v "^$" | grep -i "power\|sclk\|mclk\|fclk" | sed 's/  */ /g'
 cut -c1-125 /tmp/cw_$LABEL.json
