@@ -460,15 +460,15 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
           const float zq = bn_zh(z[4 * g + q], mu, rs);
           const float uq = bn_u(zq, gm, bt);
           const int gt = lane_mask_negative(u - uq);
-          u = lane_select(gt, uq, u);
-          zh_at = lane_select(gt, zq, zh_at);
-          arg = lane_select(gt, (unsigned)q, arg);
+          u = lane_select_valu(gt, uq, u);                           // (operands: bn_u / bn_zh results, never the accumulators themselves)
+          zh_at = lane_select_valu(gt, zq, zh_at);
+          arg = lane_select_valu(gt, (unsigned)q, arg);
         }
         const float p = fmaxf(u, 0.f);                               // +0 (all bits clear) exactly when the ReLU is off
-        const int offm = (__builtin_bit_cast(int, p) - 1) >> 31;
+        const int offm = lane_mask_negative(__builtin_bit_cast(float, __builtin_bit_cast(int, p) - 1));
         buf_st(rout, go32, p);
         buf_st(rzho, go32, zh_at);
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lane_select(offm, 4u, arg), rago, go8, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lane_select_valu(offm, 4u, arg), rago, go8, 0, 0);
       }
     }
   };

@@ -37,8 +37,11 @@ __device__ __forceinline__ float bn_u(float zh, float g, float b) { return fmaf(
 
 // Per-lane selects as bit-field operations.  v_cndmask_b32 issues at a QUARTER of the plain VALU rate on gfx950 (16 cycles, and a
 // v_cmp in front of it: tools/valu_rate_probe.hip, profiles/r3/valu_rate_probe.txt), and on the fp32 matrix pipe VALU time adds
-// to MFMA time; a lane mask kept in a VGPR (0 / -1) and v_bfi_b32 do the same select at full rate.  Inline asm because instruction
-// selection folds the C form (mask & a | ~mask & b with mask = x >> 31) back into compare + v_cndmask.
+// to MFMA time; a lane mask kept in a VGPR (0 / -1) and v_bfi_b32 / v_and_b32 do the same select at full rate.
+// Only the MASKS are inline assembly (so that instruction selection cannot fold mask-and-merge back into compare + v_cndmask); the
+// merges are plain C on the bits.  That split matters: the hazard recogniser does not look inside inline assembly, so an assembly
+// instruction must neither read a matrix result nor produce a matrix operand (MFMA -> VALU and VALU -> MFMA wait states are the
+// compiler's to insert) -- the masks read ordinary VALU / load results and feed ordinary VALU instructions only.
 __device__ __forceinline__ int lane_mask_negative(float d) {            // -1 where d's sign bit is set
   int r;
   asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(d));
@@ -49,25 +52,29 @@ template <int BIT> __device__ __forceinline__ int lane_mask_bit(unsigned v) {   
   asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(v), "n"(BIT));
   return r;
 }
-__device__ __forceinline__ float lane_select(int mask, float a, float b) {     // mask ? a : b
+__device__ __forceinline__ unsigned lane_select(int mask, unsigned a, unsigned b) {   // mask ? a : b  (v_bfi_b32)
+  return ((unsigned)mask & a) | (~(unsigned)mask & b);
+}
+__device__ __forceinline__ float lane_select(int mask, float a, float b) {
+  return __builtin_bit_cast(float, lane_select(mask, __builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)));
+}
+// The same merge as ONE v_bfi_b32 in inline assembly (instruction selection does not always fuse the C form).  Per the rule above:
+// a and b must be results of ordinary VALU instructions (never matrix accumulators) and the result must not be a matrix operand.
+__device__ __forceinline__ float lane_select_valu(int mask, float a, float b) {
   float r;
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
   return r;
 }
-__device__ __forceinline__ unsigned lane_select(int mask, unsigned a, unsigned b) {
+__device__ __forceinline__ unsigned lane_select_valu(int mask, unsigned a, unsigned b) {
   unsigned r;
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
   return r;
 }
 __device__ __forceinline__ float lane_zero_where(int mask, float b) {          // mask ? 0 : b
-  float r;
-  asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(mask), "v"(b));
-  return r;
+  return __builtin_bit_cast(float, ~(unsigned)mask & __builtin_bit_cast(unsigned, b));
 }
 __device__ __forceinline__ float lane_keep_where(int mask, float b) {          // mask ? b : 0
-  float r;
-  asm("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(mask), "v"(b));
-  return r;
+  return __builtin_bit_cast(float, (unsigned)mask & __builtin_bit_cast(unsigned, b));
 }
 
 // Out-of-image operands are fetched from this zero word by selecting the ADDRESS (never the loaded value): a predicated load
