@@ -239,6 +239,7 @@ def run_vision(args, wl, rank, world, local, dist):
         tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+    clock = clock_record(step, world) if rank == 0 and not args.no_clock else None
 
     # Secondary figure: the reference runs one validation fast_adapt per train task without backward
     # (maml_vision.py:117-124); here that half is one more fused call with with_grad=0 on T other tasks.
@@ -356,8 +357,37 @@ def run_vision(args, wl, rank, world, local, dist):
                    'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter',
                    'task_hardness': HARDNESS[wl['dataset']]},
         'post_adapt': post, 'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline,
-        'cpu_baseline': cpu, 'collective': collective, 'arithmetic': arithmetic_note(eng),
+        'cpu_baseline': cpu, 'collective': collective, 'arithmetic': arithmetic_note(eng), 'clock': clock,
     }
+
+
+def clock_record(step, world, seconds=3.0):
+    """Shader clock and socket power while the step loop keeps running (untimed, after the timed region; rocm-smi is a child
+    process that only reads).  `roofline.peak` assumes the nominal 2400 MHz; at its socket power cap the MI355X runs the conv
+    workloads near 2000 MHz (profiles/r3/clock), so read `roofline.frac` with this clock next to it.  None when world > 1 (the
+    extra steps would have to be agreed between ranks) or when rocm-smi is not on PATH."""
+    import re
+    import shutil
+    import subprocess
+    if world != 1 or not shutil.which('rocm-smi'):
+        return None
+    samples, t_end = [], time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        p = subprocess.Popen(['rocm-smi', '-c', '-P'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        while p.poll() is None:
+            step()
+        txt = p.stdout.read()
+        m, w = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', txt), re.search(r'Power \(W\): ([0-9.]+)', txt)
+        if m:
+            samples.append((int(m.group(1)), float(w.group(1)) if w else None))
+    torch.cuda.synchronize()
+    samples = samples[1:] or samples                     # the first sample may still see the clock ramp
+    if not samples:
+        return None
+    sclk = sorted(c for c, _ in samples)[len(samples) // 2]
+    watts = [x for _, x in samples if x is not None]
+    return {'sclk_mhz': sclk, 'nominal_mhz': 2400, 'socket_power_w': (sorted(watts)[len(watts) // 2] if watts else None),
+            'samples': len(samples), 'how': 'rocm-smi -c -P while the step loop runs, after the timed region'}
 
 
 def arithmetic_note(eng):
@@ -538,6 +568,7 @@ def run_trpo(args, wl, rank, world, local, dist):
                        **(cpu.pop('_post') if cpu else {})},
         'secondary': {'metric': 'meta_optimize_trpo iterations/sec', 'value': round(args.steps / dt, 3)},
         'roofline': roofline, 'cpu_baseline': cpu, 'collective': collective,
+        'clock': clock_record(step, world) if not args.no_clock else None,
     }
 
 
@@ -580,6 +611,7 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--tasks', type=int, default=0, help='override the tasks per GPU of the workload (sweeps; not a BASELINE configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-clock', action='store_true', help='skip the shader-clock / socket-power record (3 s of extra untimed steps)')
     ap.add_argument('--graph', type=int, default=-1, help='replay the fused call as a captured hipGraph (mi_engine_set_graph): 1 on, 0 off, '
                     '-1 = the workload default (on for the launch-bound few-image configurations cfg1 and cfg4)')
     ap.add_argument('--breakdown', default='', help='write a per-kernel event-time breakdown (one extra untimed step) to this file')

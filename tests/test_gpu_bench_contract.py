@@ -40,3 +40,7 @@ def test_bench_line_has_the_contract_fields():
     assert pa['compared_tasks'] >= 1 and pa['max_abs_acc_diff_per_task'] == 0.0 and pa['max_abs_loss_diff_per_task'] < 1e-3
     # what "f32" means on this build is spelled out next to it
     assert d['arithmetic']['split_bf16_operands'] in (True, False) and 'fp32' in d['arithmetic']['note']
+    # the shader clock the numbers were taken at (None only where rocm-smi is missing): the roofline peaks assume 2400 MHz
+    assert 'clock' in d
+    if d['clock'] is not None:
+        assert 500 <= d['clock']['sclk_mhz'] <= 2600 and d['clock']['nominal_mhz'] == 2400
