@@ -372,14 +372,25 @@ def clock_record(step, world, seconds=3.0):
     if world != 1 or not shutil.which('rocm-smi'):
         return None
     samples, t_end = [], time.perf_counter() + seconds
-    while time.perf_counter() < t_end:
-        p = subprocess.Popen(['rocm-smi', '-c', '-P'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-        while p.poll() is None:
-            step()
-        txt = p.stdout.read()
-        m, w = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', txt), re.search(r'Power \(W\): ([0-9.]+)', txt)
-        if m:
-            samples.append((int(m.group(1)), float(w.group(1)) if w else None))
+    try:
+        while time.perf_counter() < t_end:
+            p = subprocess.Popen(['rocm-smi', '-c', '-P'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            t_child = time.perf_counter()
+            while p.poll() is None:
+                step()
+                if time.perf_counter() - t_child > 5.0:      # a reading takes ~0.1 s: a stuck tool must not hold the bench
+                    p.kill()
+                    p.wait()
+                    t_end = 0.0
+                    break
+            txt = p.stdout.read() if p.returncode == 0 else ''
+            m, w = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', txt), re.search(r'Power \(W\): ([0-9.]+)', txt)
+            if m:
+                samples.append((int(m.group(1)), float(w.group(1)) if w else None))
+            elif not samples:
+                break                                        # no reading from this tool on this box: do not keep trying
+    except OSError:
+        pass
     torch.cuda.synchronize()
     samples = samples[1:] or samples                     # the first sample may still see the clock ramp
     if not samples:
