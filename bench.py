@@ -239,7 +239,7 @@ def run_vision(args, wl, rank, world, local, dist):
         tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
-    clock = clock_record(step, world) if rank == 0 and not args.no_clock else None
+    clock = clock_record(step, world, ms_per_step=dt / args.steps * 1e3) if rank == 0 and not args.no_clock else None
 
     # Secondary figure: the reference runs one validation fast_adapt per train task without backward
     # (maml_vision.py:117-124); here that half is one more fused call with with_grad=0 on T other tasks.
@@ -361,7 +361,7 @@ def run_vision(args, wl, rank, world, local, dist):
     }
 
 
-def clock_record(step, world, seconds=3.0):
+def clock_record(step, world, seconds=3.0, ms_per_step=None):
     """Shader clock and socket power while the step loop keeps running (untimed, after the timed region; rocm-smi is a child
     process that only reads).  `roofline.peak` assumes the nominal 2400 MHz; at its socket power cap the MI355X runs the conv
     workloads near 2000 MHz (profiles/r3/clock), so read `roofline.frac` with this clock next to it.  None when world > 1 (the
@@ -397,7 +397,9 @@ def clock_record(step, world, seconds=3.0):
         return None
     sclk = sorted(c for c, _ in samples)[len(samples) // 2]
     watts = [x for _, x in samples if x is not None]
-    return {'sclk_mhz': sclk, 'nominal_mhz': 2400, 'socket_power_w': (sorted(watts)[len(watts) // 2] if watts else None),
+    power = sorted(watts)[len(watts) // 2] if watts else None
+    return {'sclk_mhz': sclk, 'nominal_mhz': 2400, 'socket_power_w': power,
+            'joules_per_step': (round(power * ms_per_step * 1e-3, 3) if power and ms_per_step else None),    # at the cap, time follows energy
             'samples': len(samples), 'how': 'rocm-smi -c -P while the step loop runs, after the timed region'}
 
 
@@ -579,7 +581,7 @@ def run_trpo(args, wl, rank, world, local, dist):
                        **(cpu.pop('_post') if cpu else {})},
         'secondary': {'metric': 'meta_optimize_trpo iterations/sec', 'value': round(args.steps / dt, 3)},
         'roofline': roofline, 'cpu_baseline': cpu, 'collective': collective,
-        'clock': clock_record(step, world) if not args.no_clock else None,
+        'clock': clock_record(step, world, ms_per_step=dt / args.steps * 1e3) if not args.no_clock else None,
     }
 
 
