@@ -17,7 +17,8 @@
 #include "kernels.h"
 #include "bf16_split.h"
 
-// Ablation builds (timing experiments, not shipped): -DMI_WGRAD_DBG=1 no MFMAs, 2 no operand preparation, 3 no loads in the loop, 4 loads
+// Ablation builds (timing experiments, not shipped): -DMI_WGRAD_DBG=5 strip kernel with three of its six products per K step (the matrix
+// work of a two-plane operand form, DESIGN.md 8c lead 5; wrong results), =1 no MFMAs, 2 no operand preparation, 3 no loads in the loop, 4 loads
 // only; build to another file name and select it with MI_MAML_LIB (tools/wgrad_probe.py runs in one process either way).
 #ifndef MI_WGRAD_DBG
 #define MI_WGRAD_DBG 0
@@ -303,17 +304,18 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
     // step T (output row y + T of the trip that starts at row y): x rows in slots T, T+1, T+2 (mod 4), dz planes T & 1; meanwhile x row
     // y + T + 2 (raw set (T + 3) & 3) is split into slot (T + 3) & 3 and dz row y + T + 1 (raw set (T + 1) & 3) into planes (T + 1) & 1
 #define ST_MFMA(T, X, Y) if (MI_WGRAD_DBG != 1 && MI_WGRAD_DBG != 4) acc[T] = MI_BF_MFMA(X, Y, acc[T])
+#define ST_MFMA_LOW(T, X, Y) if (MI_WGRAD_DBG != 5) ST_MFMA(T, X, Y)      /* the three products a two-plane operand form would not have */
 #define ST_TAP(T, AH, AM, AL, B, V0, V1, V2, V3)                                       \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    ST_MFMA(T, AL, B.h);                                                          \
+    ST_MFMA_LOW(T, AL, B.h);                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     V0;                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    ST_MFMA(T, AH, B.l);                                                          \
+    ST_MFMA_LOW(T, AH, B.l);                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     V1;                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    ST_MFMA(T, AM, B.m);                                                          \
+    ST_MFMA_LOW(T, AM, B.m);                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     V2;                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                 \
