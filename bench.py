@@ -371,6 +371,10 @@ def clock_record(step, world, seconds=3.0, ms_per_step=None):
     import subprocess
     if world != 1 or not shutil.which('rocm-smi'):
         return None
+    # under rocprofv3 every child carries the profiler's preloaded library, which initialises the GPU before the child's own exec
+    # (rocm-smi is a '#!/usr/bin/env python3' script): no child processes from a profiled run
+    if 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
+        return None
     samples, t_end = [], time.perf_counter() + seconds
     try:
         while time.perf_counter() < t_end:
