@@ -22,6 +22,13 @@
 #include "kernels.h"
 #include "bf16_split.h"
 
+// Ablation build (timing / energy experiment, wrong results, not shipped): -DMI_CONV_ABLATE_LOW compiles out the three products of a K
+// step that a two-plane operand form would not have (DESIGN.md 8c lead 5); build to another file name and select it with MI_MAML_LIB.
+#ifdef MI_CONV_ABLATE_LOW
+#define MI_LOW_PRODUCT(X)
+#else
+#define MI_LOW_PRODUCT(X) X
+#endif
 #define EPI_NONE 0
 #define EPI_STATS 1
 #define EPI_TSTATS 2
@@ -523,15 +530,15 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
         asm volatile("" : "+v"(dst.A1[2]), "+v"(dst.A1[3]), "+v"(dst.A2[0]), "+v"(dst.A2[1]), "+v"(dst.A2[2]), "+v"(dst.A2[3])); }
 #define MI_UNIT(ca, cb, V1, V2, V3, V4)                           \
       __builtin_amdgcn_sched_barrier(0);                          \
-      acc = MI_BF_MFMA(ca.l, cb[0], acc);                         \
+      MI_LOW_PRODUCT(acc = MI_BF_MFMA(ca.l, cb[0], acc));         \
       __builtin_amdgcn_sched_barrier(0);                          \
       V1;                                                         \
       __builtin_amdgcn_sched_barrier(0);                          \
-      acc = MI_BF_MFMA(ca.h, cb[2], acc);                         \
+      MI_LOW_PRODUCT(acc = MI_BF_MFMA(ca.h, cb[2], acc));         \
       __builtin_amdgcn_sched_barrier(0);                          \
       V2;                                                         \
       __builtin_amdgcn_sched_barrier(0);                          \
-      acc = MI_BF_MFMA(ca.m, cb[1], acc);                         \
+      MI_LOW_PRODUCT(acc = MI_BF_MFMA(ca.m, cb[1], acc));         \
       __builtin_amdgcn_sched_barrier(0);                          \
       V3;                                                         \
       __builtin_amdgcn_sched_barrier(0);                          \
