@@ -2,7 +2,9 @@
 """Benchmark of the MAML hot path on MI355X: tasks/sec for BASELINE.json's configurations (headline: configs[1]).
 
     python bench.py --gpus N --steps K --warmup W [--workload cfg2] [--scaling weak|strong]
-                                                  (N > 1: launched by torch.distributed.run, one rank per GPU)
+        N > 1 from a bare shell: bench.py starts its own ranks (python -m torch.distributed.run --nproc-per-node N, before anything
+        touches the GPU) and relays rank 0's line and the job's exit code; under torch.distributed.run it is one of the ranks.
+        N = 1: a single-rank RCCL process group in-process, so the step's all-reduce and the `collective` record are the N > 1 code path.
 
 A "step" is one meta-iteration of the train half of the reference loop (vision/maml_vision.py:93-141): every rank processes its
 shard of the meta-batch (K inner steps on support, query forward, second-order outer backward) through mi_meta_batch_maml, the
@@ -20,10 +22,43 @@ import os
 import sys
 import time
 
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks as a CHILD job (never an exec; this process
+    has not touched the GPU -- nothing but the standard library is imported yet) and exit with its code.  The ranks' stdout is this
+    process's stdout, so rank 0's JSON line arrives unchanged; torchrun's own chatter goes to stderr.
+    Reference: the all-reduce point of a data-parallel run is vision/maml_vision.py:139-141."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument('--gpus', type=int, default=1)
+    known, _ = ap.parse_known_args(argv)
+    if known.gpus <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return None
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this pool: RCCL needs it in every rank
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={known.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+if __name__ == '__main__':
+    _rc = self_launch(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
 # The engine forks weight gradients onto a side stream and RCCL brings its own: with the HIP default of 4 hardware queues the
 # streams of one process collide on a queue and the overlap turns into a 5 % loss (measured: 26.5 vs 25.2 ms per step under
 # torch.distributed); 8 queues keep every stream on its own.  Must be set before the HIP runtime initialises.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import ctypes as C
 
 import numpy as np
 import torch
@@ -80,7 +115,14 @@ def init_theta(spec, seed=42):
 
 
 def make_batch(wl, task_ids):
-    return synthetic.make_meta_batch(wl['dataset'], task_ids, wl['ways'], wl['shots'], **HARDNESS[wl['dataset']])
+    """Synthetic task batches [T, 2*S*W, C, H, W] / labels, generated task by task on a small thread pool (the hash generator is numpy
+    integer arithmetic, which releases the GIL: a 32-task Mini-ImageNet batch takes seconds on one core)."""
+    from concurrent.futures import ThreadPoolExecutor
+    task_ids = list(task_ids)
+    one = lambda t: synthetic.make_task(wl['dataset'], t, wl['ways'], wl['shots'], **HARDNESS[wl['dataset']])
+    with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1, len(task_ids)))) as ex:
+        ds, ls = zip(*ex.map(one, task_ids))
+    return np.stack(ds), np.stack(ls)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -175,16 +217,27 @@ def run_vision(args, wl, rank, world, local, dist):
         spec = ModelSpec.mini_imagenet(wl['ways']) if wl['dataset'] == 'min' else ModelSpec.omniglot(wl['ways'])
     eng = MetaEngine(spec)
     use_graph = wl.get('graph', False) if args.graph < 0 else bool(args.graph)
+    eng.set_overlap(not args.no_overlap)
     eng.set_graph(use_graph)          # theta is updated in place and the task batches stay resident: every step repeats the same call
     run_batch = eng.meta_batch_anil if wl.get('anil') else eng.meta_batch
     theta0 = init_theta(spec)
     theta = theta0.cuda()
-    data, labels = make_batch(wl, task_ids)
-    data, labels = torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda()
-    adam, out = {}, {}
+    # A resident POOL of distinct task batches, rotated through by the step loop: every step adapts to tasks the parameters have not
+    # just been trained on, as the reference's loop does (tasks.sample() per task, maml_vision.py:103), so the activation statistics --
+    # and with them the power draw at the socket cap -- stay those of training instead of those of one memorised batch.  Batch b of
+    # rank r holds the global task ids b * (tasks per iteration) + (this rank's ids): every world size sees the same task set per step.
+    per_iter = global_T
+    pool = []
+    for b in range(max(1, args.pool)):
+        d, l = make_batch(wl, [b * per_iter + t for t in task_ids])
+        pool.append((torch.from_numpy(d).cuda(), torch.from_numpy(l).cuda()))
+    data, labels = pool[0]
+    adam, out = {}, {'n': 0}
 
-    def compute(th, _task_ids):                 # this rank's shard is already resident in HBM (data, labels)
-        loss, acc, grad, _ = run_batch(th, data, labels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
+    def compute(th, _task_ids):                 # this rank's shards are already resident in HBM (pool)
+        d, l = pool[out['n'] % len(pool)]
+        out['n'] += 1
+        loss, acc, grad, _ = run_batch(th, d, l, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
         return loss, acc, grad
 
     def adam_fn(th, grad, scale):               # maml_vision.py:139-141
@@ -223,7 +276,7 @@ def run_vision(args, wl, rank, world, local, dist):
     torch.cuda.synchronize()
     first = eng.profile_collect()
     eng.profile(False)
-    eng.set_overlap(True)
+    eng.set_overlap(not args.no_overlap)
     dom = pick_dominant(spec, first, n_img)
     if dom:
         eng.profile(True, *dom)
@@ -239,7 +292,7 @@ def run_vision(args, wl, rank, world, local, dist):
         tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
-    clock = clock_record(step, world, ms_per_step=dt / args.steps * 1e3) if rank == 0 and not args.no_clock else None
+    acc_after_timed, loss_after_timed = float(out['acc']), float(out['loss'])
 
     # Secondary figure: the reference runs one validation fast_adapt per train task without backward
     # (maml_vision.py:117-124); here that half is one more fused call with with_grad=0 on T other tasks.
@@ -270,12 +323,51 @@ def run_vision(args, wl, rank, world, local, dist):
     collective = collective_record(dist, world, theta, eng.param_count + 2 * T,
                                    'one in-place all-reduce per meta-iteration of [meta-gradient | per-task losses | accuracies]')
 
+    # Everything below keeps stepping (other operand form, clock sampling): parameters and optimiser state are put back afterwards, so
+    # no theta-dependent figure of this line depends on how long those legs ran.
+    snap_theta, snap_adam, snap_n = theta.clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in adam.items()}, out['n']
+
+    def timed(n):
+        fence()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        fence()
+        d = (time.perf_counter() - t) / n
+        if dist is not None:
+            tm = torch.tensor([d], device='cuda', dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            d = tm.item()
+        return d
+
+    # The same step with the hidden convolutions on the exact fp32 matrix pipe (mi_conv_set_split_bf16(0)): the headline's operand
+    # form is the split-bf16 one, this is what the arithmetic change is worth, in the same run on the same box.
+    fp32_pipe = None
+    mask = C.c_uint(0)
+    # (pooling nets only: the stride-1 hidden blocks are where the two operand forms differ; a bisecting run's variant mask is left alone)
+    if wl['dataset'] == 'min' and eng.lib.mi_conv_get_split_bf16(C.byref(mask)) and mask.value == 0x3ffff:
+        eng.lib.mi_conv_set_split_bf16(0)
+        n32 = max(3, min(5, args.steps))
+        timed(2)
+        d32 = timed(n32)
+        eng.lib.mi_conv_set_split_bf16(1)
+        fp32_pipe = {'ms_per_step': round(d32 * 1e3, 3), 'tasks_per_s': round(global_T / d32, 2), 'steps': n32,
+                     'note': 'the same step with the hidden 3x3 convolutions and weight gradients on the exact fp32 matrix pipe '
+                             '(v_mfma_f32_32x32x2_f32, mi_conv_set_split_bf16(0)); measured after the timed region'}
+    clock = clock_record(step, world, ms_per_step=dt / args.steps * 1e3) if rank == 0 and not args.no_clock else None
+    theta.copy_(snap_theta)
+    for k, v in snap_adam.items():
+        if torch.is_tensor(v):
+            adam[k].copy_(v)
+        else:
+            adam[k] = v
+    out['n'] = snap_n
+
     roofline = None
     if dom in prof:
         ms, cnt = prof[dom]
         flops, nbytes = RF.op_costs(spec, dom[0], dom[1], n_img)
-        split = bool(eng.lib.mi_conv_set_split_bf16(1))         # read the operand form of the hidden convolutions ...
-        eng.lib.mi_conv_set_split_bf16(int(split))              # ... and leave it as it was
+        split = bool(eng.lib.mi_conv_get_split_bf16(None))      # the operand form of the hidden convolutions (read, not written)
         pipe_peak, pipe = RF.mfma_peak(spec, dom[0], dom[1], split)
         bound = RF.bound_of(flops, nbytes, pipe_peak)
         h, w, ci, co, ho, wo, _, _ = RF.layer_geometry(spec)[dom[1]]
@@ -322,7 +414,7 @@ def run_vision(args, wl, rank, world, local, dist):
         torch.cuda.synchronize()
         full = eng.profile_collect()
         eng.profile(False)
-        eng.set_overlap(True)
+        eng.set_overlap(not args.no_overlap)
         tot = sum(v[0] for v in full.values())
         if rank == 0:
             with open(args.breakdown, 'w') as f:
@@ -332,7 +424,9 @@ def run_vision(args, wl, rank, world, local, dist):
                     f.write(f'{op},{layer},{cnt},{ms:.4f},{ms / cnt:.4f},{ms / tot:.4f}\n')
 
     cpu, post = None, {'query_loss_mean_all_tasks_at_init': round(init_loss_mean, 5), 'query_acc_mean_all_tasks_at_init': round(init_acc_mean, 5),
-                       'query_loss_mean_last_step': round(float(out['loss']), 5), 'query_acc_mean_last_step': round(float(out['acc']), 5)}
+                       'query_loss_mean_last_step': round(loss_after_timed, 5), 'query_acc_mean_last_step': round(acc_after_timed, 5),
+                       'task_pool': f'{len(pool)} resident batches of {T} tasks per GPU, rotated every step (each batch is met again only after '
+                                    f'{len(pool) - 1} others: the last timed step does not score a batch the parameters were just fitted to)'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, ol, oa = cpu_baseline_vision(wl, spec, theta0)
         n = len(ol)
@@ -357,7 +451,7 @@ def run_vision(args, wl, rank, world, local, dist):
                    'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter',
                    'task_hardness': HARDNESS[wl['dataset']]},
         'post_adapt': post, 'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline,
-        'cpu_baseline': cpu, 'collective': collective, 'arithmetic': arithmetic_note(eng), 'clock': clock,
+        'cpu_baseline': cpu, 'collective': collective, 'arithmetic': arithmetic_note(eng), 'fp32_pipe': fp32_pipe, 'clock': clock,
     }
 
 
@@ -378,16 +472,16 @@ def clock_record(step, world, seconds=3.0, ms_per_step=None):
     samples, t_end = [], time.perf_counter() + seconds
     try:
         while time.perf_counter() < t_end:
-            p = subprocess.Popen(['rocm-smi', '-c', '-P'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-            t_child = time.perf_counter()
-            while p.poll() is None:
-                step()
-                if time.perf_counter() - t_child > 5.0:      # a reading takes ~0.1 s: a stuck tool must not hold the bench
-                    p.kill()
-                    p.wait()
-                    t_end = 0.0
-                    break
-            txt = p.stdout.read() if p.returncode == 0 else ''
+            with subprocess.Popen(['rocm-smi', '-c', '-P'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) as p:
+                t_child = time.perf_counter()
+                while p.poll() is None:
+                    step()
+                    if time.perf_counter() - t_child > 5.0:      # a reading takes ~0.1 s: a stuck tool must not hold the bench
+                        p.kill()
+                        p.wait()
+                        t_end = 0.0
+                        break
+                txt = p.stdout.read() if p.returncode == 0 else ''
             m, w = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', txt), re.search(r'Power \(W\): ([0-9.]+)', txt)
             if m:
                 samples.append((int(m.group(1)), float(w.group(1)) if w else None))
@@ -410,8 +504,7 @@ def clock_record(step, world, seconds=3.0, ms_per_step=None):
 def arithmetic_note(eng):
     """What "f32" means for this line: inputs, outputs, accumulation and every stored tensor are fp32; with the split operand form
     (the default) the hidden convolutions and weight gradients form each fp32 product from exact three-way bf16 splits of both operands."""
-    split = bool(eng.lib.mi_conv_set_split_bf16(1))
-    eng.lib.mi_conv_set_split_bf16(int(split))
+    split = bool(eng.lib.mi_conv_get_split_bf16(None))
     if not split:
         return {'split_bf16_operands': False, 'note': 'fp32 throughout (fp32-input MFMA = an fmaf chain; fp64 for statistics and reductions)'}
     return {'split_bf16_operands': True,
@@ -449,7 +542,9 @@ def collective_record(dist, world, theta, numel, what):
         ver = '.'.join(str(x) for x in torch.cuda.nccl.version())
     except Exception:
         pass
-    return dict(backend=f'{dist.get_backend()} (RCCL on ROCm)', rccl_version=ver, world_size=dist.get_world_size(), what=what,
+    backend = str(dist.get_backend())
+    return dict(backend=backend + (' (= RCCL on ROCm)' if backend == 'nccl' else ' (not RCCL: MI_DIST_BACKEND rehearsal)'),
+                rccl_version=ver if backend == 'nccl' else None, world_size=dist.get_world_size(), what=what,
                 allreduce_numel=int(numel), allreduce_bytes=int(numel) * 4, allreduce_us=round(us, 2), timed_calls=20,
                 theta_checksum=sums[0], theta_checksum_identical_on_all_ranks=True)
 
@@ -632,6 +727,12 @@ def main():
     ap.add_argument('--graph', type=int, default=-1, help='replay the fused call as a captured hipGraph (mi_engine_set_graph): 1 on, 0 off, '
                     '-1 = the workload default (on for the launch-bound few-image configurations cfg1 and cfg4)')
     ap.add_argument('--breakdown', default='', help='write a per-kernel event-time breakdown (one extra untimed step) to this file')
+    ap.add_argument('--pool', type=int, default=8, help='distinct resident task batches the step loop rotates through (vision workloads)')
+    ap.add_argument('--no-overlap', action='store_true', help='weight gradients on the main stream too (mi_engine_set_overlap(0)): per-launch '
+                    'durations in a kernel trace are then those of kernels running alone')
+    ap.add_argument('--no-dist', action='store_true', help='N = 1 without the single-rank process group (profiler runs)')
+    ap.add_argument('--launch-check', action='store_true', help='ranks only join the process group, all-reduce one number and rank 0 prints '
+                    '{"launch_check": true, "world_size": N}: exercises the self-launch path without a GPU (MI_DIST_BACKEND=gloo)')
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
     if args.tasks:
@@ -641,16 +742,41 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if world != args.gpus:             # (a bare `python bench.py --gpus N` never gets here: self_launch started the ranks)
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
+    gloo = os.environ.get('MI_DIST_BACKEND', 'nccl') != 'nccl'
+    if args.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group('gloo' if gloo or not torch.cuda.is_available() else 'nccl')
+        one = torch.ones(1) if dist.get_backend() == 'gloo' else torch.ones(1, device=torch.device('cuda', local))
+        dist.all_reduce(one)
+        if rank == 0:
+            print(json.dumps({'launch_check': True, 'world_size': dist.get_world_size(), 'allreduce_of_ones': float(one.item()),
+                              'backend': str(dist.get_backend())}), flush=True)
+        dist.destroy_process_group()
+        return
+    if gloo and torch.cuda.device_count() < world:
+        local = local % max(1, torch.cuda.device_count())       # rehearsal of N ranks on fewer cards (collective over gloo)
     torch.cuda.set_device(local)
-    dist = None
+    dist, dist_note = None, None
+    profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
     if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run always go through RCCL (also exercised at N=1)
         import torch.distributed as dist
         init_process_group(local)               # RCCL; MI_DIST_BACKEND=gloo only to rehearse ranks that share a card
+    elif not args.no_dist and not profiled:
+        # plain `python bench.py` (the driver's N = 1 command): a single-rank RCCL group in this process, so that the step takes the
+        # same all-reduce path as N > 1 and the line carries a `collective` record
+        import torch.distributed as dist
+        os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()), 'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': str(local)})
+        try:
+            init_process_group(local)
+        except Exception as e:                  # the headline does not depend on the collective library at N = 1: say so and go on
+            dist, dist_note = None, f'single-rank process group failed: {type(e).__name__}: {e}'
     runner = run_trpo if wl.get('kind') == 'trpo' else run_vision
     line = runner(args, wl, rank, world, local, dist)
     if rank == 0:
+        if dist_note and line is not None:
+            line['collective'] = {'error': dist_note}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -597,7 +597,9 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
     // The epilogue's stores are inline assembly (buf_st_untracked): the hazard recogniser does not see that they read the accumulators, and
     // the hardware does not interlock a matrix result against a following memory instruction's data read (up to 19 wait states after a
     // 16-pass MFMA).  Spend them here, once per tile, tied to the accumulators so that no MFMA can be scheduled behind the fence.
-    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
+    // Only the BF variants store through assembly (they are the ones whose operand waits it rescues); the fp32-pipe variants keep the
+    // compiler-visible store, whose matrix-result hazard is the compiler's to cover.
+    if constexpr (BF) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
     if (!MI_CONV_XTILE) {
 #pragma unroll
       for (int st = 0; st < DEPTH; ++st) issue(cur, st, ring[st % RING]);
@@ -630,7 +632,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
         for (int rr = 0; rr < GR; ++rr) {
           const int r = grp * GR + rr;
           const float v = acc[r];
-          buf_st_untracked(rout_raw, dropped(r) ? MI_OOB : row_off(r), v);
+          if constexpr (BF) buf_st_untracked(rout_raw, dropped(r) ? MI_OOB : row_off(r), v);
+          else buf_st(rout, row_off(r), v);
           // "ReLU on" as a lane mask: p is a ReLU output (>= +0), so 0 - p carries a sign bit exactly where p > 0.  The masked
           // values are ANDs on the floats (mi_common.h): a select after the fp64 conversion is two quarter-rate v_cndmask per row
           int on = lane_mask_negative(0.f - gq.pp[rr]);
@@ -662,7 +665,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
     for (int r = 0; r < 16; ++r) {
       const unsigned ro = (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * CO * 4);
       const bool drop = BF && ((r == 0 && h == 0) || (r == 15 && h == 1));      // the halo lanes' accumulator rows (BF tiles: 30 pixels)
-      buf_st_untracked(rout_raw, drop ? MI_OOB : obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro, acc[r]);
+      if constexpr (BF) buf_st_untracked(rout_raw, drop ? MI_OOB : obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro, acc[r]);
+      else buf_st(rout, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro, acc[r]);
       const float v = drop ? 0.f : acc[r];
       if (EPI == EPI_STATS) {
         const double dv = (double)v;
@@ -1026,6 +1030,13 @@ extern "C" int mi_conv_set_split_bf16(int on) {
   g_conv_split_mask = on > 1 ? ((unsigned)on >> 8) : 0x3ffffu;
   // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
   return was;
+}
+// the operand form in force, read WITHOUT touching it (a set-and-restore would reset the bisecting mask): mask_out, when given,
+// receives the variant mask of MI_CONV_BF16X3_MASK / mi_conv_set_split_bf16
+extern "C" int mi_conv_get_split_bf16(unsigned* mask_out) {
+  const int on = conv_split_bf16() ? 1 : 0;
+  if (mask_out) *mask_out = g_conv_split_mask;
+  return on;
 }
 
 static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int nterms, int& ntiles, int& tpw, dim3& grid, int tile_pix = 32) {

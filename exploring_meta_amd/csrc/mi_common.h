@@ -42,6 +42,9 @@ __device__ __forceinline__ float bn_u(float zh, float g, float b) { return fmaf(
 // merges are plain C on the bits.  That split matters: the hazard recogniser does not look inside inline assembly, so an assembly
 // instruction must neither read a matrix result nor produce a matrix operand (MFMA -> VALU and VALU -> MFMA wait states are the
 // compiler's to insert) -- the masks read ordinary VALU / load results and feed ordinary VALU instructions only.
+// ONE documented exception: the epilogue stores of the split-bf16 stride-1 convolutions (conv_mfma.hip, buf_st_untracked) read the
+// accumulators from assembly, behind an explicit 24-wait-state s_nop fence tied to them; tools/asm_hazard_scan.py checks that fence on
+// every build (tests/test_asm_hazards.py).  The fp32-pipe variants of the same kernel use the compiler-visible store.
 __device__ __forceinline__ int lane_mask_negative(float d) {            // -1 where d's sign bit is set
   int r;
   asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(d));

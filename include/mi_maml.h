@@ -391,6 +391,9 @@ int mi_debug_conv_stamps(void* buf);
  * Values above 1 select single kernel variants or timing experiments (tools/wgrad_probe.py, csrc/conv_mfma.hip) and are not part of
  * the interface. */
 int mi_conv_set_split_bf16(int on);
+/* The operand form in force (1 split-bf16, 0 fp32 matrix pipe) read without side effects; mask_out (may be NULL) receives the variant
+ * mask a bisecting run set through MI_CONV_BF16X3_MASK / mi_conv_set_split_bf16(0x100 * mask + 1). */
+int mi_conv_get_split_bf16(unsigned* mask_out);
 
 /* ANIL-TRPO (rl/anil_trpo.py:104-129, core_functions/rl.py:409-473 with anil=True): the stored old policies were adapted with
  * the body under no_grad (rl.py:381-382) while meta_surrogate_loss re-adapts clone_module(policy) with every parameter

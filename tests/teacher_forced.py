@@ -31,7 +31,8 @@ def _unflatten(flat, shapes):
     return out
 
 
-TAU = 1e-5          # a decision is a "near-tie" if its fp64 margin (|u| at the window's maximum, or the gap to the runner-up) is below this
+TAU = 3e-6          # a decision is a "near-tie" if its fp64 margin (|u| at the window's maximum, or the gap to the runner-up) is below this
+                    # (the largest margin any run has flipped: 7.4e-7 on cfg2 / cfg3, 1.4e-6 on cfg4 at 256 tasks)
 EXPLAIN_G, EXPLAIN_H = 1e-5, 1e-4      # steps above these get the near-tie analysis (the search stops below half of them)
 MAX_TRIALS = 28
 

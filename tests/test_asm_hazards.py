@@ -41,6 +41,29 @@ _Z6kernelv:
 	;;#ASMEND
 	s_endpgm
 """
+# the hazard sits across a loop back-edge: the assembly store at the top of the body reads what the MFMA at the bottom of the previous trip wrote
+LOOP = """
+_Z6kernelv:
+	s_mov_b32 s4, 0
+.LBB0_1:
+	;;#ASMSTART
+	buffer_store_dword v1, v47, s[28:31], 0 offen
+	;;#ASMEND
+	s_add_i32 s4, s4, 1
+	s_cmp_lt_i32 s4, 8
+	v_mfma_f32_32x32x2_f32 v[0:15], v116, v114, v[0:15]
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+"""
+
+
+def test_scanner_follows_back_edges(tmp_path):
+    loop = tmp_path / 'loop.s'
+    loop.write_text(LOOP)
+    found = scan_mod.scan(str(loop))
+    assert len(found) == 1 and 'reads the result of' in found[0]
+    loop.write_text(LOOP.replace('\ts_cbranch_scc1 .LBB0_1', '\ts_nop 15\n\ts_nop 7\n\ts_cbranch_scc1 .LBB0_1'))
+    assert scan_mod.scan(str(loop)) == []
 
 
 def test_scanner_sees_both_hazards(tmp_path):

@@ -44,3 +44,28 @@ def test_bench_line_has_the_contract_fields():
     assert 'clock' in d
     if d['clock'] is not None:
         assert 500 <= d['clock']['sclk_mhz'] <= 2600 and d['clock']['nominal_mhz'] == 2400
+    # plain `python bench.py` runs its step through a single-rank RCCL group: the collective record is there at N = 1 too
+    co = d['collective']
+    assert co is not None and 'error' not in co, co
+    assert co['world_size'] == 1 and co['backend'].startswith('nccl') and co['theta_checksum_identical_on_all_ranks'] is True
+    assert d['post_adapt']['task_pool'].startswith('8 resident batches')
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (what the driver's scaling run issues): bench.py launches the two ranks itself and
+    relays rank 0's line.  Here the ranks share the box's one card, so the collective goes over gloo (RCCL refuses two ranks on one
+    GPU); everything else -- self_launch, torch.distributed.run, init_process_group, the sharded step, the all-reduce, Adam -- is the
+    N > 1 path."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['MI_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--workload', 'cfg1',
+                        '--pool', '2'], capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['global_meta_batch'] == 8 and d['config']['tasks_per_gpu'] == 4
+    assert d['value'] > 0 and abs(d['value'] - 8 * 1e3 / d['ms_per_step']) < 1e-2 * d['value']
+    co = d['collective']
+    assert co['world_size'] == 2 and co['backend'].startswith('gloo') and co['rccl_version'] is None
+    assert co['theta_checksum_identical_on_all_ranks'] is True

@@ -57,7 +57,7 @@ CASES = [
     # two different piece lengths of its weight-gradient kernel; the reference's own fp32 run: 2e-5 on task 0, 6e-2 on task 1).  The
     # floors are therefore that envelope itself -- these two cases only catch gross breakage; the decision-aware bound for this
     # configuration is the teacher-forced test at the benched size (test_gpu_full_size.py: every step <= 2e-5 of the fp64 arithmetic
-    # once decisions with margin < 1e-5 may fall either way).
+    # once decisions with margin < TAU = 3e-6 may fall either way).
     ('cfg2_min_5w5s_K5_fo', 'min', 5, 5, 5, 0.5, True, [0], 6e-2, 0.4),
     ('cfg2_min_5w5s_K5_so', 'min', 5, 5, 5, 0.5, False, [0, 1], 6e-2, 0.4),
 ]
@@ -349,7 +349,7 @@ def test_two_second_order_steps_on_plateau_free_inputs():
     pooling windows per pass and the smallest fp64 margin among them is ~1e-7 of the activations' scale, the size of one fp32
     rounding -- and which way such a window falls depends on the convolution's last bits (task 5's support pass has one at 7e-7 in
     block 3: the fp32 pipe falls with fp64, the split-bf16 form the other way, moving the task's loss by 1.3e-2).  So: per step,
-    against the fp64 arithmetic with the near-tied decisions (margin < 1e-5) allowed to fall either way, EVERY task within
+    against the fp64 arithmetic with the near-tied decisions (margin < TAU = 3e-6) allowed to fall either way, EVERY task within
     2e-5 / 2e-4 (tests/teacher_forced.py); end to end, every task without such a decision within 1e-4 / 2e-3 of the fp64 oracle, and
     at least three of the six are of that kind (five at the time of writing)."""
     import teacher_forced as TF

@@ -18,7 +18,7 @@ Hessian-vector product by as much (the tangent of the pooled value jumps to anot
 them: the reference's own fp32 leg flips a different subset.  So the bar has two parts:
   (1) raw, against each leg: median <= 1e-5 (HVP 1e-4), at most OUTLIER_SHARE of the steps above 1e-4, none above RAW_MAX;
   (2) NEAR-TIE ADJUSTED, for every step above 1e-5 (HVP 1e-4): tests/teacher_forced.py::explain_step searches the decisions whose
-      fp64 margin is below 1e-5 for the assignment under which the fp64 arithmetic reproduces the engine; every step must then
+      fp64 margin is below TAU = 3e-6 for the assignment under which the fp64 arithmetic reproduces the engine; every step must then
       agree to ADJ_G (HVP ADJ_H).  A kernel error cannot pass (2): flipping near-tied decisions only adds the handful of discrete
       vectors those decisions control, it cannot imitate a dense error -- and systematic errors below 1e-5 are the business of the
       per-kernel tests (tests/test_gpu_tangent_kernels.py, 1e-6 at these sizes)."""
@@ -37,9 +37,12 @@ import teacher_forced as TF
 pytestmark = pytest.mark.gpu
 
 # bars of the teacher-forced test (module docstring): raw maxima / outlier share against each leg, and the near-tie-adjusted maxima
-# (RAW_MAX: the one-decision envelope.  cfg2's steps reached 6.5e-3 with the fp32 operand form; at cfg4's lr 0.5 / one-shot tasks a single
-# re-routed element has reached 3.3e-2 of a step's gradient (split-bf16 form, T = 256) -- a draw, bounded here, explained in part (2).)
-RAW_MAX, OUTLIER_SHARE, ADJ_G, ADJ_H = 1e-1, 0.15, 2e-5, 2e-4
+# (RAW_MAX: the one-decision envelope, set to what is measured: cfg2's steps reached 6.5e-3 with the fp32 operand form
+# and 4.4e-3 with the split-bf16 form, cfg3's tasks 1.3e-3, cfg4 at 32 tasks 5.7e-3.  Only cfg4's 256-task leg has drawn more -- one
+# re-routed element worth 3.3e-2 of a one-shot step's gradient at lr 0.5 -- and carries its own bar, RAW_MAX_T256.  Both are draws,
+# bounded here and explained decision by decision in part (2).  OUTLIER_SHARE is asserted against the fp64 leg: the reference's fp32
+# leg is itself a draw of near-ties that depends on the host's thread count and BLAS, so its share is reported, not asserted.)
+RAW_MAX, RAW_MAX_T256, OUTLIER_SHARE, ADJ_G, ADJ_H = 3e-2, 1e-1, 0.15, 2e-5, 2e-4
 
 
 def _ref_theta(spec, seed=11):
@@ -101,8 +104,9 @@ def test_cfg2_T32_teacher_forced_per_step():
         report(f'cfg2_T32_teacher_forced[all {T} tasks, leg fp{leg}]', grad_median=float(np.median(g)), grad_max=float(g.max()),
                grad_share_above_1e4=float((g > 1e-4).mean()), hvp_median=float(np.median(h)), hvp_max=float(h.max()),
                hvp_share_above_1e4=float((h > 1e-4).mean()), query_max=float(q.max()))
-        assert np.median(g) < 1e-5 and g.max() < RAW_MAX and (g > 1e-4).mean() <= OUTLIER_SHARE, sorted(g)[-8:]
-        assert np.median(h) < 1e-4 and h.max() < RAW_MAX and (h > 1e-4).mean() <= OUTLIER_SHARE, sorted(h)[-8:]
+        share = OUTLIER_SHARE if leg == '64' else 1.0
+        assert np.median(g) < 1e-5 and g.max() < RAW_MAX and (g > 1e-4).mean() <= share, sorted(g)[-8:]
+        assert np.median(h) < 1e-4 and h.max() < RAW_MAX and (h > 1e-4).mean() <= share, sorted(h)[-8:]
         assert np.median(q) < 1e-5 and q.max() < RAW_MAX, sorted(q)[-4:]
     # (2) near-tie adjusted: every step, every task
     gx, hx, qx = (np.array(legs[k]) for k in ('gx', 'hx', 'qx'))
@@ -211,12 +215,13 @@ def test_cfg4_full_T_batched_looped_oracle(T):
     # parameters the query pass starts from differ in their last bits -- teacher forcing removes exactly that.)  Hence, end to end:
     # at least two of the nine checked tasks agree with the nearer leg to 1e-5, the median to 1e-2, and none is off by more than the one-decision
     # envelope.  Per step: every checked task agrees with the fp64 arithmetic to ADJ_G / ADJ_H once the decisions with an fp64
-    # margin below 1e-5 are allowed to fall either way.
+    # margin below TAU (3e-6) are allowed to fall either way.
     assert max(el) < 1e-6 and np.median(eg) < 1e-5 and max(eg) < 5e-3
     assert np.median(lo) < 1e-5 and max(lo) < 5e-3
     # (about half of the tasks hold such a decision: P(fewer than two clean ones among nine) is below 2 %)
     assert sum(e < 1e-5 for e in ebest) >= 2 and np.median(ebest) < 1e-2 and max(e64) < 0.3, (e2e_tasks, ebest, flipped)
-    assert np.median(raw) < 1e-5 and raw.max() < RAW_MAX and raw32.max() < RAW_MAX
+    raw_max = RAW_MAX_T256 if T == 256 else RAW_MAX
+    assert np.median(raw) < 1e-5 and raw.max() < raw_max and raw32.max() < raw_max
     assert adj_g.max() < ADJ_G and adj_h.max() < ADJ_H, (sorted(adj_g)[-4:], sorted(adj_h)[-4:])
     assert all(m < TF.TAU for m in margins)
 

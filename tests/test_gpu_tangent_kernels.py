@@ -191,8 +191,7 @@ def test_conv_fwd_bwd_at_bench_sizes(lib, name, T, n, h, w, ci, co, check):
                                   ptr(scratch), sb))
     torch.cuda.synchronize()
     tpw = lib.mi_debug_conv_tiles_per_wave(T, n, h, w, co)
-    split = lib.mi_conv_set_split_bf16(1)
-    lib.mi_conv_set_split_bf16(split)
+    split = lib.mi_conv_get_split_bf16(None)
     # resident waves: 4096 with the fp32 operands' 36 KB of staged weights per workgroup, 2048 with the split-bf16 form's 54 KB (and 30-pixel tiles)
     if name == 'bench_l2_T32':
         assert tpw == (23 if split else 11)

@@ -11,6 +11,8 @@
   python tools/asm_hazard_scan.py file.s ... # scans existing listings
 
 Every instruction counts as one wait state, `s_nop N` as N + 1: conservative for the second check, exact for the first.
+Control flow: at every label the scan continues with the history of EVERY branch that targets it next to the fall-through one (loop
+back-edges and joins), so the first assembly instruction of a loop body is checked against the last MFMAs of the previous trip.
 Exit status 1 and one line per finding when something is found."""
 import os
 import re
@@ -36,12 +38,26 @@ def regs(tok):
     return {(tok[0], int(m.group(1)))} if m else set()
 
 
-def scan(path):
-    findings, kernel, hist, inasm = [], None, [], False       # hist: (is_asm, is_mfma, dst registers, text), one entry per wait state
+def walk(path, preds=None):
+    """One pass over a listing.  `preds`: label -> the instruction histories at the branches that target it (from an earlier pass); at such
+    a label the walk continues with EVERY predecessor's history next to the fall-through one -- loop back-edges and joins included -- so
+    an assembly instruction at the top of a loop body is checked against the MFMAs at the bottom of the previous trip.  Returns
+    (findings, label -> histories at the branches to it)."""
+    findings, kernel, inasm = set(), None, False
+    hists = [[]]                 # alternative histories: (is_asm, is_mfma, dst registers, text), one entry per wait state
+    tails = {}
+    KEEP = max(WAIT_MFMA_READ, WAIT_VALU_MFMA) + 6
+
+    def push(entry, n=1):
+        for h in hists:
+            h.extend([entry] * n)
+            if len(h) > 4 * KEEP:
+                del h[:len(h) - KEEP]
+
     for line in open(path):
         m = re.match(r'^(_Z\w+):', line)
         if m:
-            kernel, hist = m.group(1), []
+            kernel, hists = m.group(1), [[]]
             continue
         t = line.strip()
         if t.startswith(';;#ASMSTART'):
@@ -50,35 +66,56 @@ def scan(path):
         if t.startswith(';;#ASMEND'):
             inasm = False
             continue
+        m = re.match(r'^(\.LBB\w+):', t)
+        if m:
+            if preds is not None:
+                for tail in preds.get((kernel, m.group(1)), []):
+                    if not any(h[-KEEP:] == tail[-KEEP:] for h in hists):
+                        hists.append(list(tail))
+            continue
         if not t or t[0] in '.;' or t.endswith(':'):
             continue
         parts = t.split(None, 1)
         op, ops = parts[0], (parts[1].split(',') if len(parts) > 1 else [])
         if op == 's_nop':
-            hist.extend([(False, False, set(), t)] * (int(ops[0]) + 1 if ops else 1))
+            push((False, False, frozenset(), t), int(ops[0]) + 1 if ops else 1)
             continue
+        if op.startswith(('s_cbranch', 's_branch')) and ops:
+            tails.setdefault((kernel, ops[0].strip()), []).append(list(max(hists, key=len)[-KEEP:]))
         is_mfma = op.startswith('v_mfma')
         is_store = op.startswith(('buffer_store', 'global_store', 'flat_store', 'ds_write', 'scratch_store'))
-        dst = set() if is_store else (regs(ops[0]) if ops else set())
+        dst = frozenset() if is_store else frozenset(regs(ops[0]) if ops else set())
         src = set()
         for o in (ops if is_store else ops[1:]):
             src |= regs(o)
-        if is_mfma:
-            ab = set()
-            for o in ops[1:3]:
-                ab |= regs(o)
-            for back, (h_asm, _, h_dst, h_txt) in enumerate(reversed(hist[-WAIT_VALU_MFMA:])):
-                if h_asm and h_txt.startswith('v_') and (h_dst & ab):
-                    findings.append(f'{os.path.basename(path)}: {kernel}: MFMA "{t[:70]}" reads an operand that inline assembly "{h_txt[:50]}" wrote {back} wait states earlier')
-                    break
-        if inasm and not is_mfma:
-            for back, (_, h_mfma, h_dst, h_txt) in enumerate(reversed(hist[-WAIT_MFMA_READ:])):
-                if h_mfma and (h_dst & src):
-                    findings.append(f'{os.path.basename(path)}: {kernel}: inline assembly "{t[:60]}" reads the result of "{h_txt[:50]}" after {back} wait states')
-                    break
-        hist.append((inasm, is_mfma, dst, t))
-        if len(hist) > 64:
-            del hist[:32]
+        for hist in hists:
+            if is_mfma:
+                ab = set()
+                for o in ops[1:3]:
+                    ab |= regs(o)
+                for back, (h_asm, _, h_dst, h_txt) in enumerate(reversed(hist[-WAIT_VALU_MFMA:])):
+                    if h_asm and h_txt.startswith('v_') and (h_dst & ab):
+                        findings.add(f'{os.path.basename(path)}: {kernel}: MFMA "{t[:70]}" reads an operand that inline assembly "{h_txt[:50]}" wrote {back} wait states earlier')
+                        break
+            if inasm and not is_mfma:
+                for back, (_, h_mfma, h_dst, h_txt) in enumerate(reversed(hist[-WAIT_MFMA_READ:])):
+                    if h_mfma and (h_dst & src):
+                        findings.add(f'{os.path.basename(path)}: {kernel}: inline assembly "{t[:60]}" reads the result of "{h_txt[:50]}" after {back} wait states')
+                        break
+        push((inasm, is_mfma, dst, t))
+        if len(hists) > 1:       # alternatives that have become equal over the window that matters collapse into one
+            uniq = []
+            for h in hists:
+                if not any(u[-KEEP:] == h[-KEEP:] for u in uniq):
+                    uniq.append(h)
+            hists = uniq
+    return sorted(findings), tails
+
+
+def scan(path):
+    """Two passes: the first collects the history at every branch, the second walks with all predecessors joined in at every label."""
+    _, tails = walk(path)
+    findings, _ = walk(path, tails)
     return findings
 
 
