@@ -48,10 +48,16 @@ def self_launch(argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+_RESULT_OUT = None
 if __name__ == '__main__':
     _rc = self_launch(sys.argv[1:])
     if _rc is not None:
         sys.exit(_rc)
+    # stdout carries ONE line, the result.  Libraries write there too (RCCL prints a five-line version banner with printf when its
+    # first communicator comes up): keep the real stdout for the result and point file descriptor 1 at stderr for everything else.
+    sys.stdout.flush()
+    _RESULT_OUT = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
 
 # The engine forks weight gradients onto a side stream and RCCL brings its own: with the HIP default of 4 hardware queues the
 # streams of one process collide on a queue and the overlap turns into a 5 % loss (measured: 26.5 vs 25.2 ms per step under
@@ -294,21 +300,39 @@ def run_vision(args, wl, rank, world, local, dist):
         dt = tmax.item()
     acc_after_timed, loss_after_timed = float(out['acc']), float(out['loss'])
 
-    # Secondary figure (SURVEY.md 8d): the reference runs one validation fast_adapt per train task without backward
-    # (maml_vision.py:117-124); here that half is one more fused call with with_grad=0 on T other tasks.
-    vdata, vlabels = make_batch(wl, [10_000 + t for t in task_ids])
+    # Secondary figure (SURVEY.md 8d, 8f rank 1): the reference runs one validation fast_adapt per train task without backward
+    # (maml_vision.py:117-124).  MAML: ONE fused call over [train tasks | validation tasks] (mi_meta_batch_maml_tv) -- the validation
+    # tasks' K support steps and query forward ride in the train tasks' launches, only the backward half is train-only.  ANIL: a second
+    # call with with_grad = 0.
+    vdata, vlabels = make_batch(wl, [10_000_000 + t for t in task_ids])
     vdata, vlabels = torch.from_numpy(vdata).cuda(), torch.from_numpy(vlabels).cuda()
+    from exploring_meta_amd.sharding import packed_outputs
+    if wl.get('anil'):
+        def step_tv():
+            step()
+            vl, va, _, _ = run_batch(theta, vdata, vlabels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], with_grad=False)
+            return va
+        how = 'train call + a second call with with_grad = 0'
+    else:
+        tv = [(torch.cat([d, vdata]), torch.cat([l, vlabels])) for d, l in pool[:2]]
 
-    def valid():
-        return run_batch(theta, vdata, vlabels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], with_grad=False)
+        def step_tv():
+            d, l = tv[out['n'] % len(tv)]
+            out['n'] += 1
+            loss, acc, grad, _ = eng.meta_batch(theta, d, l, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], grad_tasks=T)
+            flat = packed_outputs(grad, loss, acc)          # [meta-gradient | losses of both halves | accuracies of both halves]
+            if dist is not None:
+                dist.all_reduce(flat)
+            adam_fn(theta, grad, 1.0 / global_T)
+            return acc[T:]
+        how = 'one fused call over train + validation tasks (mi_meta_batch_maml_tv: grad_tasks = train tasks), one all-reduce'
 
-    valid()
+    vacc = step_tv()
     nsec = max(2, min(5, args.steps))
     fence()
     t1 = time.perf_counter()
     for _ in range(nsec):
-        step()
-        vloss, vacc, _, _ = valid()
+        vacc = step_tv()
     fence()
     dt_tv = (time.perf_counter() - t1) / nsec
     if dist is not None:
@@ -316,8 +340,10 @@ def run_vision(args, wl, rank, world, local, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_tv = tmax.item()
     secondary = {'metric': 'iterations/sec (train + validation halves)', 'value': round(1.0 / dt_tv, 3), 'ms_per_iteration': round(dt_tv * 1e3, 3),
-                 'tasks_per_iteration': f'{global_T} train + {global_T} validation', 'steps': nsec,
+                 'tasks_per_iteration': f'{global_T} train + {global_T} validation', 'steps': nsec, 'how': how,
                  'valid_acc_mean': round(float(vacc.mean()), 5)}
+    if not wl.get('anil'):
+        del tv
 
     hbm_copy_gbps = measure_stream_copy(eng)
     collective = collective_record(dist, world, theta, eng.param_count + 2 * T,
@@ -752,7 +778,7 @@ def main():
         dist.all_reduce(one)
         if rank == 0:
             print(json.dumps({'launch_check': True, 'world_size': dist.get_world_size(), 'allreduce_of_ones': float(one.item()),
-                              'backend': str(dist.get_backend())}), flush=True)
+                              'backend': str(dist.get_backend())}), file=_RESULT_OUT or sys.stdout, flush=True)
         dist.destroy_process_group()
         return
     if gloo and torch.cuda.device_count() < world:
@@ -777,7 +803,7 @@ def main():
     if rank == 0:
         if dist_note and line is not None:
             line['collective'] = {'error': dist_note}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=_RESULT_OUT or sys.stdout, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

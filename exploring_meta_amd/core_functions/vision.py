@@ -28,28 +28,29 @@ class _FusedFastAdapt(torch.autograd.Function):
     part of the fused call); ``backward`` hands it to autograd so ``eval_loss.backward()`` accumulates into ``.grad``."""
 
     @staticmethod
-    def forward(ctx, engine, data, labels, shots, steps, lr, first_order, need_grad, *params):
+    def forward(ctx, engine, data, labels, shots, steps, lr, first_order, need_grad, grad_tasks, *params):
         theta = torch.cat([p.detach().reshape(-1) for p in params]).float().contiguous()
         ctx.deferred = None
+        gt = None if grad_tasks is None else int(grad_tasks)
         if need_grad and DEFERRED_OUTER_BACKWARD:
-            ctx.deferred = (engine, theta, data, labels, shots, steps, lr, first_order)
+            ctx.deferred = (engine, theta, data, labels, shots, steps, lr, first_order, gt)
             need_grad = False
         loss, acc, grad, _ = engine.meta_batch(theta, data, labels, shots, steps, lr, first_order=first_order,
-                                               with_grad=need_grad)
+                                               with_grad=need_grad, grad_tasks=gt if need_grad else None)
         ctx.shapes = [p.shape for p in params]
         ctx.per_task = None
         ctx.save_for_backward(grad if grad is not None else torch.empty(0, device=data.device))
         # Only the SUM carries the meta-gradient (the engine reduces over tasks inside the fused call): the per-task losses are
         # values, so `losses.mean().backward()` fails loudly instead of stepping on zeros.
         ctx.mark_non_differentiable(loss, acc)
-        return loss.sum(), loss, acc
+        return (loss.sum() if gt is None else loss[:gt].sum()), loss, acc
 
     @staticmethod
     def backward(ctx, gsum, gloss, gacc):
         (grad,) = ctx.saved_tensors
         if ctx.deferred is not None:
-            engine, theta, data, labels, shots, steps, lr, first_order = ctx.deferred
-            grad = engine.meta_batch(theta, data, labels, shots, steps, lr, first_order=first_order, with_grad=True)[2]
+            engine, theta, data, labels, shots, steps, lr, first_order, gt = ctx.deferred
+            grad = engine.meta_batch(theta, data, labels, shots, steps, lr, first_order=first_order, with_grad=True, grad_tasks=gt)[2]
         if grad.numel() == 0:
             raise RuntimeError('fast_adapt was run without gradients (torch.no_grad or no parameter requires grad)')
         outs, off = [], 0
@@ -59,14 +60,16 @@ class _FusedFastAdapt(torch.autograd.Function):
                 n *= d
             outs.append((grad[off:off + n] * gsum).reshape(shp))
             off += n
-        return (None,) * 8 + tuple(outs)
+        return (None,) * 9 + tuple(outs)
 
 
-def meta_batch_adapt(learner, data, labels, adaptation_steps, shots, ways, first_order=None):
+def meta_batch_adapt(learner, data, labels, adaptation_steps, shots, ways, first_order=None, grad_tasks=None):
     """Batched entry: data [T, 2*shots*ways, C, H, W], labels [T, 2*shots*ways] on the GPU.
     Returns (loss_sum, loss[T], acc[T]); ``loss_sum.backward()`` accumulates the SUM over tasks of d valid_loss/d theta
     into the base parameters' ``.grad`` -- what T iterations of the reference loop body leave there.  ``loss[T]`` and ``acc[T]``
-    are plain values (not differentiable): weight tasks by scaling ``loss_sum``, or call once per group of tasks."""
+    are plain values (not differentiable): weight tasks by scaling ``loss_sum``, or call once per group of tasks.
+    ``grad_tasks = G``: the first G tasks are the iteration's train tasks (``loss_sum`` and the gradient cover them), the others its
+    validation tasks (reference maml_vision.py:117-124), adapted and scored in the same launches without a backward half."""
     model = learner.module if isinstance(learner, MAML) else learner
     fo = learner.first_order if first_order is None and isinstance(learner, MAML) else bool(first_order)
     lr = learner.lr
@@ -76,7 +79,7 @@ def meta_batch_adapt(learner, data, labels, adaptation_steps, shots, ways, first
     if spec.ways != ways:
         raise ValueError(f'model has {spec.ways} outputs but ways={ways}')
     data = data.reshape(data.shape[0], data.shape[1], spec.in_channels, spec.in_h, spec.in_w).float().contiguous()
-    return _FusedFastAdapt.apply(model.engine(), data, labels.contiguous(), shots, adaptation_steps, lr, fo, need, *params)
+    return _FusedFastAdapt.apply(model.engine(), data, labels.contiguous(), shots, adaptation_steps, lr, fo, need, grad_tasks, *params)
 
 
 def fast_adapt(batch, learner, loss, adaptation_steps, shots, ways, device, features=None):

@@ -46,6 +46,12 @@ struct mi_engine {
   // block 1's BatchNorm-backward sums (dgamma, dbeta and their tangents) ride in the epilogue of block 2's dgrad instead of a
   // streaming pooled_reduce pass over p, zhat, dp (needs the fused block 1 with stored zhat and a stride-1 hidden block 2)
   bool fuse_b1red = true;
+  // the tail of every pass of mi_meta_batch_maml as ONE launch (gram.hip, advance_kernel): weight-gradient partial folds, block 1's
+  // Gram-matrix assembly, the fast-weight / adjoint update and the next pass's Gram statistics -- instead of 3 reduce_partials +
+  // gram_wgrad + axpy + gram_stats launches and a memset per pass.  Same arithmetic in the same order: bit-identical results.
+  bool fuse_tail = true;
+  unsigned zoff[10] = {}, zlen[10] = {};   // conv-bias segments and the padding P..PS of a parameter-shaped vector (never written by a kernel)
+  int nzero = 0;
   unsigned* counters = nullptr;
   static constexpr int kMaxCounterTasks = 65536;
   struct SideCtx { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; } sc[1];
@@ -184,6 +190,8 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
   e->off_bl = off; off += d->ways;
   e->P = off;
   e->PS = align_up(off, 64);
+  for (const Layer& l : e->L) { e->zoff[e->nzero] = (unsigned)l.off_b; e->zlen[e->nzero] = (unsigned)l.co; e->nzero++; }
+  if (e->PS > e->P) { e->zoff[e->nzero] = (unsigned)e->P; e->zlen[e->nzero] = (unsigned)(e->PS - e->P); e->nzero++; }
   for (int wy = 0; wy < d->ways; ++wy)
     for (int i = 0; i < e->feat; ++i) {
       size_t ref;
@@ -257,6 +265,14 @@ extern "C" int mi_engine_set_fused_block1_reduce(mi_engine* e, int on) {
 extern "C" int mi_engine_set_graph(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->graph_on = on != 0;
+  return MI_OK;
+}
+
+// Ablation / test switch: 1 (default) = one "advance" launch ends every pass of mi_meta_batch_maml (weight-gradient folds, block 1's
+// Gram assembly, the update, the next pass's Gram statistics); 0 = the separate launches.  Bit-identical results.
+extern "C" int mi_engine_set_fused_tail(mi_engine* e, int on) {
+  if (!e) return MI_ERR_ARG;
+  e->fuse_tail = on != 0;
   return MI_OK;
 }
 
@@ -371,6 +387,7 @@ struct Plan {
   double* bnpart;
   float* wgpart;
   float* wgpart_side;   // partials of the weight gradients that run on the side stream
+  float* wgpart_l[8];   // fused tail: one partial buffer per block (the folds wait for the pass's advance launch)
   double *gram_part, *gram_s;   // input Gram matrix of the support images (block 1 statistics), or nullptr
   int half = 0;                 // stream context (engine SideCtx) this plan's side work uses
   float *tmp_loss, *tmp_acc;
@@ -453,6 +470,11 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   pl.bnpart = b.take<double>(bnp);
   pl.wgpart = b.take<float>(wgp);
   pl.wgpart_side = b.take<float>(wgp);
+  for (int l = 0; l < 8; ++l) pl.wgpart_l[l] = nullptr;
+  for (int l = 0; l < nl; ++l) {
+    if (l == 0 && e->fuse1) { pl.wgpart_l[0] = pl.wgpart; continue; }     // block 1's sparse partials: consumed inside the same advance launch
+    pl.wgpart_l[l] = b.take<float>(wgrad_partial_floats(geom(e->L[l], nmax), T));
+  }
   pl.gram_part = pl.gram_s = nullptr;
   if (e->fuse1 && e->gram1 && gram_supported(e->L[0].w, e->L[0].ci) && (K >= 2 || (K >= 1 && second_order))) {   // the support set is swept at least twice
     pl.gram_part = b.take<double>(gram_partial_doubles(T, ns, e->L[0].h, e->L[0].ci));
@@ -526,7 +548,7 @@ static B1Args b1_args(const mi_engine* e, Plan& pl, ActSet& A, const float* x0, 
 
 // Trunk forward: ConvBlocks on n images per task (conv + BN-stat epilogue, finalize, BN+ReLU+pool).
 static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
-                         const double* gram = nullptr) {
+                         const double* gram = nullptr, bool stats_ready = false) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   for (int l = 0; l < nl; ++l) {
@@ -534,7 +556,8 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
     if (l == 0 && e->fuse1) {
       B1Args ba = b1_args(e, pl, A, x0, n, theta);
       int blk = 0;
-      if (gram) {   // mean / variance of conv1's output as quadratic forms of this step's weights (gram.hip)
+      if (gram && stats_ready) {   // ... already formed by the advance launch that ended the previous pass
+      } else if (gram) {   // mean / variance of conv1's output as quadratic forms of this step's weights (gram.hip)
         LAUNCH(e, st, OP_GRAM_STATS, 0, launch_gram_stats(st, gram, T, L.ci, L.co, theta + L.off_w, P, nullptr, 0, 1.0 / ((double)n * L.ho * L.wo), 0, A.mu[0], A.rstd[0], nullptr, nullptr));
       } else {
         ba.fin = fin_of(e, T, 1.0 / ((double)n * L.ho * L.wo), FIN_STATS, A.mu[0], L.co, A.rstd[0], L.co);
@@ -579,8 +602,14 @@ static const float* zh_at_argmax(const mi_engine* e, const ActSet& A, int lower)
 }
 
 // Trunk backward from A.dp[last] (gradient w.r.t. the last block's output): writes gamma/beta/conv-weight gradients into g.
+// adv != nullptr (fused tail): weight-gradient folds and block 1's Gram assembly are recorded in *adv for the caller's advance launch
+// instead of being launched here; every block then writes its own partial buffer (pl.wgpart_l).
+static void adv_add_seg(AdvanceArgs* adv, size_t off, int nelem, const float* partial, int nchunks) {
+  AdvanceSeg& sg = adv->seg[adv->nseg++];
+  sg.off = (unsigned)off; sg.nelem = (unsigned)nelem; sg.partial = partial; sg.nchunks = nchunks;
+}
 static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
-                          float* g, const double* gram = nullptr) {
+                          float* g, const double* gram = nullptr, AdvanceArgs* adv = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;
   bool forked = false, red_done[9] = {false, false, false, false, false, false, false, false, false};   // [l]: block l's sums rode in block l+1's dgrad
@@ -614,11 +643,13 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
         gw.mu = A.mu[0]; gw.rstd = A.rstd[0]; gw.gamma = theta + L.off_gamma; gw.pstride = P;
         gw.dgamma = g + L.off_gamma; gw.dbeta = g + L.off_beta; gw.gstride = P;
         gw.out = g + L.off_w; gw.ostride = P; gw.ci = L.ci; gw.co = L.co; gw.inv_m = 1.0 / (double)mpix;
-        LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_gram_wgrad(st, gw, T, 0));
+        if (adv) { adv->b1_wgrad = 1; adv->gw_tangent = 0; adv->gw = gw; }
+        else LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_gram_wgrad(st, gw, T, 0));
         continue;
       }
       LAUNCH(e, st, OP_WGRAD, 0, launch_block1(st, b1, T, L.ci, B1_BWD_WGRAD, &blk));
-      LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_wgrad_reduce(st, pl.wgpart, blk, 9 * L.ci * L.co, T, g + L.off_w, P));
+      if (adv) adv_add_seg(adv, L.off_w, 9 * L.ci * L.co, pl.wgpart, blk);
+      else LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_wgrad_reduce(st, pl.wgpart, blk, 9 * L.ci * L.co, T, g + L.off_w, P));
       continue;
     }
     BnArgs ba{};
@@ -643,12 +674,13 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     wa.dz[0] = A.dz[l];
     hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
     if (ws != st) forked = true;
-    wa.partial = ws != st ? pl.wgpart_side : pl.wgpart;
+    wa.partial = adv ? pl.wgpart_l[l] : (ws != st ? pl.wgpart_side : pl.wgpart);
     wa.g = geom(L, n);
     wa.mpix = mpix;
     int nch = 0;
     LAUNCH(e, ws, OP_WGRAD, l, launch_wgrad3x3(ws, wa, T, 1, &nch));
-    LAUNCH(e, ws, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(ws, wa.partial, nch, 9 * L.ci * L.co, T, g + L.off_w, P));
+    if (adv) adv_add_seg(adv, L.off_w, 9 * L.ci * L.co, wa.partial, nch);
+    else LAUNCH(e, ws, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(ws, wa.partial, nch, 9 * L.ci * L.co, T, g + L.off_w, P));
     if (l > 0) {
       ConvArgs ca{};
       ca.in[0] = A.dz[l];
@@ -725,20 +757,23 @@ struct ExportPause {
 };
 
 // One forward (+ backward) pass of the whole net on n images per task.
+// Tb: tasks that take the backward half (the first Tb of the T; -1 = all): the validation tasks of a fused train + validation call
+// run the forward half only.  adv: fused tail (trunk_backward); the caller's advance launch then also zeroes what no kernel writes.
 static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, const int32_t* y, int n, int T,
                         const float* theta, float* g, float* loss, float* acc, float* logits, bool with_grad,
-                        const double* gram = nullptr) {
+                        const double* gram = nullptr, AdvanceArgs* adv = nullptr, bool stats_ready = false, int Tb = -1) {
   const int nl = (int)e->L.size();
-  int rc = trunk_forward(e, st, pl, A, x0, n, T, theta, gram);
+  if (Tb < 0) Tb = T;
+  int rc = trunk_forward(e, st, pl, A, x0, n, T, theta, gram, stats_ready);
   if (rc) return rc;
   rc = export_bn_stats(e, st, A, T);
   if (rc) return rc;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
-  if (with_grad) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * e->PS * sizeof(float), st));
+  if (with_grad && !adv) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * e->PS * sizeof(float), st));
   rc = head_pass(e, st, pl.hscr, A.f, y, n, T, theta, g, loss, acc, logits, A.prob, A.dl, A.df, with_grad);
-  if (rc || !with_grad) return rc;
-  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], T * n, e->head_hw, e->head_c));
-  return trunk_backward(e, st, pl, A, x0, n, T, theta, g, gram);
+  if (rc || !with_grad || Tb == 0) return rc;
+  if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], Tb * n, e->head_hw, e->head_c));
+  return trunk_backward(e, st, pl, A, x0, n, Tb, theta, g, gram, adv);
 }
 
 // hv = H(theta) v for the saved support pass A (activations) / g (its gradient): forward-over-reverse.
@@ -746,11 +781,11 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
 // cross-entropy curvature at the head, and the logit tangents J v go to ld_out.
 static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
                     const float* g, const float* v, float* hv, const double* gram = nullptr, const float* dl_fixed = nullptr,
-                    float* ld_out = nullptr) {
+                    float* ld_out = nullptr, AdvanceArgs* adv = nullptr, bool stats_ready = false) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   TanSet& X = pl.tan;
-  HIPCHK(e, hipMemsetAsync(hv, 0, (size_t)T * P * sizeof(float), st));
+  if (!adv) HIPCHK(e, hipMemsetAsync(hv, 0, (size_t)T * P * sizeof(float), st));
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
@@ -758,7 +793,8 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       B1Args b1 = b1_args(e, pl, A, x0, n, theta);
       b1.wd = v + L.off_w; b1.vstride = P;
       int blk = 0;
-      if (gram) {
+      if (gram && stats_ready) {   // ... already formed by the advance launch that ended the previous pass
+      } else if (gram) {
         LAUNCH(e, st, OP_GRAM_STATS, 0, launch_gram_stats(st, gram, T, L.ci, L.co, theta + L.off_w, P, v + L.off_w, P, 1.0 / (double)mpix, 1, X.m1[0], X.m2[0], A.mu[0], A.rstd[0]));
       } else {
         b1.fin = fin_of(e, T, 1.0 / (double)mpix, FIN_TSTATS, X.m1[0], L.co, X.m2[0], L.co);
@@ -860,11 +896,13 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
         gw.dgamma = g + L.off_gamma; gw.dbeta = g + L.off_beta; gw.gstride = P;
         gw.rdgamma = hv + L.off_gamma; gw.rdbeta = hv + L.off_beta; gw.hstride = P;
         gw.out = hv + L.off_w; gw.ostride = P; gw.ci = L.ci; gw.co = L.co; gw.inv_m = 1.0 / (double)mpix;
-        LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_gram_wgrad(st, gw, T, 1));
+        if (adv) { adv->b1_wgrad = 1; adv->gw_tangent = 1; adv->gw = gw; }
+        else LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_gram_wgrad(st, gw, T, 1));
         continue;
       }
       LAUNCH(e, st, OP_TAN_WGRAD, 0, launch_block1(st, b1, T, L.ci, B1_TBWD_WGRAD, &blk));
-      LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_wgrad_reduce(st, pl.wgpart, blk, 9 * L.ci * L.co, T, hv + L.off_w, P));
+      if (adv) adv_add_seg(adv, L.off_w, 9 * L.ci * L.co, pl.wgpart, blk);
+      else LAUNCH(e, st, OP_WGRAD_REDUCE, 0, launch_wgrad_reduce(st, pl.wgpart, blk, 9 * L.ci * L.co, T, hv + L.off_w, P));
       continue;
     }
     BnArgs ba{};
@@ -892,12 +930,13 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     if (l > 0) { wa.x[1] = X.pd[l - 1]; wa.dz[1] = A.dz[l]; }
     hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
     if (ws != st) forked = true;
-    wa.partial = ws != st ? pl.wgpart_side : pl.wgpart;
+    wa.partial = adv ? pl.wgpart_l[l] : (ws != st ? pl.wgpart_side : pl.wgpart);
     wa.g = geom(L, n);
     wa.mpix = mpix;
     int nch = 0;
     LAUNCH(e, ws, OP_TAN_WGRAD, l, launch_wgrad3x3(ws, wa, T, l > 0 ? 2 : 1, &nch));
-    LAUNCH(e, ws, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(ws, wa.partial, nch, 9 * L.ci * L.co, T, hv + L.off_w, P));
+    if (adv) adv_add_seg(adv, L.off_w, 9 * L.ci * L.co, wa.partial, nch);
+    else LAUNCH(e, ws, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(ws, wa.partial, nch, 9 * L.ci * L.co, T, hv + L.off_w, P));
     if (l > 0) {
       ConvArgs ca{};
       ca.in[0] = X.rdz[l]; ca.wt[0] = theta + L.off_w;
@@ -926,17 +965,34 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   return side_join(e, st, pl.half, forked);
 }
 
+// The part of an advance launch that does not depend on the pass: sizes, strides, the never-written elements, block 1's geometry.
+static AdvanceArgs advance_base(const mi_engine* e, float* g) {
+  AdvanceArgs a{};
+  a.g = g; a.gstride = e->PS; a.ostride = e->PS; a.n = (unsigned)e->PS;
+  a.nzero = e->nzero;
+  for (int z = 0; z < e->nzero; ++z) { a.zoff[z] = e->zoff[z]; a.zlen[z] = e->zlen[z]; }
+  a.off_w1 = (unsigned)e->L[0].off_w;
+  a.ci = (e->L[0].ci == 1 || e->L[0].ci == 3) ? e->L[0].ci : 0;
+  a.co = e->L[0].co;
+  return a;
+}
+
+// grad_tasks: the first grad_tasks of the `tasks` tasks are TRAIN tasks (query backward, second-order adjoint recursion, summed into
+// meta_grad_out); the rest are VALIDATION tasks of the same meta-iteration (reference maml_vision.py:117-124: the same clone +
+// fast_adapt without backward), whose K support steps and query forward run in the SAME launches as the train tasks'.
 static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
-                                int tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order,
-                                int with_grad, float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
+                                int tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order, int grad_tasks,
+                                float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
                                 void* workspace, size_t workspace_bytes) {
   if (!e) return fail(nullptr, MI_ERR_ARG, "null engine");
   if (!theta || !data || !labels || !loss_out || !acc_out || !workspace) return fail(e, MI_ERR_ARG, "null pointer argument");
-  if (with_grad && !meta_grad_out) return fail(e, MI_ERR_ARG, "meta_grad_out is NULL but with_grad != 0");
+  const int with_grad = grad_tasks > 0;
+  if (with_grad && !meta_grad_out) return fail(e, MI_ERR_ARG, "meta_grad_out is NULL but a gradient was asked for");
   if (tasks < 1 || shots < 1 || adapt_steps < 0) return fail(e, MI_ERR_ARG, "tasks/shots must be >= 1, adapt_steps >= 0");
+  if (grad_tasks < 0 || grad_tasks > tasks) return fail(e, MI_ERR_ARG, "grad_tasks must be in 0..tasks");
   if (ways != e->d.ways) return fail(e, MI_ERR_ARG, "ways differs from the engine's classifier width");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int T = tasks, K = adapt_steps, ns = ways * shots, nq = ways * shots;
+  const int T = tasks, Tg = grad_tasks, K = adapt_steps, ns = ways * shots, nq = ways * shots;
   const int so = (second_order && with_grad) ? 1 : 0;
   e->export_pass = 0;
   Plan pl;
@@ -944,6 +1000,10 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   if (pl.bytes > workspace_bytes)
     return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
   const size_t TP = (size_t)T * e->PS;
+  const Layer& L0 = e->L[0];
+  // (chunk 0 of the advance kernel -- the first 1024 elements -- must own all of a fused block 1's parameters: 32 filters)
+  const bool tail = e->fuse_tail && e->PS >= 1024 && (!e->fuse1 || L0.off_w + (size_t)9 * L0.ci * L0.co <= 1024);
+  const double inv_m0 = 1.0 / ((double)ns * L0.ho * L0.wo);
   LAUNCH(e, st, OP_MISC, 0, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
   if (pl.gram_s)
@@ -952,25 +1012,57 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
     ActSet& A = so ? pl.sup[k] : pl.sup[0];
     float* th = pl.theta + (size_t)k * TP;
     float* gk = pl.g + (size_t)k * TP;
-    int rc = pass_fwd_bwd(e, st, pl, A, pl.xs, pl.ys, ns, T, th, gk, pl.tmp_loss, pl.tmp_acc, nullptr, true, pl.gram_s);
+    AdvanceArgs adv = advance_base(e, gk);
+    int rc = pass_fwd_bwd(e, st, pl, A, pl.xs, pl.ys, ns, T, th, gk, pl.tmp_loss, pl.tmp_acc, nullptr, true, pl.gram_s, tail ? &adv : nullptr,
+                          tail && k > 0);
     if (rc) return rc;
-    LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, th, gk, inner_lr, TP, th + TP));
+    if (tail) {   // g_k finished, theta_{k+1} = theta_k - lr g_k, and block 1's statistics of the next support pass
+      adv.a = th; adv.out = th + TP; adv.alpha = inner_lr;
+      if (pl.gram_s && k + 1 < K) {
+        ActSet& An = so ? pl.sup[k + 1] : pl.sup[0];
+        adv.stats = 1; adv.gram = pl.gram_s; adv.out0 = An.mu[0]; adv.out1 = An.rstd[0]; adv.inv_m = inv_m0;
+      }
+      LAUNCH(e, st, OP_MISC, 2, launch_advance(st, adv, T));
+    } else {
+      LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, th, gk, inner_lr, TP, th + TP));
+    }
   }
   float* thK = pl.theta + (size_t)K * TP;
-  int rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, nq, T, thK, pl.lam, loss_out, acc_out, logits_out, with_grad != 0);
+  AdvanceArgs advq = advance_base(e, pl.lam);
+  int rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, nq, T, thK, pl.lam, loss_out, acc_out, logits_out, with_grad != 0, nullptr,
+                        (tail && with_grad) ? &advq : nullptr, false, Tg);
   if (rc) return rc;
   if (!with_grad) return MI_OK;
   // debug trace layout (floats): theta [K+1][T][P] | g [K][T][P] | lam_in [K][T][P] | hv [K][T][P], reference parameter order
   const size_t TPr = (size_t)T * e->P;
   const bool tr = e->trace && e->trace_floats >= (size_t)(4 * K + 1) * TPr;
   if (e->trace && !tr) return fail(e, MI_ERR_WORKSPACE, "debug trace buffer too small: need " + std::to_string((size_t)(4 * K + 1) * TPr) + " floats");
+  if (tr && Tg != T) return fail(e, MI_ERR_ARG, "the debug trace covers calls whose tasks all take the backward half");
+  // tangent statistics of block 1 for the Hessian-vector pass over support pass k (weights theta_k), direction = the finished vector
+  auto tangent_stats = [&](AdvanceArgs& a, int k) {
+    a.stats = 2; a.gram = pl.gram_s; a.sw = pl.theta + (size_t)k * TP + L0.off_w; a.swstride = e->PS;
+    a.mu_in = pl.sup[k].mu[0]; a.rstd_in = pl.sup[k].rstd[0]; a.out0 = pl.tan.m1[0]; a.out1 = pl.tan.m2[0]; a.inv_m = inv_m0;
+  };
+  if (tail) {   // lam = grad L_query(theta_K) finished (folds only)
+    if (so && K > 0 && pl.gram_s) tangent_stats(advq, K - 1);
+    LAUNCH(e, st, OP_MISC, 2, launch_advance(st, advq, Tg));
+  }
   if (so) {
     for (int k = K - 1; k >= 0; --k) {
       if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(2 * K + 1 + k) * TPr));
-      rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, T, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv, pl.gram_s);
+      AdvanceArgs adv = advance_base(e, pl.hv);
+      rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, Tg, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv, pl.gram_s, nullptr, nullptr,
+                    tail ? &adv : nullptr, tail);
       if (rc) return rc;
-      if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(3 * K + 1 + k) * TPr));
-      LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, pl.lam, pl.hv, inner_lr, TP, pl.lam));
+      if (tail) {   // H lam finished, lam <- lam - lr H lam, and the tangent statistics of the next Hessian-vector pass
+        adv.a = pl.lam; adv.out = pl.lam; adv.alpha = inner_lr;
+        if (k > 0 && pl.gram_s) tangent_stats(adv, k - 1);
+        LAUNCH(e, st, OP_MISC, 2, launch_advance(st, adv, Tg));
+        if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(3 * K + 1 + k) * TPr));
+      } else {
+        if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(3 * K + 1 + k) * TPr));
+        LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, pl.lam, pl.hv, inner_lr, (size_t)Tg * e->PS, pl.lam));
+      }
     }
   }
   if (tr) {
@@ -979,7 +1071,7 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
     for (int k = 0; k < K; ++k)
       HIPCHK(e, launch_scatter_tasks(st, pl.g + (size_t)k * TP, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(K + 1 + k) * TPr));
   }
-  LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, meta_grad_out));
+  LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, Tg, meta_grad_out));
   return MI_OK;
 }
 
@@ -1142,7 +1234,7 @@ static int meta_batch_entry(MetaBatchFn fn, int which, mi_engine* e, void* strea
       (unsigned long long)shots, (unsigned long long)adapt_steps, (unsigned long long)lr_bits, (unsigned long long)second_order,
       (unsigned long long)with_grad, (unsigned long long)(uintptr_t)loss_out, (unsigned long long)(uintptr_t)acc_out,
       (unsigned long long)(uintptr_t)meta_grad_out, (unsigned long long)(uintptr_t)logits_out, (unsigned long long)(uintptr_t)workspace,
-      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red};
+      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail};
   mi_engine::GraphEntry* ent = nullptr;
   for (auto& g : e->graphs)
     if (g.key == key) { ent = &g; break; }
@@ -1191,7 +1283,17 @@ extern "C" int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta
                                   int with_grad, float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
                                   void* workspace, size_t workspace_bytes) {
   return meta_batch_entry(meta_batch_maml_impl, 0, e, stream, theta, data, labels, tasks, ways, shots, adapt_steps, inner_lr,
-                          second_order, with_grad, loss_out, acc_out, meta_grad_out, logits_out, workspace, workspace_bytes);
+                          second_order, with_grad ? tasks : 0, loss_out, acc_out, meta_grad_out, logits_out, workspace, workspace_bytes);
+}
+// Train and validation halves of one meta-iteration in the same launches (reference maml_vision.py:102-124): the first grad_tasks
+// tasks are the train tasks (their summed meta-gradient goes to meta_grad_out), the rest are adapted and scored only.
+extern "C" int mi_meta_batch_maml_tv(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
+                                     int tasks, int grad_tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order,
+                                     float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
+                                     void* workspace, size_t workspace_bytes) {
+  if (grad_tasks < 0 || grad_tasks > tasks) return fail(e, MI_ERR_ARG, "grad_tasks must be in 0..tasks");
+  return meta_batch_entry(meta_batch_maml_impl, 0, e, stream, theta, data, labels, tasks, ways, shots, adapt_steps, inner_lr,
+                          second_order, grad_tasks, loss_out, acc_out, meta_grad_out, logits_out, workspace, workspace_bytes);
 }
 extern "C" int mi_meta_batch_anil(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
                                   int tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order,

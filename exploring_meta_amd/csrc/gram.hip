@@ -121,24 +121,12 @@ __global__ void gram_reduce_kernel(const double* __restrict__ partial, int nblk,
 // v[a][c] * s[a] over a in a fixed order.
 //  tangent == 0: mu = sum z / M, rstd = 1/sqrt(E[z^2] - mu^2 + eps)                       (bn_finalize FIN_STATS)
 //  tangent == 1: m1 = sum zd / M, m2 = sum zh zd / M with zh = (z - mu) rstd               (bn_finalize FIN_TSTATS)
-__global__ __launch_bounds__(256) void gram_stats_kernel(const double* __restrict__ g, int ng, int kp, const float* __restrict__ w,
-                                                          size_t wstride, const float* __restrict__ wd, size_t vstride, int co,
-                                                          double inv_m, int tangent, float* __restrict__ out0,
-                                                          float* __restrict__ out1, const float* __restrict__ mu_in,
-                                                          const float* __restrict__ rstd_in) {
-  extern __shared__ double sm[];
-  double* gs = sm;                       // [ng][ng]
-  double* ws = gs + ng * ng;             // [kp][co]
-  double* vs = ws + kp * co;             // [kp][co]   (aliases ws when !tangent)
-  double* qd = vs + (tangent ? kp * co : 0);   // [kp][co] partial products v[a][c] * rowdot(a, c)
-  const int task = blockIdx.x, tid = threadIdx.x;
-  for (int e = tid; e < ng * ng; e += 256) gs[e] = g[(size_t)task * ng * ng + e];
-  for (int e = tid; e < kp * co; e += 256) {
-    ws[e] = (double)w[(size_t)task * wstride + e];
-    if (tangent) vs[e] = (double)wd[(size_t)task * vstride + e];
-  }
-  __syncthreads();
-  if (!tangent) vs = ws;
+// The statistics proper, on tables already in LDS: gs [ng][ng], ws / vs [kp][co] (vs == ws when !tangent), qd [kp][co] scratch.
+// Called by every thread of a 256-thread workgroup; the caller has synchronised after filling the tables.
+__device__ __forceinline__ void gram_stats_body(const double* gs, const double* ws, const double* vs, double* qd, int ng, int kp, int co,
+                                                double inv_m, int tangent, float* __restrict__ out0, float* __restrict__ out1,
+                                                const float* __restrict__ mu_in, const float* __restrict__ rstd_in, int task) {
+  const int tid = threadIdx.x;
   for (int e = tid; e < kp * co; e += 256) {
     const int a = e / co, c = e - a * co;
     double rowdot = 0.0;
@@ -164,6 +152,27 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const double* __restric
       out1[(size_t)task * co + c] = (float)(rs * (quad - mu * lin) * inv_m);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gram_stats_kernel(const double* __restrict__ g, int ng, int kp, const float* __restrict__ w,
+                                                          size_t wstride, const float* __restrict__ wd, size_t vstride, int co,
+                                                          double inv_m, int tangent, float* __restrict__ out0,
+                                                          float* __restrict__ out1, const float* __restrict__ mu_in,
+                                                          const float* __restrict__ rstd_in) {
+  extern __shared__ double sm[];
+  double* gs = sm;                       // [ng][ng]
+  double* ws = gs + ng * ng;             // [kp][co]
+  double* vs = ws + kp * co;             // [kp][co]   (aliases ws when !tangent)
+  double* qd = vs + (tangent ? kp * co : 0);   // [kp][co] partial products v[a][c] * rowdot(a, c)
+  const int task = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < ng * ng; e += 256) gs[e] = g[(size_t)task * ng * ng + e];
+  for (int e = tid; e < kp * co; e += 256) {
+    ws[e] = (double)w[(size_t)task * wstride + e];
+    if (tangent) vs[e] = (double)wd[(size_t)task * vstride + e];
+  }
+  __syncthreads();
+  if (!tangent) vs = ws;
+  gram_stats_body(gs, ws, vs, qd, ng, kp, co, inv_m, tangent, out0, out1, mu_in, rstd_in, task);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -457,50 +466,134 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
 //   primal :  dW    = gr (S - dbm s - dgm Z)
 //   tangent:  R{dW} = S - (c1 dbm + gr rbm) s - (c1 dgm + gr rgm) Z - gr dgm Zd,   Zd = sum patch x zhatd = r (G wd - m1 s - m2 Z)
 // (dbm = dbeta/M, dgm = dgamma/M, rbm / rgm their tangents; S already carries c1 / gr in tangent mode.)
+__device__ __forceinline__ float gram_wgrad_elem(const GramWgArgs& a, int ng, int kp, int tangent, int task, int k, int c) {
+  const int co = a.co;
+  const double* grow = a.g + (size_t)task * ng * ng + (size_t)k * ng;      // G[k][.]; G[k][kp] = s[k]
+  const int e = k * co + c;
+  double S = 0.0;
+  const float* sp = a.spartial + (size_t)task * a.nblk * kp * co + e;
+  int b = 0;                                                                 // fixed order; 16 loads in flight per round
+  for (; b + 16 <= a.nblk; b += 16) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = sp[(size_t)(b + q) * kp * co];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) S += (double)v[q];
+  }
+  for (; b < a.nblk; ++b) S += (double)sp[(size_t)b * kp * co];
+  const float* wc = a.w + (size_t)task * a.wstride + c;
+  const float* vc = tangent ? a.wd + (size_t)task * a.vstride + c : wc;
+  double gw = 0.0, gwd = 0.0;
+#pragma unroll 9
+  for (int b2 = 0; b2 < kp; ++b2) {
+    gw = fma(grow[b2], (double)wc[(size_t)b2 * co], gw);
+    if (tangent) gwd = fma(grow[b2], (double)vc[(size_t)b2 * co], gwd);
+  }
+  const double sk = grow[kp];
+  const double mu = (double)a.mu[(size_t)task * co + c], rs = (double)a.rstd[(size_t)task * co + c];
+  const double gm = (double)a.gamma[(size_t)task * a.pstride + c];
+  const double gr = gm * rs;
+  const double dgm = (double)a.dgamma[(size_t)task * a.gstride + c] * a.inv_m, dbm = (double)a.dbeta[(size_t)task * a.gstride + c] * a.inv_m;
+  const double Z = rs * (gw - mu * sk);
+  double out;
+  if (!tangent) {
+    out = gr * (S - dbm * sk - dgm * Z);
+  } else {
+    const double m1 = (double)a.m1[(size_t)task * co + c], m2 = (double)a.m2[(size_t)task * co + c];
+    const double gmd = (double)a.gammad[(size_t)task * a.vstride + c];
+    const double c1 = gmd * rs + gm * (-rs * rs * m2);
+    const double rgm = (double)a.rdgamma[(size_t)task * a.hstride + c] * a.inv_m, rbm = (double)a.rdbeta[(size_t)task * a.hstride + c] * a.inv_m;
+    const double Zd = rs * (gwd - m1 * sk - m2 * Z);
+    out = S - (c1 * dbm + gr * rbm) * sk - (c1 * dgm + gr * rgm) * Z - gr * dgm * Zd;
+  }
+  return (float)out;
+}
+
 __global__ __launch_bounds__(64) void gram_wgrad_kernel(GramWgArgs a, int ng, int kp, int tangent) {
   // one small workgroup per (task, patch entry k): thread = output channel
   const int task = blockIdx.x, k = blockIdx.y, co = a.co;
-  const double* grow = a.g + (size_t)task * ng * ng + (size_t)k * ng;      // G[k][.]; G[k][kp] = s[k]
-  for (int c = threadIdx.x; c < co; c += 64) {
-    const int e = k * co + c;
-    double S = 0.0;
-    const float* sp = a.spartial + (size_t)task * a.nblk * kp * co + e;
-    int b = 0;                                                                 // fixed order; 16 loads in flight per round
-    for (; b + 16 <= a.nblk; b += 16) {
-      float v[16];
+  for (int c = threadIdx.x; c < co; c += 64)
+    a.out[(size_t)task * a.ostride + k * co + c] = gram_wgrad_elem(a, ng, kp, tangent, task, k, c);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The tail of a pass as one launch (kernels.h, AdvanceArgs).  Grid (chunks of 1024 elements, tasks), 256 threads.  Every element of
+// the task's gradient-shaped vector g is finished by the thread that owns it -- folded from weight-gradient partials in chunk order
+// (the order of reduce_partials_kernel), assembled from the Gram matrix (gram_wgrad_elem), zeroed, or simply read -- then
+// out = a - alpha g.  Chunk 0 holds all of block 1's parameters (gamma, beta, 9*Ci0*Co weights, bias: at most 64 + 27*32 + 32 < 1024
+// for the nets this serves); it keeps its finished values in LDS and, after a barrier, forms the next pass's block-1 BatchNorm
+// statistics from them (gram_stats_body) -- nobody else touches those elements, so an in-place update (out == a) is safe.
+__device__ __forceinline__ float advance_elem(const AdvanceArgs& a, int task, unsigned e, int ng, int kp) {
+  float* g_t = a.g + (size_t)task * a.gstride;
+  for (int z = 0; z < a.nzero; ++z)
+    if (e - a.zoff[z] < a.zlen[z]) { g_t[e] = 0.f; return 0.f; }
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    const AdvanceSeg& sg = a.seg[sgi];
+    const unsigned r = e - sg.off;
+    if (r < sg.nelem) {
+      const float* p = sg.partial + (size_t)task * sg.nchunks * sg.nelem + r;
+      float s = 0.f;
+      int c = 0;
+      for (; c + 16 <= sg.nchunks; c += 16) {           // same order as reduce_partials_kernel (16 loads in flight)
+        float v[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = sp[(size_t)(b + q) * kp * co];
+        for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(c + k) * sg.nelem];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) S += (double)v[q];
+        for (int k = 0; k < 16; ++k) s += v[k];
+      }
+      for (; c < sg.nchunks; ++c) s += p[(size_t)c * sg.nelem];
+      g_t[e] = s;
+      return s;
     }
-    for (; b < a.nblk; ++b) S += (double)sp[(size_t)b * kp * co];
-    const float* wc = a.w + (size_t)task * a.wstride + c;
-    const float* vc = tangent ? a.wd + (size_t)task * a.vstride + c : wc;
-    double gw = 0.0, gwd = 0.0;
-#pragma unroll 9
-    for (int b = 0; b < kp; ++b) {
-      gw = fma(grow[b], (double)wc[(size_t)b * co], gw);
-      if (tangent) gwd = fma(grow[b], (double)vc[(size_t)b * co], gwd);
-    }
-    const double sk = grow[kp];
-    const double mu = (double)a.mu[(size_t)task * co + c], rs = (double)a.rstd[(size_t)task * co + c];
-    const double gm = (double)a.gamma[(size_t)task * a.pstride + c];
-    const double gr = gm * rs;
-    const double dgm = (double)a.dgamma[(size_t)task * a.gstride + c] * a.inv_m, dbm = (double)a.dbeta[(size_t)task * a.gstride + c] * a.inv_m;
-    const double Z = rs * (gw - mu * sk);
-    double out;
-    if (!tangent) {
-      out = gr * (S - dbm * sk - dgm * Z);
-    } else {
-      const double m1 = (double)a.m1[(size_t)task * co + c], m2 = (double)a.m2[(size_t)task * co + c];
-      const double gmd = (double)a.gammad[(size_t)task * a.vstride + c];
-      const double c1 = gmd * rs + gm * (-rs * rs * m2);
-      const double rgm = (double)a.rdgamma[(size_t)task * a.hstride + c] * a.inv_m, rbm = (double)a.rdbeta[(size_t)task * a.hstride + c] * a.inv_m;
-      const double Zd = rs * (gwd - m1 * sk - m2 * Z);
-      out = S - (c1 * dbm + gr * rbm) * sk - (c1 * dgm + gr * rgm) * Z - gr * dgm * Zd;
-    }
-    a.out[(size_t)task * a.ostride + e] = (float)out;
   }
+  if (a.b1_wgrad) {
+    const unsigned r = e - a.off_w1;
+    if (r < (unsigned)(kp * a.co)) {
+      const float v = gram_wgrad_elem(a.gw, ng, kp, a.gw_tangent, task, (int)(r / (unsigned)a.co), (int)(r % (unsigned)a.co));
+      g_t[e] = v;
+      return v;
+    }
+  }
+  return g_t[e];
+}
+
+__global__ __launch_bounds__(256) void advance_kernel(AdvanceArgs a, int ng, int kp) {
+  extern __shared__ double sm[];
+  const int task = blockIdx.y, tid = threadIdx.x;
+  const unsigned base = blockIdx.x * 1024u;
+  const bool with_stats = a.stats != 0 && blockIdx.x == 0;
+  float* loc = reinterpret_cast<float*>(sm);            // chunk 0 with statistics: the finished block-1 weights (or direction), as float
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const unsigned e = base + it * 256u + tid;
+    if (e >= a.n) break;
+    const float gv = advance_elem(a, task, e, ng, kp);
+    float res = gv;
+    if (a.out) {
+      res = a.a[(size_t)task * a.ostride + e] - a.alpha * gv;
+      a.out[(size_t)task * a.ostride + e] = res;
+    }
+    if (with_stats) loc[e] = res;
+  }
+  if (!with_stats) return;                              // uniform per workgroup
+  __syncthreads();
+  const int co = a.co, tangent = a.stats == 2;
+  double* gs = sm + 512;                                // (the first 4 KB hold loc)
+  double* ws = gs + ng * ng;
+  double* vs = ws + kp * co;
+  double* qd = vs + (tangent ? kp * co : 0);
+  for (int e = tid; e < ng * ng; e += 256) gs[e] = a.gram[(size_t)task * ng * ng + e];
+  for (int e = tid; e < kp * co; e += 256) {
+    if (tangent) {
+      ws[e] = (double)a.sw[(size_t)task * a.swstride + e];
+      vs[e] = (double)loc[a.off_w1 + e];
+    } else {
+      ws[e] = (double)loc[a.off_w1 + e];
+    }
+  }
+  __syncthreads();
+  if (!tangent) vs = ws;
+  gram_stats_body(gs, ws, vs, qd, ng, kp, co, a.inv_m, tangent, a.out0, a.out1, a.mu_in, a.rstd_in, task);
 }
 
 static int sparse_row_pitch(int w, int ci) {
@@ -591,6 +684,15 @@ hipError_t launch_input_gram(hipStream_t st, const float* x, int tasks, int n, i
   else
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(ceil_div(ng * ng, 256), tasks), dim3(256), 0, st, partial, nblk, ng, g);
+  return hipGetLastError();
+}
+
+hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a, int tasks) {
+  const int ng = a.ci ? gram_ng(a.ci) : 0, kp = 9 * a.ci;
+  if ((a.stats || a.b1_wgrad) && (a.off_w1 + (unsigned)(kp * a.co) > 1024u || (a.ci != 1 && a.ci != 3))) return hipErrorInvalidValue;
+  if (a.nseg > 8 || a.nzero > 10) return hipErrorInvalidValue;
+  const size_t smem = a.stats ? 4096 + ((size_t)ng * ng + (size_t)(a.stats == 2 ? 3 : 2) * kp * a.co) * sizeof(double) : 0;
+  hipLaunchKernelGGL(advance_kernel, dim3(ceil_div((int)a.n, 1024), tasks), dim3(256), smem, st, a, ng, kp);
   return hipGetLastError();
 }
 

@@ -147,6 +147,30 @@ struct GramWgArgs {
 };
 hipError_t launch_gram_wgrad(hipStream_t st, const GramWgArgs& a, int tasks, int tangent);
 
+// gram.hip: the tail of a pass as ONE launch ("advance").  A forward/backward (or Hessian-vector) pass leaves its gradient-shaped
+// vector g [T][gstride] unfinished: the conv-weight segments of blocks >= 2 are still per-workgroup partials of the weight-gradient
+// kernels, block 1's weight gradient still needs its Gram-matrix assembly (GramWgArgs), conv biases / padding are unwritten.  The
+// advance kernel finishes g (same fold order as reduce_partials_kernel, same arithmetic as gram_wgrad_kernel), applies
+// out = a - alpha * g (learn2learn maml_update / the adjoint recursion; out == nullptr: finish g only) and, from the freshly written
+// block-1 weights, forms the BatchNorm statistics the NEXT pass over the support images needs from the Gram matrix (gram_stats) --
+// replacing 3 reduce_partials + gram_wgrad + axpy + gram_stats + 1 memset launches per pass.
+struct AdvanceSeg { unsigned off, nelem; const float* partial; int nchunks; };
+struct AdvanceArgs {
+  float* g; size_t gstride;
+  AdvanceSeg seg[8]; int nseg;               // g[off .. off+nelem) = sum_chunk partial[task][chunk][.]
+  unsigned zoff[10], zlen[10]; int nzero;    // g = 0 there (conv biases: train-mode BatchNorm cancels them; padding P..PS)
+  const float* a; float* out; size_t ostride; float alpha;
+  unsigned n;                                // elements per task
+  int b1_wgrad, gw_tangent; GramWgArgs gw;   // block 1's weight gradient from the Gram matrix (gw.out points into g)
+  unsigned off_w1;                           // offset of block 1's conv weights in a parameter vector
+  int stats;                                 // 0: none; 1: primal statistics with weights = out; 2: tangent statistics, direction = out (or g when out == nullptr)
+  const double* gram; int ci, co;
+  const float* sw; size_t swstride;          // stats == 2: the weights of the pass the statistics are for
+  const float *mu_in, *rstd_in;              // stats == 2
+  float *out0, *out1; double inv_m;          // mean / rstd  (stats == 2: m1 / m2), [T][co]
+};
+hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a, int tasks);
+
 // gram.hip: input Gram matrix of block 1 (BatchNorm statistics of conv1 as quadratic forms of the weights)
 int gram_blocks_per_task(int n, int h);
 size_t gram_partial_doubles(int tasks, int n, int h, int ci);

@@ -141,6 +141,11 @@ class MetaEngine:
         """Block 1's BatchNorm-backward sums in the epilogue of block 2's dgrad (default on) or as a separate streaming pass."""
         _lib.check(self.lib.mi_engine_set_fused_block1_reduce(self._h, int(on)), self._h)
 
+    def set_fused_tail(self, on):
+        """One "advance" launch at the end of every pass of `meta_batch` (default on) or the separate fold / update / statistics
+        launches; bit-identical results."""
+        _lib.check(self.lib.mi_engine_set_fused_tail(self._h, int(on)), self._h)
+
     def set_graph(self, on):
         """Replay repeated identical fused calls as one hipGraphLaunch (mi_engine_set_graph).  While on, `meta_batch` /
         `meta_batch_anil` return views of PERSISTENT output buffers (one set per call shape), because a replay writes where the
@@ -222,9 +227,11 @@ class MetaEngine:
 
     @_on_device
     def meta_batch(self, theta, data, labels, shots, adapt_steps, inner_lr, first_order=False, with_grad=True,
-                   return_logits=False):
+                   return_logits=False, grad_tasks=None):
         """theta [P] fp32; data [T, 2*shots*ways, C, H, W] fp32 (the reference's task batches, stacked); labels [T, 2*S*W]
-        int64.  Returns (loss[T], acc[T], meta_grad[P] summed over tasks or None, logits [T, S*W, ways] or None)."""
+        int64.  Returns (loss[T], acc[T], meta_grad[P] summed over tasks or None, logits [T, S*W, ways] or None).
+        grad_tasks = G (0 < G < T): the first G tasks are the meta-iteration's TRAIN tasks (the meta-gradient is summed over them), the
+        other T - G its VALIDATION tasks, adapted and scored in the same launches without a backward half (maml_vision.py:117-124)."""
         s = self.spec
         T = data.shape[0]
         n2 = 2 * shots * s.ways
@@ -238,11 +245,16 @@ class MetaEngine:
         for t, dt in ((theta, torch.float32), (data, torch.float32), (labels, torch.int64)):
             if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
                 raise ValueError('theta/data must be contiguous fp32 CUDA tensors and labels contiguous int64 CUDA')
+        if grad_tasks is None:
+            grad_tasks = T if with_grad else 0
+        if not 0 <= grad_tasks <= T:
+            raise ValueError(f'grad_tasks must be in 0..{T}, got {grad_tasks}')
+        with_grad = grad_tasks > 0
         so = (not first_order) and with_grad
         ws = self._workspace(self.workspace_bytes(T, shots, adapt_steps, so))
         loss, acc, grad, logits = self._outputs('maml', T, shots * s.ways, with_grad, return_logits)
-        rc = self._fused_call(self.lib.mi_meta_batch_maml, _ptr(theta), _ptr(data), _ptr(labels), T, s.ways, shots,
-                              adapt_steps, float(inner_lr), int(not first_order), int(with_grad), _ptr(loss),
+        rc = self._fused_call(self.lib.mi_meta_batch_maml_tv, _ptr(theta), _ptr(data), _ptr(labels), T, int(grad_tasks), s.ways, shots,
+                              adapt_steps, float(inner_lr), int(not first_order), _ptr(loss),
                               _ptr(acc), _ptr(grad), _ptr(logits), _ptr(ws), ws.numel())
         _lib.check(rc, self._h)
         return loss, acc, grad, logits

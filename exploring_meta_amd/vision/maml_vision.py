@@ -4,7 +4,8 @@
 Same experiment (seeds, model, ``MAML(model, lr, first_order)``, Adam(outer_lr), CrossEntropy, per-iteration train +
 validation meta-batches, gradient / meta_batch_size, meta-test with ``evaluate``), same flags plus ``--first_order`` (the
 reference hard-codes second order, maml_vision.py:84) -- but the ``for task in range(meta_batch_size)`` loop
-(maml_vision.py:102-124) is ONE ``meta_batch_adapt`` call per half, and with ``torchrun`` the meta-batch is sharded over
+(maml_vision.py:102-124) is ONE ``meta_batch_adapt`` call for both halves (train tasks with, validation tasks without the backward
+half: ``grad_tasks``), and with ``torchrun`` the meta-batch is sharded over
 ranks with one RCCL all-reduce.  Datasets are not available offline: tasks come from the seeded synthetic generator
 (``utils/synthetic.py``) with the reference's batch layout.
 
@@ -71,17 +72,25 @@ def run(dataset, p, first_order=False, log=print):
         # BatchNorm buffers (saved with every checkpoint, utils/experiment.py:85-90): tracked when checkpoints are written
         fold = RunningStatsFold(model.engine(), model.base, model.spec(), T, lo, hi, p['adapt_steps'] + 1,
                                 p['ways'] * p['shots']) if save_dir else None
-        if ids:
+        if ids and not fold:
+            # train and validation halves of the iteration (maml_vision.py:102-124) in ONE fused call: the first len(ids) tasks carry
+            # the backward half, the validation tasks ride through the same launches
+            d, l = train.sample_batch(ids)
+            dv, lv = valid.sample_batch([10 ** 6 + i for i in ids])
+            n = len(ids)
+            total, losses, accs = meta_batch_adapt(maml.clone(), torch.cat([d, dv]).to(device), torch.cat([l, lv]).to(device),
+                                                   p['adapt_steps'], p['shots'], p['ways'], grad_tasks=n)
+            total.backward()                                                 # accumulates the SUM over this rank's train tasks
+            sums = [losses[:n].sum(), accs[:n].sum(), losses[n:].sum(), accs[n:].sum()]
+        elif ids:                                # with checkpoints: two calls, so that the BatchNorm buffers fold in the reference's call order
             d, l = train.sample_batch(ids)
             total, losses, accs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
             total.backward()                                                 # accumulates the SUM over this rank's tasks
-            if fold:
-                fold.collect(0)
+            fold.collect(0)
             with torch.no_grad():
                 d, l = valid.sample_batch([10 ** 6 + i for i in ids])
                 _, vlosses, vaccs = meta_batch_adapt(maml.clone(), d.to(device), l.to(device), p['adapt_steps'], p['shots'], p['ways'])
-            if fold:
-                fold.collect(1)
+            fold.collect(1)
             sums = [losses.sum(), accs.sum(), vlosses.sum(), vaccs.sum()]
         else:                                    # meta_batch_size < world size: this rank owns no task, contributes zeros
             sums = [zero, zero, zero, zero]

@@ -118,6 +118,23 @@ int mi_meta_batch_maml(mi_engine* e, void* stream, const float* theta, const flo
                        float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
                        void* workspace, size_t workspace_bytes);
 
+/* The train AND the validation half of one meta-iteration in the same launches.  The reference runs, per train task, a second
+ *   learner = maml.clone(); fast_adapt(valid_batch, ...)        without backward
+ * (vision/maml_vision.py:117-124): the K support steps and the query forward of those validation tasks are the same kernels as the
+ * train tasks'.  `tasks` task batches are stacked as for mi_meta_batch_maml; the FIRST grad_tasks of them are train tasks -- query
+ * backward, second-order adjoint recursion, summed into meta_grad_out -- the remaining tasks - grad_tasks are adapted and scored only.
+ * loss_out / acc_out [tasks] cover both halves.  grad_tasks == tasks is mi_meta_batch_maml(with_grad = 1), grad_tasks == 0 is
+ * with_grad = 0; the workspace is mi_workspace_bytes(tasks, ..., second_order). */
+int mi_meta_batch_maml_tv(mi_engine* e, void* stream, const float* theta, const float* data, const int64_t* labels,
+                          int tasks, int grad_tasks, int ways, int shots, int adapt_steps, float inner_lr, int second_order,
+                          float* loss_out, float* acc_out, float* meta_grad_out, float* logits_out,
+                          void* workspace, size_t workspace_bytes);
+
+/* Ablation / test switch: 1 (default) = every pass of mi_meta_batch_maml ends in ONE "advance" launch (weight-gradient partial folds,
+ * block 1's Gram-matrix assembly, p <- p - lr g of learn2learn's maml_update / the adjoint recursion, the next pass's Gram statistics);
+ * 0 = the separate launches (reduce_partials x3, gram_wgrad, axpy, gram_stats, a memset).  Bit-identical results. */
+int mi_engine_set_fused_tail(mi_engine* e, int on);
+
 /* One meta-batch of ANIL tasks (vision/anil_vision.py:116-122 with features = Sequential(ConvBase, view(-1, fc_neurons)),
  * head = MAML(Linear(fc_neurons, ways)), :86-94): the trunk runs once per task on all 2*shots*ways images (BatchNorm over
  * support and query together, utils/data_pre.py:118-119), only the head is adapted, and the outer gradient reaches both.

@@ -195,6 +195,67 @@ def test_fused_finalize_is_bit_identical(dataset, ways, shots, K, tasks, fused1)
     assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).sum() > 0
 
 
+@pytest.mark.parametrize('dataset,ways,shots,K,fo,tasks,fused1', [
+    ('min', 5, 5, 3, False, [3, 4, 5], 1), ('min', 5, 1, 1, False, [0, 1, 2, 3, 4, 5, 6], 1), ('min', 5, 5, 2, True, [1, 2], 1),
+    ('min', 5, 1, 2, False, [2, 3], 2), ('min', 5, 1, 2, False, [2, 3], 0), ('omni', 5, 1, 2, False, [0, 1, 2, 3], 1), ('omni', 5, 1, 1, True, [4, 5], 1)])
+def test_fused_tail_is_bit_identical(dataset, ways, shots, K, fo, tasks, fused1):
+    """One `advance` launch at the end of every pass (gram.hip: weight-gradient partial folds in chunk order, block 1's Gram-matrix
+    assembly, theta_{k+1} = theta_k - lr g_k / lam <- lam - lr H lam, the next pass's Gram statistics, zeros where no kernel writes)
+    vs the separate reduce_partials / gram_wgrad / axpy / gram_stats launches and the memset: same arithmetic in the same order, so
+    loss, logits, the meta-gradient and the traced per-step vectors are bit-identical -- with the Gram path, with conv-recompute
+    statistics (fused1 = 2), with the generic block-1 kernels (fused1 = 0) and for the stride-2 Omniglot net."""
+    spec, mspec = _spec(dataset, ways)
+    theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
+    data, labels = synthetic.make_meta_batch(dataset, tasks, ways, shots)
+    d, l = torch.from_numpy(data).cuda().contiguous(), torch.from_numpy(labels).cuda().contiguous()
+    outs = []
+    for on in (1, 0, 1):
+        eng = MetaEngine(mspec)
+        eng.set_fused_block1(fused1)
+        eng.set_fused_tail(on)
+        trace = eng.set_trace(len(tasks), K) if not fo else None
+        loss, acc, grad, logits = eng.meta_batch(theta, d, l, shots, K, 0.4, first_order=fo, return_logits=True)
+        torch.cuda.synchronize()
+        outs.append((loss.cpu().numpy(), grad.cpu().numpy(), logits.cpu().numpy()) +
+                    (tuple(trace[k].cpu().numpy() for k in ('theta', 'g', 'lam_in', 'hv')) if trace else ()))
+        if trace:
+            eng.set_trace(0)
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert np.array_equal(a, b)
+    assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).sum() > 0
+
+
+def test_train_and_validation_tasks_in_one_call():
+    """mi_meta_batch_maml_tv (reference maml_vision.py:102-124): 3 train + 2 validation tasks through the same launches against the
+    two separate calls -- per-task losses / accuracies / logits of both halves, and the meta-gradient summed over the train tasks only.
+    (Not bit-identical: the launch geometry -- tiles per wave, weight-gradient chunks -- depends on the task count.)"""
+    ways, shots, K, lr = 5, 5, 2, 0.4
+    spec, mspec = _spec('min', ways)
+    theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
+    data, labels = synthetic.make_meta_batch('min', [3, 4, 5, 6, 7], ways, shots)
+    d, l = torch.from_numpy(data).cuda().contiguous(), torch.from_numpy(labels).cuda().contiguous()
+    eng = MetaEngine(mspec)
+    lt, at, gt, gl = eng.meta_batch(theta, d[:3], l[:3], shots, K, lr, return_logits=True)
+    lv, av, gv, vl = eng.meta_batch(theta, d[3:], l[3:], shots, K, lr, with_grad=False, return_logits=True)
+    lt, at, gt, gl, lv, av, vl = (x.clone() for x in (lt, at, gt, gl, lv, av, vl))
+    assert gv is None
+    loss, acc, grad, logits = eng.meta_batch(theta, d, l, shots, K, lr, return_logits=True, grad_tasks=3)
+    torch.cuda.synchronize()
+    want_l, want_a, want_lg = torch.cat([lt, lv]), torch.cat([at, av]), torch.cat([gl, vl])
+    e_l = float(((loss - want_l).abs() / want_l.abs()).max())
+    e_lg = rel_err(logits.cpu().numpy(), want_lg.cpu().numpy())
+    e_g = rel_err(grad.cpu().numpy(), gt.cpu().numpy())
+    report('train_valid_one_call', loss_rel=e_l, logits_rel=e_lg, grad_rel=e_g)
+    assert e_l < 1e-5 and e_lg < 1e-5 and e_g < 1e-4 and torch.equal(acc, want_a)
+    # the extremes are the plain calls
+    l5, a5, g5, _ = eng.meta_batch(theta, d, l, shots, K, lr, grad_tasks=5)
+    l5b, a5b, g5b, _ = eng.meta_batch(theta, d, l, shots, K, lr)
+    assert torch.equal(l5, l5b) and torch.equal(g5, g5b)
+    with pytest.raises(ValueError):
+        eng.meta_batch(theta, d, l, shots, K, lr, grad_tasks=6)
+
+
 @pytest.mark.parametrize('dataset,ways,shots,K,tasks', [('min', 5, 5, 2, [3, 4, 5]), ('min', 5, 1, 1, [0, 1, 2, 3, 4, 5, 6])])
 def test_block1_reduce_in_dgrad_epilogue_matches_streaming_pass(dataset, ways, shots, K, tasks):
     """dgamma / dbeta of block 1 (and their tangents in the Hessian-vector product) summed in the epilogue of block 2's dgrad
