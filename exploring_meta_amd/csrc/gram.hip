@@ -12,6 +12,7 @@
 // the quadratic forms on the vector unit -- more accurate than summing fp32 conv outputs.
 #include "mi_common.h"
 #include "kernels.h"
+#include "bf16_split.h"
 
 typedef double doublex4 __attribute__((ext_vector_type(4)));
 
@@ -574,6 +575,22 @@ __global__ __launch_bounds__(256) void advance_kernel(AdvanceArgs a, int ng, int
       a.out[(size_t)task * a.ostride + e] = res;
     }
     if (with_stats) loc[e] = res;
+    // weight planes for the split-bf16 convolutions (bf16_split.h): element (tap, a, b) of a block's [9][32][32] weights is piece i of
+    // one 16-byte unit in the forward set (k = a, column b) and of one in the dgrad set (k = b, column a)
+    for (int q = 0; q < a.npl; ++q) {
+      const unsigned r = e - a.pl[q].off;
+      if (r < 9216u) {
+        unsigned short ph, pm, plo;
+        bf16_split1(res, ph, pm, plo);
+        const unsigned tap = r >> 10, aa = (r >> 5) & 31u, bb = r & 31u;
+        const unsigned uf = ((tap * 2 + ((aa >> 3) & 1u)) * 3) * 64 + (aa >> 4) * 32 + bb;      // forward: k = aa
+        const unsigned ub = ((tap * 2 + ((bb >> 3) & 1u)) * 3) * 64 + (bb >> 4) * 32 + aa;      // dgrad:   k = bb
+        unsigned short* f16 = reinterpret_cast<unsigned short*>(a.pl[q].fwd + (size_t)task * a.plstride) + (size_t)uf * 8 + (aa & 7u);
+        unsigned short* b16 = reinterpret_cast<unsigned short*>(a.pl[q].bwd + (size_t)task * a.plstride) + (size_t)ub * 8 + (bb & 7u);
+        f16[0] = ph; f16[64 * 8] = pm; f16[2 * 64 * 8] = plo;
+        b16[0] = ph; b16[64 * 8] = pm; b16[2 * 64 * 8] = plo;
+      }
+    }
   }
   if (!with_stats) return;                              // uniform per workgroup
   __syncthreads();
@@ -690,7 +707,7 @@ hipError_t launch_input_gram(hipStream_t st, const float* x, int tasks, int n, i
 hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a, int tasks) {
   const int ng = a.ci ? gram_ng(a.ci) : 0, kp = 9 * a.ci;
   if ((a.stats || a.b1_wgrad) && (a.off_w1 + (unsigned)(kp * a.co) > 1024u || (a.ci != 1 && a.ci != 3))) return hipErrorInvalidValue;
-  if (a.nseg > 8 || a.nzero > 10) return hipErrorInvalidValue;
+  if (a.nseg > 8 || a.nzero > 10 || a.npl > 6) return hipErrorInvalidValue;
   const size_t smem = a.stats ? 4096 + ((size_t)ng * ng + (size_t)(a.stats == 2 ? 3 : 2) * kp * a.co) * sizeof(double) : 0;
   hipLaunchKernelGGL(advance_kernel, dim3(ceil_div((int)a.n, 1024), tasks), dim3(256), smem, st, a, ng, kp);
   return hipGetLastError();
