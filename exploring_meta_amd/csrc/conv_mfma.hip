@@ -29,6 +29,14 @@
 #else
 #define MI_LOW_PRODUCT(X) X
 #endif
+// Ablation build (timing experiment, wrong results, not shipped): -DMI_CONV_ABLATE_ROW drops the loads, splits and lane shifts of every
+// third displaced row of a tile (the operands of the row before are used again): what a tile of two output rows that fetches four input
+// rows for them would save at best.
+#ifdef MI_CONV_ABLATE_ROW
+#define MI_ROW_KEPT(i) (hg_ddy(i) != 1)
+#else
+#define MI_ROW_KEPT(i) true
+#endif
 #define EPI_NONE 0
 #define EPI_STATS 1
 #define EPI_TSTATS 2
@@ -572,19 +580,19 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
         // the loads of half-group i + 3 (the raw slot of half-group i was split during half-group i - 1)
-        if (i + HRING < NH) issue_hg(cur, i + HRING); else issue_hg(nxt, i + HRING - NH);
+        if (MI_ROW_KEPT((i + HRING) % NH)) { if (i + HRING < NH) issue_hg(cur, i + HRING); else issue_hg(nxt, i + HRING - NH); }
         const Bf16Planes& pc_ = pc[i & 1];
         Bf16Planes& nc = pc[(i + 1) & 1];
         const floatx4* rc = rawc[(i + 1) % HRING];
         const unsigned selm = cur.keep_m, selp = cur.keep_p;
         // unit 0: centre tap; meanwhile the -1 operand and the first half of the next half-group's split
         MI_READB(pb[(3 * i + 1) & 1], hg_unit(i, -1));
-        MI_UNIT(pc_, pb[(3 * i) & 1], MI_SHIFT6(opm, h, m, 0x138, selm), MI_SHIFT6B(opm, m, l, 0x138, selm), bf16_split_pair<0>(rc[0], nc),
-                bf16_split_pair<1>(rc[0], nc))
+        MI_UNIT(pc_, pb[(3 * i) & 1], if (MI_ROW_KEPT(i)) MI_SHIFT6(opm, h, m, 0x138, selm), if (MI_ROW_KEPT(i)) MI_SHIFT6B(opm, m, l, 0x138, selm),
+                if (MI_ROW_KEPT((i + 1) % NH)) bf16_split_pair<0>(rc[0], nc), if (MI_ROW_KEPT((i + 1) % NH)) bf16_split_pair<1>(rc[0], nc))
         // unit 1: tap -1; meanwhile the +1 operand and the second half of the split
         MI_READB(pb[(3 * i + 2) & 1], hg_unit(i, 1));
-        MI_UNIT(opm, pb[(3 * i + 1) & 1], MI_SHIFT6(opp, h, m, 0x130, selp), MI_SHIFT6B(opp, m, l, 0x130, selp), bf16_split_pair<2>(rc[1], nc),
-                bf16_split_pair<3>(rc[1], nc))
+        MI_UNIT(opm, pb[(3 * i + 1) & 1], if (MI_ROW_KEPT(i)) MI_SHIFT6(opp, h, m, 0x130, selp), if (MI_ROW_KEPT(i)) MI_SHIFT6B(opp, m, l, 0x130, selp),
+                if (MI_ROW_KEPT((i + 1) % NH)) bf16_split_pair<2>(rc[1], nc), if (MI_ROW_KEPT((i + 1) % NH)) bf16_split_pair<3>(rc[1], nc))
         // unit 2: tap +1
         MI_READB(pb[(3 * i + 3) & 1], hg_unit((i + 1) % NH, 0));
         MI_UNIT(opp, pb[(3 * i + 2) & 1], (void)0, (void)0, (void)0, (void)0)

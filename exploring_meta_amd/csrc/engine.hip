@@ -1050,7 +1050,8 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   if (pl.gram_s)
     LAUNCH(e, st, OP_GRAM, 0, launch_input_gram(st, pl.xs, T, ns, e->L[0].h, e->L[0].w, e->L[0].ci, pl.gram_part, pl.gram_s));
   // where the pre-split weight planes of an advance launch's finished vector go (the split-bf16 convolutions' prologue copies them)
-  const bool planes = tail && !pl.wpl_theta.empty();
+  static const bool no_wpl = getenv("MI_NO_WPL") != nullptr;      // bisecting aid: fused tail without the pre-split weight planes
+  const bool planes = tail && !pl.wpl_theta.empty() && !no_wpl;
   auto set_planes = [&](AdvanceArgs& a, unsigned char* dst) {
     a.npl = 0; a.plstride = pl.wpl_stride;
     if (!planes || !dst) return;

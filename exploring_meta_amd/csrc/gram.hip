@@ -123,19 +123,20 @@ __global__ void gram_reduce_kernel(const double* __restrict__ partial, int nblk,
 //  tangent == 0: mu = sum z / M, rstd = 1/sqrt(E[z^2] - mu^2 + eps)                       (bn_finalize FIN_STATS)
 //  tangent == 1: m1 = sum zd / M, m2 = sum zh zd / M with zh = (z - mu) rstd               (bn_finalize FIN_TSTATS)
 // The statistics proper, on tables already in LDS: gs [ng][ng], ws / vs [kp][co] (vs == ws when !tangent), qd [kp][co] scratch.
-// Called by every thread of a 256-thread workgroup; the caller has synchronised after filling the tables.
+// Called by every thread of the workgroup (NT threads); the caller has synchronised after filling the tables.
+template <int NT>
 __device__ __forceinline__ void gram_stats_body(const double* gs, const double* ws, const double* vs, double* qd, int ng, int kp, int co,
                                                 double inv_m, int tangent, float* __restrict__ out0, float* __restrict__ out1,
                                                 const float* __restrict__ mu_in, const float* __restrict__ rstd_in, int task) {
   const int tid = threadIdx.x;
-  for (int e = tid; e < kp * co; e += 256) {
+  for (int e = tid; e < kp * co; e += NT) {
     const int a = e / co, c = e - a * co;
     double rowdot = 0.0;
     for (int b = 0; b < kp; ++b) rowdot = fma(ws[b * co + c], gs[b * ng + a], rowdot);
     qd[e] = vs[e] * rowdot;
   }
   __syncthreads();
-  for (int c = tid; c < co; c += 256) {
+  for (int c = tid; c < co; c += NT) {
     double lin = 0.0, quad = 0.0;
     for (int a = 0; a < kp; ++a) {
       lin = fma(vs[a * co + c], gs[a * ng + kp], lin);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const double* __restric
   }
   __syncthreads();
   if (!tangent) vs = ws;
-  gram_stats_body(gs, ws, vs, qd, ng, kp, co, inv_m, tangent, out0, out1, mu_in, rstd_in, task);
+  gram_stats_body<256>(gs, ws, vs, qd, ng, kp, co, inv_m, tangent, out0, out1, mu_in, rstd_in, task);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -518,7 +519,8 @@ __global__ __launch_bounds__(64) void gram_wgrad_kernel(GramWgArgs a, int ng, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The tail of a pass as one launch (kernels.h, AdvanceArgs).  Grid (chunks of 1024 elements, tasks), 256 threads.  Every element of
+// The tail of a pass as one launch (kernels.h, AdvanceArgs).  Grid (chunks of 1024 elements, tasks), 1024 threads: one element each (the
+// chunk that assembles block 1's weight gradient is the launch's critical path: 864 Gram-row dot products and partial folds).  Every element of
 // the task's gradient-shaped vector g is finished by the thread that owns it -- folded from weight-gradient partials in chunk order
 // (the order of reduce_partials_kernel), assembled from the Gram matrix (gram_wgrad_elem), zeroed, or simply read -- then
 // out = a - alpha g.  Chunk 0 holds all of block 1's parameters (gamma, beta, 9*Ci0*Co weights, bias: at most 64 + 27*32 + 32 < 1024
@@ -558,17 +560,20 @@ __device__ __forceinline__ float advance_elem(const AdvanceArgs& a, int task, un
   return g_t[e];
 }
 
-__global__ __launch_bounds__(256) void advance_kernel(AdvanceArgs a, int ng, int kp) {
+__global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a, int ng, int kp) {
   extern __shared__ double sm[];
   const int task = blockIdx.y, tid = threadIdx.x;
   const unsigned base = blockIdx.x * 1024u;
   const bool with_stats = a.stats != 0 && blockIdx.x == 0;
   float* loc = reinterpret_cast<float*>(sm);            // chunk 0 with statistics: the finished block-1 weights (or direction), as float
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const unsigned e = base + it * 256u + tid;
-    if (e >= a.n) break;
-    const float gv = advance_elem(a, task, e, ng, kp);
+  const unsigned e = base + tid;
+  float gv = 0.f;
+  if (e < a.n) gv = advance_elem(a, task, e, ng, kp);
+  // Block 1's Gram assembly reads the direction's block-1 weights and gamma (GramWgArgs::wd, gammad) -- the very elements an in-place
+  // update (out == a == the direction: lam <- lam - lr H lam) is about to overwrite, all of them owned by this chunk: every thread's
+  // reads must be over before the first write.
+  if (blockIdx.x == 0 && a.b1_wgrad) __syncthreads();      // (uniform)
+  if (e < a.n) {
     float res = gv;
     if (a.out) {
       res = a.a[(size_t)task * a.ostride + e] - a.alpha * gv;
@@ -599,8 +604,8 @@ __global__ __launch_bounds__(256) void advance_kernel(AdvanceArgs a, int ng, int
   double* ws = gs + ng * ng;
   double* vs = ws + kp * co;
   double* qd = vs + (tangent ? kp * co : 0);
-  for (int e = tid; e < ng * ng; e += 256) gs[e] = a.gram[(size_t)task * ng * ng + e];
-  for (int e = tid; e < kp * co; e += 256) {
+  for (int e = tid; e < ng * ng; e += 1024) gs[e] = a.gram[(size_t)task * ng * ng + e];
+  for (int e = tid; e < kp * co; e += 1024) {
     if (tangent) {
       ws[e] = (double)a.sw[(size_t)task * a.swstride + e];
       vs[e] = (double)loc[a.off_w1 + e];
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(256) void advance_kernel(AdvanceArgs a, int ng, int
   }
   __syncthreads();
   if (!tangent) vs = ws;
-  gram_stats_body(gs, ws, vs, qd, ng, kp, co, a.inv_m, tangent, a.out0, a.out1, a.mu_in, a.rstd_in, task);
+  gram_stats_body<1024>(gs, ws, vs, qd, ng, kp, co, a.inv_m, tangent, a.out0, a.out1, a.mu_in, a.rstd_in, task);
 }
 
 static int sparse_row_pitch(int w, int ci) {
@@ -709,7 +714,7 @@ hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a, int tasks) {
   if ((a.stats || a.b1_wgrad) && (a.off_w1 + (unsigned)(kp * a.co) > 1024u || (a.ci != 1 && a.ci != 3))) return hipErrorInvalidValue;
   if (a.nseg > 8 || a.nzero > 10 || a.npl > 6) return hipErrorInvalidValue;
   const size_t smem = a.stats ? 4096 + ((size_t)ng * ng + (size_t)(a.stats == 2 ? 3 : 2) * kp * a.co) * sizeof(double) : 0;
-  hipLaunchKernelGGL(advance_kernel, dim3(ceil_div((int)a.n, 1024), tasks), dim3(256), smem, st, a, ng, kp);
+  hipLaunchKernelGGL(advance_kernel, dim3(ceil_div((int)a.n, 1024), tasks), dim3(1024), smem, st, a, ng, kp);
   return hipGetLastError();
 }
 

@@ -226,11 +226,13 @@ def test_fused_tail_is_bit_identical(dataset, ways, shots, K, fo, tasks, fused1)
     assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).sum() > 0
 
 
-def test_train_and_validation_tasks_in_one_call():
+@pytest.mark.parametrize('K,grad_bar', [(1, 1e-4), (2, 1e-3)])
+def test_train_and_validation_tasks_in_one_call(K, grad_bar):
     """mi_meta_batch_maml_tv (reference maml_vision.py:102-124): 3 train + 2 validation tasks through the same launches against the
     two separate calls -- per-task losses / accuracies / logits of both halves, and the meta-gradient summed over the train tasks only.
-    (Not bit-identical: the launch geometry -- tiles per wave, weight-gradient chunks -- depends on the task count.)"""
-    ways, shots, K, lr = 5, 5, 2, 0.4
+    (Not bit-identical: the launch geometry -- tiles per wave, weight-gradient chunks, hence the fp32 partial-sum order -- is sized from
+    the whole launch; two inner steps amplify that rounding difference as in test_eval_only_and_batching_equivalence, same bar.)"""
+    ways, shots, lr = 5, 5, 0.4
     spec, mspec = _spec('min', ways)
     theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
     data, labels = synthetic.make_meta_batch('min', [3, 4, 5, 6, 7], ways, shots)
@@ -246,8 +248,8 @@ def test_train_and_validation_tasks_in_one_call():
     e_l = float(((loss - want_l).abs() / want_l.abs()).max())
     e_lg = rel_err(logits.cpu().numpy(), want_lg.cpu().numpy())
     e_g = rel_err(grad.cpu().numpy(), gt.cpu().numpy())
-    report('train_valid_one_call', loss_rel=e_l, logits_rel=e_lg, grad_rel=e_g)
-    assert e_l < 1e-5 and e_lg < 1e-5 and e_g < 1e-4 and torch.equal(acc, want_a)
+    report(f'train_valid_one_call[K{K}]', loss_rel=e_l, logits_rel=e_lg, grad_rel=e_g)
+    assert e_l < 1e-5 and e_lg < 1e-5 and e_g < grad_bar and torch.equal(acc, want_a)
     # the extremes are the plain calls
     l5, a5, g5, _ = eng.meta_batch(theta, d, l, shots, K, lr, grad_tasks=5)
     l5b, a5b, g5b, _ = eng.meta_batch(theta, d, l, shots, K, lr)
