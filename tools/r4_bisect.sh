@@ -1,5 +1,9 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4_b1
-timeout -k 10 600 python -m pytest tests/test_gpu_engine.py -q -x > gpurun_out/r4_b1/engine.log 2>&1; echo "engine rc=$?"
-tail -n 3 gpurun_out/r4_b1/engine.log
-timeout -k 10 300 python tools/t_sweep.py --workload cfg2 --tasks 1,4,32 --out gpurun_out/r4_b1/t_sweep.md > gpurun_out/r4_b1/t_sweep.log 2>&1; cat gpurun_out/r4_b1/t_sweep.md | tail -4
+O=gpurun_out/r4_b2; mkdir -p $O
+for D in 0 1 2 4 8 15; do
+  MI_ADV_DBG=$D timeout -k 10 200 python bench.py --workload cfg4 --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-dist --breakdown $O/bd_cfg4_$D.csv > $O/cfg4_$D.json 2> $O/cfg4_$D.err
+  echo "dbg=$D $(grep '^misc,2' $O/bd_cfg4_$D.csv) | $(python3 -c "import json;d=json.loads(open('$O/cfg4_$D.json').read().splitlines()[-1]);print(d['ms_per_step'])")"
+done
+timeout -k 10 200 python bench.py --tasks 4 --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-dist --breakdown $O/bd_cfg2_T4.csv > $O/cfg2_T4.json 2> $O/cfg2_T4.err
+timeout -k 10 200 python bench.py --tasks 1 --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-dist --breakdown $O/bd_cfg2_T1.csv > $O/cfg2_T1.json 2> $O/cfg2_T1.err
+head -30 $O/bd_cfg2_T4.csv
