@@ -24,15 +24,5 @@ __device__ __forceinline__ void bf16_split2(floatx2 v, unsigned& h, unsigned& m,
   const floatx2 q = {bf16_sub(r[0], __uint_as_float(m << 16)), bf16_sub(r[1], __uint_as_float(m & 0xffff0000u))};   // exact
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
 }
-// one value (the weight-plane producer of gram.hip: same roundings as bf16_split2, lane 0 of the pair)
-__device__ __forceinline__ void bf16_split1(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
-  unsigned hh, mm, ll;
-  bf16_split2(floatx2{x, 0.f}, hh, mm, ll);
-  h = (unsigned short)(hh & 0xffffu); m = (unsigned short)(mm & 0xffffu); l = (unsigned short)(ll & 0xffffu);
-}
-// Pre-split weight planes of one 32 -> 32 filter 3x3 block in the stride-1 kernel's LDS operand order (conv_mfma.hip): 16-byte unit
-// ((tap*2 + kb)*3 + plane)*64 + hb*32 + jj holds the 8 bf16 pieces k = hb*16 + kb*8 + 0..7 of output column jj.
-#define MI_WPL_UNITS (9 * 2 * 3 * 64)
-#define MI_WPL_BYTES (MI_WPL_UNITS * 16)
 #define MI_BF8(q) __builtin_bit_cast(bf16x8, (mi_u32x4{(q)[0], (q)[1], (q)[2], (q)[3]}))
 #define MI_BF_MFMA(x, y, acc) __builtin_amdgcn_mfma_f32_32x32x16_bf16(MI_BF8(x), MI_BF8(y), acc, 0, 0, 0)

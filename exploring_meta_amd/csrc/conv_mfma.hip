@@ -325,22 +325,6 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
     mi_u32x4* l4 = reinterpret_cast<mi_u32x4*>(lds);
     constexpr int NIT = NSTEP * 2 * 64, IPT = (NIT + NT - 1) / NT;   // items (8 weights of one output channel) per thread
     // all of a thread's loads first, then the splits: one memory latency per workgroup instead of one per item
-    // terms whose planes the producer of the weights already wrote in exactly this order (ConvArgs::wpl): a straight 16-byte copy
-    bool presplit[NTERMS], legacy = false;
-#pragma unroll
-    for (int term = 0; term < NTERMS; ++term) {
-      presplit[term] = CI == 32 && a.wpl[term] != nullptr;
-      legacy = legacy || !presplit[term];
-      if (presplit[term]) {
-        const mi_u32x4* src = reinterpret_cast<const mi_u32x4*>(a.wpl[term] + (size_t)task * a.wplstride);
-        mi_u32x4 v[(MI_WPL_UNITS + NT - 1) / NT];
-#pragma unroll
-        for (int q = 0; q < (MI_WPL_UNITS + NT - 1) / NT; ++q) { const int u = tid + q * NT; v[q] = src[u < MI_WPL_UNITS ? u : 0]; }
-#pragma unroll
-        for (int q = 0; q < (MI_WPL_UNITS + NT - 1) / NT; ++q) { const int u = tid + q * NT; if (u < MI_WPL_UNITS) l4[term * MI_WPL_UNITS + u] = v[q]; }
-      }
-    }
-    if (legacy) {                                   // (uniform: a kernel argument decides)
     floatx4 w0[IPT], w1[IPT];
 #pragma unroll
     for (int q = 0; q < IPT; ++q) {
@@ -349,7 +333,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
       const int jj = ln & 31, hb = ln >> 5, kb = grp & 1, stp = grp >> 1;
       const int cc = stp % NCC, tt = stp / NCC, term = tt / 9, tap = tt - term * 9;
       const int k0 = cc * 32 + hb * 16 + kb * 8;
-      const bool live = it < NIT && !presplit[term < NTERMS ? term : 0];
+      const bool live = it < NIT;
       const float* wsrc = a.wt[live ? term : 0] + (size_t)task * a.wstride;
       if (MODE == 0) {
         const float* src = wsrc + ((size_t)(live ? tap : 0) * CI + k0) * CO + cbase + jj;
@@ -364,8 +348,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
 #pragma unroll
     for (int q = 0; q < IPT; ++q) {
       const int it = tid + q * NT;
-      const int term_q = (it >> 7) / (9 * NCC);              // (it >> 6 = step*2 + kb, step = (term*9 + tap)*NCC + cc)
-      if (it < NIT && !presplit[term_q < NTERMS ? term_q : 0]) {
+      if (it < NIT) {
         const int ln = it & 63, grp = it >> 6;
         Bf16Planes pw;
         bf16_split8(w0[q], w1[q], pw);
@@ -373,7 +356,6 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
         l4[(grp * 3 + 1) * 64 + ln] = mi_u32x4{pw.m[0], pw.m[1], pw.m[2], pw.m[3]};
         l4[(grp * 3 + 2) * 64 + ln] = mi_u32x4{pw.l[0], pw.l[1], pw.l[2], pw.l[3]};
       }
-    }
     }
   }
 #pragma unroll 3

@@ -13,7 +13,6 @@
 #include "mi_common.h"
 #include "kernels.h"
 #include "../../include/mi_maml.h"
-#include "bf16_split.h"
 
 #define EPI_NONE 0
 #define EPI_STATS 1
@@ -141,29 +140,6 @@ static bool dgrad_carries_reduce(const mi_engine* e, int l) {
   if (!e->fuse_b1red || l < 1 || l >= (int)e->L.size()) return false;
   const Layer& L = e->L[l];
   return L.stride == 1 && L.ci == L.co && L.co == e->L[l - 1].co && L.h == L.ho && L.w == L.wo && (L.ci == 32 || L.ci == 64);
-}
-
-// Blocks whose weights the advance kernel also leaves as pre-split bf16 planes (the split-bf16 stride-1 kernels with 32 filters): slot
-// index among them, or -1.
-static int wpl_slot(const mi_engine* e, int l) {
-  int slot = 0;
-  for (int i = 1; i < (int)e->L.size(); ++i) {
-    const Layer& L = e->L[i];
-    const bool ok = L.stride == 1 && L.ci == 32 && L.co == 32 && L.h == L.ho && L.w == L.wo;
-    if (i == l) return (ok && slot < 6) ? slot : -1;
-    if (ok) ++slot;
-  }
-  return -1;
-}
-static int wpl_slots(const mi_engine* e) {
-  int n = 0;
-  for (int i = 1; i < (int)e->L.size(); ++i) if (wpl_slot(e, i) >= 0) ++n;
-  return n;
-}
-// plane set of block l inside a per-task record: mode 0 = forward, 1 = dgrad
-static const unsigned char* wpl_of(const mi_engine* e, const unsigned char* base, int l, int mode) {
-  const int slot = wpl_slot(e, l);
-  return (base && slot >= 0) ? base + ((size_t)slot * 2 + mode) * MI_WPL_BYTES : nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -412,12 +388,6 @@ struct Plan {
   float* wgpart;
   float* wgpart_side;   // partials of the weight gradients that run on the side stream
   float* wgpart_l[8];   // fused tail: one partial buffer per block (the folds wait for the pass's advance launch)
-  // fused tail: pre-split bf16 weight planes of the 32 -> 32 stride-1 blocks (bf16_split.h) of every theta_k and of the direction lam,
-  // written by the advance launches, [T][slot][fwd | dgrad][MI_WPL_BYTES]; cur_*: the sets the pass being issued reads (or nullptr)
-  std::vector<unsigned char*> wpl_theta;
-  unsigned char* wpl_dir = nullptr;
-  size_t wpl_stride = 0;
-  const unsigned char *cur_wpl_theta = nullptr, *cur_wpl_dir = nullptr;
   double *gram_part, *gram_s;   // input Gram matrix of the support images (block 1 statistics), or nullptr
   int half = 0;                 // stream context (engine SideCtx) this plan's side work uses
   float *tmp_loss, *tmp_acc;
@@ -504,13 +474,6 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   for (int l = 0; l < nl; ++l) {
     if (l == 0 && e->fuse1) { pl.wgpart_l[0] = pl.wgpart; continue; }     // block 1's sparse partials: consumed inside the same advance launch
     pl.wgpart_l[l] = b.take<float>(wgrad_partial_floats(geom(e->L[l], nmax), T));
-  }
-  pl.wpl_theta.clear();
-  pl.wpl_dir = nullptr;
-  pl.wpl_stride = (size_t)wpl_slots(e) * 2 * MI_WPL_BYTES;
-  if (e->fuse_tail && pl.wpl_stride) {
-    for (int k = 0; k <= K; ++k) pl.wpl_theta.push_back(b.take<unsigned char>((size_t)T * pl.wpl_stride));
-    if (second_order && K > 0) pl.wpl_dir = b.take<unsigned char>((size_t)T * pl.wpl_stride);
   }
   pl.gram_part = pl.gram_s = nullptr;
   if (e->fuse1 && e->gram1 && gram_supported(e->L[0].w, e->L[0].ci) && (K >= 2 || (K >= 1 && second_order))) {   // the support set is swept at least twice
@@ -613,7 +576,6 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
     ca.in[0] = l == 0 ? x0 : A.p[l - 1];
     ca.wt[0] = theta + L.off_w;
     ca.wstride = P;
-    ca.wpl[0] = wpl_of(e, pl.cur_wpl_theta, l, 0); ca.wplstride = pl.wpl_stride;
     ca.out = A.z[l];
     ca.partial = pl.bnpart;
     ca.g = geom(L, n);
@@ -724,7 +686,6 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       ca.in[0] = A.dz[l];
       ca.wt[0] = theta + L.off_w;
       ca.wstride = P;
-      ca.wpl[0] = wpl_of(e, pl.cur_wpl_theta, l, 1); ca.wplstride = pl.wpl_stride;
       ca.out = A.dp[l - 1];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
@@ -859,7 +820,6 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ca.wt[0] = v + L.off_w;
     if (l > 0) { ca.in[1] = X.pd[l - 1]; ca.wt[1] = theta + L.off_w; }
     ca.wstride = P;
-    ca.wpl[0] = wpl_of(e, pl.cur_wpl_dir, l, 0); ca.wpl[1] = wpl_of(e, pl.cur_wpl_theta, l, 0); ca.wplstride = pl.wpl_stride;
     ca.out = X.zd[l];
     ca.z = A.z[l]; ca.mu = A.mu[l]; ca.rstd = A.rstd[l];
     ca.partial = pl.bnpart;
@@ -982,7 +942,6 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       ca.in[0] = X.rdz[l]; ca.wt[0] = theta + L.off_w;
       ca.in[1] = A.dz[l]; ca.wt[1] = v + L.off_w;
       ca.wstride = P;
-      ca.wpl[0] = wpl_of(e, pl.cur_wpl_theta, l, 1); ca.wpl[1] = wpl_of(e, pl.cur_wpl_dir, l, 1); ca.wplstride = pl.wpl_stride;
       ca.out = X.dpd[cur ^ 1];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
@@ -1049,27 +1008,11 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
   if (pl.gram_s)
     LAUNCH(e, st, OP_GRAM, 0, launch_input_gram(st, pl.xs, T, ns, e->L[0].h, e->L[0].w, e->L[0].ci, pl.gram_part, pl.gram_s));
-  // where the pre-split weight planes of an advance launch's finished vector go (the split-bf16 convolutions' prologue copies them)
-  static const bool no_wpl = getenv("MI_NO_WPL") != nullptr;      // bisecting aid: fused tail without the pre-split weight planes
-  const bool planes = tail && !pl.wpl_theta.empty() && !no_wpl;
-  auto set_planes = [&](AdvanceArgs& a, unsigned char* dst) {
-    a.npl = 0; a.plstride = pl.wpl_stride;
-    if (!planes || !dst) return;
-    for (int l = 1; l < (int)e->L.size(); ++l) {
-      const int slot = wpl_slot(e, l);
-      if (slot < 0) continue;
-      a.pl[a.npl].off = (unsigned)e->L[l].off_w;
-      a.pl[a.npl].fwd = dst + ((size_t)slot * 2 + 0) * MI_WPL_BYTES;
-      a.pl[a.npl].bwd = dst + ((size_t)slot * 2 + 1) * MI_WPL_BYTES;
-      a.npl++;
-    }
-  };
   const bool stats0 = tail && pl.gram_s && K > 0;
-  if (planes || stats0) {   // theta_0: its weight planes and block 1's statistics of the first support pass (nothing folded, nothing written)
+  if (stats0) {   // block 1's statistics of the first support pass, from theta_0 (nothing folded, nothing written)
     AdvanceArgs a0 = advance_base(e, pl.theta);
     a0.nzero = 0;
-    if (stats0) { a0.stats = 1; a0.gram = pl.gram_s; a0.out0 = pl.sup[0].mu[0]; a0.out1 = pl.sup[0].rstd[0]; a0.inv_m = inv_m0; }
-    set_planes(a0, planes ? pl.wpl_theta[0] : nullptr);
+    a0.stats = 1; a0.gram = pl.gram_s; a0.out0 = pl.sup[0].mu[0]; a0.out1 = pl.sup[0].rstd[0]; a0.inv_m = inv_m0;
     LAUNCH(e, st, OP_MISC, 2, launch_advance(st, a0, T));
   }
   for (int k = 0; k < K; ++k) {
@@ -1077,13 +1020,11 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
     float* th = pl.theta + (size_t)k * TP;
     float* gk = pl.g + (size_t)k * TP;
     AdvanceArgs adv = advance_base(e, gk);
-    pl.cur_wpl_theta = planes ? pl.wpl_theta[k] : nullptr;
     int rc = pass_fwd_bwd(e, st, pl, A, pl.xs, pl.ys, ns, T, th, gk, pl.tmp_loss, pl.tmp_acc, nullptr, true, pl.gram_s, tail ? &adv : nullptr,
                           tail && pl.gram_s);
     if (rc) return rc;
-    if (tail) {   // g_k finished, theta_{k+1} = theta_k - lr g_k, its weight planes, and block 1's statistics of the next support pass
+    if (tail) {   // g_k finished, theta_{k+1} = theta_k - lr g_k, and block 1's statistics of the next support pass
       adv.a = th; adv.out = th + TP; adv.alpha = inner_lr;
-      set_planes(adv, planes ? pl.wpl_theta[k + 1] : nullptr);
       if (pl.gram_s && k + 1 < K) {
         ActSet& An = so ? pl.sup[k + 1] : pl.sup[0];
         adv.stats = 1; adv.gram = pl.gram_s; adv.out0 = An.mu[0]; adv.out1 = An.rstd[0]; adv.inv_m = inv_m0;
@@ -1095,7 +1036,6 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   }
   float* thK = pl.theta + (size_t)K * TP;
   AdvanceArgs advq = advance_base(e, pl.lam);
-  pl.cur_wpl_theta = planes ? pl.wpl_theta[K] : nullptr;
   int rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, nq, T, thK, pl.lam, loss_out, acc_out, logits_out, with_grad != 0, nullptr,
                         (tail && with_grad) ? &advq : nullptr, false, Tg);
   if (rc) return rc;
@@ -1112,22 +1052,18 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   };
   if (tail) {   // lam = grad L_query(theta_K) finished (folds only)
     if (so && K > 0 && pl.gram_s) tangent_stats(advq, K - 1);
-    set_planes(advq, (so && K > 0) ? pl.wpl_dir : nullptr);
     LAUNCH(e, st, OP_MISC, 2, launch_advance(st, advq, Tg));
   }
   if (so) {
     for (int k = K - 1; k >= 0; --k) {
       if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(2 * K + 1 + k) * TPr));
       AdvanceArgs adv = advance_base(e, pl.hv);
-      pl.cur_wpl_theta = planes ? pl.wpl_theta[k] : nullptr;
-      pl.cur_wpl_dir = planes ? pl.wpl_dir : nullptr;
       rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, Tg, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv, pl.gram_s, nullptr, nullptr,
                     tail ? &adv : nullptr, tail);
       if (rc) return rc;
       if (tail) {   // H lam finished, lam <- lam - lr H lam, and the tangent statistics of the next Hessian-vector pass
         adv.a = pl.lam; adv.out = pl.lam; adv.alpha = inner_lr;
         if (k > 0 && pl.gram_s) tangent_stats(adv, k - 1);
-        set_planes(adv, k > 0 ? pl.wpl_dir : nullptr);
         LAUNCH(e, st, OP_MISC, 2, launch_advance(st, adv, Tg));
         if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(3 * K + 1 + k) * TPr));
       } else {

@@ -12,7 +12,6 @@
 // the quadratic forms on the vector unit -- more accurate than summing fp32 conv outputs.
 #include "mi_common.h"
 #include "kernels.h"
-#include "bf16_split.h"
 
 typedef double doublex4 __attribute__((ext_vector_type(4)));
 
@@ -468,23 +467,13 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
 //   primal :  dW    = gr (S - dbm s - dgm Z)
 //   tangent:  R{dW} = S - (c1 dbm + gr rbm) s - (c1 dgm + gr rgm) Z - gr dgm Zd,   Zd = sum patch x zhatd = r (G wd - m1 s - m2 Z)
 // (dbm = dbeta/M, dgm = dgamma/M, rbm / rgm their tangents; S already carries c1 / gr in tangent mode.)
-// DEEP: 64 instead of 16 partial loads in flight per round (same order) -- for few-task calls, where a task's partials number up to 256
-template <bool DEEP = false>
 __device__ __forceinline__ float gram_wgrad_elem(const GramWgArgs& a, int ng, int kp, int tangent, int task, int k, int c) {
   const int co = a.co;
   const double* grow = a.g + (size_t)task * ng * ng + (size_t)k * ng;      // G[k][.]; G[k][kp] = s[k]
   const int e = k * co + c;
   double S = 0.0;
   const float* sp = a.spartial + (size_t)task * a.nblk * kp * co + e;
-  int b = 0;                                                                 // fixed order; 64 / 16 loads in flight per round
-  // (few tasks per call: the sparse kernel spreads a task over up to 256 workgroups, and a round of loads is one trip to memory)
-  for (; DEEP && b + 64 <= a.nblk; b += 64) {
-    float v[64];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) v[q] = sp[(size_t)(b + q) * kp * co];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) S += (double)v[q];
-  }
+  int b = 0;                                                                 // fixed order; 16 loads in flight per round
   for (; b + 16 <= a.nblk; b += 16) {
     float v[16];
 #pragma unroll
@@ -536,7 +525,6 @@ __global__ __launch_bounds__(64) void gram_wgrad_kernel(GramWgArgs a, int ng, in
 // out = a - alpha g.  Chunk 0 holds all of block 1's parameters (gamma, beta, 9*Ci0*Co weights, bias: at most 64 + 27*32 + 32 < 1024
 // for the nets this serves); it keeps its finished values in LDS and, after a barrier, forms the next pass's block-1 BatchNorm
 // statistics from them (gram_stats_body) -- nobody else touches those elements, so an in-place update (out == a) is safe.
-template <bool DEEP>
 __device__ __forceinline__ float advance_elem(const AdvanceArgs& a, int task, unsigned e, int ng, int kp) {
   float* g_t = a.g + (size_t)task * a.gstride;
   for (int z = 0; z < a.nzero; ++z)
@@ -548,13 +536,6 @@ __device__ __forceinline__ float advance_elem(const AdvanceArgs& a, int task, un
       const float* p = sg.partial + (size_t)task * sg.nchunks * sg.nelem + r;
       float s = 0.f;
       int c = 0;
-      for (; DEEP && c + 64 <= sg.nchunks; c += 64) {   // same order as reduce_partials_kernel, more loads in flight
-        float v[64];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) v[k] = p[(size_t)(c + k) * sg.nelem];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) s += v[k];
-      }
       for (; c + 16 <= sg.nchunks; c += 16) {           // same order as reduce_partials_kernel (16 loads in flight)
         float v[16];
 #pragma unroll
@@ -570,7 +551,7 @@ __device__ __forceinline__ float advance_elem(const AdvanceArgs& a, int task, un
   if (a.b1_wgrad) {
     const unsigned r = e - a.off_w1;
     if (r < (unsigned)(kp * a.co)) {
-      const float v = gram_wgrad_elem<DEEP>(a.gw, ng, kp, a.gw_tangent, task, (int)(r / (unsigned)a.co), (int)(r % (unsigned)a.co));
+      const float v = gram_wgrad_elem(a.gw, ng, kp, a.gw_tangent, task, (int)(r / (unsigned)a.co), (int)(r % (unsigned)a.co));
       g_t[e] = v;
       return v;
     }
@@ -578,7 +559,6 @@ __device__ __forceinline__ float advance_elem(const AdvanceArgs& a, int task, un
   return g_t[e];
 }
 
-template <bool DEEP>
 __global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a, int ng, int kp) {
   extern __shared__ double sm[];
   const int task = blockIdx.y, tid = threadIdx.x;
@@ -587,7 +567,7 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a, int ng, in
   float* loc = reinterpret_cast<float*>(sm);            // chunk 0 with statistics: the finished block-1 weights (or direction), as float
   const unsigned e = base + tid;
   float gv = 0.f;
-  if (e < a.n) gv = advance_elem<DEEP>(a, task, e, ng, kp);
+  if (e < a.n) gv = advance_elem(a, task, e, ng, kp);
   // Block 1's Gram assembly reads the direction's block-1 weights and gamma (GramWgArgs::wd, gammad) -- the very elements an in-place
   // update (out == a == the direction: lam <- lam - lr H lam) is about to overwrite, all of them owned by this chunk: every thread's
   // reads must be over before the first write.
@@ -599,22 +579,6 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a, int ng, in
       a.out[(size_t)task * a.ostride + e] = res;
     }
     if (with_stats) loc[e] = res;
-    // weight planes for the split-bf16 convolutions (bf16_split.h): element (tap, a, b) of a block's [9][32][32] weights is piece i of
-    // one 16-byte unit in the forward set (k = a, column b) and of one in the dgrad set (k = b, column a)
-    for (int q = 0; q < a.npl; ++q) {
-      const unsigned r = e - a.pl[q].off;
-      if (r < 9216u) {
-        unsigned short ph, pm, plo;
-        bf16_split1(res, ph, pm, plo);
-        const unsigned tap = r >> 10, aa = (r >> 5) & 31u, bb = r & 31u;
-        const unsigned uf = ((tap * 2 + ((aa >> 3) & 1u)) * 3) * 64 + (aa >> 4) * 32 + bb;      // forward: k = aa
-        const unsigned ub = ((tap * 2 + ((bb >> 3) & 1u)) * 3) * 64 + (bb >> 4) * 32 + aa;      // dgrad:   k = bb
-        unsigned short* f16 = reinterpret_cast<unsigned short*>(a.pl[q].fwd + (size_t)task * a.plstride) + (size_t)uf * 8 + (aa & 7u);
-        unsigned short* b16 = reinterpret_cast<unsigned short*>(a.pl[q].bwd + (size_t)task * a.plstride) + (size_t)ub * 8 + (bb & 7u);
-        f16[0] = ph; f16[64 * 8] = pm; f16[2 * 64 * 8] = plo;
-        b16[0] = ph; b16[64 * 8] = pm; b16[2 * 64 * 8] = plo;
-      }
-    }
   }
   if (!with_stats) return;                              // uniform per workgroup
   __syncthreads();
@@ -730,21 +694,17 @@ hipError_t launch_input_gram(hipStream_t st, const float* x, int tasks, int n, i
 
 hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a_in, int tasks) {
   AdvanceArgs a = a_in;
-  // timing experiments (wrong results): MI_ADV_DBG bit 0 = no weight planes, bit 1 = no Gram statistics, bit 2 = no Gram assembly of
-  // block 1's weight gradient, bit 3 = no weight-gradient folds
+  // timing experiments (wrong results): MI_ADV_DBG bit 1 = no Gram statistics, bit 2 = no Gram assembly of block 1's weight gradient,
+  // bit 3 = no weight-gradient folds
   static const int dbg = getenv("MI_ADV_DBG") ? atoi(getenv("MI_ADV_DBG")) : 0;
-  if (dbg & 1) a.npl = 0;
   if (dbg & 2) a.stats = 0;
   if (dbg & 4) a.b1_wgrad = 0;
   if (dbg & 8) a.nseg = 0;
   const int ng = a.ci ? gram_ng(a.ci) : 0, kp = 9 * a.ci;
   if ((a.stats || a.b1_wgrad) && (a.off_w1 + (unsigned)(kp * a.co) > 1024u || (a.ci != 1 && a.ci != 3))) return hipErrorInvalidValue;
-  if (a.nseg > 8 || a.nzero > 10 || a.npl > 6) return hipErrorInvalidValue;
+  if (a.nseg > 8 || a.nzero > 10) return hipErrorInvalidValue;
   const size_t smem = a.stats ? 4096 + ((size_t)ng * ng + (size_t)(a.stats == 2 ? 3 : 2) * kp * a.co) * sizeof(double) : 0;
-  bool deep = a.b1_wgrad && a.gw.nblk >= 64;
-  for (int q = 0; q < a.nseg; ++q) deep = deep || a.seg[q].nchunks >= 64;
-  if (deep) hipLaunchKernelGGL(advance_kernel<true>, dim3(ceil_div((int)a.n, 1024), tasks), dim3(1024), smem, st, a, ng, kp);
-  else hipLaunchKernelGGL(advance_kernel<false>, dim3(ceil_div((int)a.n, 1024), tasks), dim3(1024), smem, st, a, ng, kp);
+  hipLaunchKernelGGL(advance_kernel, dim3(ceil_div((int)a.n, 1024), tasks), dim3(1024), smem, st, a, ng, kp);
   return hipGetLastError();
 }
 

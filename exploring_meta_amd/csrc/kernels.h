@@ -22,11 +22,6 @@ struct ConvArgs {
   int mpix;             // n*ho*wo
   int ntiles, tiles_per_wave;
   int split_bf16;       // set by launch_conv3x3: this launch takes the split-bf16 form (30-pixel tiles)
-  // split-bf16 form, 32 filters: the term's weights already split into bf16 planes in LDS operand order (bf16_split.h, MI_WPL_BYTES per
-  // task and block; written by the advance kernel of gram.hip next to the vector itself) -- the prologue is then a straight copy instead
-  // of strided loads + splits in every workgroup.  nullptr: split in the prologue.  mode 0 takes the forward set, mode 1 the dgrad set.
-  const unsigned char* wpl[2];
-  size_t wplstride;     // bytes per task
 };
 
 struct WgradArgs {
@@ -173,10 +168,6 @@ struct AdvanceArgs {
   const float* sw; size_t swstride;          // stats == 2: the weights of the pass the statistics are for
   const float *mu_in, *rstd_in;              // stats == 2
   float *out0, *out1; double inv_m;          // mean / rstd  (stats == 2: m1 / m2), [T][co]
-  // weight planes of the finished vector (out, or g when out == nullptr) for the split-bf16 stride-1 convolutions: per eligible block
-  // its conv-weight offset and where its forward / dgrad plane sets go (per-task stride plstride bytes)
-  struct { unsigned off; unsigned char* fwd; unsigned char* bwd; } pl[6];
-  int npl; size_t plstride;
 };
 hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a, int tasks);
 
