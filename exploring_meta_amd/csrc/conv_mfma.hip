@@ -21,6 +21,7 @@
 #include "mi_common.h"
 #include "kernels.h"
 #include "bf16_split.h"
+#include "fold.h"
 
 // Ablation build (timing / energy experiment, wrong results, not shipped): -DMI_CONV_ABLATE_LOW compiles out the three products of a K
 // step that a two-plane operand form would not have (DESIGN.md 8c lead 5); build to another file name and select it with MI_MAML_LIB.
@@ -997,26 +998,28 @@ __global__ __launch_bounds__(256) void wgrad3x3_first_mfma_kernel(WgradArgs a) {
   }
 }
 
-// out[task*ostride + e] = sum_chunk partial[task][chunk][e]   (fixed order => deterministic)
+// out[task*ostride + e] = sum_chunk partial[task][chunk][e]   (fixed order => deterministic): the canonical fold of fold.h -- thread
+// (slice, element) adds its slice's rounds, the slices meet in LDS.  One slice up to 16 chunks (the plain sequential sum).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nchunks, int nelem,
-                                                              float* __restrict__ out, size_t ostride) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+                                                              float* __restrict__ out, size_t ostride, int S) {
+  __shared__ float part[256];
+  const int epw = 256 / S;
+  const int el = threadIdx.x % epw, sl = threadIdx.x / epw;
+  const int e = blockIdx.x * epw + el;
   const int task = blockIdx.y;
-  if (e >= nelem) return;
-  const float* p = partial + (size_t)task * nchunks * nelem + e;
-  float s = 0.f;
-  // same summation order as a plain loop, but 16 loads in flight: with few tasks per call the weight-gradient kernels leave 100+
-  // partials per task, and the loop the compiler made of `s += p[c * nelem]` waited for memory every few chunks (27 us for 128)
-  int c = 0;
-  for (; c + 16 <= nchunks; c += 16) {
-    float v[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(c + k) * nelem];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s += v[k];
+  float v = 0.f;
+  if (e < nelem) v = fold_slice<float>(partial + (size_t)task * nchunks * nelem + e, (size_t)nelem, nchunks, S, sl);
+  if (S == 1) {
+    if (e < nelem) out[(size_t)task * ostride + e] = v;
+    return;
   }
-  for (; c < nchunks; ++c) s += p[(size_t)c * nelem];
-  out[(size_t)task * ostride + e] = s;
+  part[threadIdx.x] = v;
+  __syncthreads();
+  if (sl == 0 && e < nelem) {
+    float t = part[el];
+    for (int q = 1; q < S; ++q) t += part[q * epw + el];
+    out[(size_t)task * ostride + e] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1371,8 +1374,9 @@ hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, i
 // dW[task] = sum over chunks of the wgrad partials, written at out + task*ostride (tap-major [9][ci][co]).
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* partial, int nchunks, int nelem, int tasks, float* out,
                                size_t ostride) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nelem, 256), tasks), dim3(256), 0, st, partial, nchunks, nelem, out,
-                     ostride);
+  const int S = fold_slices(nchunks);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(nelem, 256 / S), tasks), dim3(256), 0, st, partial, nchunks, nelem, out,
+                     ostride, S);
   return hipGetLastError();
 }
 

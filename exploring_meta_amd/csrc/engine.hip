@@ -379,6 +379,7 @@ struct TanSet {
 };
 struct Plan {
   float *theta, *g, *lam, *hv;
+  float* lam2;          // fused tail: the adjoint recursion ping-pongs between lam and lam2 (the advance launch must not update in place)
   float *xs, *xq;
   int32_t *ys, *yq;
   std::vector<ActSet> sup;
@@ -432,6 +433,7 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   pl.g = b.take<float>(TP * (K > 0 ? K : 1));
   pl.lam = b.take<float>(TP);
   pl.hv = b.take<float>(TP);
+  pl.lam2 = (second_order && K > 0) ? b.take<float>(TP) : nullptr;
   const size_t img = (size_t)e->d.in_h * e->d.in_w * e->d.in_channels;
   pl.xs = b.take<float>((size_t)T * ns * img);
   pl.xq = b.take<float>((size_t)T * nq * img);
@@ -974,6 +976,7 @@ static AdvanceArgs advance_base(const mi_engine* e, float* g) {
   a.off_w1 = (unsigned)e->L[0].off_w;
   a.ci = (e->L[0].ci == 1 || e->L[0].ci == 3) ? e->L[0].ci : 0;
   a.co = e->L[0].co;
+  a.counter = e->counters;
   return a;
 }
 
@@ -1001,8 +1004,7 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
     return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
   const size_t TP = (size_t)T * e->PS;
   const Layer& L0 = e->L[0];
-  // (chunk 0 of the advance kernel -- the first 1024 elements -- must own all of a fused block 1's parameters: 32 filters)
-  const bool tail = e->fuse_tail && e->PS >= 1024 && (!e->fuse1 || L0.off_w + (size_t)9 * L0.ci * L0.co <= 1024);
+  const bool tail = e->fuse_tail && e->counters && T <= mi_engine::kMaxCounterTasks && 1024 % L0.co == 0;
   const double inv_m0 = 1.0 / ((double)ns * L0.ho * L0.wo);
   LAUNCH(e, st, OP_MISC, 0, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
@@ -1054,21 +1056,24 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
     if (so && K > 0 && pl.gram_s) tangent_stats(advq, K - 1);
     LAUNCH(e, st, OP_MISC, 2, launch_advance(st, advq, Tg));
   }
+  float *lam_cur = pl.lam, *lam_nxt = pl.lam2;
   if (so) {
     for (int k = K - 1; k >= 0; --k) {
-      if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(2 * K + 1 + k) * TPr));
+      if (tr) HIPCHK(e, launch_scatter_tasks(st, lam_cur, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(2 * K + 1 + k) * TPr));
       AdvanceArgs adv = advance_base(e, pl.hv);
-      rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, Tg, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, pl.lam, pl.hv, pl.gram_s, nullptr, nullptr,
+      rc = pass_hvp(e, st, pl, pl.sup[k], pl.xs, ns, Tg, pl.theta + (size_t)k * TP, pl.g + (size_t)k * TP, lam_cur, pl.hv, pl.gram_s, nullptr, nullptr,
                     tail ? &adv : nullptr, tail);
       if (rc) return rc;
-      if (tail) {   // H lam finished, lam <- lam - lr H lam, and the tangent statistics of the next Hessian-vector pass
-        adv.a = pl.lam; adv.out = pl.lam; adv.alpha = inner_lr;
+      if (tail) {   // H lam finished, lam' = lam - lr H lam (into the other buffer: the row workgroups of the advance launch read lam's
+                    // block-1 entries while others write lam'), and the tangent statistics of the next Hessian-vector pass
+        adv.a = lam_cur; adv.out = lam_nxt; adv.alpha = inner_lr;
         if (k > 0 && pl.gram_s) tangent_stats(adv, k - 1);
         LAUNCH(e, st, OP_MISC, 2, launch_advance(st, adv, Tg));
+        float* t = lam_cur; lam_cur = lam_nxt; lam_nxt = t;
         if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(3 * K + 1 + k) * TPr));
       } else {
         if (tr) HIPCHK(e, launch_scatter_tasks(st, pl.hv, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(3 * K + 1 + k) * TPr));
-        LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, pl.lam, pl.hv, inner_lr, (size_t)Tg * e->PS, pl.lam));
+        LAUNCH(e, st, OP_MISC, 2, launch_axpy(st, lam_cur, pl.hv, inner_lr, (size_t)Tg * e->PS, lam_cur));
       }
     }
   }
@@ -1078,7 +1083,7 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
     for (int k = 0; k < K; ++k)
       HIPCHK(e, launch_scatter_tasks(st, pl.g + (size_t)k * TP, e->perm_dev, (int)e->P, (int)e->PS, T, e->trace + (size_t)(K + 1 + k) * TPr));
   }
-  LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, pl.lam, e->perm_dev, (int)e->P, (int)e->PS, Tg, meta_grad_out));
+  LAUNCH(e, st, OP_MISC, 3, launch_scatter_sum(st, lam_cur, e->perm_dev, (int)e->P, (int)e->PS, Tg, meta_grad_out));
   return MI_OK;
 }
 

@@ -12,6 +12,7 @@
 // the quadratic forms on the vector unit -- more accurate than summing fp32 conv outputs.
 #include "mi_common.h"
 #include "kernels.h"
+#include "fold.h"
 
 typedef double doublex4 __attribute__((ext_vector_type(4)));
 
@@ -467,21 +468,13 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
 //   primal :  dW    = gr (S - dbm s - dgm Z)
 //   tangent:  R{dW} = S - (c1 dbm + gr rbm) s - (c1 dgm + gr rgm) Z - gr dgm Zd,   Zd = sum patch x zhatd = r (G wd - m1 s - m2 Z)
 // (dbm = dbeta/M, dgm = dgamma/M, rbm / rgm their tangents; S already carries c1 / gr in tangent mode.)
-__device__ __forceinline__ float gram_wgrad_elem(const GramWgArgs& a, int ng, int kp, int tangent, int task, int k, int c) {
+// S = the element's folded sparse part (canonical fold of fold.h over the nblk workgroup partials, fp64)
+__device__ __forceinline__ const float* gram_wgrad_partials(const GramWgArgs& a, int kp, int task, int k, int c) {
+  return a.spartial + (size_t)task * a.nblk * kp * a.co + k * a.co + c;
+}
+__device__ __forceinline__ float gram_wgrad_elem(const GramWgArgs& a, int ng, int kp, int tangent, int task, int k, int c, double S) {
   const int co = a.co;
   const double* grow = a.g + (size_t)task * ng * ng + (size_t)k * ng;      // G[k][.]; G[k][kp] = s[k]
-  const int e = k * co + c;
-  double S = 0.0;
-  const float* sp = a.spartial + (size_t)task * a.nblk * kp * co + e;
-  int b = 0;                                                                 // fixed order; 16 loads in flight per round
-  for (; b + 16 <= a.nblk; b += 16) {
-    float v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = sp[(size_t)(b + q) * kp * co];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) S += (double)v[q];
-  }
-  for (; b < a.nblk; ++b) S += (double)sp[(size_t)b * kp * co];
   const float* wc = a.w + (size_t)task * a.wstride + c;
   const float* vc = tangent ? a.wd + (size_t)task * a.vstride + c : wc;
   double gw = 0.0, gwd = 0.0;
@@ -513,87 +506,142 @@ __device__ __forceinline__ float gram_wgrad_elem(const GramWgArgs& a, int ng, in
 __global__ __launch_bounds__(64) void gram_wgrad_kernel(GramWgArgs a, int ng, int kp, int tangent) {
   // one small workgroup per (task, patch entry k): thread = output channel
   const int task = blockIdx.x, k = blockIdx.y, co = a.co;
-  for (int c = threadIdx.x; c < co; c += 64)
-    a.out[(size_t)task * a.ostride + k * co + c] = gram_wgrad_elem(a, ng, kp, tangent, task, k, c);
+  for (int c = threadIdx.x; c < co; c += 64) {
+    const double S = fold_all<double>(gram_wgrad_partials(a, kp, task, k, c), (size_t)kp * co, a.nblk);
+    a.out[(size_t)task * a.ostride + k * co + c] = gram_wgrad_elem(a, ng, kp, tangent, task, k, c, S);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The tail of a pass as one launch (kernels.h, AdvanceArgs).  Grid (chunks of 1024 elements, tasks), 1024 threads: one element each (the
-// chunk that assembles block 1's weight gradient is the launch's critical path: 864 Gram-row dot products and partial folds).  Every element of
-// the task's gradient-shaped vector g is finished by the thread that owns it -- folded from weight-gradient partials in chunk order
-// (the order of reduce_partials_kernel), assembled from the Gram matrix (gram_wgrad_elem), zeroed, or simply read -- then
-// out = a - alpha g.  Chunk 0 holds all of block 1's parameters (gamma, beta, 9*Ci0*Co weights, bias: at most 64 + 27*32 + 32 < 1024
-// for the nets this serves); it keeps its finished values in LDS and, after a barrier, forms the next pass's block-1 BatchNorm
-// statistics from them (gram_stats_body) -- nobody else touches those elements, so an in-place update (out == a) is safe.
-__device__ __forceinline__ float advance_elem(const AdvanceArgs& a, int task, unsigned e, int ng, int kp) {
-  float* g_t = a.g + (size_t)task * a.gstride;
+// The tail of a pass as one launch (kernels.h, AdvanceArgs).  1024 threads per workgroup, grid (chunk workgroups + row workgroups, tasks).
+//   chunk workgroups: thread (slice, element) -- S = the launch's largest fold_slices() slices of 1024 / S elements.  Every element of the
+//     task's gradient-shaped vector g is finished: folded from weight-gradient partials (the canonical order of fold.h: the slices of an
+//     element meet in LDS), zeroed, or simply read; then out = a - alpha g.
+//   row workgroups (a.b1_wgrad): one per patch entry k of block 1 -- the Gram-matrix assembly of dW1[k][.] (gram_wgrad_elem), its sparse
+//     part folded by (slice, channel) threads in fp64.  The chunk workgroups skip those elements.
+//   Gram statistics of the next pass (a.stats): they need ALL of block 1's finished weights, which several workgroups produce -- those
+//     workgroups store them write-through, count their arrival (finalize.h protocol: acknowledged stores, barrier, one relaxed
+//     agent-scope add per workgroup) and the one that arrives last reads them back with agent-scope loads and runs gram_stats_body.
+// Because the row workgroups read the direction's block-1 entries (GramWgArgs::wd, gammad) that other workgroups update, the update must
+// not be in place when a.b1_wgrad is set: the engine ping-pongs lam between two buffers.
+struct AdvanceElem { int kind; float v; };   // kind 0: v is the value (g untouched), 1: v is the value and g must be written, 2: another workgroup owns it
+__device__ __forceinline__ AdvanceElem advance_classify(const AdvanceArgs& a, int task, unsigned e, int kp, int S, int sl, float* part, int epw, int el) {
+  const float* g_t = a.g + (size_t)task * a.gstride;
   for (int z = 0; z < a.nzero; ++z)
-    if (e - a.zoff[z] < a.zlen[z]) { g_t[e] = 0.f; return 0.f; }
+    if (e - a.zoff[z] < a.zlen[z]) return AdvanceElem{1, 0.f};
   for (int sgi = 0; sgi < a.nseg; ++sgi) {
     const AdvanceSeg& sg = a.seg[sgi];
     const unsigned r = e - sg.off;
     if (r < sg.nelem) {
-      const float* p = sg.partial + (size_t)task * sg.nchunks * sg.nelem + r;
-      float s = 0.f;
-      int c = 0;
-      for (; c + 16 <= sg.nchunks; c += 16) {           // same order as reduce_partials_kernel (16 loads in flight)
-        float v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(c + k) * sg.nelem];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += v[k];
-      }
-      for (; c < sg.nchunks; ++c) s += p[(size_t)c * sg.nelem];
-      g_t[e] = s;
-      return s;
+      const int Ss = fold_slices(sg.nchunks);
+      float v = 0.f;
+      if (sl < Ss) v = fold_slice<float>(sg.partial + (size_t)task * sg.nchunks * sg.nelem + r, (size_t)sg.nelem, sg.nchunks, Ss, sl);
+      if (Ss > 1) part[sl * epw + el] = v;
+      return AdvanceElem{Ss > 1 ? 3 + Ss : 1, v};          // kind > 3: the slices 0 .. kind - 4 sit in `part`
     }
   }
-  if (a.b1_wgrad) {
-    const unsigned r = e - a.off_w1;
-    if (r < (unsigned)(kp * a.co)) {
-      const float v = gram_wgrad_elem(a.gw, ng, kp, a.gw_tangent, task, (int)(r / (unsigned)a.co), (int)(r % (unsigned)a.co));
-      g_t[e] = v;
-      return v;
-    }
-  }
-  return g_t[e];
+  if (a.b1_wgrad && e - a.off_w1 < (unsigned)(kp * a.co)) return AdvanceElem{2, 0.f};
+  return AdvanceElem{0, sl == 0 ? g_t[e] : 0.f};
 }
 
-__global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a, int ng, int kp) {
+// arrival of one contributor of block 1's finished weights; true in the workgroup that arrived last (uniform per workgroup)
+__device__ __forceinline__ bool advance_arrive(unsigned* counter, unsigned arrivals, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's write-through stores are acknowledged (finalize.h)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (prev + 1u == arrivals);
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  const bool last = *flag != 0;
+  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return last;
+}
+
+__global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a, int ng, int kp, int S, int nchunk_wg, unsigned arrivals) {
   extern __shared__ double sm[];
   const int task = blockIdx.y, tid = threadIdx.x;
-  const unsigned base = blockIdx.x * 1024u;
-  const bool with_stats = a.stats != 0 && blockIdx.x == 0;
-  float* loc = reinterpret_cast<float*>(sm);            // chunk 0 with statistics: the finished block-1 weights (or direction), as float
-  const unsigned e = base + tid;
-  float gv = 0.f;
-  if (e < a.n) gv = advance_elem(a, task, e, ng, kp);
-  // Block 1's Gram assembly reads the direction's block-1 weights and gamma (GramWgArgs::wd, gammad) -- the very elements an in-place
-  // update (out == a == the direction: lam <- lam - lr H lam) is about to overwrite, all of them owned by this chunk: every thread's
-  // reads must be over before the first write.
-  if (blockIdx.x == 0 && a.b1_wgrad) __syncthreads();      // (uniform)
-  if (e < a.n) {
-    float res = gv;
-    if (a.out) {
-      res = a.a[(size_t)task * a.ostride + e] - a.alpha * gv;
-      a.out[(size_t)task * a.ostride + e] = res;
+  float* part = reinterpret_cast<float*>(sm);            // [S][epw] slice sums (4 KB); row workgroups: [slices][co] doubles
+  int* flag = reinterpret_cast<int*>(sm + 512);          // (byte 4096)
+  const unsigned w1_lo = a.off_w1, w1_n = (unsigned)(kp * a.co);
+  const float* res_t = (a.out ? a.out : a.g) + (size_t)task * (a.out ? a.ostride : a.gstride);    // where the finished vector lives
+  bool contributor = false;
+  if ((int)blockIdx.x < nchunk_wg) {
+    const int epw = 1024 / S, el = tid % epw, sl = tid / epw;
+    const unsigned e = blockIdx.x * (unsigned)epw + el;
+    AdvanceElem r{2, 0.f};
+    if (e < a.n) r = advance_classify(a, task, e, kp, S, sl, part, epw, el);
+    if (S > 1) __syncthreads();
+    if (sl == 0 && e < a.n && r.kind != 2) {
+      float gv = r.v;
+      if (r.kind > 3) {
+        gv = part[el];
+        for (int q = 1; q < r.kind - 3; ++q) gv += part[q * epw + el];
+      }
+      const bool in_w1 = a.stats && !a.b1_wgrad && e - w1_lo < w1_n;     // a contributor's element: must be visible to the last arriver
+      float* g_t = a.g + (size_t)task * a.gstride;
+      if (r.kind != 0) {
+        if (in_w1 && !a.out) __hip_atomic_store(g_t + e, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else g_t[e] = gv;
+      }
+      if (a.out) {
+        const float res = a.a[(size_t)task * a.ostride + e] - a.alpha * gv;
+        float* o = a.out + (size_t)task * a.ostride + e;
+        if (in_w1) __hip_atomic_store(o, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *o = res;
+      }
     }
-    if (with_stats) loc[e] = res;
+    // (uniform per workgroup) does this chunk hold any of block 1's weights while no row workgroups exist?
+    const unsigned lo = blockIdx.x * (unsigned)epw, hi = lo + (unsigned)epw;
+    contributor = a.stats && !a.b1_wgrad && lo < w1_lo + w1_n && hi > w1_lo;
+  } else {
+    // ---- row workgroup: dW1[k][.] of block 1 from the Gram matrix
+    const int k = blockIdx.x - nchunk_wg, co = a.co;
+    const int c = tid % co, sl = tid / co;
+    const int Sb = fold_slices(a.gw.nblk);
+    double* dpart = sm + 520;                              // [Sb][co] doubles (behind part / flag)
+    double sv = 0.0;
+    if (sl < Sb) sv = fold_slice<double>(gram_wgrad_partials(a.gw, kp, task, k, c), (size_t)kp * co, a.gw.nblk, Sb, sl);
+    if (Sb > 1) {
+      if (sl < Sb) dpart[sl * co + c] = sv;
+      __syncthreads();
+    }
+    if (sl == 0) {
+      double Ssum = Sb > 1 ? dpart[c] : sv;
+      for (int q = 1; q < Sb; ++q) Ssum += dpart[q * co + c];
+      const float gv = gram_wgrad_elem(a.gw, ng, kp, a.gw_tangent, task, k, c, Ssum);
+      const unsigned e = w1_lo + (unsigned)(k * co + c);
+      float* g_t = a.g + (size_t)task * a.gstride;
+      if (a.stats && !a.out) __hip_atomic_store(g_t + e, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else g_t[e] = gv;
+      if (a.out) {
+        const float res = a.a[(size_t)task * a.ostride + e] - a.alpha * gv;
+        float* o = a.out + (size_t)task * a.ostride + e;
+        if (a.stats) __hip_atomic_store(o, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *o = res;
+      }
+    }
+    contributor = a.stats != 0;
   }
-  if (!with_stats) return;                              // uniform per workgroup
-  __syncthreads();
+  if (!contributor) return;                                // uniform per workgroup
+  if (!advance_arrive(a.counter + task, arrivals, flag)) return;
+  // ---- last arriver: block 1's BatchNorm statistics of the next pass from the finished weights (or direction)
   const int co = a.co, tangent = a.stats == 2;
-  double* gs = sm + 512;                                // (the first 4 KB hold loc)
+  double* gs = sm + 520;
   double* ws = gs + ng * ng;
   double* vs = ws + kp * co;
   double* qd = vs + (tangent ? kp * co : 0);
+  __syncthreads();                                         // (dpart is dead)
   for (int e = tid; e < ng * ng; e += 1024) gs[e] = a.gram[(size_t)task * ng * ng + e];
   for (int e = tid; e < kp * co; e += 1024) {
+    const double fin = (double)__hip_atomic_load(res_t + w1_lo + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tangent) {
       ws[e] = (double)a.sw[(size_t)task * a.swstride + e];
-      vs[e] = (double)loc[a.off_w1 + e];
+      vs[e] = fin;
     } else {
-      ws[e] = (double)loc[a.off_w1 + e];
+      ws[e] = fin;
     }
   }
   __syncthreads();
@@ -701,10 +749,26 @@ hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a_in, int tasks) {
   if (dbg & 4) a.b1_wgrad = 0;
   if (dbg & 8) a.nseg = 0;
   const int ng = a.ci ? gram_ng(a.ci) : 0, kp = 9 * a.ci;
-  if ((a.stats || a.b1_wgrad) && (a.off_w1 + (unsigned)(kp * a.co) > 1024u || (a.ci != 1 && a.ci != 3))) return hipErrorInvalidValue;
+  if ((a.stats || a.b1_wgrad) && (a.ci != 1 && a.ci != 3)) return hipErrorInvalidValue;
   if (a.nseg > 8 || a.nzero > 10) return hipErrorInvalidValue;
-  const size_t smem = a.stats ? 4096 + ((size_t)ng * ng + (size_t)(a.stats == 2 ? 3 : 2) * kp * a.co) * sizeof(double) : 0;
-  hipLaunchKernelGGL(advance_kernel, dim3(ceil_div((int)a.n, 1024), tasks), dim3(1024), smem, st, a, ng, kp);
+  if (a.stats && !a.counter) return hipErrorInvalidValue;
+  if (a.b1_wgrad && a.out && a.out == a.a) return hipErrorInvalidValue;      // the row workgroups read what an in-place update overwrites
+  if ((a.stats || a.b1_wgrad) && (1024 % a.co != 0)) return hipErrorInvalidValue;
+  int S = 1;
+  for (int q = 0; q < a.nseg; ++q) { const int sq = fold_slices(a.seg[q].nchunks); if (sq > S) S = sq; }
+  const int epw = 1024 / S;
+  const int nchunk_wg = ceil_div((int)a.n, epw);
+  const int nrow_wg = a.b1_wgrad ? kp : 0;
+  unsigned arrivals = 0;
+  if (a.stats) {
+    if (a.b1_wgrad) arrivals = (unsigned)kp;
+    else arrivals = (unsigned)(ceil_div((int)a.off_w1 + kp * a.co, epw) - (int)a.off_w1 / epw);
+  }
+  // LDS: slice sums / flag (4096 + 64 B), then the row workgroups' fp64 slice sums and, in the last arriver, the statistics tables
+  size_t smem = 4160 + (size_t)8 * a.co * sizeof(double);
+  if (a.stats) smem = 4160 + ((size_t)ng * ng + (size_t)(a.stats == 2 ? 3 : 2) * kp * a.co) * sizeof(double);
+  if (smem < 4160 + (size_t)8 * a.co * sizeof(double)) smem = 4160 + (size_t)8 * a.co * sizeof(double);
+  hipLaunchKernelGGL(advance_kernel, dim3(nchunk_wg + nrow_wg, tasks), dim3(1024), smem, st, a, ng, kp, S, nchunk_wg, arrivals);
   return hipGetLastError();
 }
 

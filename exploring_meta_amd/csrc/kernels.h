@@ -168,6 +168,7 @@ struct AdvanceArgs {
   const float* sw; size_t swstride;          // stats == 2: the weights of the pass the statistics are for
   const float *mu_in, *rstd_in;              // stats == 2
   float *out0, *out1; double inv_m;          // mean / rstd  (stats == 2: m1 / m2), [T][co]
+  unsigned* counter;                         // stats != 0: one zero-initialised arrival counter per task (left at zero)
 };
 hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a, int tasks);
 
