@@ -1219,9 +1219,10 @@ static void rows_split(const ConvGeom& g, int tasks, int& rh, int& nunits, int& 
   const int nz = (g.ci / 32) * (g.co / 32);
   // Workgroups per task: the kernel keeps 9 x 16 accumulator registers, two workgroups per CU are resident (512 on the chip).  A
   // launch takes ceil(workgroups / 512) rounds of (units per workgroup + the LDS reduction epilogue, worth ~16 units) each: pick
-  // the split with the smallest product, never fewer than 8 units per wave.  (T = 32 tasks of 5 images: 16 workgroups per task =
+  // the split with the smallest product.  (T = 32 tasks of 5 images: 16 workgroups per task =
   // ONE round of 40 units instead of 20 = 1.25 rounds of 32.)
-  int max_bpt = ceil_div(nunits, 32);
+  // (never fewer than two units per wave on average; the 10x10 block's 250 units per task go to 16 workgroups at 32 tasks per call)
+  int max_bpt = ceil_div(nunits, 8);
   if (max_bpt > 128) max_bpt = 128;
   if (max_bpt < 1) max_bpt = 1;
   int best = 1;

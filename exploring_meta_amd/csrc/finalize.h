@@ -62,15 +62,15 @@ __device__ __forceinline__ void mi_fold_partials(const double* p, int nblk, int 
   const int slices = 256 / c, sl = t / c, ch = t - sl * c;
   double s = 0.0, q = 0.0;
   if (t < 256 && sl < slices) {
-    // four partials in flight per thread (the write-through loads miss every cache: ~1 us each if issued one by one), summed in
-    // the same order as a one-by-one loop
+    // eight partials in flight per thread (the write-through loads miss every cache: ~1 us each if issued one by one; a few-task launch
+    // leaves up to ~370 partials per task, 46 per thread), summed in the same order as a one-by-one loop
     const size_t step = (size_t)slices * 2 * c;
     const double* ps = p + (size_t)sl * 2 * c + ch;
     int b = sl;
-    for (; b + 3 * slices < nblk; b += 4 * slices, ps += 4 * step) {
-      double v0[4], v1[4];
+    for (; b + 7 * slices < nblk; b += 8 * slices, ps += 8 * step) {
+      double v0[8], v1[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         if (COHERENT) {
           v0[u] = __hip_atomic_load(ps + u * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           v1[u] = __hip_atomic_load(ps + u * step + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -80,7 +80,7 @@ __device__ __forceinline__ void mi_fold_partials(const double* p, int nblk, int 
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { s += v0[u]; q += v1[u]; }
+      for (int u = 0; u < 8; ++u) { s += v0[u]; q += v1[u]; }
     }
     for (; b < nblk; b += slices, ps += step) {
       if (COHERENT) {
