@@ -371,7 +371,7 @@ def run_vision(args, wl, rank, world, local, dist):
     fp32_pipe = None
     mask = C.c_uint(0)
     # (pooling nets only: the stride-1 hidden blocks are where the two operand forms differ; a bisecting run's variant mask is left alone)
-    if wl['dataset'] == 'min' and eng.lib.mi_conv_get_split_bf16(C.byref(mask)) and mask.value == 0x3ffff:
+    if wl['dataset'] == 'min' and not args.no_fp32_pipe and eng.lib.mi_conv_get_split_bf16(C.byref(mask)) and mask.value == 0x3ffff:
         eng.lib.mi_conv_set_split_bf16(0)
         n32 = max(3, min(5, args.steps))
         timed(2)
@@ -756,6 +756,7 @@ def main():
     ap.add_argument('--pool', type=int, default=8, help='distinct resident task batches the step loop rotates through (vision workloads)')
     ap.add_argument('--no-overlap', action='store_true', help='weight gradients on the main stream too (mi_engine_set_overlap(0)): per-launch '
                     'durations in a kernel trace are then those of kernels running alone')
+    ap.add_argument('--no-fp32-pipe', action='store_true', help='skip the fp32-pipe leg (counter passes: only the shipped operand form is launched)')
     ap.add_argument('--no-dist', action='store_true', help='N = 1 without the single-rank process group (profiler runs)')
     ap.add_argument('--launch-check', action='store_true', help='ranks only join the process group, all-reduce one number and rank 0 prints '
                     '{"launch_check": true, "world_size": N}: exercises the self-launch path without a GPU (MI_DIST_BACKEND=gloo)')

@@ -12,6 +12,7 @@
 // 16 more MFMAs per tile with one accumulator, no LDS traffic.
 #include "mi_common.h"
 #include "kernels.h"
+#include "bf16_split.h"
 
 struct Win4 { int n, wy, wx; };
 __device__ __forceinline__ Win4 win_advance(Win4 w, int delta, int hp, int wp) {   // delta < wp
@@ -321,8 +322,13 @@ template <> struct B1Vec<1> {
 //    float although their z differ then resolved by z instead of by position -- about one window per 10^6, each worth up to
 //    ~1e-3 of a task's block-1 weight gradient; 24 more VALU instructions per tile buy the exact rule);
 //  * this lane's 15 conv weights live in registers (no LDS at all), the first MFMA of a tile takes C = 0 as an inline constant.
-template <int CI0, bool ARG>
+//  * BF (three-channel inputs): the convolution on the split-bf16 operand form (bf16_split.h) -- the lane's 15 patch values and 15
+//    weights padded to 16, each the exact sum of three bf16 pieces, twelve v_mfma_f32_32x32x16_bf16 (two K steps x six products)
+//    instead of fifteen fp32-input MFMAs: a quarter of the matrix-pipe cycles for 72 more vector instructions per tile, which issue in
+//    the bf16 MFMAs' shadow instead of adding to their time (mi_conv_set_split_bf16 selects the form, as for the hidden blocks).
+template <int CI0, bool ARG, bool BF = false>
 __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
+  static_assert(!BF || CI0 == 3, "the split form packs a lane's 15 = 5 taps x 3 channels values into one K = 16 slab per lane half");
   constexpr int K = 9 * CI0, NTH = 5, KH = NTH * CI0;
   typedef typename B1Vec<CI0>::type xvec;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -340,6 +346,15 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
     for (int kk = 0; kk < KH; ++kk) {
       const int k = h * KH + kk;
       wreg[kk] = *(k < K ? w0 + (size_t)k * CO + ch : mi_zero_word);
+    }
+  }
+  // BF: the same 15 weights (+ a zero) as bf16 planes, pairs packed: registers 0..3 = K step 0 (slots 0..7), 4..7 = K step 1
+  unsigned wph[BF ? 8 : 1], wpm[BF ? 8 : 1], wpl[BF ? 8 : 1];
+  if constexpr (BF) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const floatx2 pr = {wreg[2 * q], (2 * q + 1 < KH) ? wreg[(2 * q + 1 < KH) ? 2 * q + 1 : 0] : 0.f};
+      bf16_split2(pr, wph[q], wpm[q], wpl[q]);
     }
   }
   // ---- per-channel constants
@@ -429,11 +444,34 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
     floatx16 z;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    if constexpr (BF) {
+      // the lane's 16 K slots: taps 5h .. 5h+4 x 3 channels, then a zero; split in pairs, six products per K step of 16 (small terms first,
+      // as in the hidden blocks' kernel)
+      unsigned xh[8], xm[8], xl[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i0 = 2 * q, i1 = 2 * q + 1;
+        const floatx2 pr = {B1Vec<CI0>::get(o.av[i0 / 3], i0 % 3), i1 < KH ? B1Vec<CI0>::get(o.av[(i1 < KH ? i1 : 0) / 3], (i1 < KH ? i1 : 0) % 3) : 0.f};
+        bf16_split2(pr, xh[q], xm[q], xl[q]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned* ah = xh + 4 * ks; const unsigned* am = xm + 4 * ks; const unsigned* al = xl + 4 * ks;
+        const unsigned* bh = wph + 4 * ks; const unsigned* bm = wpm + 4 * ks; const unsigned* bl = wpl + 4 * ks;
+        z = MI_BF_MFMA(al, bh, z);
+        z = MI_BF_MFMA(ah, bl, z);
+        z = MI_BF_MFMA(am, bm, z);
+        z = MI_BF_MFMA(am, bh, z);
+        z = MI_BF_MFMA(ah, bm, z);
+        z = MI_BF_MFMA(ah, bh, z);
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < NTH; ++t)
 #pragma unroll
       for (int c = 0; c < CI0; ++c)
         z = __builtin_amdgcn_mfma_f32_32x32x2f32(B1Vec<CI0>::get(o.av[t], c), wreg[t * CI0 + c], z, 0, 0, 0);
+    }
     // ---- epilogue: window 2g + h of the tile sits in registers 4g .. 4g + 3 (positions 0..3)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -490,6 +528,7 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+extern "C" int mi_conv_get_split_bf16(unsigned* mask_out);     // conv_mfma.hip: the operand form in force
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co) {
   return (ci == 1 || ci == 3) && stride == 1 && pool && (h % 2 == 0) && (w % 2 == 0) && (w / 2 >= 8) && (co % 32 == 0);
 }
@@ -533,7 +572,10 @@ hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, 
   // tasks -- more than ~198 84x84x3 images per task -- fall back to the general kernel)
   const size_t x_task_bytes = (size_t)a.n * a.hh * a.ww * ci * 4, p_task_bytes = (size_t)a.n * (a.hh / 2) * (a.ww / 2) * a.co * 4;
   if (!force_general && (mode == B1_FWD || mode == B1_TFWD_ARG) && x_task_bytes < (1u << 24) && p_task_bytes < MI_OOB) {
-    if (ci == 3) {
+    if (ci == 3 && mi_conv_get_split_bf16(nullptr) && !getenv("MI_B1_FP32")) {     // (MI_B1_FP32: A/B aid, the fp32 pipe for block 1 only)
+      if (mode == B1_FWD) hipLaunchKernelGGL((block1_fwd_kernel<3, false, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((block1_fwd_kernel<3, true, true>), grid, dim3(256), 0, st, a);
+    } else if (ci == 3) {
       if (mode == B1_FWD) hipLaunchKernelGGL((block1_fwd_kernel<3, false>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((block1_fwd_kernel<3, true>), grid, dim3(256), 0, st, a);
     } else if (ci == 1) {

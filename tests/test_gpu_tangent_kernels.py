@@ -343,18 +343,32 @@ def test_block1_kernels(lib, name, T, n, h, w, ci, co, check):
     run(4, out0=m1, out1=m2, ostride=co)                                          # TSTATS
     run(5, p_out=pd, zh_out=zhdm)                                                 # TFWD
     run(8, p_out=pd2, zh_out=zhdm2)                                               # TFWD_ARG
-    # modes 1 and 8 ran through the lean block1_fwd_kernel; the general block1_kernel (fallback for very large tasks) must agree bit
-    # for bit: pooled values, zhat at the argmax and the argmax byte itself (both take the FIRST maximum of u, the reference's rule)
+    # modes 1 and 8 ran through the lean block1_fwd_kernel; the general block1_kernel (fallback for very large tasks) takes the FIRST
+    # maximum of u as well (the reference's rule).  With the fp32 operand form the two agree bit for bit: pooled values, zhat at the
+    # argmax and the argmax byte.  With the split-bf16 form (three-channel inputs, the default) the lean kernel's conv1 is the six-product
+    # bf16 sum -- fp32-equivalent, not bit-identical -- so values agree to rounding and the argmax wherever the window's two largest u are
+    # not tied to the last bits.
     p_g, zh_g, pd_g, zhd_g = (f32(T, n, hp, wp, co) for _ in range(4))
     arg_g = torch.full((T, n, hp, wp, co), 255, dtype=torch.uint8, device='cuda')
     run(1 | 0x100, p_out=p_g, zh_out=zh_g, arg_out=arg_g)
     torch.cuda.synchronize()
-    assert torch.equal(p_g, p)
-    assert torch.equal(arg_g, arg) and torch.equal(zh_g, zhm)
+    bf_lean = bool(lib.mi_conv_get_split_bf16(None)) and ci == 3
     arg_keep = arg.clone()
+    if not bf_lean:
+        assert torch.equal(p_g, p)
+        assert torch.equal(arg_g, arg) and torch.equal(zh_g, zhm)
+    else:
+        same_g = arg_g == arg
+        assert float(same_g.float().mean()) > 0.9999
+        assert float((p_g - p).abs().max()) < 2e-5 and float((zh_g - zhm).abs()[same_g].max()) < 2e-5
     run(8 | 0x100, p_out=pd_g, zh_out=zhd_g)
     torch.cuda.synchronize()
-    assert torch.allclose(pd_g, pd2, rtol=0, atol=0) and torch.equal(zhd_g, zhdm2) and torch.equal(arg, arg_keep)
+    assert torch.equal(arg, arg_keep)
+    if not bf_lean:
+        assert torch.allclose(pd_g, pd2, rtol=0, atol=0) and torch.equal(zhd_g, zhdm2)
+    else:                                                       # both read the stored argmax: only the conv's rounding differs
+        sc_pd = float(pd2.abs().max())
+        assert float((pd_g - pd2).abs().max()) < 1e-5 * max(1.0, sc_pd) and float((zhd_g - zhdm2).abs().max()) < 1e-5 * max(1.0, float(zhdm2.abs().max()))
     run(6, out0=hb, out1=hb[:, co:], ostride=gstride)                             # TBWD_REDUCE
     run(7, out0=hb[:, 2 * co:], ostride=gstride)                                  # TBWD_WGRAD
     # pooled-resolution reductions and the Gram-matrix weight gradient (the path the engine takes by default)
@@ -500,7 +514,10 @@ def test_block1_argmax_byte_follows_the_reference_tie_rule_on_plateau_inputs(lib
         _lib.check(lib.mi_block1_run(stream(), mode, C.byref(a), ptr(p), ptr(zh), ptr(arg), None, None, 0, ptr(scratch), sb))
         torch.cuda.synchronize()
         res[tag] = arg.cpu().long()
-    assert torch.equal(res['lean'], res['general'])
+    if not bool(lib.mi_conv_get_split_bf16(None)):
+        assert torch.equal(res['lean'], res['general'])
+    else:      # split-bf16 conv1 in the lean kernel: the two agree except where a window's two largest u are tied to the last bits
+        assert float((res['lean'] != res['general']).double().mean()) < 1e-4
     got = res['lean']
     n_tied = n_near = n_bad = 0
     for t in range(T):

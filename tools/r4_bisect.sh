@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4_b5; mkdir -p $O
-timeout -k 10 900 python -m pytest tests -q -x -m gpu > $O/tests.log 2>&1; echo "tests rc=$?"
-tail -n 3 $O/tests.log
-timeout -k 10 300 python tools/t_sweep.py --workload cfg2 --tasks 1,2,4,8,16,32 --out $O/t_sweep.md > $O/t_sweep.log 2>&1; cat $O/t_sweep.md | tail -7
-for T in 1 4; do
-timeout -k 10 200 python bench.py --tasks $T --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-dist --breakdown $O/bd_cfg2_T$T.csv > $O/cfg2_T$T.json 2> $O/cfg2_T$T.err
-done
-timeout -k 10 200 python bench.py --workload cfg4 --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-dist --breakdown $O/bd_cfg4.csv > $O/cfg4.json 2> $O/cfg4.err
-python3 -c "import json;d=json.loads(open('$O/cfg4.json').read().splitlines()[-1]);print('cfg4', d['ms_per_step'])"
+O=gpurun_out/r4_b6; mkdir -p $O
+timeout -k 10 900 python -m pytest tests/test_gpu_tangent_kernels.py tests/test_gpu_engine.py tests/test_gpu_kernels.py -q -x > $O/tests_a.log 2>&1; echo "tests_a rc=$?"; tail -n 2 $O/tests_a.log
+for rep in 1 2; do for B in 0 1; do
+  if [ $B = 1 ]; then export MI_B1_FP32=1; else unset MI_B1_FP32; fi
+  timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --breakdown $O/bd_b1fp32_$B.csv > $O/cfg2_b1fp32_$B.json 2> $O/err.txt
+  echo "rep=$rep b1_fp32=$B $(python3 -c "import json;d=json.loads(open('$O/cfg2_b1fp32_$B.json').read().splitlines()[-1]);print(d['ms_per_step'])") $(grep -E '^bn_relu_pool_fwd,0|^bn_tangent_fwd,0' $O/bd_b1fp32_$B.csv | tr '\n' ' ')"
+done; done
+unset MI_B1_FP32
+timeout -k 10 1000 python -m pytest tests -q -x -m gpu > $O/tests_all.log 2>&1; echo "tests_all rc=$?"; tail -n 3 $O/tests_all.log
