@@ -323,8 +323,8 @@ template <> struct B1Vec<1> {
 //    ~1e-3 of a task's block-1 weight gradient; 24 more VALU instructions per tile buy the exact rule);
 //  * this lane's 15 conv weights live in registers (no LDS at all), the first MFMA of a tile takes C = 0 as an inline constant.
 //  * BF (three-channel inputs): the convolution on the split-bf16 operand form (bf16_split.h) -- the lane's 15 patch values and 15
-//    weights padded to 16, each the exact sum of three bf16 pieces, twelve v_mfma_f32_32x32x16_bf16 (two K steps x six products)
-//    instead of fifteen fp32-input MFMAs: a quarter of the matrix-pipe cycles for 72 more vector instructions per tile, which issue in
+//    weights padded to 16, each the exact sum of three bf16 pieces, sixteen v_mfma_f32_32x32x16_bf16 (two K steps x eight products:
+//    every cross term down to 2^-24 kept) instead of fifteen fp32-input MFMAs: half of the matrix-pipe cycles for 72 more vector instructions per tile, which issue in
 //    the bf16 MFMAs' shadow instead of adding to their time (mi_conv_set_split_bf16 selects the form, as for the hidden blocks).
 template <int CI0, bool ARG, bool BF = false>
 __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
@@ -348,12 +348,17 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
       wreg[kk] = *(k < K ? w0 + (size_t)k * CO + ch : mi_zero_word);
     }
   }
-  // BF: the same 15 weights (+ a zero) as bf16 planes, pairs packed: registers 0..3 = K step 0 (slots 0..7), 4..7 = K step 1
+  // BF: the same 15 weights (+ slot 15) as bf16 planes, pairs packed: registers 0..3 = K step 0 (slots 0..7), 4..7 = K step 1.
+  // FWD folds the BatchNorm normalisation into the product: the weights are scaled by rstd and slot 15 -- a constant 1 on the patch
+  // side, -mu * rstd on the weight side of lane half 0 -- carries the shift, so the accumulators ARE zhat = (z - mu) * rstd (to fp32
+  // rounding) and the epilogue's two instructions per position that formed it are gone (32 of ~220 per tile).
   unsigned wph[BF ? 8 : 1], wpm[BF ? 8 : 1], wpl[BF ? 8 : 1];
   if constexpr (BF) {
+    const float wscale = ARG ? 1.f : a.rstd[(size_t)task * CO + ch];
+    const float w15 = (ARG || h != 0) ? 0.f : -(a.mu[(size_t)task * CO + ch] * wscale);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const floatx2 pr = {wreg[2 * q], (2 * q + 1 < KH) ? wreg[(2 * q + 1 < KH) ? 2 * q + 1 : 0] : 0.f};
+      const floatx2 pr = {wreg[2 * q] * wscale, (2 * q + 1 < KH) ? wreg[(2 * q + 1 < KH) ? 2 * q + 1 : 0] * wscale : w15};
       bf16_split2(pr, wph[q], wpm[q], wpl[q]);
     }
   }
@@ -451,13 +456,20 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int i0 = 2 * q, i1 = 2 * q + 1;
-        const floatx2 pr = {B1Vec<CI0>::get(o.av[i0 / 3], i0 % 3), i1 < KH ? B1Vec<CI0>::get(o.av[(i1 < KH ? i1 : 0) / 3], (i1 < KH ? i1 : 0) % 3) : 0.f};
+        const floatx2 pr = {B1Vec<CI0>::get(o.av[i0 / 3], i0 % 3), i1 < KH ? B1Vec<CI0>::get(o.av[(i1 < KH ? i1 : 0) / 3], (i1 < KH ? i1 : 0) % 3) : 1.f};   // slot 15: the constant 1 (FWD's shift; ARG's weight there is 0)
         bf16_split2(pr, xh[q], xm[q], xl[q]);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const unsigned* ah = xh + 4 * ks; const unsigned* am = xm + 4 * ks; const unsigned* al = xl + 4 * ks;
         const unsigned* bh = wph + 4 * ks; const unsigned* bm = wpm + 4 * ks; const unsigned* bl = wpl + 4 * ks;
+        // EIGHT products here, not the hidden blocks' six: the two 2^-24 cross terms (m x l) stay in.  Conv1's inputs are raw pixels
+        // (0..255: the channel mean of z is many times its deviation), so a dropped 2^-24 of every product is 2^-24 of a partial sum several
+        // times larger than zhat -- measurable in which near-tied pooling decisions flip (teacher-forced margins up to ~5e-6 with six
+        // products against 1.4e-6 with the fp32 pipe); with eight the only dropped term is l x l (2^-32) and the matrix pipe still has
+        // 16 x 32 cycles per tile against the vector unit's ~750
+        z = MI_BF_MFMA(al, bm, z);
+        z = MI_BF_MFMA(am, bl, z);
         z = MI_BF_MFMA(al, bh, z);
         z = MI_BF_MFMA(ah, bl, z);
         z = MI_BF_MFMA(am, bm, z);
@@ -490,16 +502,17 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
         // positions whose u round to the same float resolve by position even when their z differ.  "uq > u" is taken as the sign
         // of u - uq (the difference of two finite floats is exact near a tie, so it is negative exactly when uq > u) and the three
         // selects are v_bfi_b32 on that lane mask (mi_common.h lane_select)
-        float zh_at = bn_zh(z[4 * g], mu, rs);
+        float zh_at = BF ? z[4 * g] : bn_zh(z[4 * g], mu, rs);            // (BF: the accumulators already hold zhat)
         float u = bn_u(zh_at, gm, bt);
         unsigned arg = 0u;
 #pragma unroll
         for (int q = 1; q < 4; ++q) {
-          const float zq = bn_zh(z[4 * g + q], mu, rs);
+          const float zq = BF ? z[4 * g + q] : bn_zh(z[4 * g + q], mu, rs);
           const float uq = bn_u(zq, gm, bt);
           const int gt = lane_mask_negative(u - uq);
           u = lane_select_valu(gt, uq, u);                           // (operands: bn_u / bn_zh results, never the accumulators themselves)
-          zh_at = lane_select_valu(gt, zq, zh_at);
+          // (BF: zq / zh_at are matrix results -- the merge must stay visible to the hazard recogniser: the C form, not the assembly one)
+          zh_at = BF ? lane_select(gt, zq, zh_at) : lane_select_valu(gt, zq, zh_at);
           arg = lane_select_valu(gt, (unsigned)q, arg);
         }
         const float p = fmaxf(u, 0.f);                               // +0 (all bits clear) exactly when the ReLU is off
@@ -528,7 +541,24 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-extern "C" int mi_conv_get_split_bf16(unsigned* mask_out);     // conv_mfma.hip: the operand form in force
+// Operand form of the two lean forward kernels' conv1 (three-channel inputs): 0 (default) = the fp32 matrix pipe, bit-identical to the
+// general block-1 kernel; 1 = split bf16, eight products (mi_block1_set_split_bf16 / MI_B1_BF16X3=1).  Measured on one box at cfg2's
+// size: bn_relu_pool_fwd 0.156 -> 0.139 ms, bn_tangent_fwd 0.147 -> 0.133 ms per launch, the meta-iteration within the run-to-run
+// spread either way (16.45 / 16.36 and 16.60 / 16.79 ms in two A/B pairs: the workload sits at the socket power cap) -- and every change
+// of conv1's rounding redraws which near-tied pooling decisions flip, so the default stays on the form the parity tables were taken with.
+static int g_b1_split = -1;
+static bool block1_split_bf16() {
+  if (g_b1_split < 0) {
+    const char* e = getenv("MI_B1_BF16X3");
+    g_b1_split = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return g_b1_split != 0;
+}
+extern "C" int mi_block1_set_split_bf16(int on) {
+  const int was = block1_split_bf16() ? 1 : 0;
+  g_b1_split = on ? 1 : 0;
+  return was;
+}
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co) {
   return (ci == 1 || ci == 3) && stride == 1 && pool && (h % 2 == 0) && (w % 2 == 0) && (w / 2 >= 8) && (co % 32 == 0);
 }
@@ -572,7 +602,7 @@ hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, 
   // tasks -- more than ~198 84x84x3 images per task -- fall back to the general kernel)
   const size_t x_task_bytes = (size_t)a.n * a.hh * a.ww * ci * 4, p_task_bytes = (size_t)a.n * (a.hh / 2) * (a.ww / 2) * a.co * 4;
   if (!force_general && (mode == B1_FWD || mode == B1_TFWD_ARG) && x_task_bytes < (1u << 24) && p_task_bytes < MI_OOB) {
-    if (ci == 3 && mi_conv_get_split_bf16(nullptr) && !getenv("MI_B1_FP32")) {     // (MI_B1_FP32: A/B aid, the fp32 pipe for block 1 only)
+    if (ci == 3 && block1_split_bf16()) {
       if (mode == B1_FWD) hipLaunchKernelGGL((block1_fwd_kernel<3, false, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((block1_fwd_kernel<3, true, true>), grid, dim3(256), 0, st, a);
     } else if (ci == 3) {

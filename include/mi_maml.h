@@ -411,6 +411,12 @@ int mi_conv_set_split_bf16(int on);
 /* The operand form in force (1 split-bf16, 0 fp32 matrix pipe) read without side effects; mask_out (may be NULL) receives the variant
  * mask a bisecting run set through MI_CONV_BF16X3_MASK / mi_conv_set_split_bf16(0x100 * mask + 1). */
 int mi_conv_get_split_bf16(unsigned* mask_out);
+/* Operand form of conv1 inside the two lean block-1 forward kernels (ConvBlock 1 of a three-channel net: conv + BatchNorm + ReLU + pool
+ * with the conv output never stored, and its tangent from the stored argmax; reference core_functions/vision_models.py:188-193).
+ * 0 (default; MI_B1_BF16X3=1 starts with 1): the fp32 matrix pipe, bit-identical to the general block-1 kernel.  1: split bf16 with all
+ * eight products down to 2^-24 (raw-pixel inputs: the six-product form of the hidden blocks is measurably noisier here) and the
+ * BatchNorm normalisation folded into the product.  Returns the previous setting. */
+int mi_block1_set_split_bf16(int on);
 
 /* ANIL-TRPO (rl/anil_trpo.py:104-129, core_functions/rl.py:409-473 with anil=True): the stored old policies were adapted with
  * the body under no_grad (rl.py:381-382) while meta_surrogate_loss re-adapts clone_module(policy) with every parameter

@@ -264,10 +264,7 @@ def test_cfg3_anil_T32_batched_looped_oracle():
            vs_oracle_loss_rel=max(lo), flipped_decisions=len(margins), largest_flipped_margin=max(margins) if margins else 0.0)
     # batched vs looped: identical arithmetic per task (measured 1e-7)
     assert max(el) < 1e-5 and e_sum < 1e-4
-    # (raw figures are draws of the ~2 near-tied decisions a task's single backward pass holds -- each worth 1e-4 .. 1e-3 of its trunk
-    # gradient -- and every change of a kernel's rounding redraws them: median of the nine tasks 6.8e-5 with fp32-pipe block-1 kernels,
-    # 1.02e-4 with their split-bf16 form.  The statement that cannot be met by luck is the adjusted one below.)
-    assert max(lo) < 1e-4 and e64.max() < RAW_MAX and e32.max() < RAW_MAX and np.median(np.minimum(e64, e32)) < 3e-4
+    assert max(lo) < 1e-4 and e64.max() < RAW_MAX and e32.max() < RAW_MAX and np.median(np.minimum(e64, e32)) < 1e-4
     assert ex.max() < ADJ_G and all(m < TF.TAU for m in margins), sorted(ex)[-4:]
     assert all(float(acc[r['t']]) == r['acc64'] for r in res)
 

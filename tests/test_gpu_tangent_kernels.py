@@ -19,11 +19,14 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope='module', params=['split_bf16', 'fp32_pipe'])
 def lib(request):
-    """Every case runs with both operand forms of the 32-channel stride-1 convolutions (mi_conv_set_split_bf16): same bars."""
+    """Every case runs with both operand forms of the 32-channel stride-1 convolutions (mi_conv_set_split_bf16) -- and, with them, of the
+    lean block-1 forward kernels' conv1 (mi_block1_set_split_bf16, off by default in the engine): same bars."""
     lb = _lib.load()
     was = lb.mi_conv_set_split_bf16(1 if request.param == 'split_bf16' else 0)
+    was1 = lb.mi_block1_set_split_bf16(1 if request.param == 'split_bf16' else 0)
     yield lb
     lb.mi_conv_set_split_bf16(was)
+    lb.mi_block1_set_split_bf16(was1)
 
 
 def _rand(seed, shape, lo=-1.0, hi=1.0):
@@ -352,7 +355,7 @@ def test_block1_kernels(lib, name, T, n, h, w, ci, co, check):
     arg_g = torch.full((T, n, hp, wp, co), 255, dtype=torch.uint8, device='cuda')
     run(1 | 0x100, p_out=p_g, zh_out=zh_g, arg_out=arg_g)
     torch.cuda.synchronize()
-    bf_lean = bool(lib.mi_conv_get_split_bf16(None)) and ci == 3
+    bf_lean = bool(lib.mi_conv_get_split_bf16(None)) and ci == 3          # (the fixture switches the block-1 form together with the hidden blocks')
     arg_keep = arg.clone()
     if not bf_lean:
         assert torch.equal(p_g, p)
