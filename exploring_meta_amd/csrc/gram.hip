@@ -517,8 +517,8 @@ __global__ __launch_bounds__(64) void gram_wgrad_kernel(GramWgArgs a, int ng, in
 //   chunk workgroups: thread (slice, element) -- S = the launch's largest fold_slices() slices of 1024 / S elements.  Every element of the
 //     task's gradient-shaped vector g is finished: folded from weight-gradient partials (the canonical order of fold.h: the slices of an
 //     element meet in LDS), zeroed, or simply read; then out = a - alpha g.
-//   row workgroups (a.b1_wgrad): one per patch entry k of block 1 -- the Gram-matrix assembly of dW1[k][.] (gram_wgrad_elem), its sparse
-//     part folded by (slice, channel) threads in fp64.  The chunk workgroups skip those elements.
+//   row workgroups (a.b1_wgrad): the Gram-matrix assembly of block 1's dW1[k][.] (gram_wgrad_elem), thread (row k, slice, channel), the
+//     sparse part folded in fp64 -- a workgroup takes 1024 / (co * slices) rows.  The chunk workgroups skip those elements.
 //   Gram statistics of the next pass (a.stats): they need ALL of block 1's finished weights, which several workgroups produce -- those
 //     workgroups store them write-through, count their arrival (finalize.h protocol: acknowledged stores, barrier, one relaxed
 //     agent-scope add per workgroup) and the one that arrives last reads them back with agent-scope loads and runs gram_stats_body.
@@ -597,20 +597,24 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a, int ng, in
     const unsigned lo = blockIdx.x * (unsigned)epw, hi = lo + (unsigned)epw;
     contributor = a.stats && !a.b1_wgrad && lo < w1_lo + w1_n && hi > w1_lo;
   } else {
-    // ---- row workgroup: dW1[k][.] of block 1 from the Gram matrix
-    const int k = blockIdx.x - nchunk_wg, co = a.co;
-    const int c = tid % co, sl = tid / co;
+    // ---- row workgroup: rows k of dW1[k][.] of block 1 from the Gram matrix -- 1024 / (co * Sb) rows per workgroup, thread
+    // (row, slice, channel): two workgroups per task at 32 tasks per call (2 slices), seven at 4 tasks or fewer (8 slices)
+    const int co = a.co;
     const int Sb = fold_slices(a.gw.nblk);
-    double* dpart = sm + 520;                              // [Sb][co] doubles (behind part / flag)
+    const int rpw = 1024 / (co * Sb);
+    const int c = tid % co, sl = (tid / co) % Sb, rl = tid / (co * Sb);
+    const int k = ((int)blockIdx.x - nchunk_wg) * rpw + rl;
+    const bool live = rl < rpw && k < kp;
+    double* dpart = sm + 520;                              // [rpw][Sb][co] doubles (behind part / flag)
     double sv = 0.0;
-    if (sl < Sb) sv = fold_slice<double>(gram_wgrad_partials(a.gw, kp, task, k, c), (size_t)kp * co, a.gw.nblk, Sb, sl);
+    if (live) sv = fold_slice<double>(gram_wgrad_partials(a.gw, kp, task, k, c), (size_t)kp * co, a.gw.nblk, Sb, sl);
     if (Sb > 1) {
-      if (sl < Sb) dpart[sl * co + c] = sv;
+      if (live) dpart[(rl * Sb + sl) * co + c] = sv;
       __syncthreads();
     }
-    if (sl == 0) {
-      double Ssum = Sb > 1 ? dpart[c] : sv;
-      for (int q = 1; q < Sb; ++q) Ssum += dpart[q * co + c];
+    if (live && sl == 0) {
+      double Ssum = sv;
+      for (int q = 1; q < Sb; ++q) Ssum += dpart[(rl * Sb + q) * co + c];
       const float gv = gram_wgrad_elem(a.gw, ng, kp, a.gw_tangent, task, k, c, Ssum);
       const unsigned e = w1_lo + (unsigned)(k * co + c);
       float* g_t = a.g + (size_t)task * a.gstride;
@@ -758,16 +762,16 @@ hipError_t launch_advance(hipStream_t st, const AdvanceArgs& a_in, int tasks) {
   for (int q = 0; q < a.nseg; ++q) { const int sq = fold_slices(a.seg[q].nchunks); if (sq > S) S = sq; }
   const int epw = 1024 / S;
   const int nchunk_wg = ceil_div((int)a.n, epw);
-  const int nrow_wg = a.b1_wgrad ? kp : 0;
+  const int nrow_wg = a.b1_wgrad ? ceil_div(kp, 1024 / (a.co * fold_slices(a.gw.nblk))) : 0;
   unsigned arrivals = 0;
   if (a.stats) {
-    if (a.b1_wgrad) arrivals = (unsigned)kp;
+    if (a.b1_wgrad) arrivals = (unsigned)nrow_wg;
     else arrivals = (unsigned)(ceil_div((int)a.off_w1 + kp * a.co, epw) - (int)a.off_w1 / epw);
   }
   // LDS: slice sums / flag (4096 + 64 B), then the row workgroups' fp64 slice sums and, in the last arriver, the statistics tables
-  size_t smem = 4160 + (size_t)8 * a.co * sizeof(double);
+  size_t smem = 4160 + (size_t)1024 * sizeof(double);
   if (a.stats) smem = 4160 + ((size_t)ng * ng + (size_t)(a.stats == 2 ? 3 : 2) * kp * a.co) * sizeof(double);
-  if (smem < 4160 + (size_t)8 * a.co * sizeof(double)) smem = 4160 + (size_t)8 * a.co * sizeof(double);
+  if (smem < 4160 + (size_t)1024 * sizeof(double)) smem = 4160 + (size_t)1024 * sizeof(double);
   hipLaunchKernelGGL(advance_kernel, dim3(nchunk_wg + nrow_wg, tasks), dim3(1024), smem, st, a, ng, kp, S, nchunk_wg, arrivals);
   return hipGetLastError();
 }

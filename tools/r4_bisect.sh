@@ -1,8 +1,9 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4_b8; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -q -m gpu > $O/tests_all.log 2>&1; echo "tests_all rc=$?"; tail -n 6 $O/tests_all.log
-for B in 0 1; do
-  if [ $B = 1 ]; then export MI_B1_FP32=1; else unset MI_B1_FP32; fi
-  timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --breakdown $O/bd_b1fp32_$B.csv > $O/cfg2_b1fp32_$B.json 2> $O/err.txt
-  echo "b1_fp32=$B $(python3 -c "import json;d=json.loads(open('$O/cfg2_b1fp32_$B.json').read().splitlines()[-1]);print(d['ms_per_step'])") $(grep -E '^bn_relu_pool_fwd,0|^bn_tangent_fwd,0' $O/bd_b1fp32_$B.csv | tr '\n' ' ')"
+O=gpurun_out/r4_b10; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_engine.py -q -x > $O/engine.log 2>&1; echo "engine rc=$?"; tail -n 2 $O/engine.log
+for T in 32 4 1; do
+timeout -k 10 200 python bench.py --tasks $T --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --breakdown $O/bd_cfg2_T$T.csv > $O/cfg2_T$T.json 2> $O/cfg2_T$T.err
+echo "T=$T $(python3 -c "import json;d=json.loads(open('$O/cfg2_T$T.json').read().splitlines()[-1]);print(d['ms_per_step'])") $(grep '^misc,2' $O/bd_cfg2_T$T.csv)"
 done
+timeout -k 10 200 python bench.py --workload cfg4 --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --breakdown $O/bd_cfg4.csv > $O/cfg4.json 2> $O/cfg4.err
+echo "cfg4 $(python3 -c "import json;d=json.loads(open('$O/cfg4.json').read().splitlines()[-1]);print(d['ms_per_step'])") $(grep '^misc,2' $O/bd_cfg4.csv)"
