@@ -300,50 +300,52 @@ def run_vision(args, wl, rank, world, local, dist):
         dt = tmax.item()
     acc_after_timed, loss_after_timed = float(out['acc']), float(out['loss'])
 
-    # Secondary figure: the reference runs one validation fast_adapt per train task without backward
-    # (maml_vision.py:117-124).  MAML: ONE fused call over [train tasks | validation tasks] (mi_meta_batch_maml_tv) -- the validation
-    # tasks' K support steps and query forward ride in the train tasks' launches, only the backward half is train-only.  ANIL: a second
-    # call with with_grad = 0.
-    vdata, vlabels = make_batch(wl, [10_000_000 + t for t in task_ids])
-    vdata, vlabels = torch.from_numpy(vdata).cuda(), torch.from_numpy(vlabels).cuda()
-    from exploring_meta_amd.sharding import packed_outputs
-    if wl.get('anil'):
-        def step_tv():
-            step()
-            vl, va, _, _ = run_batch(theta, vdata, vlabels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], with_grad=False)
-            return va
-        how = 'train call + a second call with with_grad = 0'
-    else:
-        tv = [(torch.cat([d, vdata]), torch.cat([l, vlabels])) for d, l in pool[:2]]
+    secondary = None
+    if not args.no_secondary:
+        # Secondary figure: the reference runs one validation fast_adapt per train task without backward
+        # (maml_vision.py:117-124).  MAML: ONE fused call over [train tasks | validation tasks] (mi_meta_batch_maml_tv) -- the validation
+        # tasks' K support steps and query forward ride in the train tasks' launches, only the backward half is train-only.  ANIL: a second
+        # call with with_grad = 0.
+        vdata, vlabels = make_batch(wl, [10_000_000 + t for t in task_ids])
+        vdata, vlabels = torch.from_numpy(vdata).cuda(), torch.from_numpy(vlabels).cuda()
+        from exploring_meta_amd.sharding import packed_outputs
+        if wl.get('anil'):
+            def step_tv():
+                step()
+                vl, va, _, _ = run_batch(theta, vdata, vlabels, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], with_grad=False)
+                return va
+            how = 'train call + a second call with with_grad = 0'
+        else:
+            tv = [(torch.cat([d, vdata]), torch.cat([l, vlabels])) for d, l in pool[:2]]
 
-        def step_tv():
-            d, l = tv[out['n'] % len(tv)]
-            out['n'] += 1
-            loss, acc, grad, _ = eng.meta_batch(theta, d, l, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], grad_tasks=T)
-            flat = packed_outputs(grad, loss, acc)          # [meta-gradient | losses of both halves | accuracies of both halves]
-            if dist is not None:
-                dist.all_reduce(flat)
-            adam_fn(theta, grad, 1.0 / global_T)
-            return acc[T:]
-        how = 'one fused call over train + validation tasks (mi_meta_batch_maml_tv: grad_tasks = train tasks), one all-reduce'
+            def step_tv():
+                d, l = tv[out['n'] % len(tv)]
+                out['n'] += 1
+                loss, acc, grad, _ = eng.meta_batch(theta, d, l, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'], grad_tasks=T)
+                flat = packed_outputs(grad, loss, acc)          # [meta-gradient | losses of both halves | accuracies of both halves]
+                if dist is not None:
+                    dist.all_reduce(flat)
+                adam_fn(theta, grad, 1.0 / global_T)
+                return acc[T:]
+            how = 'one fused call over train + validation tasks (mi_meta_batch_maml_tv: grad_tasks = train tasks), one all-reduce'
 
-    vacc = step_tv()
-    nsec = max(2, min(5, args.steps))
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(nsec):
         vacc = step_tv()
-    fence()
-    dt_tv = (time.perf_counter() - t1) / nsec
-    if dist is not None:
-        tmax = torch.tensor([dt_tv], device='cuda', dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_tv = tmax.item()
-    secondary = {'metric': 'iterations/sec (train + validation halves)', 'value': round(1.0 / dt_tv, 3), 'ms_per_iteration': round(dt_tv * 1e3, 3),
-                 'tasks_per_iteration': f'{global_T} train + {global_T} validation', 'steps': nsec, 'how': how,
-                 'valid_acc_mean': round(float(vacc.mean()), 5)}
-    if not wl.get('anil'):
-        del tv
+        nsec = max(2, min(5, args.steps))
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(nsec):
+            vacc = step_tv()
+        fence()
+        dt_tv = (time.perf_counter() - t1) / nsec
+        if dist is not None:
+            tmax = torch.tensor([dt_tv], device='cuda', dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_tv = tmax.item()
+        secondary = {'metric': 'iterations/sec (train + validation halves)', 'value': round(1.0 / dt_tv, 3), 'ms_per_iteration': round(dt_tv * 1e3, 3),
+                     'tasks_per_iteration': f'{global_T} train + {global_T} validation', 'steps': nsec, 'how': how,
+                     'valid_acc_mean': round(float(vacc.mean()), 5)}
+        if not wl.get('anil'):
+            del tv
 
     hbm_copy_gbps = measure_stream_copy(eng)
     collective = collective_record(dist, world, theta, eng.param_count + 2 * T,
@@ -756,6 +758,8 @@ def main():
     ap.add_argument('--pool', type=int, default=8, help='distinct resident task batches the step loop rotates through (vision workloads)')
     ap.add_argument('--no-overlap', action='store_true', help='weight gradients on the main stream too (mi_engine_set_overlap(0)): per-launch '
                     'durations in a kernel trace are then those of kernels running alone')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the train + validation leg (counter passes: its fused call launches the same '
+                    'kernels with twice the tasks, which a per-kernel counter table cannot tell from the timed workload)')
     ap.add_argument('--no-fp32-pipe', action='store_true', help='skip the fp32-pipe leg (counter passes: only the shipped operand form is launched)')
     ap.add_argument('--no-dist', action='store_true', help='N = 1 without the single-rank process group (profiler runs)')
     ap.add_argument('--launch-check', action='store_true', help='ranks only join the process group, all-reduce one number and rank 0 prints '
