@@ -362,154 +362,6 @@ __global__ __launch_bounds__(256) void bn_tan_bwd_apply_kernel(BnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Small maps (the net's LAST block: 10x10 maps of Mini-ImageNet, 2x2 of Omniglot): BatchNorm-backward sums AND the apply pass in ONE
-// workgroup per task -- the sums of the last block cannot ride in a dgrad epilogue (there is no block above it), and as two launches
-// they cost two launch latencies for ~0.4 MB per task.  1024 threads: thread = (window slot, channel quad) as in the kernels above; phase 1
-// accumulates the task's sums in fp64 (per thread, then one fixed-order fold through LDS), writes dgamma / dbeta (tangent: R{dgamma},
-// R{dbeta}) where bn_finalize would, phase 2 re-reads z (L2-resident) and writes dz (R{dz}).  Same formulas as bn_bwd_reduce / _apply and
-// their tangent versions; only the order of the fp64 partial sums differs.
-template <int POOL, bool TAN>
-__global__ __launch_bounds__(1024) void bn_bwd_small_kernel(BnArgs a) {
-  __shared__ double red[1024 * 2];                  // per thread: 4 channels x 2 quantities, folded in two halves
-  __shared__ float sums[2 * 256];                   // [2][c] finished sums (as float: what the apply kernels read back from memory)
-  const int quads = a.c >> 2;
-  const int quad = threadIdx.x % quads, wl = threadIdx.x / quads, wpb = 1024 / quads;
-  const int task = blockIdx.x, c0 = quad * 4;
-  const WinIter<POOL> it(a);
-  const size_t z_task = (size_t)a.n * a.ho * a.wo * a.c;
-  const size_t p_task = (size_t)a.n * it.hp * it.wp * a.c;
-  const ChanConst k = load_consts(a, task, c0);
-  const float* z_t = a.z + (size_t)task * z_task;
-  const float* zd_t = TAN ? a.zd + (size_t)task * z_task : nullptr;
-  const float* dp_t = a.dp + (size_t)task * p_task;
-  const float* dpd_t = TAN ? a.dpd + (size_t)task * p_task : nullptr;
-  float m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
-  if (TAN) { load4(a.m1 + (size_t)task * a.c + c0, m1); load4(a.m2 + (size_t)task * a.c + c0, m2); }
-  // ---- phase 1: the sums
-  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-  {
-    Window<POOL> w;
-    for (int win = wl; win < it.nwin; win += wpb) {
-      w.locate(a, it, win, c0);
-      if (!w.pooled) continue;
-      floatx4 umax, zh_at, zd_at;
-      scan_window<POOL, TAN>(w, z_t, zd_t, k, umax, zh_at, zd_at);
-      const floatx4 d = *reinterpret_cast<const floatx4*>(dp_t + w.poff);
-      floatx4 dd = {0.f, 0.f, 0.f, 0.f};
-      if (TAN) dd = *reinterpret_cast<const floatx4*>(dpd_t + w.poff);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bool on = umax[c] > 0.f;
-        const float du = on ? d[c] : 0.f;
-        if (!TAN) {
-          s1[c] += (double)du;
-          s0[c] += (double)du * (double)zh_at[c];
-        } else {
-          const float dud = on ? dd[c] : 0.f;
-          const float zhd = k.r[c] * (zd_at[c] - m1[c] - zh_at[c] * m2[c]);
-          s1[c] += (double)dud;
-          s0[c] += (double)dud * (double)zh_at[c] + (double)du * (double)zhd;
-        }
-      }
-    }
-  }
-  float* out0 = TAN ? const_cast<float*>(a.rdgamma) : const_cast<float*>(a.dgamma);
-  float* out1 = TAN ? const_cast<float*>(a.rdbeta) : const_cast<float*>(a.dbeta);
-  const size_t ostride = TAN ? a.hstride : a.gstride;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {            // quantity 0 (dgamma-like), then quantity 1 (dbeta-like): 1024 x 2 doubles of LDS at a time
-    __syncthreads();
-    red[threadIdx.x * 2 + 0] = half == 0 ? s0[0] : s1[0];
-    red[threadIdx.x * 2 + 1] = half == 0 ? s0[1] : s1[1];
-    __syncthreads();
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    if ((int)threadIdx.x < quads) {
-      for (int w = 0; w < wpb; ++w) { t0 += red[(w * quads + threadIdx.x) * 2 + 0]; t1 += red[(w * quads + threadIdx.x) * 2 + 1]; }
-    }
-    __syncthreads();
-    red[threadIdx.x * 2 + 0] = half == 0 ? s0[2] : s1[2];
-    red[threadIdx.x * 2 + 1] = half == 0 ? s0[3] : s1[3];
-    __syncthreads();
-    if ((int)threadIdx.x < quads) {
-      for (int w = 0; w < wpb; ++w) { t2 += red[(w * quads + threadIdx.x) * 2 + 0]; t3 += red[(w * quads + threadIdx.x) * 2 + 1]; }
-      const int cc = 4 * threadIdx.x;
-      float* o = (half == 0 ? out0 : out1) + (size_t)task * ostride + cc;
-      const float f0 = (float)t0, f1 = (float)t1, f2 = (float)t2, f3 = (float)t3;
-      o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f3;
-      sums[half * 256 + cc + 0] = f0; sums[half * 256 + cc + 1] = f1; sums[half * 256 + cc + 2] = f2; sums[half * 256 + cc + 3] = f3;
-    }
-  }
-  __syncthreads();
-  // ---- phase 2: the apply pass (bn_bwd_apply_kernel / bn_tan_bwd_apply_kernel with the sums just formed)
-  float* out_t = a.out + (size_t)task * z_task;
-  float gd[4] = {0, 0, 0, 0}, dgm[4], dbm[4], rgm[4] = {0, 0, 0, 0}, rbm[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, gr[4];
-  if (TAN) {
-    load4(a.gammad + (size_t)task * a.vstride + c0, gd);
-    load4(a.dgamma + (size_t)task * a.gstride + c0, dgm);     // the PRIMAL sums (pass k's gradient vector)
-    load4(a.dbeta + (size_t)task * a.gstride + c0, dbm);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { rgm[c] = sums[c0 + c]; rbm[c] = sums[256 + c0 + c]; }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { dgm[c] = sums[c0 + c]; dbm[c] = sums[256 + c0 + c]; }
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    dgm[c] *= a.inv_m; dbm[c] *= a.inv_m; rgm[c] *= a.inv_m; rbm[c] *= a.inv_m;
-    gr[c] = k.g[c] * k.r[c];
-    if (TAN) {
-      const float rd = -k.r[c] * k.r[c] * m2[c];
-      c1[c] = gd[c] * k.r[c] + k.g[c] * rd;
-    }
-  }
-  Window<POOL> w;
-  for (int win = wl; win < it.nwin; win += wpb) {
-    w.locate(a, it, win, c0);
-    w.analyse(z_t, k);
-    float d[4] = {0.f, 0.f, 0.f, 0.f}, dd[4] = {0.f, 0.f, 0.f, 0.f};
-    if (w.pooled) { load4(dp_t + w.poff, d); if (TAN) load4(dpd_t + w.poff, dd); }
-#pragma unroll
-    for (int p = 0; p < Window<POOL>::NP; ++p) {
-      if (!w.exists[p]) continue;
-      float zdv[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
-      if (TAN) load4(zd_t + w.off[p], zdv);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bool sel = w.pooled && w.arg[c] == p && w.umax[c] > 0.f;
-        const float du = sel ? d[c] : 0.f;
-        const float zh = w.zh[p][c];
-        if (!TAN) {
-          o[c] = gr[c] * (du - dbm[c] - zh * dgm[c]);
-        } else {
-          const float dud = sel ? dd[c] : 0.f;
-          const float zhd = k.r[c] * (zdv[c] - m1[c] - zh * m2[c]);
-          const float e = du - dbm[c] - zh * dgm[c];
-          o[c] = c1[c] * e + gr[c] * (dud - rbm[c] - zhd * dgm[c] - zh * rgm[c]);
-        }
-      }
-      store4(out_t + w.off[p], o);
-    }
-  }
-}
-
-// one task's map small enough for a single workgroup to sweep twice (z: 320 KB at 25 images x 10x10 x 32 channels)
-bool bn_bwd_small_ok(const BnArgs& a) {
-  return (size_t)a.n * a.ho * a.wo * a.c * sizeof(float) <= (size_t)512 * 1024 && a.c % 4 == 0 && a.c <= 256 && 1024 % (a.c / 4) == 0;
-}
-hipError_t launch_bn_bwd_small(hipStream_t st, const BnArgs& a, int tasks, int pool, int tangent) {
-  if (!bn_bwd_small_ok(a)) return hipErrorInvalidValue;
-  dim3 grid(tasks);
-  if (tangent) {
-    if (pool) hipLaunchKernelGGL((bn_bwd_small_kernel<1, true>), grid, dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL((bn_bwd_small_kernel<0, true>), grid, dim3(1024), 0, st, a);
-  } else {
-    if (pool) hipLaunchKernelGGL((bn_bwd_small_kernel<1, false>), grid, dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL((bn_bwd_small_kernel<0, false>), grid, dim3(1024), 0, st, a);
-  }
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Fold per-workgroup fp64 partials [T][nblk][2][c] in block order.
 //  FIN_STATS : (sum z, sum z^2)        -> out0 = mean, out1 = 1/sqrt(biased var + eps)
 //  FIN_TSTATS: (sum zd, sum zh zd)     -> out0 = m1,   out1 = m2

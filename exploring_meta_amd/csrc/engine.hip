@@ -50,8 +50,6 @@ struct mi_engine {
   // Gram-matrix assembly, the fast-weight / adjoint update and the next pass's Gram statistics -- instead of 3 reduce_partials +
   // gram_wgrad + axpy + gram_stats launches and a memset per pass.  Same arithmetic in the same order: bit-identical results.
   bool fuse_tail = true;
-  // BatchNorm-backward sums and apply pass of a block with small maps (the last block) as one launch, one workgroup per task
-  bool fuse_small_bn = true;
   unsigned zoff[10] = {}, zlen[10] = {};   // conv-bias segments and the padding P..PS of a parameter-shaped vector (never written by a kernel)
   int nzero = 0;
   unsigned* counters = nullptr;
@@ -275,15 +273,6 @@ extern "C" int mi_engine_set_graph(mi_engine* e, int on) {
 extern "C" int mi_engine_set_fused_tail(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->fuse_tail = on != 0;
-  return MI_OK;
-}
-
-// Ablation / test switch: 1 (default) = the last block's BatchNorm backward (sums + apply pass, primal and tangent) as one launch per pass
-// where a task's map fits one workgroup (bn_bwd_small_kernel); 0 = reduce, finalize and apply launches.  Same formulas, another order
-// of the fp64 partial sums.
-extern "C" int mi_engine_set_fused_small_bn(mi_engine* e, int on) {
-  if (!e) return MI_ERR_ARG;
-  e->fuse_small_bn = on != 0;
   return MI_OK;
 }
 
@@ -673,19 +662,15 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
+    if (!red_done[l]) {
+      ba.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P);
+      LAUNCH(e, st, OP_BN_BWD_REDUCE, l, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
+      if (!ba.fin.counter)
+        LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
+    }
     ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
     ba.out = A.dz[l];
-    if (!red_done[l] && e->fuse_small_bn && bn_bwd_small_ok(ba)) {   // the last block's small maps: sums and apply pass in one launch
-      LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_small(st, ba, T, L.pool, 0));
-    } else {
-      if (!red_done[l]) {
-        ba.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P);
-        LAUNCH(e, st, OP_BN_BWD_REDUCE, l, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
-        if (!ba.fin.counter)
-          LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P));
-      }
-      LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
-    }
+    LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = A.dz[l];
@@ -932,19 +917,15 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
+    if (!red_done[l]) {
+      ba.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P);
+      LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, l, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
+      if (!ba.fin.counter)
+        LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
+    }
     ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
     ba.out = X.rdz[l];
-    if (!red_done[l] && e->fuse_small_bn && bn_bwd_small_ok(ba)) {
-      LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_bwd_small(st, ba, T, L.pool, 1));
-    } else {
-      if (!red_done[l]) {
-        ba.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P);
-        LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, l, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
-        if (!ba.fin.counter)
-          LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P));
-      }
-      LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
-    }
+    LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = X.rdz[l];
@@ -1265,7 +1246,7 @@ static int meta_batch_entry(MetaBatchFn fn, int which, mi_engine* e, void* strea
       (unsigned long long)shots, (unsigned long long)adapt_steps, (unsigned long long)lr_bits, (unsigned long long)second_order,
       (unsigned long long)with_grad, (unsigned long long)(uintptr_t)loss_out, (unsigned long long)(uintptr_t)acc_out,
       (unsigned long long)(uintptr_t)meta_grad_out, (unsigned long long)(uintptr_t)logits_out, (unsigned long long)(uintptr_t)workspace,
-      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 64ull * e->fuse_small_bn};
+      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail};
   mi_engine::GraphEntry* ent = nullptr;
   for (auto& g : e->graphs)
     if (g.key == key) { ent = &g; break; }

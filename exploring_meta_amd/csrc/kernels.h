@@ -88,10 +88,6 @@ hipError_t launch_bn_bwd_apply(hipStream_t st, const BnArgs& a, int tasks, int p
 hipError_t launch_bn_tan_fwd(hipStream_t st, const BnArgs& a, int tasks, int pool);
 hipError_t launch_bn_tan_bwd_reduce(hipStream_t st, const BnArgs& a, int tasks, int pool, int* nblk);
 hipError_t launch_bn_tan_bwd_apply(hipStream_t st, const BnArgs& a, int tasks, int pool);
-// small maps: the reduction AND the apply pass (primal or tangent) of one block in one launch, one workgroup per task; a.dgamma / a.dbeta
-// (tangent: a.rdgamma / a.rdbeta) are WRITTEN with the sums -- what bn_finalize leaves there -- before the apply phase uses them
-bool bn_bwd_small_ok(const BnArgs& a);
-hipError_t launch_bn_bwd_small(hipStream_t st, const BnArgs& a, int tasks, int pool, int tangent);
 
 // block1.hip -- fused first ConvBlock with conv recompute
 struct B1Args {

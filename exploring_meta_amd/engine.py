@@ -146,10 +146,6 @@ class MetaEngine:
         launches; bit-identical results."""
         _lib.check(self.lib.mi_engine_set_fused_tail(self._h, int(on)), self._h)
 
-    def set_fused_small_bn(self, on):
-        """The last block's BatchNorm backward (sums + apply) as one launch per pass (default on) or as separate launches."""
-        _lib.check(self.lib.mi_engine_set_fused_small_bn(self._h, int(on)), self._h)
-
     def set_graph(self, on):
         """Replay repeated identical fused calls as one hipGraphLaunch (mi_engine_set_graph).  While on, `meta_batch` /
         `meta_batch_anil` return views of PERSISTENT output buffers (one set per call shape), because a replay writes where the

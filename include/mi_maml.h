@@ -134,11 +134,6 @@ int mi_meta_batch_maml_tv(mi_engine* e, void* stream, const float* theta, const 
  * block 1's Gram-matrix assembly, p <- p - lr g of learn2learn's maml_update / the adjoint recursion, the next pass's Gram statistics);
  * 0 = the separate launches (reduce_partials x3, gram_wgrad, axpy, gram_stats, a memset).  Bit-identical results. */
 int mi_engine_set_fused_tail(mi_engine* e, int on);
-/* Ablation / test switch: 1 (default) = the BatchNorm backward of a block whose per-task map is small (the last ConvBlock: 10x10 maps of
- * MiniImagenetCNN, 2x2 of OmniglotCNN; autograd's batch_norm backward, reference core_functions/vision_models.py:188-193) runs its
- * per-channel sums and its apply pass in ONE launch with one workgroup per task; 0 = separate reduce / apply launches.  Results agree to
- * the rounding of two fp64 sums. */
-int mi_engine_set_fused_small_bn(mi_engine* e, int on);
 
 /* One meta-batch of ANIL tasks (vision/anil_vision.py:116-122 with features = Sequential(ConvBase, view(-1, fc_neurons)),
  * head = MAML(Linear(fc_neurons, ways)), :86-94): the trunk runs once per task on all 2*shots*ways images (BatchNorm over

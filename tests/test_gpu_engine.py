@@ -226,29 +226,6 @@ def test_fused_tail_is_bit_identical(dataset, ways, shots, K, fo, tasks, fused1)
     assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).sum() > 0
 
 
-@pytest.mark.parametrize('dataset,ways,shots,K,fo,tasks', [('min', 5, 5, 2, False, [3, 4, 5]), ('min', 5, 1, 1, False, [0, 1, 2, 3, 4, 5, 6]),
-                                                         ('omni', 5, 1, 2, False, [0, 1, 2]), ('min', 5, 5, 2, True, [1, 2])])
-def test_fused_small_bn_matches_separate_launches(dataset, ways, shots, K, fo, tasks):
-    """The last block's BatchNorm backward as ONE launch per pass (bn_bwd_small_kernel: per-channel sums and the apply pass in one
-    workgroup per task, primal and tangent) against the reduce / finalize / apply launches: the same formulas, the fp64 partial sums in
-    another order -- dgamma / dbeta agree to the rounding of an fp64 sum to fp32, and so does everything downstream."""
-    spec, mspec = _spec(dataset, ways)
-    theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
-    data, labels = synthetic.make_meta_batch(dataset, tasks, ways, shots)
-    d, l = torch.from_numpy(data).cuda().contiguous(), torch.from_numpy(labels).cuda().contiguous()
-    outs = []
-    for on in (1, 0):
-        eng = MetaEngine(mspec)
-        eng.set_fused_small_bn(on)
-        loss, acc, grad, logits = eng.meta_batch(theta, d, l, shots, K, 0.1, first_order=fo, return_logits=True)
-        torch.cuda.synchronize()
-        outs.append((loss.cpu().numpy(), grad.cpu().numpy(), logits.cpu().numpy(), acc.cpu().numpy()))
-    e_l = float(np.max(np.abs(outs[0][0] - outs[1][0]) / np.abs(outs[1][0])))
-    e_g = rel_err(outs[0][1], outs[1][1])
-    report(f'fused_small_bn[{dataset},{shots}shot,K{K},fo{int(fo)}]', loss_rel=e_l, grad_rel=e_g)
-    assert e_l < 1e-6 and e_g < 2e-6 and np.array_equal(outs[0][3], outs[1][3])
-
-
 @pytest.mark.parametrize('K,grad_bar', [(1, 1e-4), (2, 1e-3)])
 def test_train_and_validation_tasks_in_one_call(K, grad_bar):
     """mi_meta_batch_maml_tv (reference maml_vision.py:102-124): 3 train + 2 validation tasks through the same launches against the
