@@ -545,7 +545,8 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 // general block-1 kernel; 1 = split bf16, eight products (mi_block1_set_split_bf16 / MI_B1_BF16X3=1).  Measured on one box at cfg2's
 // size: bn_relu_pool_fwd 0.156 -> 0.139 ms, bn_tangent_fwd 0.147 -> 0.133 ms per launch, the meta-iteration within the run-to-run
 // spread either way (16.45 / 16.36 and 16.60 / 16.79 ms in two A/B pairs: the workload sits at the socket power cap) -- and every change
-// of conv1's rounding redraws which near-tied pooling decisions flip, so the default stays on the form the parity tables were taken with.
+// of conv1's rounding redraws which near-tied pooling decisions flip: tools/accuracy_parity.py (6400 predictions) reads 0.016 % from the
+// reference's fp64 accuracy with the fp32 pipe and 0.203 % with this form (profiles/r4/accuracy_parity_cfg2*.md).  Default: fp32 pipe.
 static int g_b1_split = -1;
 static bool block1_split_bf16() {
   if (g_b1_split < 0) {
