@@ -45,6 +45,17 @@ pytestmark = pytest.mark.gpu
 RAW_MAX, RAW_MAX_T256, OUTLIER_SHARE, ADJ_G, ADJ_H = 3e-2, 1e-1, 0.15, 2e-5, 2e-4
 
 
+@pytest.fixture(params=['split_bf16', 'fp32_pipe'])
+def conv_form(request):
+    """Operand form of the 32-channel stride-1 convolutions and weight gradients (mi_conv_set_split_bf16) for one test: the per-step
+    bars below hold for each form separately, so a regression in one is not absorbed by the other's envelope."""
+    from exploring_meta_amd import _lib
+    lb = _lib.load()
+    was = lb.mi_conv_set_split_bf16(1 if request.param == 'split_bf16' else 0)
+    yield request.param
+    lb.mi_conv_set_split_bf16(was)
+
+
 def _ref_theta(spec, seed=11):
     return OrderedDict((k, torch.from_numpy(v)) for k, v in synthetic.ref_init_weights(R.param_shapes(spec), seed).items())
 
@@ -58,7 +69,7 @@ def _unflatten(flat, shapes):
     return out
 
 
-def test_cfg2_T32_teacher_forced_per_step():
+def test_cfg2_T32_teacher_forced_per_step(conv_form):
     """BASELINE config 2 exactly as benchmarked (32 tasks, 5-way 5-shot, K = 5, lr 0.5, second order, the bench's synthetic
     tasks and initial parameters): every inner-step gradient and every Hessian-vector product of ALL 32 tasks against the
     oracle at the engine's own theta_k (oracle legs in CPU worker processes); the theta recursion and the adjoint recursion
@@ -87,7 +98,7 @@ def test_cfg2_T32_teacher_forced_per_step():
     flips = []
     for r in res:
         t = r['t']
-        report(f'cfg2_T32_teacher_forced[task {t}]', grad_rel_vs_fp64=r['g64'], grad_rel_vs_ref_fp32=r['g32'], hvp_rel_vs_fp64=r['h64'],
+        report(f'cfg2_T32_teacher_forced[{conv_form}][task {t}]', grad_rel_vs_fp64=r['g64'], grad_rel_vs_ref_fp32=r['g32'], hvp_rel_vs_fp64=r['h64'],
                hvp_rel_vs_ref_fp32=r['h32'], query_grad_rel_vs_fp64=r['q64'][2], query_grad_rel_vs_ref_fp32=r['q32'][2],
                loss=float(loss[t]), loss_fp64=r['q64'][0], loss_ref_fp32=r['q32'][0])
         for k in ('g64', 'g32', 'h64', 'h32', 'gx', 'hx'):
@@ -101,7 +112,7 @@ def test_cfg2_T32_teacher_forced_per_step():
         assert float(acc[t]) == r['q64'][1]
     for leg in ('64', '32'):      # (1) raw, against the reference arithmetic in fp64 and in the reference's own precision
         g, h, q = (np.array(legs[k + leg]) for k in 'ghq')
-        report(f'cfg2_T32_teacher_forced[all {T} tasks, leg fp{leg}]', grad_median=float(np.median(g)), grad_max=float(g.max()),
+        report(f'cfg2_T32_teacher_forced[{conv_form}][all {T} tasks, leg fp{leg}]', grad_median=float(np.median(g)), grad_max=float(g.max()),
                grad_share_above_1e4=float((g > 1e-4).mean()), hvp_median=float(np.median(h)), hvp_max=float(h.max()),
                hvp_share_above_1e4=float((h > 1e-4).mean()), query_max=float(q.max()))
         share = OUTLIER_SHARE if leg == '64' else 1.0
@@ -111,7 +122,7 @@ def test_cfg2_T32_teacher_forced_per_step():
     # (2) near-tie adjusted: every step, every task
     gx, hx, qx = (np.array(legs[k]) for k in ('gx', 'hx', 'qx'))
     margins = [abs(fl['margin']) for fl in flips]
-    report(f'cfg2_T32_teacher_forced[all {T} tasks, near-tie adjusted]', grad_max=float(gx.max()), hvp_max=float(hx.max()),
+    report(f'cfg2_T32_teacher_forced[{conv_form}][all {T} tasks, near-tie adjusted]', grad_max=float(gx.max()), hvp_max=float(hx.max()),
            query_max=float(qx.max()), flipped_decisions=len(flips), largest_flipped_margin=max(margins) if margins else 0.0)
     assert gx.max() < ADJ_G and qx.max() < ADJ_G, (sorted(gx)[-4:], sorted(qx)[-4:])
     assert hx.max() < ADJ_H, sorted(hx)[-4:]
