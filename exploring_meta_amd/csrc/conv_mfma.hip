@@ -560,6 +560,13 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
       acc = MI_BF_MFMA(ca.h, cb[0], acc);                         \
       __builtin_amdgcn_sched_barrier(0);
 #define MI_READB(dst, U) { dst[0] = l4[((U) * 3 + 0) * 64]; dst[1] = l4[((U) * 3 + 1) * 64]; dst[2] = l4[((U) * 3 + 2) * 64]; }
+      // Ablation build (timing / energy experiment, wrong results, not shipped): -DMI_CONV_ABLATE_LDS reads the weight planes of one unit
+      // in three from LDS and uses them for the other two -- what sharing a weight read between two tiles of a wave could save at most.
+#ifdef MI_CONV_ABLATE_LDS
+#define MI_READB2(dst, U) { dst[0] = pb[0][0]; dst[1] = pb[0][1]; dst[2] = pb[0][2]; asm volatile("" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2])); }
+#else
+#define MI_READB2(dst, U) MI_READB(dst, U)
+#endif
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
         // the loads of half-group i + 3 (the raw slot of half-group i was split during half-group i - 1)
@@ -569,11 +576,11 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
         const floatx4* rc = rawc[(i + 1) % HRING];
         const unsigned selm = cur.keep_m, selp = cur.keep_p;
         // unit 0: centre tap; meanwhile the -1 operand and the first half of the next half-group's split
-        MI_READB(pb[(3 * i + 1) & 1], hg_unit(i, -1));
+        MI_READB2(pb[(3 * i + 1) & 1], hg_unit(i, -1));
         MI_UNIT(pc_, pb[(3 * i) & 1], if (MI_ROW_KEPT(i)) MI_SHIFT6(opm, h, m, 0x138, selm), if (MI_ROW_KEPT(i)) MI_SHIFT6B(opm, m, l, 0x138, selm),
                 if (MI_ROW_KEPT((i + 1) % NH)) bf16_split_pair<0>(rc[0], nc), if (MI_ROW_KEPT((i + 1) % NH)) bf16_split_pair<1>(rc[0], nc))
         // unit 1: tap -1; meanwhile the +1 operand and the second half of the split
-        MI_READB(pb[(3 * i + 2) & 1], hg_unit(i, 1));
+        MI_READB2(pb[(3 * i + 2) & 1], hg_unit(i, 1));
         MI_UNIT(opm, pb[(3 * i + 1) & 1], if (MI_ROW_KEPT(i)) MI_SHIFT6(opp, h, m, 0x130, selp), if (MI_ROW_KEPT(i)) MI_SHIFT6B(opp, m, l, 0x130, selp),
                 if (MI_ROW_KEPT((i + 1) % NH)) bf16_split_pair<2>(rc[1], nc), if (MI_ROW_KEPT((i + 1) % NH)) bf16_split_pair<3>(rc[1], nc))
         // unit 2: tap +1
@@ -581,6 +588,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
         MI_UNIT(opp, pb[(3 * i + 2) & 1], (void)0, (void)0, (void)0, (void)0)
       }
 #undef MI_READB
+#undef MI_READB2
 #undef MI_UNIT
 #undef MI_SHIFT6B
 #undef MI_SHIFT6
