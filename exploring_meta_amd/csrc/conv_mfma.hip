@@ -276,7 +276,13 @@ __device__ __forceinline__ void buf_st_untracked(mi_u32x4 rsrc, unsigned off, fl
 struct Bf16Planes { unsigned h[4], m[4], l[4]; };              // 8 values: three bf16x8 operands
 template <int P>
 __device__ __forceinline__ void bf16_split_pair(const floatx4& x, Bf16Planes& p) {       // values 2P, 2P + 1 of the eight (x = their float4)
+#ifdef MI_CONV_ABLATE_SPLIT
+  // Ablation build (timing / energy experiment, wrong results, not shipped): the loaded bits stand in for the three planes -- what operands
+  // that arrive already split (written as planes by their producer) would save at most, before their 50 % larger loads.
+  p.h[P] = __builtin_bit_cast(unsigned, x[(P & 1) * 2]); p.m[P] = __builtin_bit_cast(unsigned, x[(P & 1) * 2 + 1]); p.l[P] = p.h[P] ^ p.m[P];
+#else
   bf16_split2(floatx2{x[(P & 1) * 2], x[(P & 1) * 2 + 1]}, p.h[P], p.m[P], p.l[P]);
+#endif
   asm volatile("" : "+v"(p.h[P]), "+v"(p.m[P]), "+v"(p.l[P]));     // computed HERE (instruction selection otherwise sinks the split to its use)
 }
 __device__ __forceinline__ void bf16_split8(const floatx4& x0, const floatx4& x1, Bf16Planes& p) {
