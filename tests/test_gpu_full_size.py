@@ -347,3 +347,43 @@ def test_last_arriver_fold_is_bit_identical_at_benched_size(cfg):
                 bad.append((rep, name, int((a != b).sum())))
     report(f'last_arriver_fold_stress[{cfg}]', repeats=30, mismatches=len(bad))
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize('cfg', ['cfg2_T32', 'cfg4_T256'])
+def test_fused_tail_is_bit_identical_at_benched_size(cfg):
+    """The one-launch pass tail (gram.hip advance_kernel) at the sizes bench.py times: its Gram statistics are formed by whichever
+    workgroup of a task finishes last, from block-1 weights that other workgroups -- on other XCDs -- have just written (write-through
+    stores, acknowledged, counted: the finalize.h protocol), and its folds run as slices that meet in LDS.  20 repeated fused calls
+    against ONE call with the separate reduce / assemble / update / statistics launches: same arithmetic in the same order, so loss,
+    accuracy, meta-gradient and the BatchNorm batch statistics of every block of every forward pass (block 1's come from the tail's
+    statistics) must be bit-identical every time -- a stale weight or a lost arrival would move them."""
+    if cfg == 'cfg2_T32':
+        ways, shots, K, lr, T, seed = 5, 5, 5, 0.5, 32, 42
+    else:
+        ways, shots, K, lr, T, seed = 5, 1, 1, 0.5, 256, 11
+    spec, mspec = R.mini_imagenet_spec(ways), ModelSpec.mini_imagenet(ways)
+    theta = R.flatten_params(_ref_theta(spec, seed)).float().cuda().contiguous()
+    data, labels = synthetic.make_meta_batch('min', list(range(T)), ways, shots)
+    d, l = torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda()
+    eng = MetaEngine(mspec)
+
+    def call():
+        stats = eng.set_bn_export(T, K + 1)
+        loss, acc, grad, _ = eng.meta_batch(theta, d, l, shots, K, lr)
+        torch.cuda.synchronize()
+        out = (loss.clone(), acc.clone(), grad.clone(), stats.clone())
+        eng.set_bn_export(0)
+        return out
+
+    eng.set_fused_tail(0)
+    want = call()
+    assert all(torch.isfinite(x).all() for x in want) and float(want[3].abs().sum()) > 0
+    eng.set_fused_tail(1)
+    bad = []
+    for rep in range(20):
+        got = call()
+        for name, a, b in zip(('loss', 'acc', 'grad', 'bn_stats'), got, want):
+            if not torch.equal(a, b):
+                bad.append((rep, name, int((a != b).sum())))
+    report(f'fused_tail_stress[{cfg}]', repeats=20, mismatches=len(bad))
+    assert not bad, bad[:10]
