@@ -374,11 +374,11 @@ def run_vision(args, wl, rank, world, local, dist):
     mask = C.c_uint(0)
     # (pooling nets only: the stride-1 hidden blocks are where the two operand forms differ; a bisecting run's variant mask is left alone)
     if wl['dataset'] == 'min' and not args.no_fp32_pipe and eng.lib.mi_conv_get_split_bf16(C.byref(mask)) and mask.value == 0x3ffff:
-        eng.lib.mi_conv_set_split_bf16(0)
+        form_was = eng.lib.mi_conv_set_split_bf16(0)
         n32 = max(3, min(5, args.steps))
         timed(2)
         d32 = timed(n32)
-        eng.lib.mi_conv_set_split_bf16(1)
+        eng.lib.mi_conv_set_split_bf16(form_was)
         fp32_pipe = {'ms_per_step': round(d32 * 1e3, 3), 'tasks_per_s': round(global_T / d32, 2), 'steps': n32,
                      'note': 'the same step with the hidden 3x3 convolutions and weight gradients on the exact fp32 matrix pipe '
                              '(v_mfma_f32_32x32x2_f32, mi_conv_set_split_bf16(0)); measured after the timed region'}

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
   const float* dp_t = a.dp ? a.dp + (size_t)task * p_task : nullptr;
   const float* dpd_t = a.dpd ? a.dpd + (size_t)task * p_task : nullptr;
   float* out_t = a.out ? a.out + (size_t)task * p_task : nullptr;
+  unsigned am = 0u;                                          // forward modes: largest magnitude written to `out` (B1Args::amax_out)
   float* zho_t = a.zh_out ? a.zh_out + (size_t)task * p_task : nullptr;
   uint8_t* ago_t = (MODE == B1_FWD && a.arg_out) ? a.arg_out + (size_t)task * p_task : nullptr;
   const uint8_t* agi_t = ARG ? a.arg_in + (size_t)task * p_task : nullptr;
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
         const float zhd_s = rs * (zd_at - m1 - zh_s * m2);
         const bool on_s = ag < 4;
         if (wvalid) {
-          out_t[poff] = on_s ? gmd * zh_s + gm * zhd_s + btd : 0.f;
+          const float pdv = on_s ? gmd * zh_s + gm * zhd_s + btd : 0.f;
+          out_t[poff] = pdv;
+          mi_amax_acc(am, pdv);
           if (zho_t) zho_t[poff] = on_s ? zhd_s : 0.f;
         }
         continue;
@@ -207,12 +210,12 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
       if (MODE == B1_STATS || MODE == B1_TSTATS) continue;
       const bool on = umax > 0.f;
       if (MODE == B1_FWD) {
-        if (wvalid) out_t[poff] = on ? umax : 0.f;
+        if (wvalid) { out_t[poff] = on ? umax : 0.f; mi_amax_acc(am, on ? umax : 0.f); }
         if (zho_t && wvalid) zho_t[poff] = zh_at;          // lets the BN-backward reductions run at pooled resolution
         if (ago_t && wvalid) ago_t[poff] = (uint8_t)(on ? arg : 4);   // ... and the weight gradient find du without conv1
       } else if (MODE == B1_TFWD) {
         const float ud = gmd * zh_at + gm * zhd_at + btd;
-        if (wvalid) out_t[poff] = on ? ud : 0.f;
+        if (wvalid) { out_t[poff] = on ? ud : 0.f; mi_amax_acc(am, on ? ud : 0.f); }
         if (zho_t && wvalid) zho_t[poff] = zhd_at;
       } else {
         const bool ld = wvalid && on;
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
     }
   }
 
+  if ((MODE == B1_FWD || MODE == B1_TFWD || MODE == B1_TFWD_ARG) && a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
   if (RED) {
     // lanes l and l^32 hold the same channel; 4 waves -> one fp64 partial per workgroup
     s0 += __shfl_xor(s0, 32, 64);
@@ -385,6 +389,8 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
   const mi_rsrc ragi = __builtin_amdgcn_make_buffer_rsrc((void*)(ARG ? a.arg_in + (size_t)task * p_elems : (const uint8_t*)a.out), 0,
                                                          ARG ? p_elems : 0u, 0x00020000);
 
+  unsigned am = 0u;                                            // largest magnitude written to `out` (B1Args::amax_out)
+  const bool want_amax = a.amax_out != nullptr;
   // ---- per-lane tap table: byte displacement of tap 5h + t from the pixel under the kernel centre
   int toff[NTH];
 #pragma unroll
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
         z = __builtin_amdgcn_mfma_f32_32x32x2f32(B1Vec<CI0>::get(o.av[t], c), wreg[t * CI0 + c], z, 0, 0, 0);
     }
     // ---- epilogue: window 2g + h of the tile sits in registers 4g .. 4g + 3 (positions 0..3)
+    float pv[4];                                                 // the four values this lane stores to `out`
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const unsigned go32 = o32 + (unsigned)(2 * g * CO * 4), go8 = o8 + (unsigned)(2 * g * CO);
@@ -495,8 +502,10 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
         const int b0 = lane_mask_bit<0>(agv), b1 = lane_mask_bit<1>(agv), off = lane_mask_bit<2>(agv);
         const float zd_at = lane_select(b1, lane_select(b0, z[4 * g + 3], z[4 * g + 2]), lane_select(b0, z[4 * g + 1], z[4 * g]));
         const float zhd_s = rs * (zd_at - m1 - o.zh[g] * m2);
-        buf_st(rout, go32, lane_zero_where(off, gmd * o.zh[g] + gm * zhd_s + btd));
+        const float pdv = lane_zero_where(off, gmd * o.zh[g] + gm * zhd_s + btd);
+        buf_st(rout, go32, pdv);
         buf_st(rzho, go32, lane_zero_where(off, zhd_s));
+        pv[g] = pdv;
       } else {
         // the reference's rule exactly (MaxPool2d after BN + ReLU, vision_models.py:188-193): FIRST maximum of u itself, so two
         // positions whose u round to the same float resolve by position even when their z differ.  "uq > u" is taken as the sign
@@ -519,7 +528,17 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
         const int offm = lane_mask_negative(__builtin_bit_cast(float, __builtin_bit_cast(int, p) - 1));
         buf_st(rout, go32, p);
         buf_st(rzho, go32, zh_at);
+        pv[g] = p;
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lane_select_valu(offm, 4u, arg), rago, go8, 0, 0);
+      }
+    }
+    if (want_amax) {                                             // (kernel-uniform; a task's last tile may be partial: tile-uniform)
+      if (tl * 8 + 8 <= nwin) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mi_amax_acc(am, pv[g]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mi_amax_acc(am, tl * 8 + 2 * g + h < nwin ? pv[g] : 0.f);
       }
     }
   };
@@ -538,6 +557,7 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
     compute_tile(tile, B);
     tile += 4;
   }
+  if (want_amax) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

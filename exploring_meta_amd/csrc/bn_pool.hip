@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
   BN_THREAD_SETUP(POOL)
   float* out_t = a.out + (size_t)task * p_task;
   float* zh_t = a.zh_out ? a.zh_out + (size_t)task * p_task : nullptr;
+  unsigned am = 0u;                                          // largest magnitude written (BnArgs::amax_out)
   Window<POOL> w;
   for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
     w.locate(a, it, win, c0);
@@ -192,10 +193,11 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
     scan_window<POOL, false>(w, z_t, nullptr, k, umax, zh_at, zd_at);      // running maximum, zhat carried along (no per-position arrays)
     floatx4 o;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = fmaxf(umax[c], 0.f);
+    for (int c = 0; c < 4; ++c) { o[c] = fmaxf(umax[c], 0.f); mi_amax_acc(am, o[c]); }
     *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
     if (zh_t) *reinterpret_cast<floatx4*>(zh_t + w.poff) = zh_at;
   }
+  if (a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
 }
 
 template <int POOL>
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnArgs a) {
   load4(a.dbeta + (size_t)task * a.gstride + c0, dbm);
 #pragma unroll
   for (int c = 0; c < 4; ++c) { dgm[c] *= a.inv_m; dbm[c] *= a.inv_m; gr[c] = k.g[c] * k.r[c]; }
+  unsigned am = 0u;                                          // largest magnitude written (BnArgs::amax_out)
   Window<POOL> w;
   for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
     w.locate(a, it, win, c0);
@@ -244,10 +247,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnArgs a) {
       for (int c = 0; c < 4; ++c) {
         const float du = (w.pooled && w.arg[c] == p && w.umax[c] > 0.f) ? d[c] : 0.f;
         o[c] = gr[c] * (du - dbm[c] - w.zh[p][c] * dgm[c]);
+        mi_amax_acc(am, o[c]);
       }
       store4(out_t + w.off[p], o);
     }
   }
+  if (a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
 }
 
 // tangent forward: pd = [u>0 at argmax] * (gammad*zh + gamma*zhd + betad),  zhd = r (zd - m1 - zh m2)
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(256) void bn_tan_fwd_kernel(BnArgs a) {
   load4(a.m2 + (size_t)task * a.c + c0, m2);
   load4(a.gammad + (size_t)task * a.vstride + c0, gd);
   load4(a.betad + (size_t)task * a.vstride + c0, bd);
+  unsigned am = 0u;                                          // largest magnitude written (BnArgs::amax_out)
   Window<POOL> w;
   for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
     w.locate(a, it, win, c0);
@@ -274,10 +280,12 @@ __global__ __launch_bounds__(256) void bn_tan_fwd_kernel(BnArgs a) {
       const float ud = gd[c] * zh_at[c] + k.g[c] * zhd + bd[c];
       o[c] = (umax[c] > 0.f) ? ud : 0.f;
       zo[c] = zhd;
+      mi_amax_acc(am, o[c]);
     }
     *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
     if (a.zh_out) *reinterpret_cast<floatx4*>(a.zh_out + (size_t)task * p_task + w.poff) = zo;
   }
+  if (a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
 }
 
 // tangent backward reductions: R{dbeta} = sum dud ; R{dgamma} = sum (dud zh + du zhd)   (argmax positions only)
@@ -336,6 +344,7 @@ __global__ __launch_bounds__(256) void bn_tan_bwd_apply_kernel(BnArgs a) {
     c1[c] = gd[c] * k.r[c] + k.g[c] * rd;
     gr[c] = k.g[c] * k.r[c];
   }
+  unsigned am = 0u;                                          // largest magnitude written (BnArgs::amax_out)
   Window<POOL> w;
   for (int win = blockIdx.x * wpb + wl; win < it.nwin; win += gridDim.x * wpb) {
     w.locate(a, it, win, c0);
@@ -355,10 +364,12 @@ __global__ __launch_bounds__(256) void bn_tan_bwd_apply_kernel(BnArgs a) {
         const float zhd = k.r[c] * (zdv[c] - m1[c] - zh * m2[c]);
         const float e = du - dbm[c] - zh * dgm[c];
         o[c] = c1[c] * e + gr[c] * (dud - rbm[c] - zhd * dgm[c] - zh * rgm[c]);
+        mi_amax_acc(am, o[c]);
       }
       store4(out_t + w.off[p], o);
     }
   }
+  if (a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

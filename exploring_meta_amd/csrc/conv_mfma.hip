@@ -111,10 +111,13 @@ __device__ __forceinline__ void conv_prefetch_z(float* zpre, const float* __rest
 // MODE 0: forward   out[o] = sum_tap in[o*S + d - 1] * W[tap]            weights [9][CI][CO]
 // MODE 1: dgrad     out[i] = sum_tap in[(i + 1 - d)/S] * W[tap]^T        weights [9][CO_op][CI_op] (the forward layout)
 // waves per workgroup: the 2-term variants stage 2 x 36 KB of weights, so 8 waves share one copy (2 workgroups = 4 waves/SIMD)
-template <int CI, int NTERMS, bool BF = false> struct ConvWaves {
+template <int CI, int NTERMS, bool BF = false, bool F16 = false> struct ConvWaves {
   // (split-bf16 form at 64 filters: 108 KB of weight planes per workgroup -> one workgroup per CU, so eight waves share it)
-  static constexpr int value = ((NTERMS == 2 && CI == 32) || (BF && CI == 64)) ? 8 : 4;
+  // (fp16 form: always eight -- two workgroups per CU share two staged weight copies among 16 waves, four per SIMD)
+  static constexpr int value = (F16 || (NTERMS == 2 && CI == 32) || (BF && CI == 64)) ? 8 : 4;
 };
+// fp16 form: the variants that fit 128 registers are built for four waves per SIMD (the tangent-statistics epilogue does not)
+template <int EPI, bool F16> struct ConvWavesPerSimd { static constexpr int value = (F16 && EPI != 2 /* EPI_TSTATS */) ? 4 : 1; };
 // Measured (rocprofv3 SQ counters + hipOccupancy): the 2-term EPI_TSTATS variant takes 178 VGPRs, so one 8-wave workgroup is
 // resident per CU (1.8 waves/SIMD) while the 2-term dgrad (108 VGPRs, two workgroups, 2.9 waves/SIMD) reaches the same 74 % MFMA
 // busy fraction: occupancy is not the limiter.  Forcing <= 128 VGPRs (__launch_bounds__(512, 4)) spills 17 dwords into the
@@ -296,9 +299,13 @@ __device__ unsigned long long* g_conv_stamps = nullptr;
 #endif
 #define CV_STAMP(k) do { if (cstamp && tid == 0) cstamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <int CI, int NTERMS, int EPI, int MODE, bool BF = false>
-__global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3x3_s1_mfma_kernel(ConvArgs a) {
-  constexpr int NW = ConvWaves<CI, NTERMS, BF>::value, NT = NW * 64, CO = CI;
+// F16 (with BF): the two-plane fp16 operand form (bf16_split.h) -- same tiles, loads and lane shifts, two planes and three products
+// per K step, the scales from ConvArgs::amax (activations, per task) and from the staged weights themselves (per workgroup).
+template <int CI, int NTERMS, int EPI, int MODE, bool BF = false, bool F16 = false>
+__global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (ConvWavesPerSimd<EPI, F16>::value)) void conv3x3_s1_mfma_kernel(ConvArgs a) {
+  static_assert(BF || !F16, "the fp16 form is a variant of the split kernel");
+  constexpr int NW = ConvWaves<CI, NTERMS, BF, F16>::value, NT = NW * 64, CO = CI;
+  constexpr int NPL = F16 ? 2 : 3;                              // operand planes
   constexpr int NCC = CI / 32, NSTEP = NTERMS * 9 * NCC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -328,6 +335,9 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
   // BF: three bf16 planes per weight, in MFMA operand order: 16-B unit ((step*2 + kb)*3 + plane)*64 + lane holds, for lane (h, j),
   // the 8 values k = cc*32 + h*16 + kb*8 + 0..7 of output channel cbase + j  (step = (term*9 + tap)*NCC + cc)
   constexpr int NQ = BF ? 0 : NTERMS * 9 * CI * 32 / 4;
+  float f16_sa[NTERMS], f16_sw[NTERMS], f16_inv = 1.f;           // F16: scales of the activations / the weights per term, 1 / (their product)
+#pragma unroll
+  for (int t = 0; t < NTERMS; ++t) { f16_sa[t] = 1.f; f16_sw[t] = 1.f; }
   if constexpr (BF) {
     mi_u32x4* l4 = reinterpret_cast<mi_u32x4*>(lds);
     constexpr int NIT = NSTEP * 2 * 64, IPT = (NIT + NT - 1) / NT;   // items (8 weights of one output channel) per thread
@@ -352,16 +362,68 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
         w1[q] = *reinterpret_cast<const floatx4*>(src + 4);
       }
     }
+    if constexpr (F16) {
+      // the weights' scale: the largest magnitude among the weights THIS workgroup stages (all taps and input channels of its 32
+      // filters: every K sum of its accumulators runs over exactly these), per term -- threads, then lanes, then waves through LDS
+      float mx[NTERMS];
+#pragma unroll
+      for (int t = 0; t < NTERMS; ++t) mx[t] = 0.f;
+#pragma unroll
+      for (int q = 0; q < IPT; ++q) {
+        const int it = tid + q * NT;
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m = fmaxf(m, fmaxf(fabsf(w0[q][i]), fabsf(w1[q][i])));
+        if (it >= NIT) m = 0.f;
+        if (NTERMS == 1) mx[0] = fmaxf(mx[0], m);
+        else { const bool t1 = (it >> 7) / NCC >= 9; mx[0] = fmaxf(mx[0], t1 ? 0.f : m); mx[NTERMS - 1] = fmaxf(mx[NTERMS - 1], t1 ? m : 0.f); }
+      }
+      float* red = lds + (size_t)NSTEP * 2 * NPL * 64 * 4;       // behind the planes (the launcher adds 64 B)
+#pragma unroll
+      for (int t = 0; t < NTERMS; ++t) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], o, 64));
+        if (lane == 0) red[wave * NTERMS + t] = mx[t];
+      }
+      __syncthreads();
+      int kk[2][2] = {{0, 0}, {0, 0}};                           // [term][0 = activations, 1 = weights]
+#pragma unroll
+      for (int t = 0; t < NTERMS; ++t) {
+        float m = red[t];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w * NTERMS + t]);
+        kk[t][1] = f16_scale_exp(__float_as_uint(m));
+        kk[t][0] = f16_scale_exp(a.amax[t][(size_t)task * MI_CELL_STRIDE]);
+      }
+      if (NTERMS == 2) f16_common_scale(kk);
+#pragma unroll
+      for (int t = 0; t < NTERMS; ++t) {
+        f16_sa[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_pow2(kk[t][0]))));
+        f16_sw[t] = f16_pow2(kk[t][1]);
+      }
+      f16_inv = f16_pow2(-(kk[0][0] + kk[0][1]));
+    }
 #pragma unroll
     for (int q = 0; q < IPT; ++q) {
       const int it = tid + q * NT;
       if (it < NIT) {
         const int ln = it & 63, grp = it >> 6;
-        Bf16Planes pw;
-        bf16_split8(w0[q], w1[q], pw);
-        l4[(grp * 3 + 0) * 64 + ln] = mi_u32x4{pw.h[0], pw.h[1], pw.h[2], pw.h[3]};
-        l4[(grp * 3 + 1) * 64 + ln] = mi_u32x4{pw.m[0], pw.m[1], pw.m[2], pw.m[3]};
-        l4[(grp * 3 + 2) * 64 + ln] = mi_u32x4{pw.l[0], pw.l[1], pw.l[2], pw.l[3]};
+        if constexpr (F16) {
+          const float sw = (NTERMS == 2 && (grp >> 1) / NCC >= 9) ? f16_sw[NTERMS - 1] : f16_sw[0];
+          unsigned ph[4], pl[4];
+          f16_split2_v(floatx2{w0[q][0], w0[q][1]}, sw, ph[0], pl[0]);
+          f16_split2_v(floatx2{w0[q][2], w0[q][3]}, sw, ph[1], pl[1]);
+          f16_split2_v(floatx2{w1[q][0], w1[q][1]}, sw, ph[2], pl[2]);
+          f16_split2_v(floatx2{w1[q][2], w1[q][3]}, sw, ph[3], pl[3]);
+          l4[(grp * 2 + 0) * 64 + ln] = mi_u32x4{ph[0], ph[1], ph[2], ph[3]};
+          l4[(grp * 2 + 1) * 64 + ln] = mi_u32x4{pl[0], pl[1], pl[2], pl[3]};
+        } else {
+          Bf16Planes pw;
+          bf16_split8(w0[q], w1[q], pw);
+          l4[(grp * 3 + 0) * 64 + ln] = mi_u32x4{pw.h[0], pw.h[1], pw.h[2], pw.h[3]};
+          l4[(grp * 3 + 1) * 64 + ln] = mi_u32x4{pw.m[0], pw.m[1], pw.m[2], pw.m[3]};
+          l4[(grp * 3 + 2) * 64 + ln] = mi_u32x4{pw.l[0], pw.l[1], pw.l[2], pw.l[3]};
+        }
       }
     }
   }
@@ -510,7 +572,15 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
   Bf16Planes pc[2], opm, opp;                                  // centre planes (double-buffered over half-groups), shifted operands
   mi_u32x4 pb[2][3];
   const mi_u32x4* l4 = reinterpret_cast<const mi_u32x4*>(lds) + lane;
-  if constexpr (BF) {
+  // F16: values 2P, 2P + 1 of a half-group's eight (x = their float4) into planes h / l of nc, scaled by the term's activation scale
+#define MI_F16_PAIR(P, X, NC, S) { f16_split2(floatx2{(X)[((P) & 1) * 2], (X)[((P) & 1) * 2 + 1]}, S, NC.h[P], NC.l[P]); \
+                                   asm volatile("" : "+v"(NC.h[P]), "+v"(NC.l[P])); }
+  if constexpr (F16) {
+    MI_F16_PAIR(0, rawc[0][0], pc[0], f16_sa[0]) MI_F16_PAIR(1, rawc[0][0], pc[0], f16_sa[0])
+    MI_F16_PAIR(2, rawc[0][1], pc[0], f16_sa[0]) MI_F16_PAIR(3, rawc[0][1], pc[0], f16_sa[0])
+    const int u0 = hg_unit(0, 0);
+    pb[0][0] = l4[(u0 * 2 + 0) * 64]; pb[0][1] = l4[(u0 * 2 + 1) * 64];
+  } else if constexpr (BF) {
     bf16_split8(rawc[0][0], rawc[0][1], pc[0]);
     const int u0 = hg_unit(0, 0);
     pb[0][0] = l4[(u0 * 3 + 0) * 64]; pb[0][1] = l4[(u0 * 3 + 1) * 64]; pb[0][2] = l4[(u0 * 3 + 2) * 64];
@@ -533,7 +603,48 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
         zpre[r] = buf_ld(rz, obase + ((r >> 3) ? (unsigned)(16 * CO * 4) : 0u) + ro);
       }
     }
-    if constexpr (BF) {
+    if constexpr (F16) {
+      // Half-group i: three units (horizontal displacement 0, -1, +1) of three products each; between them the lane shifts of this
+      // half-group's planes (4 registers x 2 planes per displaced operand) and the split of the next half-group's eight values
+#define MI_SHIFT(dst, P, R, CTRL, SEL) dst.P[R] = (unsigned)__builtin_amdgcn_mov_dpp((int)pc_.P[R], CTRL, 0xf, 0xf, true) & SEL;
+#define MI_SHIFT4(dst, P, CTRL, SEL)                                                                     \
+      { MI_SHIFT(dst, P, 0, CTRL, SEL) MI_SHIFT(dst, P, 1, CTRL, SEL) MI_SHIFT(dst, P, 2, CTRL, SEL) MI_SHIFT(dst, P, 3, CTRL, SEL) \
+        asm volatile("" : "+v"(dst.P[0]), "+v"(dst.P[1]), "+v"(dst.P[2]), "+v"(dst.P[3])); }
+#define MI_UNIT3(ca, cb, V0, V1, V2)                              \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      acc = MI_F16_MFMA(ca.l, cb[0], acc);                        \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      V0;                                                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      acc = MI_F16_MFMA(ca.h, cb[1], acc);                        \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      V1;                                                         \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      acc = MI_F16_MFMA(ca.h, cb[0], acc);                        \
+      __builtin_amdgcn_sched_barrier(0);                          \
+      V2;                                                         \
+      __builtin_amdgcn_sched_barrier(0);
+#define MI_READB(dst, U) { dst[0] = l4[((U) * 2 + 0) * 64]; dst[1] = l4[((U) * 2 + 1) * 64]; }
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        if (i + HRING < NH) issue_hg(cur, i + HRING); else issue_hg(nxt, i + HRING - NH);
+        const Bf16Planes& pc_ = pc[i & 1];
+        Bf16Planes& nc = pc[(i + 1) & 1];
+        const floatx4* rc = rawc[(i + 1) % HRING];
+        const float sn = f16_sa[hg_term((i + 1) % NH)];         // (compile-time index)
+        const unsigned selm = cur.keep_m, selp = cur.keep_p;
+        MI_READB(pb[(3 * i + 1) & 1], hg_unit(i, -1));
+        MI_UNIT3(pc_, pb[(3 * i) & 1], MI_SHIFT4(opm, h, 0x138, selm), MI_SHIFT4(opm, l, 0x138, selm), MI_F16_PAIR(0, rc[0], nc, sn))
+        MI_READB(pb[(3 * i + 2) & 1], hg_unit(i, 1));
+        MI_UNIT3(opm, pb[(3 * i + 1) & 1], MI_SHIFT4(opp, h, 0x130, selp), MI_SHIFT4(opp, l, 0x130, selp), MI_F16_PAIR(1, rc[0], nc, sn))
+        MI_READB(pb[(3 * i + 3) & 1], hg_unit((i + 1) % NH, 0));
+        MI_UNIT3(opp, pb[(3 * i + 2) & 1], MI_F16_PAIR(2, rc[1], nc, sn), MI_F16_PAIR(3, rc[1], nc, sn), (void)0)
+      }
+#undef MI_READB
+#undef MI_UNIT3
+#undef MI_SHIFT4
+#undef MI_SHIFT
+    } else if constexpr (BF) {
       // shifted operand: lane <- the centre planes one lane over, zero in the image's first / last column (one v_and_b32_dpp per register)
 #define MI_SHIFT(dst, P, R, CTRL, SEL) dst.P[R] = (unsigned)__builtin_amdgcn_mov_dpp((int)pc_.P[R], CTRL, 0xf, 0xf, true) & SEL;
 #define MI_SHIFT6(dst, A0, A1, CTRL, SEL)                                                               \
@@ -624,6 +735,10 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF>::value * 64)) void conv3
     // Only the BF variants store through assembly (they are the ones whose operand waits it rescues); the fp32-pipe variants keep the
     // compiler-visible store, whose matrix-result hazard is the compiler's to cover.
     if constexpr (BF) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
+    if constexpr (F16) {                                       // the operands' scales out of the sums (a power of two: exact)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= f16_inv;
+    }
     if (!MI_CONV_XTILE) {
 #pragma unroll
       for (int st = 0; st < DEPTH; ++st) issue(cur, st, ring[st % RING]);
@@ -1038,41 +1153,51 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host launchers
-// Split-bf16 operands for the 32-channel stride-1 kernels (default on; MI_CONV_BF16X3=0 / mi_conv_set_split_bf16(0) = the fp32 pipe everywhere)
+// Operand form of the 32- / 64-channel stride-1 kernels: 0 = the fp32 pipe everywhere, 1 = three bf16 planes (six products), 2 = two
+// scaled fp16 planes (three products; launches whose operands come without a largest-magnitude cell take form 1).
+// MI_CONV_BF16X3 / mi_conv_set_split_bf16.
+#ifndef MI_CONV_DEFAULT_FORM
+#define MI_CONV_DEFAULT_FORM 1
+#endif
 static int g_conv_split_bf16 = -1;
 static unsigned g_conv_split_mask = 0x3ffffu;                   // debug: which variants take the split form: conv bit ((terms-1)*2 + mode)*4 + epi, weight gradient bit 16 + (terms-1)
 static bool conv_split_bf16() {
   if (g_conv_split_bf16 < 0) {
     const char* e = getenv("MI_CONV_BF16X3");
-    g_conv_split_bf16 = e ? (atoi(e) != 0) : 1;
+    g_conv_split_bf16 = e ? (atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e))) : MI_CONV_DEFAULT_FORM;
     const char* m = getenv("MI_CONV_BF16X3_MASK");              // bisecting aid (hex): the variant mask of mi_conv_set_split_bf16
     if (m) g_conv_split_mask = (unsigned)strtoul(m, nullptr, 16);
   }
   return g_conv_split_bf16 != 0;
 }
 extern "C" int mi_conv_set_split_bf16(int on) {
-  const int was = conv_split_bf16() ? 1 : 0;
-  g_conv_split_bf16 = on ? 1 : 0;
-  g_conv_split_mask = on > 1 ? ((unsigned)on >> 8) : 0x3ffffu;
-  // on = 0x100 * mask + 1: only the variants in mask (bisecting aid)
+  conv_split_bf16();
+  const int was = g_conv_split_bf16;
+  g_conv_split_bf16 = (on & 0xff) > 2 ? 2 : (on & 0xff);
+  g_conv_split_mask = on > 0xff ? ((unsigned)on >> 8) : 0x3ffffu;
+  // on = 0x100 * mask + form: only the variants in mask (bisecting aid)
   return was;
 }
+int conv_operand_form() { conv_split_bf16(); return g_conv_split_bf16; }
 // the operand form in force, read WITHOUT touching it (a set-and-restore would reset the bisecting mask): mask_out, when given,
 // receives the variant mask of MI_CONV_BF16X3_MASK / mi_conv_set_split_bf16
 extern "C" int mi_conv_get_split_bf16(unsigned* mask_out) {
-  const int on = conv_split_bf16() ? 1 : 0;
+  conv_split_bf16();
+  const int on = g_conv_split_bf16;
   if (mask_out) *mask_out = g_conv_split_mask;
   return on;
 }
 
-static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int nterms, int& ntiles, int& tpw, dim3& grid, int tile_pix = 32) {
+static inline void conv_grid(int mpix, int tasks, int cot, int nw, int ci, int nterms, int& ntiles, int& tpw, dim3& grid, int tile_pix = 32,
+                             bool four_per_simd = false) {
   ntiles = ceil_div(mpix, tile_pix);
   // One balanced round: give every resident wave ceil(tiles / slots) tiles -- more, shorter waves would run as 2.x rounds whose last
   // round is mostly idle.  Resident waves: 4 per SIMD by registers (<= 128 VGPRs in every variant), limited by the LDS copy of the
   // weights (160 KB per CU): 36 KB per 32-channel term and workgroup -> 4096 waves on the chip; the 64-channel kernels stage 74 KB
   // (one term, two workgroups of 4 waves per CU) or 147 KB (two terms, one workgroup) -> 2048 / 1024 waves.
   // Split-bf16 32-channel kernels: 54 KB (one term, two 4-wave workgroups per CU) / 108 KB (two terms, one 8-wave workgroup) -> 2048.
-  const long slots = tile_pix != 32 ? 2048 : (ci >= 64 ? (nterms == 2 ? 1024 : 2048) : 4096);   // (split form: 2 waves per SIMD in every variant)
+  // (split-bf16 form: 2 waves per SIMD in every variant; fp16 form: 4, except with the tangent-statistics epilogue)
+  const long slots = four_per_simd ? 4096 : (tile_pix != 32 ? 2048 : (ci >= 64 ? (nterms == 2 ? 1024 : 2048) : 4096));
   long total = (long)ntiles * tasks * cot;
   tpw = (int)((total + slots - 1) / slots);
   if (tpw < 1) tpw = 1;
@@ -1104,23 +1229,24 @@ static hipError_t launch_conv_t(hipStream_t st, ConvArgs& a, dim3 grid) {
   hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS>::value * 64), lds, st, a);
   return hipGetLastError();
 }
-template <int CI, int NTERMS, int EPI, int MODE>
+template <int CI, int NTERMS, int EPI, int MODE, bool F16>
 static hipError_t launch_conv_s1_bf(hipStream_t st, ConvArgs& a, dim3 grid) {
-  const size_t lds = (size_t)NTERMS * 9 * CI * 32 * 6;       // three bf16 planes
-  auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE, true>;
+  const size_t lds = (size_t)NTERMS * 9 * CI * 32 * (F16 ? 4 : 6) + (F16 ? 64 : 0);   // three bf16 planes / two fp16 planes + the weight maxima
+  auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE, true, F16>;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS, true>::value * 64), lds, st, a);
+  hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS, true, F16>::value * 64), lds, st, a);
   return hipGetLastError();
 }
 template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
   if constexpr (CI == 32 || (CI == 64 && NTERMS == 1)) {
-    if (a.split_bf16) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE>(st, a, grid);
+    if (a.split_bf16 == 2) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE, true>(st, a, grid);
+    if (a.split_bf16) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE, false>(st, a, grid);
   }
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);
   auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE>;
@@ -1167,11 +1293,12 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
   int ntiles, tpw;
   dim3 grid;
   // the split-bf16 form of the stride-1 kernel (32 filters; 64 filters with one term): tiles of 30 output pixels, 2048 resident waves
-  a.split_bf16 = (a.g.ci == 32 || (a.g.ci == 64 && nterms == 1)) && conv_s1_ok(a) && conv_split_bf16() &&
-                 (epi == EPI_BRED ? mode == 1 : (mode == 0 || epi == EPI_NONE)) &&
-                 ((g_conv_split_mask >> (((nterms - 1) * 2 + mode) * 4 + epi)) & 1u);
-  const int nw = ((nterms == 2 && a.g.ci == 32) || (a.split_bf16 && a.g.ci == 64)) ? 8 : 4;     // ConvWaves<CI, NTERMS, BF>
-  conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid, a.split_bf16 ? 30 : 32);
+  a.split_bf16 = ((a.g.ci == 32 || (a.g.ci == 64 && nterms == 1)) && conv_s1_ok(a) && conv_split_bf16() &&
+                  (epi == EPI_BRED ? mode == 1 : (mode == 0 || epi == EPI_NONE)) &&
+                  ((g_conv_split_mask >> (((nterms - 1) * 2 + mode) * 4 + epi)) & 1u)) ? g_conv_split_bf16 : 0;
+  if (a.split_bf16 == 2 && (!a.amax[0] || (nterms == 2 && !a.amax[1]))) a.split_bf16 = 1;      // no scales: the bf16 form
+  const int nw = (a.split_bf16 == 2 || (nterms == 2 && a.g.ci == 32) || (a.split_bf16 && a.g.ci == 64)) ? 8 : 4;     // ConvWaves<CI, NTERMS, BF, F16>
+  conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid, a.split_bf16 ? 30 : 32, a.split_bf16 == 2 && epi != EPI_TSTATS);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   if (blocks_per_task) *blocks_per_task = grid.x;
@@ -1337,6 +1464,8 @@ static void launch_rows(hipStream_t st, const WgradArgs& a, dim3 grid, int rh) {
 
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out) {
   const int s = a.g.stride;
+  a.form = conv_operand_form();
+  if (a.form == 2 && !(a.amax_x[0] && a.amax_dz[0] && (nterms == 1 || (a.amax_x[1] && a.amax_dz[1])))) a.form = 1;   // no scales: the bf16 form
   if (use_rows_kernel(a.g) && conv_split_bf16() && (g_conv_split_mask & (1u << (16 + (nterms - 1)))) && wgrad_bf16_strips(a.g) &&
       (size_t)a.g.n * a.g.h * a.g.w * a.g.ci * 4 < (size_t)MI_OOB && !((g_conv_split_mask >> 21) & 1u)) {   // bit 21 (debug): the unit form on wide maps too
     int rows, ipb, blocks;

@@ -393,6 +393,12 @@ struct Plan {
   int half = 0;                 // stream context (engine SideCtx) this plan's side work uses
   float *tmp_loss, *tmp_acc;
   float* hscr;   // head scratch: R{dl} [T][n][ways], row loss [T][n], row hit [T][n]
+  // fp16 operand form (bf16_split.h): largest-magnitude cells [slot][T], one slot per tensor a convolution reads, handed out in launch
+  // order (cell_bind: the tensor's producer is about to run; cell_of: a consumer asks) and zeroed once per call (plan_begin)
+  unsigned* cells;
+  int cell_cap, cell_used = 0, cell_T = 0;
+  bool f16 = false;
+  std::vector<std::pair<const void*, unsigned*>> cellmap;
   size_t bytes;
 };
 
@@ -507,7 +513,44 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
       X.rdf = nullptr;
     }
   }
+  pl.cell_cap = 8 + (K + 1) * 2 * nl + K * 4 * nl + 4 * nl;      // p and dz per block and pass, pd and R{dz} per Hessian-vector pass, spare
+  pl.cells = b.take<unsigned>((size_t)pl.cell_cap * T * MI_CELL_STRIDE);
+  pl.cell_T = T;
   pl.bytes = align_up(b.off, 256);
+}
+
+// ---- fp16 operand form: the largest-magnitude cell of every tensor a convolution reads
+static int plan_begin(mi_engine* e, hipStream_t st, Plan& pl) {
+  pl.f16 = conv_operand_form() == 2;
+  pl.cell_used = 0;
+  pl.cellmap.clear();
+  if (pl.f16) HIPCHK(e, hipMemsetAsync(pl.cells, 0, (size_t)pl.cell_cap * pl.cell_T * MI_CELL_STRIDE * sizeof(unsigned), st));
+  return MI_OK;
+}
+// the producer of `tensor` is about to be launched: a fresh cell for it to fold max |tensor| into (nullptr: no fp16 form, or no slot
+// left -- its consumers then ask launch_amax, or fail there)
+static unsigned* cell_bind(mi_engine* e, Plan& pl, const void* tensor) {
+  static const bool no_hooks = getenv("MI_F16_NO_PRODUCER_AMAX") && atoi(getenv("MI_F16_NO_PRODUCER_AMAX")) != 0;   // debug: every cell from launch_amax
+  if (!pl.f16 || !tensor) return nullptr;
+  for (auto it = pl.cellmap.begin(); it != pl.cellmap.end(); ++it)
+    if (it->first == tensor) { pl.cellmap.erase(it); break; }      // the tensor is being rewritten: its old cell is stale
+  if (no_hooks || pl.cell_used >= pl.cell_cap) return nullptr;
+  unsigned* c = pl.cells + (size_t)(pl.cell_used++) * pl.cell_T * MI_CELL_STRIDE;
+  pl.cellmap.emplace_back(tensor, c);
+  return c;
+}
+// a convolution is about to read `tensor` ([T][per_task] floats): its cell -- from its producer, else a reduction launch here
+static int cell_of(mi_engine* e, hipStream_t st, Plan& pl, const float* tensor, size_t per_task, int T, const unsigned** out) {
+  *out = nullptr;
+  if (!pl.f16 || !tensor) return MI_OK;
+  for (const auto& kv : pl.cellmap)
+    if (kv.first == tensor) { *out = kv.second; return MI_OK; }
+  if (pl.cell_used >= pl.cell_cap) return fail(e, MI_ERR_WORKSPACE, "fp16 operand form: no largest-magnitude cell left for this call");
+  unsigned* c = pl.cells + (size_t)(pl.cell_used++) * pl.cell_T * MI_CELL_STRIDE;
+  pl.cellmap.emplace_back(tensor, c);
+  LAUNCH(e, st, OP_MISC, 5, launch_amax(st, tensor, per_task, T, c));
+  *out = c;
+  return MI_OK;
 }
 
 // Debug/test aid: byte offsets inside the workspace of a mi_meta_batch_maml call with these sizes.
@@ -548,6 +591,13 @@ static B1Args b1_args(const mi_engine* e, Plan& pl, ActSet& A, const float* x0, 
   return a;
 }
 
+// (fp16 operand form) the largest-magnitude cell of a tensor a convolution is about to read, on the caller's stream `st`
+#define CELL(ptr, per_task, out)                                                   \
+  do {                                                                             \
+    const int _crc = cell_of(e, st, pl, ptr, per_task, T, &(out));                 \
+    if (_crc) return _crc;                                                         \
+  } while (0)
+
 // Trunk forward: ConvBlocks on n images per task (conv + BN-stat epilogue, finalize, BN+ReLU+pool).
 static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
                          const double* gram = nullptr, bool stats_ready = false) {
@@ -571,6 +621,7 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
       ba.out = A.p[0];
       ba.zh_out = A.zhm;
       ba.arg_out = A.arg0;
+      ba.amax_out = cell_bind(e, pl, ba.out);
       LAUNCH(e, st, OP_BN_FWD, 0, launch_block1(st, ba, T, L.ci, B1_FWD, nullptr));
       continue;
     }
@@ -584,6 +635,7 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
     ca.mpix = n * L.ho * L.wo;
     int blk = 0;
     ca.fin = fin_of(e, T, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co);
+    if (l >= 1) CELL(ca.in[0], (size_t)n * L.h * L.w * L.ci, ca.amax[0]);
     LAUNCH(e, st, OP_CONV_FWD, l, launch_conv3x3(st, ca, T, 1, EPI_STATS, 0, &blk));
     if (!ca.fin.counter)
       LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co));
@@ -593,6 +645,7 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
     ba.out = A.p[l];
     ba.zh_out = A.zhl[l];
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
+    ba.amax_out = cell_bind(e, pl, ba.out);
     LAUNCH(e, st, OP_BN_FWD, l, launch_bn_fwd(st, ba, T, L.pool));
   }
   return MI_OK;
@@ -670,10 +723,15 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     }
     ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
     ba.out = A.dz[l];
+    ba.amax_out = cell_bind(e, pl, ba.out);
     LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = A.dz[l];
+    if (l >= 1) {
+      CELL(wa.x[0], (size_t)n * L.h * L.w * L.ci, wa.amax_x[0]);
+      CELL(wa.dz[0], (size_t)n * L.ho * L.wo * L.co, wa.amax_dz[0]);
+    }
     hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
     if (ws != st) forked = true;
     wa.partial = adv ? pl.wgpart_l[l] : (ws != st ? pl.wgpart_side : pl.wgpart);
@@ -689,6 +747,7 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       ca.wt[0] = theta + L.off_w;
       ca.wstride = P;
       ca.out = A.dp[l - 1];
+      ca.amax[0] = wa.amax_dz[0];
       ca.g = geom_dgrad(L, n);
       ca.mpix = n * L.h * L.w;
       const float* zh_lo = dgrad_carries_reduce(e, l) ? zh_at_argmax(e, A, l - 1) : nullptr;
@@ -811,8 +870,10 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       b1.zh_out = A.zhm ? X.zhdm : nullptr;
       if (A.zhm && A.arg0) {   // the forward pass kept zhat and the argmax: one conv with the direction's weights suffices
         b1.arg_in = A.arg0; b1.zh_in = A.zhm;
+        b1.amax_out = cell_bind(e, pl, b1.out);
         LAUNCH(e, st, OP_BN_TAN_FWD, 0, launch_block1(st, b1, T, L.ci, B1_TFWD_ARG, nullptr));
       } else {
+        b1.amax_out = cell_bind(e, pl, b1.out);
         LAUNCH(e, st, OP_BN_TAN_FWD, 0, launch_block1(st, b1, T, L.ci, B1_TFWD, nullptr));
       }
       continue;
@@ -829,6 +890,10 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ca.mpix = mpix;
     int blk = 0;
     ca.fin = fin_of(e, T, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co);
+    if (l >= 1) {
+      CELL(ca.in[0], (size_t)n * L.h * L.w * L.ci, ca.amax[0]);
+      CELL(ca.in[1], (size_t)n * L.h * L.w * L.ci, ca.amax[1]);
+    }
     LAUNCH(e, st, OP_TAN_CONV, l, launch_conv3x3(st, ca, T, l > 0 ? 2 : 1, EPI_TSTATS, 0, &blk));
     if (!ca.fin.counter)
       LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co));
@@ -839,6 +904,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ba.out = X.pd[l];
     ba.zh_out = A.zhl[l] ? X.zhdl[l] : nullptr;
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
+    ba.amax_out = cell_bind(e, pl, ba.out);
     LAUNCH(e, st, OP_BN_TAN_FWD, l, launch_bn_tan_fwd(st, ba, T, L.pool));
   }
   const float* fd = X.pd[nl - 1];
@@ -925,11 +991,18 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     }
     ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
     ba.out = X.rdz[l];
+    ba.amax_out = cell_bind(e, pl, ba.out);
     LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = X.rdz[l];
     if (l > 0) { wa.x[1] = X.pd[l - 1]; wa.dz[1] = A.dz[l]; }
+    if (l >= 1) {
+      CELL(wa.x[0], (size_t)n * L.h * L.w * L.ci, wa.amax_x[0]);
+      CELL(wa.dz[0], (size_t)n * L.ho * L.wo * L.co, wa.amax_dz[0]);
+      CELL(wa.x[1], (size_t)n * L.h * L.w * L.ci, wa.amax_x[1]);
+      CELL(wa.dz[1], (size_t)n * L.ho * L.wo * L.co, wa.amax_dz[1]);
+    }
     hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
     if (ws != st) forked = true;
     wa.partial = adv ? pl.wgpart_l[l] : (ws != st ? pl.wgpart_side : pl.wgpart);
@@ -943,6 +1016,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       ConvArgs ca{};
       ca.in[0] = X.rdz[l]; ca.wt[0] = theta + L.off_w;
       ca.in[1] = A.dz[l]; ca.wt[1] = v + L.off_w;
+      ca.amax[0] = wa.amax_dz[0]; ca.amax[1] = wa.amax_dz[1];
       ca.wstride = P;
       ca.out = X.dpd[cur ^ 1];
       ca.g = geom_dgrad(L, n);
@@ -1006,6 +1080,7 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   const Layer& L0 = e->L[0];
   const bool tail = e->fuse_tail && e->counters && T <= mi_engine::kMaxCounterTasks && 1024 % L0.co == 0;
   const double inv_m0 = 1.0 / ((double)ns * L0.ho * L0.wo);
+  { const int brc = plan_begin(e, st, pl); if (brc) return brc; }
   LAUNCH(e, st, OP_MISC, 0, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
   if (pl.gram_s)
@@ -1146,6 +1221,9 @@ static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, An
   ap.scratch.wgpart = b.take<float>(wgp);
   ap.scratch.wgpart_side = b.take<float>(wgp);
   ap.scratch.gram_part = ap.scratch.gram_s = nullptr;
+  ap.scratch.cell_cap = 8 + 4 * (int)e->L.size();
+  ap.scratch.cells = b.take<unsigned>((size_t)ap.scratch.cell_cap * T * MI_CELL_STRIDE);
+  ap.scratch.cell_T = T;
   if (e->fuse1 && e->gram1 && gram_supported(e->L[0].w, e->L[0].ci)) {   // statistics + weight gradient of block 1 from the Gram matrix
     ap.scratch.gram_part = b.take<double>(gram_partial_doubles(T, 2 * n, e->L[0].h, e->L[0].ci));
     ap.scratch.gram_s = b.take<double>(gram_doubles(T, e->L[0].ci));
@@ -1183,7 +1261,9 @@ static int meta_batch_anil_impl(mi_engine* e, void* stream, const float* theta, 
   const double* gram = (with_grad && workspace) ? ap.scratch.gram_s : nullptr;       // pays off only with a backward pass
   if (gram)
     LAUNCH(e, st, OP_GRAM, 0, launch_input_gram(st, ap.x, T, 2 * n, e->L[0].h, e->L[0].w, e->L[0].ci, ap.scratch.gram_part, ap.scratch.gram_s));
-  int rc = trunk_forward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta, gram);     // features(data) on all rows
+  int rc = plan_begin(e, st, ap.scratch);
+  if (rc) return rc;
+  rc = trunk_forward(e, st, ap.scratch, ap.act, ap.x, 2 * n, T, ap.theta, gram);     // features(data) on all rows
   if (rc) return rc;
   e->export_pass = 0;
   rc = export_bn_stats(e, st, ap.act, T);
@@ -1246,7 +1326,7 @@ static int meta_batch_entry(MetaBatchFn fn, int which, mi_engine* e, void* strea
       (unsigned long long)shots, (unsigned long long)adapt_steps, (unsigned long long)lr_bits, (unsigned long long)second_order,
       (unsigned long long)with_grad, (unsigned long long)(uintptr_t)loss_out, (unsigned long long)(uintptr_t)acc_out,
       (unsigned long long)(uintptr_t)meta_grad_out, (unsigned long long)(uintptr_t)logits_out, (unsigned long long)(uintptr_t)workspace,
-      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail};
+      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 256ull * (unsigned)conv_operand_form()};
   mi_engine::GraphEntry* ent = nullptr;
   for (auto& g : e->graphs)
     if (g.key == key) { ent = &g; break; }
@@ -1327,6 +1407,7 @@ extern "C" int mi_forward_logits(mi_engine* e, void* stream, const float* theta,
   make_plan(e, workspace, tasks, n, n, 0, 0, pl);
   if (pl.bytes > workspace_bytes)
     return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
+  { const int brc = plan_begin(e, st, pl); if (brc) return brc; }
   LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xq));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
   HIPCHK(e, hipMemsetAsync(pl.yq, 0, (size_t)tasks * n * sizeof(int32_t), st));
@@ -1368,6 +1449,8 @@ extern "C" int mi_learner_forward(mi_engine* e, void* stream, const float* theta
   if (rep_out && (rep_layer < 1 || rep_layer > nl)) return fail(e, MI_ERR_ARG, "rep_layer must be in 1..layers");
   if (!logits_out && !rep_out) return fail(e, MI_ERR_ARG, "nothing to compute: logits_out and rep_out are both NULL");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  rc = plan_begin(e, st, pl);
+  if (rc) return rc;
   LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xq));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, theta_tasks == 1 ? 0 : e->P, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
   HIPCHK(e, hipMemsetAsync(pl.yq, 0, (size_t)tasks * n * sizeof(int32_t), st));
@@ -1391,6 +1474,8 @@ extern "C" int mi_learner_backward(mi_engine* e, void* stream, const float* thet
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nl = (int)e->L.size();
   ActSet& A = pl.qry;
+  rc = plan_begin(e, st, pl);
+  if (rc) return rc;
   LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xq));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, theta_tasks == 1 ? 0 : e->P, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
   rc = trunk_forward(e, st, pl, A, pl.xq, n, tasks, pl.theta);
@@ -1445,6 +1530,7 @@ extern "C" int mi_learner_hvp(mi_engine* e, void* stream, const float* theta, in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nl = (int)e->L.size();
   const size_t pstride = theta_tasks == 1 ? 0 : e->P;
+  { const int brc = plan_begin(e, st, pl); if (brc) return brc; }
   ActSet& A = pl.sup[0];
   LAUNCH(e, st, OP_MISC, 0, launch_nchw_to_nhwc(st, x, (size_t)tasks * n, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs));
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, pstride, e->perm_dev, (int)e->P, (int)e->PS, tasks, pl.theta));
@@ -1555,6 +1641,9 @@ extern "C" int mi_conv3x3_bn_stats(void* stream, const float* x, const float* w9
   ca.mpix = n * ca.g.ho * ca.g.wo;
   if ((size_t)tasks * conv_max_blocks_per_task(ca.g) * 2 * co * sizeof(double) > scratch_bytes)
     return fail(nullptr, MI_ERR_WORKSPACE, "scratch too small");
+  hipError_t aerr = hipSuccess;      // (fp16 operand form: the input's largest magnitude per task, a reduction launch of its own here)
+  ca.amax[0] = standalone_amax(st, 0, x, (size_t)n * h * wd * ci, tasks, &aerr);
+  HIPCHK0(aerr);
   int blk = 0;
   HIPCHK0(launch_conv3x3(st, ca, tasks, 1, EPI_STATS, 0, &blk));
   HIPCHK0(launch_bn_finalize(st, ca.partial, blk, tasks, co, 1.0 / (double)ca.mpix, FIN_STATS, mu, co, rstd, co));
@@ -1600,12 +1689,18 @@ extern "C" int mi_conv3x3_bwd(void* stream, const float* x, const float* dz, con
   wa.g = ConvGeom{n, h, wd, ho, wo, ci, co, stride};
   wa.mpix = n * ho * wo;
   if (wgrad_partial_floats(wa.g, tasks) * sizeof(float) > scratch_bytes) return fail(nullptr, MI_ERR_WORKSPACE, "scratch too small");
+  hipError_t aerr = hipSuccess;
+  wa.amax_x[0] = standalone_amax(st, 0, x, (size_t)n * h * wd * ci, tasks, &aerr);
+  HIPCHK0(aerr);
+  wa.amax_dz[0] = standalone_amax(st, 1, dz, (size_t)n * ho * wo * co, tasks, &aerr);
+  HIPCHK0(aerr);
   int nch = 0;
   HIPCHK0(launch_wgrad3x3(st, wa, tasks, 1, &nch));
   HIPCHK0(launch_wgrad_reduce(st, wa.partial, nch, 9 * ci * co, tasks, dw9, gstride));
   if (dx) {
     ConvArgs ca{};
     ca.in[0] = dz; ca.wt[0] = w9; ca.wstride = pstride; ca.out = dx;
+    ca.amax[0] = wa.amax_dz[0];
     ca.g = ConvGeom{n, ho, wo, h, wd, co, ci, stride};
     ca.mpix = n * h * wd;
     HIPCHK0(launch_conv3x3(st, ca, tasks, 1, EPI_NONE, 1, nullptr));

@@ -21,7 +21,8 @@ struct ConvArgs {
   ConvGeom g;
   int mpix;             // n*ho*wo
   int ntiles, tiles_per_wave;
-  int split_bf16;       // set by launch_conv3x3: this launch takes the split-bf16 form (30-pixel tiles)
+  int split_bf16;       // set by launch_conv3x3: the operand form of this launch -- 0 fp32 pipe, 1 split-bf16, 2 scaled fp16 planes (30-pixel tiles)
+  const unsigned* amax[2];   // fp16 form: cell [task * MI_CELL_STRIDE] = the exponent field (fp32 bits) of max |in[term]| of the task (written by the tensor's producer, launch_amax otherwise)
 };
 
 struct WgradArgs {
@@ -30,6 +31,8 @@ struct WgradArgs {
   float* partial;       // [T][nchunks][9][ci][co]
   ConvGeom g;
   int mpix, chunk_pix, nchunks, nterms;
+  const unsigned* amax_x[2]; const unsigned* amax_dz[2];   // fp16 form: cells (as ConvArgs::amax) of x[term] / dz[term] (all given, or none)
+  int form;             // set by launch_wgrad3x3 (as ConvArgs::split_bf16)
 };
 
 struct BnArgs {
@@ -46,6 +49,8 @@ struct BnArgs {
   const float* dp;      // [T][n][hp][wp][c]
   const float* dpd;
   float* out;
+  unsigned* amax_out;   // optional cells [task * MI_CELL_STRIDE]: the kernels that write `out` fold the exponent of max |out| per task into them (zeroed by the
+                        // caller; the fp16 operand form of the convolution that reads `out` next takes its scale from there)
   float* zh_out;        // forward kernels, optional [T][n][hp][wp][c]: zhat (tangent forward: its tangent) at every pooled output's argmax --
                         // what the BatchNorm-backward sums need besides p and dp, so they can ride in the next block's dgrad epilogue
   double* partial;      // [T][nblk][2][c]
@@ -71,6 +76,7 @@ int pooled_reduce_blocks(int rows, int c, int tasks);
 hipError_t launch_pooled_reduce(hipStream_t st, const PoolRedArgs& a, int tasks, int tangent, int* nblk);
 
 // conv_mfma.hip
+int conv_operand_form();   // 0 fp32 pipe, 1 split-bf16, 2 scaled fp16 planes (mi_conv_set_split_bf16)
 hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int epi, int mode, int* blocks_per_task);
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out);
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* partial, int nchunks, int nelem, int tasks, float* out, size_t ostride);
@@ -101,6 +107,7 @@ struct B1Args {
   const float *rdgamma, *rdbeta; size_t hstride;
   const float* dp; const float* dpd;      // [T][n][H/2][W/2][Co]
   float* out;                // p or pd
+  unsigned* amax_out;        // optional (forward modes): cells of max |out| per task, as BnArgs::amax_out
   float* zh_out;             // optional: zhat (FWD) / its tangent (TFWD) at each window's argmax, same shape as out
   uint8_t* arg_out;          // optional (FWD): argmax position 0..3 of every window, 4 where the maximum did not pass the ReLU
   const uint8_t* arg_in; const float* zh_in;   // TFWD_ARG: the two tensors FWD stored (no primal conv recompute)
@@ -222,6 +229,8 @@ hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* src, size_t images, 
 hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* perm, int p, int pstride, int tasks, float* out_ref);
 hipError_t launch_axpy(hipStream_t st, const float* a, const float* b, float alpha, size_t n, float* out);
 hipError_t launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes);
+hipError_t launch_amax(hipStream_t st, const float* x, size_t per_task, int tasks, unsigned* cell);   // cell[task * MI_CELL_STRIDE] = max(itself, exponent bits of max |x[task]|)
+const unsigned* standalone_amax(hipStream_t st, int slot, const float* x, size_t per_task, int tasks, hipError_t* err);
 struct BnExportArgs {
   const float* mu[8]; const float* rstd[8];     // [T][c_l] per block
   int c[8], off[8];

@@ -105,5 +105,30 @@ __device__ __forceinline__ void buf_st(mi_rsrc r, unsigned off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
 }
 
+// Largest-magnitude cells (the fp16 operand form's per-(task, tensor) scale, bf16_split.h): a producer folds the bit patterns of |x| of
+// the values it writes into `m` (mi_amax_acc), reduces over the wave and commits ONE atomic max per wave at the end of the kernel.
+// Unsigned maxima of non-negative fp32 bit patterns: order-independent, so the cell -- and everything scaled by it -- is reproducible.
+__device__ __forceinline__ void mi_amax_acc(unsigned& m, float v) {
+  const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+  m = b > m ? b : m;
+}
+// Only the exponent is committed (all the scale needs).  One atomic per WORKGROUP (waves meet in LDS; every thread of the workgroup
+// must call this), and a task's cell sits alone in a 256-byte line (MI_CELL_STRIDE words apart): device-scope atomics on one line are
+// served one at a time, ~12 ns each across the XCDs' L2s -- one atomic per wave on 32 adjacent cells cost a 13 us kernel 100 us.
+#define MI_CELL_STRIDE 64
+__device__ __forceinline__ void mi_amax_commit(unsigned m, unsigned* cell) {
+  __shared__ unsigned mi_amax_red[16];
+  m &= 0x7f800000u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0) mi_amax_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (int)((blockDim.x + 63) >> 6);
+    for (int w = 1; w < nw; ++w) m = mi_amax_red[w] > m ? mi_amax_red[w] : m;
+    if (m != 0u) atomicMax(cell, m);
+  }
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

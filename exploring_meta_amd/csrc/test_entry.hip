@@ -33,6 +33,10 @@ extern "C" int mi_conv3x3_tangent(void* stream, const float* x0, const float* w0
   ca.mpix = n * ca.g.ho * ca.g.wo;
   if ((size_t)tasks * conv_max_blocks_per_task(ca.g) * 2 * co * sizeof(double) > scratch_bytes)
     return mi_internal_fail(MI_ERR_WORKSPACE, "mi_conv3x3_tangent: scratch too small");
+  // (fp16 operand form: the operands' largest magnitudes, which the engine's producers leave behind, from a reduction launch here)
+  hipError_t aerr = hipSuccess;
+  ca.amax[0] = standalone_amax(S(stream), 0, x0, (size_t)n * h * wd * ci, tasks, &aerr); TCHK(aerr);
+  if (x1) { ca.amax[1] = standalone_amax(S(stream), 1, x1, (size_t)n * h * wd * ci, tasks, &aerr); TCHK(aerr); }
   int blk = 0;
   TCHK(launch_conv3x3(S(stream), ca, tasks, x1 ? 2 : 1, EPI_TSTATS, 0, &blk));
   TCHK(launch_bn_finalize(S(stream), ca.partial, blk, tasks, co, 1.0 / (double)ca.mpix, FIN_TSTATS, m1, co, m2, co));
@@ -53,6 +57,11 @@ extern "C" int mi_conv3x3_bwd2(void* stream, const float* x0, const float* dz0, 
   wa.mpix = n * ho * wo;
   if (wgrad_partial_floats(wa.g, tasks) * sizeof(float) > scratch_bytes)
     return mi_internal_fail(MI_ERR_WORKSPACE, "mi_conv3x3_bwd2: scratch too small");
+  hipError_t aerr = hipSuccess;
+  wa.amax_x[0] = standalone_amax(S(stream), 0, x0, (size_t)n * h * wd * ci, tasks, &aerr); TCHK(aerr);
+  wa.amax_dz[0] = standalone_amax(S(stream), 1, dz0, (size_t)n * ho * wo * co, tasks, &aerr); TCHK(aerr);
+  wa.amax_x[1] = standalone_amax(S(stream), 2, x1, (size_t)n * h * wd * ci, tasks, &aerr); TCHK(aerr);
+  wa.amax_dz[1] = standalone_amax(S(stream), 3, dz1, (size_t)n * ho * wo * co, tasks, &aerr); TCHK(aerr);
   int nch = 0;
   TCHK(launch_wgrad3x3(S(stream), wa, tasks, 2, &nch));
   TCHK(launch_wgrad_reduce(S(stream), wa.partial, nch, 9 * ci * co, tasks, dw9, gstride));
@@ -60,6 +69,7 @@ extern "C" int mi_conv3x3_bwd2(void* stream, const float* x0, const float* dz0, 
     ConvArgs ca{};
     // R{dx} = dgrad(dz0, w0) + dgrad(dz1, w1)
     ca.in[0] = dz0; ca.wt[0] = w0; ca.in[1] = dz1; ca.wt[1] = w1; ca.wstride = pstride; ca.out = dx;
+    ca.amax[0] = wa.amax_dz[0]; ca.amax[1] = wa.amax_dz[1];
     ca.g = ConvGeom{n, ho, wo, h, wd, co, ci, stride};
     ca.mpix = n * h * wd;
     TCHK(launch_conv3x3(S(stream), ca, tasks, 2, EPI_NONE, 1, nullptr));

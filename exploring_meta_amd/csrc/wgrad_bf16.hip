@@ -82,6 +82,39 @@ __device__ __forceinline__ void split_dz_pair(const float* v, DzPl& p) {
   bf16_split2(floatx2{v[2 * P], v[2 * P + 1]}, p.h[P], p.m[P], p.l[P]);
   asm volatile("" : "+v"(p.h[P]), "+v"(p.m[P]), "+v"(p.l[P]));
 }
+// F16: the two-plane fp16 form (bf16_split.h) -- planes h and l only, the value scaled by s (wave-uniform) on the way
+template <int P, bool F16>
+__device__ __forceinline__ void split_x(const float* v, RowPl& p, float s) {
+  if constexpr (F16) {
+    f16_split2(floatx2{v[2 * P], v[2 * P + 1]}, s, p.h[P], p.l[P]);
+    asm volatile("" : "+v"(p.h[P]), "+v"(p.l[P]));
+  } else {
+    split_x_pair<P>(v, p);
+  }
+}
+template <int P, bool F16>
+__device__ __forceinline__ void split_dz(const float* v, DzPl& p, float s) {
+  if constexpr (F16) {
+    f16_split2(floatx2{v[2 * P], v[2 * P + 1]}, s, p.h[P], p.l[P]);
+    asm volatile("" : "+v"(p.h[P]), "+v"(p.l[P]));
+  } else {
+    split_dz_pair<P>(v, p);
+  }
+}
+// scales of the operands of every term (x, dz) and the factor that takes them out of the sums again; all wave-uniform
+struct F16Scales { float sx[2], sd[2], inv; };
+__device__ __forceinline__ F16Scales f16_wgrad_scales(const WgradArgs& a, int task) {
+  int kk[2][2] = {{0, 0}, {0, 0}};
+  for (int t = 0; t < a.nterms; ++t) { kk[t][0] = f16_scale_exp(a.amax_x[t][(size_t)task * MI_CELL_STRIDE]); kk[t][1] = f16_scale_exp(a.amax_dz[t][(size_t)task * MI_CELL_STRIDE]); }
+  if (a.nterms == 2) f16_common_scale(kk);
+  F16Scales r;
+  for (int t = 0; t < 2; ++t) {
+    r.sx[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_pow2(kk[t][0]))));
+    r.sd[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f16_pow2(kk[t][1]))));
+  }
+  r.inv = f16_pow2(-(kk[0][0] + kk[0][1]));
+  return r;
+}
 __device__ __forceinline__ void odd_plane(const unsigned* e, unsigned* o) {   // (v1,v2) = high half of (v0,v1) | low half of (v2,v3) ...
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbit(e[i + 1], e[i], 16);
@@ -90,7 +123,7 @@ __device__ __forceinline__ void odd_plane(const unsigned* e, unsigned* o) {   //
 
 }  // namespace
 
-template <int C>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile))
+template <int C, bool F16>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile))
 __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   __shared__ float red[4 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -114,6 +147,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   const mi_rsrc rx1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1p + (size_t)task * t_elems), 0, tb, 0x00020000);
   const mi_rsrc rd1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d1p + (size_t)task * t_elems), 0, tb, 0x00020000);
   const unsigned lane_x = (unsigned)(cit * 32 + j) * 4u, lane_dz = (unsigned)(cot * 32 + j) * 4u;
+  F16Scales fs = {{1.f, 1.f}, {1.f, 1.f}, 1.f};
+  if constexpr (F16) fs = f16_wgrad_scales(a, task);
 
   floatx16 acc[9];
 #pragma unroll
@@ -130,7 +165,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   OddPl po[2];
   DzPl pb[2];
   // six plane products of one tap, the next row's (or unit's) operand preparation spread between them
-#define WG_MFMA(T, X, Y) if (MI_WGRAD_DBG != 1 && MI_WGRAD_DBG != 4) acc[T] = MI_BF_MFMA(X, Y, acc[T])
+  // (F16: three products -- l b_h, h b_l, h b_h -- with the same preparation slots between them)
+#define WG_MFMA(T, X, Y) if (MI_WGRAD_DBG != 1 && MI_WGRAD_DBG != 4) { if constexpr (F16) acc[T] = MI_F16_MFMA(X, Y, acc[T]); else acc[T] = MI_BF_MFMA(X, Y, acc[T]); }
+#define WG_MFMA3(T, X, Y) if constexpr (!F16) { WG_MFMA(T, X, Y); }    /* the three products only the three-plane form has */
 #define WG_TAP(T, AH, AM, AL, B, V0, V1, V2, V3)                                       \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   WG_MFMA(T, AL, B.h);                                                                 \
@@ -141,32 +178,33 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   __builtin_amdgcn_sched_barrier(0);                                                   \
   if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { V1; }                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                   \
-  WG_MFMA(T, AM, B.m);                                                            \
+  WG_MFMA3(T, AM, B.m);                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { V2; }                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                   \
-  WG_MFMA(T, AM, B.h);                                                            \
+  WG_MFMA3(T, AM, B.h);                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { V3; }                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                   \
-  WG_MFMA(T, AH, B.m);                                                            \
+  WG_MFMA3(T, AH, B.m);                                                           \
   WG_MFMA(T, AH, B.h);                                                            \
   __builtin_amdgcn_sched_barrier(0);
   // one row of taps (3r, 3r + 1, 3r + 2) from planes (E, O) against B; meanwhile row NR of raw set NRAW is prepared into (NE, NO) and,
   // where NR == 0 (the next unit), its dz into NB
-#define WG_ROW(R, E, O, B, NRAW, NR, NE, NO, NB, FRAW)                                                                         \
-  WG_TAP(3 * (R) + 0, (E.h), (E.m), (E.l), B, split_x_pair<0>(NRAW.xa[NR], NE), split_x_pair<1>(NRAW.xa[NR], NE),        \
-         split_x_pair<2>(NRAW.xa[NR], NE), split_x_pair<3>(NRAW.xa[NR], NE))                                             \
-  WG_TAP(3 * (R) + 1, (O.h), (O.m), (O.l), B, split_x_pair<4>(NRAW.xa[NR], NE), odd_plane(NE.h, NO.h), odd_plane(NE.m, NO.m), \
+  // (SXN / SDN: the scales of the unit whose rows / dz are being prepared -- the unit after this one where NR == 0)
+#define WG_ROW(R, E, O, B, NRAW, NR, NE, NO, NB, FRAW, SXN, SDN)                                                               \
+  WG_TAP(3 * (R) + 0, (E.h), (E.m), (E.l), B, (split_x<0, F16>(NRAW.xa[NR], NE, SXN)), (split_x<1, F16>(NRAW.xa[NR], NE, SXN)),        \
+         (split_x<2, F16>(NRAW.xa[NR], NE, SXN)), (split_x<3, F16>(NRAW.xa[NR], NE, SXN)))                                             \
+  WG_TAP(3 * (R) + 1, (O.h), (O.m), (O.l), B, (split_x<4, F16>(NRAW.xa[NR], NE, SXN)), odd_plane(NE.h, NO.h), if constexpr (!F16) odd_plane(NE.m, NO.m), \
          odd_plane(NE.l, NO.l))                                                                                          \
   WG_TAP(3 * (R) + 2, (E.h + 1), (E.m + 1), (E.l + 1), B,                                                                \
-         if (NR == 0) split_dz_pair<0>(NRAW.b, NB), if (NR == 0) split_dz_pair<1>(NRAW.b, NB),                           \
-         if (NR == 0) split_dz_pair<2>(NRAW.b, NB), if (NR == 0) split_dz_pair<3>(NRAW.b, NB))
+         if (NR == 0) (split_dz<0, F16>(NRAW.b, NB, SDN)), if (NR == 0) (split_dz<1, F16>(NRAW.b, NB, SDN)),                           \
+         if (NR == 0) (split_dz<2, F16>(NRAW.b, NB, SDN)), if (NR == 0) (split_dz<3, F16>(NRAW.b, NB, SDN)))
   // one unit: raw set K % 3 (its row 0 and dz are already in planes, buffers K & 1), the next unit in raw set (K + 1) % 3
 #define WG_UNIT(K)                                                                              \
-  WG_ROW(0, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[(K) % 3], 1, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[(K) & 1], raw[((K) + 2) % 3])       \
-  WG_ROW(1, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[(K) & 1], raw[(K) % 3], 2, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[((K) + 2) % 3])       \
-  WG_ROW(2, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[((K) + 1) % 3], 0, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[((K) + 1) & 1], raw[((K) + 2) % 3])
+  WG_ROW(0, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[(K) % 3], 1, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[(K) & 1], raw[((K) + 2) % 3], sx_cur, sd_cur)       \
+  WG_ROW(1, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[(K) & 1], raw[(K) % 3], 2, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[((K) + 2) % 3], sx_cur, sd_cur)       \
+  WG_ROW(2, pe[(K) & 1], po[(K) & 1], pb[(K) & 1], raw[((K) + 1) % 3], 0, pe[((K) + 1) & 1], po[((K) + 1) & 1], pb[((K) + 1) & 1], raw[((K) + 2) % 3], sx_nxt, sd_nxt)
 
   int u = ub0 + wave;
   {
@@ -175,10 +213,13 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
     WG_LOAD(0, raw[1], u + 4, p1); WG_LOAD(1, raw[1], u + 4, p1); WG_LOAD(2, raw[1], u + 4, p1); WG_LOAD(3, raw[1], u + 4, p1);
   }
   // prologue: row 0 and dz of the first unit
-  split_x_pair<0>(raw[0].xa[0], pe[0]); split_x_pair<1>(raw[0].xa[0], pe[0]); split_x_pair<2>(raw[0].xa[0], pe[0]);
-  split_x_pair<3>(raw[0].xa[0], pe[0]); split_x_pair<4>(raw[0].xa[0], pe[0]);
-  odd_plane(pe[0].h, po[0].h); odd_plane(pe[0].m, po[0].m); odd_plane(pe[0].l, po[0].l);
-  split_dz_pair<0>(raw[0].b, pb[0]); split_dz_pair<1>(raw[0].b, pb[0]); split_dz_pair<2>(raw[0].b, pb[0]); split_dz_pair<3>(raw[0].b, pb[0]);
+  {
+    const float sx0 = u >= nunits ? fs.sx[1] : fs.sx[0], sd0 = u >= nunits ? fs.sd[1] : fs.sd[0];
+    split_x<0, F16>(raw[0].xa[0], pe[0], sx0); split_x<1, F16>(raw[0].xa[0], pe[0], sx0); split_x<2, F16>(raw[0].xa[0], pe[0], sx0);
+    split_x<3, F16>(raw[0].xa[0], pe[0], sx0); split_x<4, F16>(raw[0].xa[0], pe[0], sx0);
+    odd_plane(pe[0].h, po[0].h); if constexpr (!F16) odd_plane(pe[0].m, po[0].m); odd_plane(pe[0].l, po[0].l);
+    split_dz<0, F16>(raw[0].b, pb[0], sd0); split_dz<1, F16>(raw[0].b, pb[0], sd0); split_dz<2, F16>(raw[0].b, pb[0], sd0); split_dz<3, F16>(raw[0].b, pb[0], sd0);
+  }
   // Six units per trip: the raw sets rotate with period three, the plane buffers with period two (a unit has three rows, so the row
   // planes of unit K start in buffer K & 1 and end there, the next unit's row 0 lands in (K + 1) & 1).  No exit and no skip inside
   // a trip (either makes the compiler keep a second copy of the 144 accumulator registers and move between them): a unit past the
@@ -188,6 +229,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   {                                                                         \
     const int fv = u + 4 * ((K) + 2);      /* the unit two ahead: its loads go out before this unit's MFMAs (between them they were slower) */ \
     const WUnitPos fpos = pos_of(fv);                                       \
+    const bool t1c_ = u + 4 * (K) >= nunits, t1n_ = u + 4 * ((K) + 1) >= nunits;   /* second term: this unit / the next one */ \
+    const float sx_cur = t1c_ ? fs.sx[1] : fs.sx[0], sd_cur = t1c_ ? fs.sd[1] : fs.sd[0];   \
+    const float sx_nxt = t1n_ ? fs.sx[1] : fs.sx[0], sd_nxt = t1n_ ? fs.sd[1] : fs.sd[0];   \
+    (void)sd_cur;                                                           \
     if (MI_WGRAD_DBG != 3) {                                                \
       WG_LOAD(0, raw[((K) + 2) % 3], fv, fpos); WG_LOAD(1, raw[((K) + 2) % 3], fv, fpos);   \
       WG_LOAD(2, raw[((K) + 2) % 3], fv, fpos); WG_LOAD(3, raw[((K) + 2) % 3], fv, fpos);   \
@@ -214,7 +259,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = tid + 256 * q;
-      const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      if constexpr (F16) v *= fs.inv;                          // the operands' scales out of the sums (a power of two: exact)
       const int r = e >> 6, l = e & 63;
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
       pt[((size_t)tap * C + cit * 32 + row) * C + cot * 32 + col] = v;
@@ -234,7 +280,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
 struct StripItem { int n, c0, ya, yb; bool ok; };
 struct XRowPl { RowPl e; };                                     // (the odd packing is rebuilt per step: 12 instructions instead of 12 resident registers per row)
 
-template <int C>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile))
+template <int C, bool F16>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile))
 __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   __shared__ float red[4 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -253,6 +299,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   const unsigned rowb = (unsigned)(W * C * 4);                 // bytes of one image row
   constexpr int NCT = C / 32;
   const int cit = blockIdx.z / NCT, cot = blockIdx.z - cit * NCT;
+  F16Scales fs = {{1.f, 1.f}, {1.f, 1.f}, 1.f};
+  if constexpr (F16) fs = f16_wgrad_scales(a, task);
 
   floatx16 acc[9];
 #pragma unroll
@@ -268,6 +316,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   for (int item = ub0 + wave; item < ub1; item += 4) {
     const int term = item >= nitems ? 1 : 0;
     const int it = item - term * nitems;
+    const float sxi = term ? fs.sx[1] : fs.sx[0], sdi = term ? fs.sd[1] : fs.sd[0];     // (F16) this item's operand scales
     const int n = it / (nseg * nh);
     const int rem = it - n * nseg * nh;
     const int s16 = rem / nh, half = rem - s16 * nh;
@@ -290,10 +339,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
       _Pragma("unroll") for (int c = 1; c < 10; ++c) rawx[SET][c] = buf_ld(rr_, vo + (unsigned)((c - 1) * C * 4)); }
 #define ST_LOADD(SET, YY) { const mi_rsrc rr_ = drow(YY);                                                                  \
       _Pragma("unroll") for (int c = 0; c < 8; ++c) rawd[SET][c] = buf_ld(rr_, vod + (unsigned)(c * C * 4)); }
-#define ST_SPLITX(SET, SLOT) { split_x_pair<0>(rawx[SET], xr[SLOT].e); split_x_pair<1>(rawx[SET], xr[SLOT].e); split_x_pair<2>(rawx[SET], xr[SLOT].e); \
-      split_x_pair<3>(rawx[SET], xr[SLOT].e); split_x_pair<4>(rawx[SET], xr[SLOT].e); }
-#define ST_SPLITD(SET, BUF) { split_dz_pair<0>(rawd[SET], dzp[BUF]); split_dz_pair<1>(rawd[SET], dzp[BUF]); split_dz_pair<2>(rawd[SET], dzp[BUF]); \
-      split_dz_pair<3>(rawd[SET], dzp[BUF]); }
+#define ST_SPLITX(SET, SLOT) { split_x<0, F16>(rawx[SET], xr[SLOT].e, sxi); split_x<1, F16>(rawx[SET], xr[SLOT].e, sxi); split_x<2, F16>(rawx[SET], xr[SLOT].e, sxi); \
+      split_x<3, F16>(rawx[SET], xr[SLOT].e, sxi); split_x<4, F16>(rawx[SET], xr[SLOT].e, sxi); }
+#define ST_SPLITD(SET, BUF) { split_dz<0, F16>(rawd[SET], dzp[BUF], sdi); split_dz<1, F16>(rawd[SET], dzp[BUF], sdi); split_dz<2, F16>(rawd[SET], dzp[BUF], sdi); \
+      split_dz<3, F16>(rawd[SET], dzp[BUF], sdi); }
     // prologue: x rows ya - 1, ya, ya + 1 (slots 0, 1, 2) and dz row ya; then the ring: x rows ya + 2 .. ya + 4, dz rows ya + 1 .. ya + 3
     ST_LOADX(0, ya - 1) ST_LOADX(1, ya) ST_LOADX(2, ya + 1) ST_LOADD(0, ya)
     ST_SPLITX(0, 0) ST_SPLITX(1, 1) ST_SPLITX(2, 2) ST_SPLITD(0, 0)
@@ -303,31 +352,33 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
     ST_LOADX(3, ya + 2) ST_LOADD(1, ya + 1) ST_LOADX(0, ya + 3) ST_LOADD(2, ya + 2)
     // step T (output row y + T of the trip that starts at row y): x rows in slots T, T+1, T+2 (mod 4), dz planes T & 1; meanwhile x row
     // y + T + 2 (raw set (T + 3) & 3) is split into slot (T + 3) & 3 and dz row y + T + 1 (raw set (T + 1) & 3) into planes (T + 1) & 1
-#define ST_MFMA(T, X, Y) if (MI_WGRAD_DBG != 1 && MI_WGRAD_DBG != 4) acc[T] = MI_BF_MFMA(X, Y, acc[T])
-#define ST_MFMA_LOW(T, X, Y) if (MI_WGRAD_DBG != 5) ST_MFMA(T, X, Y)      /* the three products a two-plane operand form would not have */
+  // (F16: three products -- l b_h, h b_l, h b_h -- with the same preparation slots between them)
+#define ST_MFMA(T, X, Y) if (MI_WGRAD_DBG != 1 && MI_WGRAD_DBG != 4) { if constexpr (F16) acc[T] = MI_F16_MFMA(X, Y, acc[T]); else acc[T] = MI_BF_MFMA(X, Y, acc[T]); }
+#define ST_MFMA_LOW(T, X, Y) if (MI_WGRAD_DBG != 5) ST_MFMA(T, X, Y)      /* (ablation build: the bf16 form without three of its six products) */
+#define ST_MFMA3(T, X, Y) if constexpr (!F16) { ST_MFMA(T, X, Y); }          /* the three products only the three-plane form has */
 #define ST_TAP(T, AH, AM, AL, B, V0, V1, V2, V3)                                       \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    ST_MFMA_LOW(T, AL, B.h);                                                      \
+    if constexpr (F16) { ST_MFMA(T, AL, B.h); } else { ST_MFMA_LOW(T, AL, B.h); }   \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     V0;                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    ST_MFMA_LOW(T, AH, B.l);                                                      \
+    if constexpr (F16) { ST_MFMA(T, AH, B.l); } else { ST_MFMA_LOW(T, AH, B.l); }   \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     V1;                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    ST_MFMA_LOW(T, AM, B.m);                                                      \
+    if constexpr (!F16) { ST_MFMA_LOW(T, AM, B.m); }                              \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     V2;                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    ST_MFMA(T, AM, B.h);                                                          \
+    ST_MFMA3(T, AM, B.h);                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     V3;                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    ST_MFMA(T, AH, B.m);                                                          \
+    ST_MFMA3(T, AH, B.m);                                                         \
     ST_MFMA(T, AH, B.h);                                                          \
     __builtin_amdgcn_sched_barrier(0);
 #define ST_ROW(R, X, B, V3, V4, V5, V6, V7, V8, V9, V10, V11)                                                     \
-    ST_TAP(3 * (R) + 0, (X.e.h), (X.e.m), (X.e.l), B, ST_PREP(odd_plane(X.e.h, ot.h)), ST_PREP(odd_plane(X.e.m, ot.m)), ST_PREP(odd_plane(X.e.l, ot.l)), V3)   \
+    ST_TAP(3 * (R) + 0, (X.e.h), (X.e.m), (X.e.l), B, ST_PREP(odd_plane(X.e.h, ot.h)), ST_PREP(if constexpr (!F16) odd_plane(X.e.m, ot.m)), ST_PREP(odd_plane(X.e.l, ot.l)), V3)   \
     ST_TAP(3 * (R) + 1, (ot.h), (ot.m), (ot.l), B, V4, V5, V6, V7)                                                \
     ST_TAP(3 * (R) + 2, (X.e.h + 1), (X.e.m + 1), (X.e.l + 1), B, V8, V9, V10, V11)
 #define ST_PREP(X) if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { X; }
@@ -338,9 +389,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
       const float* rd_ = rawd[((T) + 1) & 3];                                                                     \
       DzPl& nd = dzp[((T) + 1) & 1];                                                                              \
       const DzPl& cd = dzp[(T) & 1];                                                                              \
-      ST_ROW(0, xr[(T) & 3], cd, ST_PREP(split_x_pair<0>(rx_, nx.e)), ST_PREP(split_x_pair<1>(rx_, nx.e)), ST_PREP(split_x_pair<2>(rx_, nx.e)),      \
-             ST_PREP(split_x_pair<3>(rx_, nx.e)), ST_PREP(split_x_pair<4>(rx_, nx.e)), ST_PREP(split_dz_pair<0>(rd_, nd)), ST_PREP(split_dz_pair<1>(rd_, nd)), \
-             ST_PREP(split_dz_pair<2>(rd_, nd)), ST_PREP(split_dz_pair<3>(rd_, nd)))                                \
+      ST_ROW(0, xr[(T) & 3], cd, ST_PREP((split_x<0, F16>(rx_, nx.e, sxi))), ST_PREP((split_x<1, F16>(rx_, nx.e, sxi))), ST_PREP((split_x<2, F16>(rx_, nx.e, sxi))),      \
+             ST_PREP((split_x<3, F16>(rx_, nx.e, sxi))), ST_PREP((split_x<4, F16>(rx_, nx.e, sxi))), ST_PREP((split_dz<0, F16>(rd_, nd, sdi))), ST_PREP((split_dz<1, F16>(rd_, nd, sdi))), \
+             ST_PREP((split_dz<2, F16>(rd_, nd, sdi))), ST_PREP((split_dz<3, F16>(rd_, nd, sdi))))                                \
       ST_ROW(1, xr[((T) + 1) & 3], cd,                                                                            \
              if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADX(1, y + 4) else if ((T) == 2) ST_LOADX(3, y + 6),          \
              if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADD(3, y + 3) else if ((T) == 2) ST_LOADD(1, y + 5),          \
@@ -357,6 +408,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
 #undef ST_PREP
 #undef ST_ROW
 #undef ST_TAP
+#undef ST_MFMA3
+#undef ST_MFMA_LOW
 #undef ST_MFMA
 #undef ST_SPLITD
 #undef ST_SPLITX
@@ -374,7 +427,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = tid + 256 * q;
-      const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      if constexpr (F16) v *= fs.inv;                          // the operands' scales out of the sums (a power of two: exact)
       const int r = e >> 6, l = e & 63;
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
       pt[((size_t)tap * C + cit * 32 + row) * C + cot * 32 + col] = v;
@@ -401,8 +455,13 @@ int wgrad_bf16_strip_items(const ConvGeom& g, int rows) {
 }
 hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid, int rows) {
   a.mpix = wgrad_bf16_strip_rows(a.g, rows);                   // (the kernel takes the rows per piece in this field)
-  if (a.g.ci == 64) hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<64>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad3x3_strip_bf16_kernel<32>, grid, dim3(256), 0, st, a);
+  if (a.form == 2) {
+    if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<64, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, true>), grid, dim3(256), 0, st, a);
+  } else {
+    if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<64, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, false>), grid, dim3(256), 0, st, a);
+  }
   return hipGetLastError();
 }
 
@@ -415,7 +474,12 @@ bool wgrad_bf16_ok(const ConvGeom& g) {
 int wgrad_bf16_units(const ConvGeom& g) { return g.n * ((g.h + 1) / 2) * ((g.w + 7) / 8); }
 
 hipError_t launch_wgrad_rows_bf16(hipStream_t st, const WgradArgs& a, dim3 grid) {
-  if (a.g.ci == 64) hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<64>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad3x3_rows_bf16_kernel<32>, grid, dim3(256), 0, st, a);
+  if (a.form == 2) {
+    if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<64, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<32, true>), grid, dim3(256), 0, st, a);
+  } else {
+    if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<64, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad3x3_rows_bf16_kernel<32, false>), grid, dim3(256), 0, st, a);
+  }
   return hipGetLastError();
 }

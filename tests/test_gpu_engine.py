@@ -63,12 +63,12 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=['split_bf16', 'fp32_pipe'])
+@pytest.fixture(params=['split_f16', 'split_bf16', 'fp32_pipe'])
 def conv_form(request):
     """Operand form of the 32-channel stride-1 convolutions (mi_conv_set_split_bf16) for the duration of one test."""
     from exploring_meta_amd import _lib
     lb = _lib.load()
-    was = lb.mi_conv_set_split_bf16(1 if request.param == 'split_bf16' else 0)
+    was = lb.mi_conv_set_split_bf16({'split_f16': 2, 'split_bf16': 1, 'fp32_pipe': 0}[request.param])
     yield request.param
     lb.mi_conv_set_split_bf16(was)
 
