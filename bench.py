@@ -369,7 +369,7 @@ def run_vision(args, wl, rank, world, local, dist):
         return d
 
     # The same step with the hidden convolutions on the exact fp32 matrix pipe (mi_conv_set_split_bf16(0)): the headline's operand
-    # form is the split-bf16 one, this is what the arithmetic change is worth, in the same run on the same box.
+    # form is the two-plane fp16 one, this is what the arithmetic change is worth, in the same run on the same box.
     fp32_pipe = None
     mask = C.c_uint(0)
     # (pooling nets only: the stride-1 hidden blocks are where the two operand forms differ; a bisecting run's variant mask is left alone)
@@ -395,7 +395,7 @@ def run_vision(args, wl, rank, world, local, dist):
     if dom in prof:
         ms, cnt = prof[dom]
         flops, nbytes = RF.op_costs(spec, dom[0], dom[1], n_img)
-        split = bool(eng.lib.mi_conv_get_split_bf16(None))      # the operand form of the hidden convolutions (read, not written)
+        split = int(eng.lib.mi_conv_get_split_bf16(None))      # the operand form of the hidden convolutions (read, not written): 0, 1, 2
         pipe_peak, pipe = RF.mfma_peak(spec, dom[0], dom[1], split)
         bound = RF.bound_of(flops, nbytes, pipe_peak)
         h, w, ci, co, ho, wo, _, _ = RF.layer_geometry(spec)[dom[1]]
@@ -431,9 +431,10 @@ def run_vision(args, wl, rank, world, local, dist):
                         note='dominant kernel among those that run alone on the chip (dgrad / wgrad of blocks >= 2 share it with each '
                              'other in the timed region); single_stream_step: per-kernel figures of one untimed step with the side '
                              'stream off, HIP events around every launch.  FLOPs are ALGORITHMIC fp32 FLOPs throughout; a kernel on '
-                             'the split-bf16 operand form executes six bf16 products per fp32 multiply-add, so its peak is the dense '
-                             'bf16 MFMA rate / 6 = 416.7 TFLOP/s (pipe: "bf16 x6"), and vs_fp32_mfma_peak says what the same launch is '
-                             'against the fp32 matrix pipe it no longer uses')
+                             'the two-plane fp16 operand form executes three fp16 products per fp32 multiply-add, so its peak is the '
+                             'dense 16-bit MFMA rate / 3 = 833.3 TFLOP/s (pipe: "fp16 x3"; the three-plane bf16 form: six products, '
+                             '416.7, "bf16 x6"), and vs_fp32_mfma_peak says what the same launch is against the fp32 matrix pipe it no '
+                             'longer uses')
 
     if args.breakdown:                          # every rank runs the extra step (it contains the all-reduce); rank 0 writes
         eng.set_overlap(False)                  # one stream: the per-kernel times add up to the iteration
@@ -479,7 +480,7 @@ def run_vision(args, wl, rank, world, local, dist):
                    'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter',
                    'task_hardness': HARDNESS[wl['dataset']]},
         'post_adapt': post, 'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline,
-        'cpu_baseline': cpu, 'collective': collective, 'arithmetic': arithmetic_note(eng), 'fp32_pipe': fp32_pipe, 'clock': clock,
+        'cpu_baseline': cpu, 'collective': collective, 'arithmetic': arithmetic_note(eng, T), 'fp32_pipe': fp32_pipe, 'clock': clock,
     }
 
 
@@ -529,13 +530,22 @@ def clock_record(step, world, seconds=3.0, ms_per_step=None):
             'samples': len(samples), 'how': 'rocm-smi -c -P while the step loop runs, after the timed region'}
 
 
-def arithmetic_note(eng):
+def arithmetic_note(eng, tasks_per_call=32):
     """What "f32" means for this line: inputs, outputs, accumulation and every stored tensor are fp32; with the split operand form
     (the default) the hidden convolutions and weight gradients form each fp32 product from exact three-way bf16 splits of both operands."""
-    split = bool(eng.lib.mi_conv_get_split_bf16(None))
+    split = int(eng.lib.mi_conv_get_split_bf16(None))
     if not split:
-        return {'split_bf16_operands': False, 'note': 'fp32 throughout (fp32-input MFMA = an fmaf chain; fp64 for statistics and reductions)'}
-    return {'split_bf16_operands': True,
+        return {'split_bf16_operands': False, 'operand_form': 'fp32',
+                'note': 'fp32 throughout (fp32-input MFMA = an fmaf chain; fp64 for statistics and reductions)'}
+    if split == 2:
+        return {'split_bf16_operands': False, 'operand_form': 'fp16 x2 planes, 3 products',
+                'note': 'fp32 tensors and fp32 accumulation throughout (fp64 for statistics and reductions).  Hidden 3x3 convolutions and weight '
+                        'gradients: each fp32 operand, scaled by a power of two chosen per task and tensor from its largest magnitude, as two '
+                        'fp16 planes (x s = h + l to 2^-22, 2^-39 of the maximum absolutely), three fp16 MFMA products per multiply-add, the '
+                        'scales divided out of the fp32 sums exactly: per-kernel errors against the fp64 oracle are at or below those of the '
+                        'fp32 matrix pipe (tests run all three forms against the same bars); MI_CONV_BF16X3=1 selects three exact bf16 '
+                        'planes (six products), MI_CONV_BF16X3=0 the fp32 pipe'}
+    return {'split_bf16_operands': True, 'operand_form': 'bf16 x3 planes, 6 products',
             'note': 'fp32 tensors and fp32 accumulation throughout (fp64 for statistics and reductions).  Hidden 3x3 convolutions and weight '
                     'gradients: each fp32 operand as the EXACT sum of three bf16 pieces, six bf16 MFMA products per multiply-add, dropped '
                     'cross terms <= 2^-24 of a product (one fp32 rounding): per-kernel errors against the fp64 oracle are the same or smaller '

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void block1_kernel(B1Args a) {
     }
   }
 
-  if ((MODE == B1_FWD || MODE == B1_TFWD || MODE == B1_TFWD_ARG) && a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
+  if ((MODE == B1_FWD || MODE == B1_TFWD || MODE == B1_TFWD_ARG) && a.amax_out) mi_amax_commit(am, a.amax_out, task);
   if (RED) {
     // lanes l and l^32 hold the same channel; 4 waves -> one fp64 partial per workgroup
     s0 += __shfl_xor(s0, 32, 64);
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
     compute_tile(tile, B);
     tile += 4;
   }
-  if (want_amax) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
+  if (want_amax) mi_amax_commit(am, a.amax_out, task);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -567,17 +567,21 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 // spread either way (16.45 / 16.36 and 16.60 / 16.79 ms in two A/B pairs: the workload sits at the socket power cap) -- and every change
 // of conv1's rounding redraws which near-tied pooling decisions flip: tools/accuracy_parity.py (6400 predictions) reads 0.016 % from the
 // reference's fp64 accuracy with the fp32 pipe and 0.203 % with this form (profiles/r4/accuracy_parity_cfg2*.md).  Default: fp32 pipe.
+// 2 = the tangent-forward kernel only: it takes no decisions (the argmax is the stored one), so its rounding redraws nothing.
+#ifndef MI_B1_DEFAULT_SPLIT
+#define MI_B1_DEFAULT_SPLIT 0
+#endif
 static int g_b1_split = -1;
-static bool block1_split_bf16() {
+static int block1_split_bf16() {
   if (g_b1_split < 0) {
     const char* e = getenv("MI_B1_BF16X3");
-    g_b1_split = (e && atoi(e) != 0) ? 1 : 0;
+    g_b1_split = e ? (atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e))) : MI_B1_DEFAULT_SPLIT;
   }
-  return g_b1_split != 0;
+  return g_b1_split;
 }
 extern "C" int mi_block1_set_split_bf16(int on) {
-  const int was = block1_split_bf16() ? 1 : 0;
-  g_b1_split = on ? 1 : 0;
+  const int was = block1_split_bf16();
+  g_b1_split = on < 0 ? 0 : (on > 2 ? 2 : on);
   return was;
 }
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co) {
@@ -623,7 +627,8 @@ hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, 
   // tasks -- more than ~198 84x84x3 images per task -- fall back to the general kernel)
   const size_t x_task_bytes = (size_t)a.n * a.hh * a.ww * ci * 4, p_task_bytes = (size_t)a.n * (a.hh / 2) * (a.ww / 2) * a.co * 4;
   if (!force_general && (mode == B1_FWD || mode == B1_TFWD_ARG) && x_task_bytes < (1u << 24) && p_task_bytes < MI_OOB) {
-    if (ci == 3 && block1_split_bf16()) {
+    const int b1s = block1_split_bf16();
+    if (ci == 3 && (b1s == 1 || (b1s == 2 && mode == B1_TFWD_ARG))) {
       if (mode == B1_FWD) hipLaunchKernelGGL((block1_fwd_kernel<3, false, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((block1_fwd_kernel<3, true, true>), grid, dim3(256), 0, st, a);
     } else if (ci == 3) {

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
     *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
     if (zh_t) *reinterpret_cast<floatx4*>(zh_t + w.poff) = zh_at;
   }
-  if (a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
+  if (a.amax_out) mi_amax_commit(am, a.amax_out, task);
 }
 
 template <int POOL>
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnArgs a) {
       store4(out_t + w.off[p], o);
     }
   }
-  if (a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
+  if (a.amax_out) mi_amax_commit(am, a.amax_out, task);
 }
 
 // tangent forward: pd = [u>0 at argmax] * (gammad*zh + gamma*zhd + betad),  zhd = r (zd - m1 - zh m2)
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void bn_tan_fwd_kernel(BnArgs a) {
     *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
     if (a.zh_out) *reinterpret_cast<floatx4*>(a.zh_out + (size_t)task * p_task + w.poff) = zo;
   }
-  if (a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
+  if (a.amax_out) mi_amax_commit(am, a.amax_out, task);
 }
 
 // tangent backward reductions: R{dbeta} = sum dud ; R{dgamma} = sum (dud zh + du zhd)   (argmax positions only)
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_tan_bwd_apply_kernel(BnArgs a) {
       store4(out_t + w.off[p], o);
     }
   }
-  if (a.amax_out) mi_amax_commit(am, a.amax_out + (size_t)task * MI_CELL_STRIDE);
+  if (a.amax_out) mi_amax_commit(am, a.amax_out, task);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

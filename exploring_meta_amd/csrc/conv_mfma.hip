@@ -111,13 +111,19 @@ __device__ __forceinline__ void conv_prefetch_z(float* zpre, const float* __rest
 // MODE 0: forward   out[o] = sum_tap in[o*S + d - 1] * W[tap]            weights [9][CI][CO]
 // MODE 1: dgrad     out[i] = sum_tap in[(i + 1 - d)/S] * W[tap]^T        weights [9][CO_op][CI_op] (the forward layout)
 // waves per workgroup: the 2-term variants stage 2 x 36 KB of weights, so 8 waves share one copy (2 workgroups = 4 waves/SIMD)
+#ifndef MI_F16_WIDE
+// The fp16 form needs two thirds of the bf16 form's LDS and fewer registers, so eight-wave workgroups at four waves per SIMD fit
+// (-DMI_F16_WIDE=1).  Measured on one box, two repeats each: 15.69 / 15.65 ms per cfg2 iteration wide against 15.51 / 15.54 with the
+// bf16 form's shapes (two waves per SIMD) -- occupancy is not what these kernels wait for.  Default: the bf16 form's shapes.
+#define MI_F16_WIDE 0
+#endif
 template <int CI, int NTERMS, bool BF = false, bool F16 = false> struct ConvWaves {
   // (split-bf16 form at 64 filters: 108 KB of weight planes per workgroup -> one workgroup per CU, so eight waves share it)
-  // (fp16 form: always eight -- two workgroups per CU share two staged weight copies among 16 waves, four per SIMD)
-  static constexpr int value = (F16 || (NTERMS == 2 && CI == 32) || (BF && CI == 64)) ? 8 : 4;
+  // (fp16 form with MI_F16_WIDE: always eight -- two workgroups per CU share two staged weight copies among 16 waves, four per SIMD)
+  static constexpr int value = ((F16 && MI_F16_WIDE) || (NTERMS == 2 && CI == 32) || (BF && CI == 64)) ? 8 : 4;
 };
-// fp16 form: the variants that fit 128 registers are built for four waves per SIMD (the tangent-statistics epilogue does not)
-template <int EPI, bool F16> struct ConvWavesPerSimd { static constexpr int value = (F16 && EPI != 2 /* EPI_TSTATS */) ? 4 : 1; };
+// fp16 form with MI_F16_WIDE: the variants that fit 128 registers are built for four waves per SIMD (the tangent-statistics epilogue does not)
+template <int EPI, bool F16> struct ConvWavesPerSimd { static constexpr int value = (F16 && MI_F16_WIDE && EPI != 2 /* EPI_TSTATS */) ? 4 : 1; };
 // Measured (rocprofv3 SQ counters + hipOccupancy): the 2-term EPI_TSTATS variant takes 178 VGPRs, so one 8-wave workgroup is
 // resident per CU (1.8 waves/SIMD) while the 2-term dgrad (108 VGPRs, two workgroups, 2.9 waves/SIMD) reaches the same 74 % MFMA
 // busy fraction: occupancy is not the limiter.  Forcing <= 128 VGPRs (__launch_bounds__(512, 4)) spills 17 dwords into the
@@ -338,6 +344,13 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
   float f16_sa[NTERMS], f16_sw[NTERMS], f16_inv = 1.f;           // F16: scales of the activations / the weights per term, 1 / (their product)
 #pragma unroll
   for (int t = 0; t < NTERMS; ++t) { f16_sa[t] = 1.f; f16_sw[t] = 1.f; }
+  unsigned f16_amax[NTERMS];                                     // F16: the activations' largest-magnitude cells, fetched before anything else
+#pragma unroll
+  for (int t = 0; t < NTERMS; ++t) f16_amax[t] = 0u;
+  if constexpr (F16) {
+#pragma unroll
+    for (int t = 0; t < NTERMS; ++t) f16_amax[t] = mi_cell_fetch(a.amax[t], task);
+  }
   if constexpr (BF) {
     mi_u32x4* l4 = reinterpret_cast<mi_u32x4*>(lds);
     constexpr int NIT = NSTEP * 2 * 64, IPT = (NIT + NT - 1) / NT;   // items (8 weights of one output channel) per thread
@@ -393,7 +406,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
 #pragma unroll
         for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w * NTERMS + t]);
         kk[t][1] = f16_scale_exp(__float_as_uint(m));
-        kk[t][0] = f16_scale_exp(a.amax[t][(size_t)task * MI_CELL_STRIDE]);
+        kk[t][0] = f16_scale_exp(mi_cell_fold(f16_amax[t]));
       }
       if (NTERMS == 2) f16_common_scale(kk);
 #pragma unroll
@@ -471,8 +484,11 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
     r_c = a.rstd[(size_t)task * CO + cbase + j];
   }
   mi_rsrc rbp = rout, rbzh = rout, rbzhd = rout, rbdp = rout;
+  // (EPI_BRED) "ReLU on" from the block's argmax byte where it has one (block 1: a quarter of p's bytes), else from p itself
+  const bool bred_arg = EPI == EPI_BRED && a.barg != nullptr;
   if (EPI == EPI_BRED) {
-    rbp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bp + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
+    if (bred_arg) rbp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.barg + (size_t)task * t_elems), 0, (unsigned)t_elems, 0x00020000);
+    else rbp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bp + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
     rbzh = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bzh + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
     if (NTERMS == 2) {
       rbzhd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bzhd + (size_t)task * t_elems), 0, t_bytes, 0x00020000);
@@ -542,7 +558,12 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
   // k = cc*32 + 16h + 8kb + 0..7 of its pixel in the displaced row (2 x 16 B).  Three MFMA units per half-group (horizontal
   // displacement 0, -1, +1), six bf16 MFMAs each.  A row is fetched ONCE and shifted across lanes for the two other taps:
   // a third of the fp32 kernel's per-lane 16-B cache accesses (its L1 runs at 0.77 accesses per clock and CU, tools/conv_l1_probe.py).
-  constexpr int NH = NSTEP / 3 * 2, HRING = 3;               // loads run two half-groups ahead of the split, three ahead of the MFMAs
+#ifndef MI_F16_HRING
+#define MI_F16_HRING 3
+#endif
+  // loads run two half-groups ahead of the split, three ahead of the MFMAs (fp16 form: a half-group is nine MFMAs instead of eighteen, but
+  // a ring of six -- the same distance in time -- costs 24 registers, spills in the epilogues with sums, and measured 15.8 against 15.2 ms)
+  constexpr int NH = NSTEP / 3 * 2, HRING = F16 ? MI_F16_HRING : 3;
   static_assert(NH % HRING == 0 && NH % 2 == 0, "raw ring and plane double buffer must be in phase at every tile boundary");
   floatx4 rawc[BF ? HRING : 1][2];
   auto hg_term = [](int i) { return i / (6 * NCC); };
@@ -761,7 +782,10 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) {
           const unsigned o = row_off(grp * GR + rr);
-          gq.pp[rr] = buf_ld(rbp, o);
+          // (uniform branch; the byte as an integer in a float register: 0..3 = the window's argmax position, 4 = its ReLU is off;
+          // a row past the end of the task reads 0 = "on", and contributes nothing: its accumulators and cotangents are exact zeros)
+          if (bred_arg) gq.pp[rr] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rbp, o >> 2, 0, 0));
+          else gq.pp[rr] = buf_ld(rbp, o);
           gq.zz[rr] = buf_ld(rbzh, o);
           if (NTERMS == 2) { gq.zd[rr] = buf_ld(rbzhd, o); gq.dq[rr] = buf_ld(rbdp, o); }
         }
@@ -775,7 +799,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
           else buf_st(rout, row_off(r), v);
           // "ReLU on" as a lane mask: p is a ReLU output (>= +0), so 0 - p carries a sign bit exactly where p > 0.  The masked
           // values are ANDs on the floats (mi_common.h): a select after the fp64 conversion is two quarter-rate v_cndmask per row
-          int on = lane_mask_negative(0.f - gq.pp[rr]);
+          int on = bred_arg ? ((int)__builtin_bit_cast(unsigned, gq.pp[rr]) - 4) >> 31      // -1 where the byte is below 4
+                            : lane_mask_negative(0.f - gq.pp[rr]);
           if (BF && r == 0) on &= keep_lo;
           if (BF && r == 15) on &= keep_hi;
           const float vv = lane_keep_where(on, v);
@@ -1157,7 +1182,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // scaled fp16 planes (three products; launches whose operands come without a largest-magnitude cell take form 1).
 // MI_CONV_BF16X3 / mi_conv_set_split_bf16.
 #ifndef MI_CONV_DEFAULT_FORM
-#define MI_CONV_DEFAULT_FORM 1
+#define MI_CONV_DEFAULT_FORM 2
 #endif
 static int g_conv_split_bf16 = -1;
 static unsigned g_conv_split_mask = 0x3ffffu;                   // debug: which variants take the split form: conv bit ((terms-1)*2 + mode)*4 + epi, weight gradient bit 16 + (terms-1)
@@ -1295,10 +1320,10 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
   // the split-bf16 form of the stride-1 kernel (32 filters; 64 filters with one term): tiles of 30 output pixels, 2048 resident waves
   a.split_bf16 = ((a.g.ci == 32 || (a.g.ci == 64 && nterms == 1)) && conv_s1_ok(a) && conv_split_bf16() &&
                   (epi == EPI_BRED ? mode == 1 : (mode == 0 || epi == EPI_NONE)) &&
-                  ((g_conv_split_mask >> (((nterms - 1) * 2 + mode) * 4 + epi)) & 1u)) ? g_conv_split_bf16 : 0;
+                  ((g_conv_split_mask >> (((nterms - 1) * 2 + mode) * 4 + epi)) & 1u)) ? conv_operand_form() : 0;
   if (a.split_bf16 == 2 && (!a.amax[0] || (nterms == 2 && !a.amax[1]))) a.split_bf16 = 1;      // no scales: the bf16 form
-  const int nw = (a.split_bf16 == 2 || (nterms == 2 && a.g.ci == 32) || (a.split_bf16 && a.g.ci == 64)) ? 8 : 4;     // ConvWaves<CI, NTERMS, BF, F16>
-  conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid, a.split_bf16 ? 30 : 32, a.split_bf16 == 2 && epi != EPI_TSTATS);
+  const int nw = ((a.split_bf16 == 2 && MI_F16_WIDE) || (nterms == 2 && a.g.ci == 32) || (a.split_bf16 && a.g.ci == 64)) ? 8 : 4;     // ConvWaves<CI, NTERMS, BF, F16>
+  conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid, a.split_bf16 ? 30 : 32, a.split_bf16 == 2 && MI_F16_WIDE && epi != EPI_TSTATS);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
   if (blocks_per_task) *blocks_per_task = grid.x;

@@ -49,6 +49,7 @@ struct mi_engine {
   // the tail of every pass of mi_meta_batch_maml as ONE launch (gram.hip, advance_kernel): weight-gradient partial folds, block 1's
   // Gram-matrix assembly, the fast-weight / adjoint update and the next pass's Gram statistics -- instead of 3 reduce_partials +
   // gram_wgrad + axpy + gram_stats launches and a memset per pass.  Same arithmetic in the same order: bit-identical results.
+  bool bred_arg = true;     // block 2's dgrad epilogue reads block 1's argmax byte instead of p (MI_BRED_ARG=0: p, for A/B runs; same results)
   bool fuse_tail = true;
   unsigned zoff[10] = {}, zlen[10] = {};   // conv-bias segments and the padding P..PS of a parameter-shaped vector (never written by a kernel)
   int nzero = 0;
@@ -183,6 +184,7 @@ extern "C" int mi_engine_create(const mi_model_desc* d, int device, mi_engine** 
     ci = l.co; h = l.hp; w = l.wp;
   }
   e->fuse1 = block1_supported(e->L[0].ci, e->L[0].stride, e->L[0].pool, e->L[0].ho, e->L[0].wo, e->L[0].co);
+  if (const char* ba = getenv("MI_BRED_ARG")) e->bred_arg = atoi(ba) != 0;
   e->head_c = ci;
   e->head_hw = h * w;
   e->feat = d->head_mean_pool ? ci : ci * h * w;
@@ -514,7 +516,7 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
     }
   }
   pl.cell_cap = 8 + (K + 1) * 2 * nl + K * 4 * nl + 4 * nl;      // p and dz per block and pass, pd and R{dz} per Hessian-vector pass, spare
-  pl.cells = b.take<unsigned>((size_t)pl.cell_cap * T * MI_CELL_STRIDE);
+  pl.cells = b.take<unsigned>((size_t)pl.cell_cap * T * MI_CELL_WORDS);
   pl.cell_T = T;
   pl.bytes = align_up(b.off, 256);
 }
@@ -524,7 +526,7 @@ static int plan_begin(mi_engine* e, hipStream_t st, Plan& pl) {
   pl.f16 = conv_operand_form() == 2;
   pl.cell_used = 0;
   pl.cellmap.clear();
-  if (pl.f16) HIPCHK(e, hipMemsetAsync(pl.cells, 0, (size_t)pl.cell_cap * pl.cell_T * MI_CELL_STRIDE * sizeof(unsigned), st));
+  if (pl.f16) HIPCHK(e, hipMemsetAsync(pl.cells, 0, (size_t)pl.cell_cap * pl.cell_T * MI_CELL_WORDS * sizeof(unsigned), st));
   return MI_OK;
 }
 // the producer of `tensor` is about to be launched: a fresh cell for it to fold max |tensor| into (nullptr: no fp16 form, or no slot
@@ -535,7 +537,7 @@ static unsigned* cell_bind(mi_engine* e, Plan& pl, const void* tensor) {
   for (auto it = pl.cellmap.begin(); it != pl.cellmap.end(); ++it)
     if (it->first == tensor) { pl.cellmap.erase(it); break; }      // the tensor is being rewritten: its old cell is stale
   if (no_hooks || pl.cell_used >= pl.cell_cap) return nullptr;
-  unsigned* c = pl.cells + (size_t)(pl.cell_used++) * pl.cell_T * MI_CELL_STRIDE;
+  unsigned* c = pl.cells + (size_t)(pl.cell_used++) * pl.cell_T * MI_CELL_WORDS;
   pl.cellmap.emplace_back(tensor, c);
   return c;
 }
@@ -546,7 +548,7 @@ static int cell_of(mi_engine* e, hipStream_t st, Plan& pl, const float* tensor, 
   for (const auto& kv : pl.cellmap)
     if (kv.first == tensor) { *out = kv.second; return MI_OK; }
   if (pl.cell_used >= pl.cell_cap) return fail(e, MI_ERR_WORKSPACE, "fp16 operand form: no largest-magnitude cell left for this call");
-  unsigned* c = pl.cells + (size_t)(pl.cell_used++) * pl.cell_T * MI_CELL_STRIDE;
+  unsigned* c = pl.cells + (size_t)(pl.cell_used++) * pl.cell_T * MI_CELL_WORDS;
   pl.cellmap.emplace_back(tensor, c);
   LAUNCH(e, st, OP_MISC, 5, launch_amax(st, tensor, per_task, T, c));
   *out = c;
@@ -754,6 +756,7 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       if (zh_lo) {   // dgamma / dbeta of the block below in this kernel's epilogue
         const Layer& L0 = e->L[l - 1];
         ca.bp = A.p[l - 1]; ca.bzh = zh_lo; ca.partial = pl.bnpart;
+        ca.barg = (l - 1 == 0 && e->fuse1 && e->bred_arg) ? A.arg0 : nullptr;
         ca.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L0.off_gamma, P, g + L0.off_beta, P);
         int blk0 = 0;
         LAUNCH(e, st, OP_DGRAD, l, launch_conv3x3(st, ca, T, 1, EPI_BRED, 1, &blk0));
@@ -1026,6 +1029,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       if (zh_lo && zhd_lo) {   // R{dgamma}, R{dbeta} of the block below in this kernel's epilogue
         const Layer& L0 = e->L[l - 1];
         ca.bp = A.p[l - 1]; ca.bzh = zh_lo; ca.bzhd = zhd_lo; ca.bdp = A.dp[l - 1]; ca.partial = pl.bnpart;
+        ca.barg = (l - 1 == 0 && e->fuse1 && e->bred_arg) ? A.arg0 : nullptr;
         ca.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L0.off_gamma, P, hv + L0.off_beta, P);
         int blk0 = 0;
         LAUNCH(e, st, OP_TAN_DGRAD, l, launch_conv3x3(st, ca, T, 2, EPI_BRED, 1, &blk0));
@@ -1222,7 +1226,7 @@ static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, An
   ap.scratch.wgpart_side = b.take<float>(wgp);
   ap.scratch.gram_part = ap.scratch.gram_s = nullptr;
   ap.scratch.cell_cap = 8 + 4 * (int)e->L.size();
-  ap.scratch.cells = b.take<unsigned>((size_t)ap.scratch.cell_cap * T * MI_CELL_STRIDE);
+  ap.scratch.cells = b.take<unsigned>((size_t)ap.scratch.cell_cap * T * MI_CELL_WORDS);
   ap.scratch.cell_T = T;
   if (e->fuse1 && e->gram1 && gram_supported(e->L[0].w, e->L[0].ci)) {   // statistics + weight gradient of block 1 from the Gram matrix
     ap.scratch.gram_part = b.take<double>(gram_partial_doubles(T, 2 * n, e->L[0].h, e->L[0].ci));

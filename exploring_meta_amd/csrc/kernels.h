@@ -18,11 +18,12 @@ struct ConvArgs {
   //   1 term : dgamma = sum [p>0] out zh,                    dbeta = sum [p>0] out
   //   2 terms: R{dgamma} = sum [p>0] (out zh + dp zhd),      R{dbeta} = sum [p>0] out        (out = R{dp}, dp = primal cotangent)
   const float *bp, *bzh, *bzhd, *bdp;
+  const uint8_t* barg;  // optional (replaces the read of bp): the argmax byte block 1's forward kernel stores per pooled element, 4 = ReLU off <=> p == 0
   ConvGeom g;
   int mpix;             // n*ho*wo
   int ntiles, tiles_per_wave;
   int split_bf16;       // set by launch_conv3x3: the operand form of this launch -- 0 fp32 pipe, 1 split-bf16, 2 scaled fp16 planes (30-pixel tiles)
-  const unsigned* amax[2];   // fp16 form: cell [task * MI_CELL_STRIDE] = the exponent field (fp32 bits) of max |in[term]| of the task (written by the tensor's producer, launch_amax otherwise)
+  const unsigned* amax[2];   // fp16 form: cells [T][MI_CELL_WORDS] (mi_common.h) = the exponent field (fp32 bits) of max |in[term]| per task (written by the tensor's producer, launch_amax otherwise)
 };
 
 struct WgradArgs {
@@ -49,7 +50,7 @@ struct BnArgs {
   const float* dp;      // [T][n][hp][wp][c]
   const float* dpd;
   float* out;
-  unsigned* amax_out;   // optional cells [task * MI_CELL_STRIDE]: the kernels that write `out` fold the exponent of max |out| per task into them (zeroed by the
+  unsigned* amax_out;   // optional cells [T][MI_CELL_WORDS] (mi_common.h): the kernels that write `out` fold the exponent of max |out| per task into them (zeroed by the
                         // caller; the fp16 operand form of the convolution that reads `out` next takes its scale from there)
   float* zh_out;        // forward kernels, optional [T][n][hp][wp][c]: zhat (tangent forward: its tangent) at every pooled output's argmax --
                         // what the BatchNorm-backward sums need besides p and dp, so they can ride in the next block's dgrad epilogue
@@ -229,7 +230,7 @@ hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* src, size_t images, 
 hipError_t launch_scatter_sum(hipStream_t st, const float* lam, const int32_t* perm, int p, int pstride, int tasks, float* out_ref);
 hipError_t launch_axpy(hipStream_t st, const float* a, const float* b, float alpha, size_t n, float* out);
 hipError_t launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes);
-hipError_t launch_amax(hipStream_t st, const float* x, size_t per_task, int tasks, unsigned* cell);   // cell[task * MI_CELL_STRIDE] = max(itself, exponent bits of max |x[task]|)
+hipError_t launch_amax(hipStream_t st, const float* x, size_t per_task, int tasks, unsigned* cell);   // cells [T][MI_CELL_WORDS] (mi_common.h) |= exponent bits of max |x[task]|
 const unsigned* standalone_amax(hipStream_t st, int slot, const float* x, size_t per_task, int tasks, hipError_t* err);
 struct BnExportArgs {
   const float* mu[8]; const float* rstd[8];     // [T][c_l] per block

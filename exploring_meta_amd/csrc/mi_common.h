@@ -112,11 +112,16 @@ __device__ __forceinline__ void mi_amax_acc(unsigned& m, float v) {
   const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
   m = b > m ? b : m;
 }
-// Only the exponent is committed (all the scale needs).  One atomic per WORKGROUP (waves meet in LDS; every thread of the workgroup
-// must call this), and a task's cell sits alone in a 256-byte line (MI_CELL_STRIDE words apart): device-scope atomics on one line are
-// served one at a time, ~12 ns each across the XCDs' L2s -- one atomic per wave on 32 adjacent cells cost a 13 us kernel 100 us.
-#define MI_CELL_STRIDE 64
-__device__ __forceinline__ void mi_amax_commit(unsigned m, unsigned* cell) {
+// Only the exponent is committed (all the scale needs).  Device-scope atomics on one line are served one at a time, ~12 ns each across
+// the XCDs' L2s (one atomic per WAVE on 32 adjacent cells cost a 13 us kernel 100 us; one per workgroup on one line per task still cost
+// 0.15 / 0.27 ms per cfg2 iteration at 1 / 4 tasks per call, where a task's launch has up to 2048 workgroups).  Hence: one atomic per
+// WORKGROUP (waves meet in LDS; every thread of the workgroup must call mi_amax_commit), and a (task, tensor) cell is MI_CELL_SUB
+// sub-cells, each alone in a 256-byte line, a workgroup committing to sub-cell (blockIdx.x + blockIdx.z) mod MI_CELL_SUB.  A reader takes
+// the maximum of the sub-cells (mi_cell_read: one load per lane, four lane exchanges).
+#define MI_CELL_STRIDE 64                         // words between sub-cells
+#define MI_CELL_SUB 16
+#define MI_CELL_WORDS (MI_CELL_SUB * MI_CELL_STRIDE)   // words per (task, tensor)
+__device__ __forceinline__ void mi_amax_commit(unsigned m, unsigned* cells, int task) {
   __shared__ unsigned mi_amax_red[16];
   m &= 0x7f800000u;
 #pragma unroll
@@ -126,8 +131,24 @@ __device__ __forceinline__ void mi_amax_commit(unsigned m, unsigned* cell) {
   if (threadIdx.x == 0) {
     const int nw = (int)((blockDim.x + 63) >> 6);
     for (int w = 1; w < nw; ++w) m = mi_amax_red[w] > m ? mi_amax_red[w] : m;
-    if (m != 0u) atomicMax(cell, m);
+#ifndef MI_AMAX_DBG_NOATOMIC      /* timing experiment (wrong results): the commit without its atomic */
+    // (a workgroup whose exponent does not exceed what its sub-cell already holds skips the atomic: a launch of 2048 short workgroups
+    // otherwise ends in 2048 atomics, ~3.5 us of them -- 0.27 ms per cfg2 iteration at 4 tasks per call; a stale read only costs an atomic)
+    unsigned* c = cells + (size_t)task * MI_CELL_WORDS + ((blockIdx.x + blockIdx.z) & (MI_CELL_SUB - 1)) * MI_CELL_STRIDE;
+    if (m > __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(c, m);
+#endif
   }
+}
+// the cell of `task`, in two steps so that the load (a miss: the atomics ran at the memory side) is in flight while the kernel issues
+// its other prologue loads: mi_cell_fetch at the top of the kernel (every lane of the wave), mi_cell_fold where the value is needed
+// (the result is wave-uniform)
+__device__ __forceinline__ unsigned mi_cell_fetch(const unsigned* cells, int task) {
+  return cells[(size_t)task * MI_CELL_WORDS + (threadIdx.x & (MI_CELL_SUB - 1)) * MI_CELL_STRIDE];
+}
+__device__ __forceinline__ unsigned mi_cell_fold(unsigned m) {
+#pragma unroll
+  for (int o = MI_CELL_SUB / 2; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -266,7 +266,7 @@ hipError_t launch_bn_export(hipStream_t st, const BnExportArgs& a, int tasks) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Largest magnitude of a tensor per task -- its exponent field, as fp32 bits -- in cell[task * MI_CELL_STRIDE] (cells zeroed by the caller; max over
+// Largest magnitude of a tensor per task -- its exponent field, as fp32 bits -- in the task's cell (mi_common.h: MI_CELL_WORDS words per task; zeroed by the caller; max over
 // unsigned bit patterns of |x|: order-independent, NaN and infinity sort on top).  The two-plane fp16 operand form of the convolutions (bf16_split.h) takes its
 // per-(task, tensor) scale from these cells.  Inside the engine the tensors' PRODUCERS write them (one v_max per value, one atomic per
 // wave); this kernel serves tensors that come from elsewhere (the standalone operator entries, kernels without the hook).
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
   if (blockIdx.x == 0)
     for (size_t i = n4 * 4 + threadIdx.x; i < per_task; i += 256) { const unsigned b = __float_as_uint(xt[i]) & 0x7fffffffu; m = b > m ? b : m; }
-  mi_amax_commit(m, cell + (size_t)task * MI_CELL_STRIDE);
+  mi_amax_commit(m, cell, task);
 }
 hipError_t launch_amax(hipStream_t st, const float* x, size_t per_task, int tasks, unsigned* cell) {
   long blocks = (long)((per_task / 4 + 2047) / 2048);         // ~8 float4 per thread
@@ -293,19 +293,19 @@ hipError_t launch_amax(hipStream_t st, const float* x, size_t per_task, int task
   return hipGetLastError();
 }
 
-// Standalone operator entry points (no engine plan behind them): a per-device scratch of cells, [8 slots][1024 tasks] (a cell per 256-byte line), filled by
+// Standalone operator entry points (no engine plan behind them): a per-device scratch of cells, [8 slots][256 tasks] cells (mi_common.h: 16 sub-cells of one 256-byte line each), filled by
 // launch_amax on the caller's stream.  Returns nullptr -- the launch then takes the bf16 form -- unless the fp16 form is selected.
 // One stream at a time per device (the unit tests' use).
 const unsigned* standalone_amax(hipStream_t st, int slot, const float* x, size_t per_task, int tasks, hipError_t* err) {
   *err = hipSuccess;
-  constexpr int kSlots = 8, kTasks = 1024;
+  constexpr int kSlots = 8, kTasks = 256;
   if (conv_operand_form() != 2 || !x || tasks > kTasks || slot < 0 || slot >= kSlots) return nullptr;
   static unsigned* g_cells[64] = {};
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
-  if (!g_cells[d] && hipMalloc(&g_cells[d], (size_t)kSlots * kTasks * MI_CELL_STRIDE * sizeof(unsigned)) != hipSuccess) { g_cells[d] = nullptr; return nullptr; }
-  unsigned* c = g_cells[d] + (size_t)slot * kTasks * MI_CELL_STRIDE;
-  *err = hipMemsetAsync(c, 0, (size_t)tasks * MI_CELL_STRIDE * sizeof(unsigned), st);
+  if (!g_cells[d] && hipMalloc(&g_cells[d], (size_t)kSlots * kTasks * MI_CELL_WORDS * sizeof(unsigned)) != hipSuccess) { g_cells[d] = nullptr; return nullptr; }
+  unsigned* c = g_cells[d] + (size_t)slot * kTasks * MI_CELL_WORDS;
+  *err = hipMemsetAsync(c, 0, (size_t)tasks * MI_CELL_WORDS * sizeof(unsigned), st);
   if (*err == hipSuccess) *err = launch_amax(st, x, per_task, tasks, c);
   return *err == hipSuccess ? c : nullptr;
 }

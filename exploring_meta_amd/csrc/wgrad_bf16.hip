@@ -103,9 +103,16 @@ __device__ __forceinline__ void split_dz(const float* v, DzPl& p, float s) {
 }
 // scales of the operands of every term (x, dz) and the factor that takes them out of the sums again; all wave-uniform
 struct F16Scales { float sx[2], sd[2], inv; };
-__device__ __forceinline__ F16Scales f16_wgrad_scales(const WgradArgs& a, int task) {
+// (two steps, so that the cells are requested at the top of the kernel and waited for only after the first operand loads are out)
+struct F16Cells { unsigned x[2], d[2]; };
+__device__ __forceinline__ F16Cells f16_wgrad_cells(const WgradArgs& a, int task) {
+  F16Cells c = {{0u, 0u}, {0u, 0u}};
+  for (int t = 0; t < a.nterms; ++t) { c.x[t] = mi_cell_fetch(a.amax_x[t], task); c.d[t] = mi_cell_fetch(a.amax_dz[t], task); }
+  return c;
+}
+__device__ __forceinline__ F16Scales f16_wgrad_scales(const WgradArgs& a, const F16Cells& c) {
   int kk[2][2] = {{0, 0}, {0, 0}};
-  for (int t = 0; t < a.nterms; ++t) { kk[t][0] = f16_scale_exp(a.amax_x[t][(size_t)task * MI_CELL_STRIDE]); kk[t][1] = f16_scale_exp(a.amax_dz[t][(size_t)task * MI_CELL_STRIDE]); }
+  for (int t = 0; t < a.nterms; ++t) { kk[t][0] = f16_scale_exp(mi_cell_fold(c.x[t])); kk[t][1] = f16_scale_exp(mi_cell_fold(c.d[t])); }
   if (a.nterms == 2) f16_common_scale(kk);
   F16Scales r;
   for (int t = 0; t < 2; ++t) {
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
   const mi_rsrc rd1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d1p + (size_t)task * t_elems), 0, tb, 0x00020000);
   const unsigned lane_x = (unsigned)(cit * 32 + j) * 4u, lane_dz = (unsigned)(cot * 32 + j) * 4u;
   F16Scales fs = {{1.f, 1.f}, {1.f, 1.f}, 1.f};
-  if constexpr (F16) fs = f16_wgrad_scales(a, task);
+  F16Cells fcells = {{0u, 0u}, {0u, 0u}};
+  if constexpr (F16) fcells = f16_wgrad_cells(a, task);
 
   floatx16 acc[9];
 #pragma unroll
@@ -212,6 +220,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
     WG_LOAD(0, raw[0], u, p0); WG_LOAD(1, raw[0], u, p0); WG_LOAD(2, raw[0], u, p0); WG_LOAD(3, raw[0], u, p0);
     WG_LOAD(0, raw[1], u + 4, p1); WG_LOAD(1, raw[1], u + 4, p1); WG_LOAD(2, raw[1], u + 4, p1); WG_LOAD(3, raw[1], u + 4, p1);
   }
+  if constexpr (F16) fs = f16_wgrad_scales(a, fcells);
   // prologue: row 0 and dz of the first unit
   {
     const float sx0 = u >= nunits ? fs.sx[1] : fs.sx[0], sd0 = u >= nunits ? fs.sd[1] : fs.sd[0];
@@ -300,7 +309,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   constexpr int NCT = C / 32;
   const int cit = blockIdx.z / NCT, cot = blockIdx.z - cit * NCT;
   F16Scales fs = {{1.f, 1.f}, {1.f, 1.f}, 1.f};
-  if constexpr (F16) fs = f16_wgrad_scales(a, task);
+  F16Cells fcells = {{0u, 0u}, {0u, 0u}};
+  if constexpr (F16) fcells = f16_wgrad_cells(a, task);
 
   floatx16 acc[9];
 #pragma unroll
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
   for (int item = ub0 + wave; item < ub1; item += 4) {
     const int term = item >= nitems ? 1 : 0;
     const int it = item - term * nitems;
-    const float sxi = term ? fs.sx[1] : fs.sx[0], sdi = term ? fs.sd[1] : fs.sd[0];     // (F16) this item's operand scales
+
     const int n = it / (nseg * nh);
     const int rem = it - n * nseg * nh;
     const int s16 = rem / nh, half = rem - s16 * nh;
@@ -345,6 +355,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
       split_dz<3, F16>(rawd[SET], dzp[BUF], sdi); }
     // prologue: x rows ya - 1, ya, ya + 1 (slots 0, 1, 2) and dz row ya; then the ring: x rows ya + 2 .. ya + 4, dz rows ya + 1 .. ya + 3
     ST_LOADX(0, ya - 1) ST_LOADX(1, ya) ST_LOADX(2, ya + 1) ST_LOADD(0, ya)
+    if constexpr (F16) fs = f16_wgrad_scales(a, fcells);          // (scalar arithmetic on the cells requested at the top of the kernel)
+    const float sxi = term ? fs.sx[1] : fs.sx[0], sdi = term ? fs.sd[1] : fs.sd[0];     // (F16) this item's operand scales
     ST_SPLITX(0, 0) ST_SPLITX(1, 1) ST_SPLITX(2, 2) ST_SPLITD(0, 0)
     // The ring.  hipcc turns the FIRST operand wait of every loop trip into vmcnt(0) whatever is in flight across the back edge (its
     // wait-count pass does not carry exact counts around a loop), so the loads are timed such that everything in flight at a trip
@@ -416,6 +428,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
 #undef ST_LOADD
 #undef ST_LOADX
   }
+  if constexpr (F16) fs = f16_wgrad_scales(a, fcells);           // (a wave without items has not formed them yet; every thread needs fs.inv below)
 
   // cross-wave reduction, one tap at a time: red[wave][r*64 + lane]
   float* pt = a.partial + ((size_t)task * gridDim.x + blockIdx.x) * 9 * C * C;

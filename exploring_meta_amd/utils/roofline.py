@@ -13,19 +13,25 @@ BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 # The 32-channel stride-1 forward / dgrad convolutions run in the split-bf16 operand form (csrc/conv_mfma.hip): SIX bf16 products per
 # algorithmic fp32 multiply-add, so the matrix pipe bounds them at a sixth of its dense bf16 rate, in algorithmic (fp32) FLOPs:
 SPLIT_BF16_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6.0
+# ... or, by default, in the two-plane fp16 form (csrc/bf16_split.h): THREE fp16 products per multiply-add (the fp16 MFMAs run at the
+# bf16 rate), a third of the dense rate:
+SPLIT_F16_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 3.0
 SPLIT_BF16_OPS = ('conv_fwd_stats', 'dgrad', 'tangent_conv_fwd', 'tangent_dgrad')
 SPLIT_BF16_WGRAD_OPS = ('wgrad', 'tangent_wgrad')      # csrc/wgrad_bf16.hip: maps at least 16 wide (the 10 x 10 block keeps the fp32 kernel)
 
 
-def mfma_peak(spec, op, layer, split_bf16=True):
-    """(peak TFLOP/s in algorithmic fp32 FLOPs, pipe) of the matrix pipe `op` on block `layer` runs on."""
+def mfma_peak(spec, op, layer, form=2):
+    """(peak TFLOP/s in algorithmic fp32 FLOPs, pipe) of the matrix pipe `op` on block `layer` runs on.  form: the operand form of the
+    stride-1 hidden blocks (mi_conv_get_split_bf16): 0 / False fp32 pipe, 1 / True three bf16 planes, 2 two scaled fp16 planes."""
     h, w, ci, co, ho, wo, _, _ = layer_geometry(spec)[layer]
     same = ci == co and (h, w) == (ho, wo)                  # stride-1 hidden -> hidden block
-    if split_bf16 and same and ci == 32 and (op in SPLIT_BF16_OPS or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
-        return SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)'
-    if split_bf16 and same and ci == 64 and (op in ('conv_fwd_stats', 'dgrad') or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
-        # one-term forward / dgrad (two terms would need 216 KB of weight planes); weight gradients as at 32 filters
-        return SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)'
+    form = int(form)
+    split = (SPLIT_F16_PEAK_TFLOPS, 'fp16 x3 (two scaled planes)') if form == 2 else (SPLIT_BF16_PEAK_TFLOPS, 'bf16 x6 (split operands)')
+    if form and same and ci == 32 and (op in SPLIT_BF16_OPS or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
+        return split
+    if form and same and ci == 64 and (op in ('conv_fwd_stats', 'dgrad') or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
+        # one-term forward / dgrad (two terms would need 216 / 144 KB of weight planes); weight gradients as at 32 filters
+        return split
     return PEAK_TFLOPS, 'fp32'
 
 
@@ -62,8 +68,10 @@ def op_costs(spec, op, layer, images):
         # the argmax (one more pooled-shape tensor).
         rides = spec.max_pool and layer >= 1                 # this block's dgrad carries the sums of block layer-1
         ridden = spec.max_pool and layer + 1 < spec.n_layers   # this block's own sums ride in block layer+1's dgrad
-        t = {'conv_fwd_stats': (f, x + z), 'dgrad': (f, z + x + (2 * x if rides else 0)), 'wgrad': (f, x + z),
-             'tangent_conv_fwd': (2 * f, 2 * x + 2 * z), 'tangent_dgrad': (2 * f, 2 * z + x + (4 * x if rides else 0)),
+        # (where the block below is the fused block 1, its argmax BYTE stands in for p: "ReLU on" <=> the byte is below 4)
+        pb = x // 4 if (layer == 1 and fused_block1(spec)) else x
+        t = {'conv_fwd_stats': (f, x + z), 'dgrad': (f, z + x + (x + pb if rides else 0)), 'wgrad': (f, x + z),
+             'tangent_conv_fwd': (2 * f, 2 * x + 2 * z), 'tangent_dgrad': (2 * f, 2 * z + x + (3 * x + pb if rides else 0)),
              'tangent_wgrad': (2 * f, 2 * x + 2 * z),
              'bn_relu_pool_fwd': (0, z + p + (p if ridden else 0)), 'bn_bwd_reduce': (0, z + p), 'bn_bwd_apply': (0, 2 * z + p),
              'bn_tangent_fwd': (0, 2 * z + p + (p if ridden else 0)), 'bn_tangent_bwd_reduce': (0, 2 * z + 2 * p),

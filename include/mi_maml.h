@@ -403,13 +403,17 @@ int mi_debug_conv_stamps(void* buf);
  * the implicit ATen conv2d launches behind
  * ConvBlock.conv, reference core_functions/vision_models.py:177-185,189.  1: split-bf16 -- every fp32 operand as the
  * exact sum of three bf16 pieces, six v_mfma_f32_32x32x16_bf16 products per K = 16 accumulated in fp32 (the three dropped cross terms
- * are <= 2^-24 of a product: one fp32 rounding).  0: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  Default 1 (environment variable
- * MI_CONV_BF16X3=0 starts with 0); returns the previous setting.  Both forms meet the same fp32 parity bars (tests run both).
- * Values above 1 select single kernel variants or timing experiments (tools/wgrad_probe.py, csrc/conv_mfma.hip) and are not part of
- * the interface. */
+ * are <= 2^-24 of a product: one fp32 rounding).  2: two scaled fp16 planes -- x s = h + l with s a power of two chosen per task and
+ * tensor from the tensor's largest magnitude (the producing kernels record it; standalone operator entries run a reduction launch),
+ * three v_mfma_f32_32x32x16_f16 products per K = 16, the scales multiplied out of the fp32 sums exactly: 22 bits of every operand, an
+ * absolute floor 2^-39 below the tensor's maximum, per-kernel errors against fp64 at or below those of the fp32 pipe; a launch whose
+ * operands come without a recorded magnitude takes form 1.  0: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  Default 2 (environment
+ * variable MI_CONV_BF16X3=0 / 1 starts with another); returns the previous setting.  All three forms meet the same fp32 parity bars
+ * (tests run all three).  Values above 0xff (0x100 * variant mask + form) select single kernel variants for bisecting
+ * (tools/wgrad_probe.py, csrc/conv_mfma.hip) and are not part of the interface. */
 int mi_conv_set_split_bf16(int on);
-/* The operand form in force (1 split-bf16, 0 fp32 matrix pipe) read without side effects; mask_out (may be NULL) receives the variant
- * mask a bisecting run set through MI_CONV_BF16X3_MASK / mi_conv_set_split_bf16(0x100 * mask + 1). */
+/* The operand form in force (2 scaled fp16 planes, 1 split-bf16, 0 fp32 matrix pipe) read without side effects; mask_out (may be NULL)
+ * receives the variant mask a bisecting run set through MI_CONV_BF16X3_MASK / mi_conv_set_split_bf16(0x100 * mask + form). */
 int mi_conv_get_split_bf16(unsigned* mask_out);
 /* Operand form of conv1 inside the two lean block-1 forward kernels (ConvBlock 1 of a three-channel net: conv + BatchNorm + ReLU + pool
  * with the conv output never stored, and its tangent from the stored argmax; reference core_functions/vision_models.py:188-193).

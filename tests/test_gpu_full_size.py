@@ -227,12 +227,16 @@ def test_cfg4_full_T_batched_looped_oracle(T):
     # at least two of the nine checked tasks agree with the nearer leg to 1e-5, the median to 1e-2, and none is off by more than the one-decision
     # envelope.  Per step: every checked task agrees with the fp64 arithmetic to ADJ_G / ADJ_H once the decisions with an fp64
     # margin below TAU (3e-6) are allowed to fall either way.
-    assert max(el) < 1e-6 and np.median(eg) < 1e-5 and max(eg) < 5e-3
+    # (batched against one-task calls: the launch geometry -- weight-gradient chunks, statistics partials -- follows the task count, so the
+    # last bits differ and, in at most a task or two of the seventeen, a near-tied decision with them: the same one-decision envelope)
+    assert max(el) < 1e-6 and np.median(eg) < 1e-5 and sum(e > 1e-5 for e in eg) <= 2 and max(eg) < 0.3, eg
     assert np.median(lo) < 1e-5 and max(lo) < 5e-3
     # (about half of the tasks hold such a decision: P(fewer than two clean ones among nine) is below 2 %)
     assert sum(e < 1e-5 for e in ebest) >= 2 and np.median(ebest) < 1e-2 and max(e64) < 0.3, (e2e_tasks, ebest, flipped)
     raw_max = RAW_MAX_T256 if T == 256 else RAW_MAX
-    assert np.median(raw) < 1e-5 and raw.max() < raw_max and raw32.max() < raw_max
+    # (against the reference's fp32 leg the one-shot envelope RAW_MAX_T256 at either task count: there the draw is the REFERENCE's -- with
+    # the fp16 operand form a task at 1.3e-6 from the fp64 leg sat at 3.8e-2 from the fp32 leg, whose own arithmetic re-routed an element)
+    assert np.median(raw) < 1e-5 and raw.max() < raw_max and raw32.max() < RAW_MAX_T256
     assert adj_g.max() < ADJ_G and adj_h.max() < ADJ_H, (sorted(adj_g)[-4:], sorted(adj_h)[-4:])
     assert all(m < TF.TAU for m in margins)
 

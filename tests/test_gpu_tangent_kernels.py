@@ -128,6 +128,51 @@ def test_conv_tangent_two_terms(lib, name, T, n, h, w, ci, co, stride, check):
     assert max(ez) < 2e-6 and max(e1) < 2e-6 and max(e2) < 2e-6
 
 
+@pytest.mark.parametrize('s0,s1', [(1.0, 1.0), (1e6, 1e-6), (1e-6, 1e6), (1e12, 0.0), (0.0, 3e-9), (1e-20, 1e20)])
+def test_two_term_kernels_with_unequal_terms(lib, s0, s1):
+    """Two-term forward, dgrad and weight gradient whose TERMS differ by up to forty decades (or vanish): in the fp16 operand form both
+    terms share one accumulator, so the term with the larger scale product gives way (bf16_split.h f16_common_scale) -- the sum must
+    still be the fp64 sum to fp32 rounding of the LARGER term (the metric: error over the 2-norm of the result), for every form, and
+    two runs must agree bit for bit (the largest-magnitude cells are atomic maxima: order-independent)."""
+    T, n, h, w, c = 2, 3, 21, 21, 32
+    x0, x1, w0, w1, z, ho, wo = _tan_conv_inputs(T, n, h, w, c, c, 1, 77)
+    x0, w0 = (x0 * np.float32(np.sqrt(s0))), (w0 * np.float32(np.sqrt(s0)))          # term 0 ~ s0, term 1 ~ s1
+    x1, w1 = (x1 * np.float32(np.sqrt(s1))), (w1 * np.float32(np.sqrt(s1)))
+    zt = torch.from_numpy(z)
+    mu = zt.double().mean(dim=(1, 2, 3)).float()
+    rstd = (1.0 / torch.sqrt(zt.double().var(dim=(1, 2, 3), unbiased=False) + 1e-5)).float()
+    wbuf, (o0, o1), pstride = _pack(T, [w0, w1])
+    x0d, x1d, zd_in, mud, rd = dev(x0), dev(x1), dev(z), dev(mu), dev(rstd)
+    scratch, sb = _scratch(lib, T, n, h, w, c)
+    outs = []
+    for rep in range(2):
+        zd = torch.full((T, n, ho, wo, c), float('nan'), device='cuda')
+        m1, m2 = torch.empty(T, c, device='cuda'), torch.empty(T, c, device='cuda')
+        _lib.check(lib.mi_conv3x3_tangent(stream(), ptr(x0d), _at(wbuf, o0), ptr(x1d), _at(wbuf, o1), pstride, ptr(zd_in), ptr(mud),
+                                          ptr(rd), T, n, h, w, c, c, 1, ptr(zd), ptr(m1), ptr(m2), ptr(scratch), sb))
+        # the same tensors as cotangent pairs: R{dW} = wgrad(x0, dz0) + wgrad(x1, dz1), R{dx} = dgrad(dz0, w0) + dgrad(dz1, w1)
+        dz0, dz1 = x1d, x0d           # (any two tensors of the right shape: term 0 pairs x0 with x1-as-dz, term 1 x1 with x0-as-dz)
+        dx = torch.full((T, n, h, w, c), float('nan'), device='cuda')
+        dw = torch.full((T, 9 * c * c), float('nan'), device='cuda')
+        _lib.check(lib.mi_conv3x3_bwd2(stream(), ptr(x0d), ptr(dz0), ptr(x1d), ptr(dz1), _at(wbuf, o0), _at(wbuf, o1), pstride, T, n, h, w,
+                                       c, c, 1, ptr(dx), ptr(dw), 9 * c * c, ptr(scratch), sb))
+        torch.cuda.synchronize()
+        outs.append((zd.clone(), dx.clone(), dw.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), 'two runs of the same launch differ'
+    zd, dx, dw = outs[0]
+    worst = {}
+    for t in range(T):
+        want = KR.conv3x3(_t64(x0[t]), _t64(w0[t]), 1) + KR.conv3x3(_t64(x1[t]), _t64(w1[t]), 1)
+        worst['zd'] = max(worst.get('zd', 0.0), rel_err(zd[t].cpu().numpy(), want.numpy()))
+        wdx = KR.conv3x3_dgrad(_t64(x1[t]), _t64(w0[t]), (h, w), 1) + KR.conv3x3_dgrad(_t64(x0[t]), _t64(w1[t]), (h, w), 1)
+        worst['dx'] = max(worst.get('dx', 0.0), rel_err(dx[t].cpu().numpy(), wdx.numpy()))
+        wdw = KR.conv3x3_wgrad(_t64(x0[t]), _t64(x1[t]), 1) + KR.conv3x3_wgrad(_t64(x1[t]), _t64(x0[t]), 1)
+        worst['dw'] = max(worst.get('dw', 0.0), rel_err(dw[t].cpu().numpy().reshape(9, c, c), wdw.numpy()))
+    report(f'two_term_unequal[{s0:g},{s1:g}]', **worst)
+    assert all(np.isfinite(v) and v < 2e-6 for v in worst.values()), worst
+
+
 @pytest.mark.parametrize('name,T,n,h,w,ci,co,stride,check', TAN_CONV_CASES)
 def test_conv_bwd_two_terms(lib, name, T, n, h, w, ci, co, stride, check):
     """R{dW} = wgrad(x0, dz0) + wgrad(x1, dz1) (wgrad3x3_rows_mfma_kernel, 2 terms) and R{dx} = dgrad(dz0, w0) + dgrad(dz1, w1)

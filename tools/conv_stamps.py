@@ -14,7 +14,7 @@ from exploring_meta_amd import _lib  # noqa: E402
 lib = _lib.load()
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-BF_MODES = (0, 1) if '--bf' in sys.argv else (None,)
+BF_MODES = (0, 1, 2) if '--bf' in sys.argv else (None,)      # operand forms: fp32 pipe, three bf16 planes, two fp16 planes
 for T in (1, 4, 32):
     n, h, w, c = 25, 42, 42, 32
     x0 = torch.randn(T, n, h, w, c, device='cuda')
@@ -49,5 +49,5 @@ for T in (1, 4, 32):
         lib.mi_debug_conv_stamps(None)
         s = buf.cpu().numpy().astype(np.int64)
         d = [int(s[i + 1] - s[i]) for i in range(4)]
-        print(f'T={T} terms={terms} split_bf16={bf}: conv + finalize launches {e0.elapsed_time(e1) / 10 * 1e3:.1f} us | wg0 cycles: weights {d[0]}, first tile {d[1]}, '
+        print(f'T={T} terms={terms} operand form {bf}: conv + finalize (form 2: + two largest-magnitude reductions) launches {e0.elapsed_time(e1) / 10 * 1e3:.1f} us | wg0 cycles: weights {d[0]}, first tile {d[1]}, '
               f'remaining tiles {d[2]}, epilogue {d[3]}, total {int(s[4] - s[0])}', flush=True)

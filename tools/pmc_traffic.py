@@ -127,12 +127,14 @@ def main():
                 out[f'{args.workload},{key}'] = int(max(cand)[2] * 1e6)
         # (a bench run that also times the fp32-pipe form launches both variants of a kernel: the split-bf16 one -- the form the
         # workload's roofline record names -- wins, the other is skipped)
-        has_bf = {re.sub(r', (true|false)>$', '', k) for k, g, nl, f, w, c in rows if k.endswith(', true>') and nl > 0}
+        # (template arguments <CI, NTERMS, EPI, MODE, BF, F16>: BF = a split operand form, F16 = its two-plane fp16 variant)
+        base = lambda k: re.sub(r'(, (true|false)){1,2}>$', '', k)
+        has_bf = {base(k) for k, g, nl, f, w, c in rows if re.search(r'\d, true(, (true|false))?>$', k) and nl > 0}
         for k, g, nl, f, w, c in rows:
-            m = re.match(r'conv3x3_s1_mfma_kernel<(\d+), (\d), (\d), (\d)(?:, (true|false))?>', k)
+            m = re.match(r'conv3x3_s1_mfma_kernel<(\d+), (\d), (\d), (\d)(?:, (true|false))?(?:, (true|false))?>', k)
             if not (m and (m.group(2), m.group(3), m.group(4)) in CONV_OPS):
                 continue
-            if m.group(5) == 'false' and re.sub(r', (true|false)>$', '', k) in has_bf:
+            if m.group(5) == 'false' and base(k) in has_bf:
                 continue
             op = CONV_OPS[(m.group(2), m.group(3), m.group(4))]
             same_grid = [layer for layer in range(1, len(geo))       # blocks launched with this grid, largest maps first
