@@ -417,9 +417,12 @@ int mi_conv_set_split_bf16(int on);
 int mi_conv_get_split_bf16(unsigned* mask_out);
 /* Operand form of conv1 inside the two lean block-1 forward kernels (ConvBlock 1 of a three-channel net: conv + BatchNorm + ReLU + pool
  * with the conv output never stored, and its tangent from the stored argmax; reference core_functions/vision_models.py:188-193).
- * 0 (default; MI_B1_BF16X3=1 starts with 1): the fp32 matrix pipe, bit-identical to the general block-1 kernel.  1: split bf16 with all
+ * 0: the fp32 matrix pipe, bit-identical to the general block-1 kernel.  1: split bf16 with all
  * eight products down to 2^-24 (raw-pixel inputs: the six-product form of the hidden blocks is measurably noisier here) and the
- * BatchNorm normalisation folded into the product.  Returns the previous setting. */
+ * BatchNorm normalisation folded into the product.  2 (default; MI_B1_BF16X3=0 / 1 starts with another): the split form in the
+ * tangent-forward kernel only -- it takes no pooling / ReLU decisions (the argmax is the forward pass's stored one), so its rounding
+ * cannot re-route anything; the forward kernel, whose rounding decides near-tied windows, stays on the fp32 pipe.
+ * Returns the previous setting. */
 int mi_block1_set_split_bf16(int on);
 
 /* ANIL-TRPO (rl/anil_trpo.py:104-129, core_functions/rl.py:409-473 with anil=True): the stored old policies were adapted with
