@@ -25,6 +25,15 @@ BODY(k_rowdpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mo
 BODY(k_cnd, "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc")
 BODY(k_cnddpp, "v_cndmask_b32_dpp %0, %1, %8, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %1, %2, %8, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %2, %3, %8, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %3, %4, %8, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %4, %5, %8, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %5, %6, %8, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %6, %7, %8, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %7, %0, %8, vcc wave_shr:1 row_mask:0xf bank_mask:0xf")
 BODY(k_lshl, "v_lshlrev_b32 %0, 16, %0\n v_lshlrev_b32 %1, 16, %1\n v_lshlrev_b32 %2, 16, %2\n v_lshlrev_b32 %3, 16, %3\n v_lshlrev_b32 %4, 16, %4\n v_lshlrev_b32 %5, 16, %5\n v_lshlrev_b32 %6, 16, %6\n v_lshlrev_b32 %7, 16, %7")
+// the fp16 split's instructions (bf16_split.h): scale-and-round, residual from the packed half, pair conversion
+BODY(k_mixlo, "v_fma_mixlo_f16 %0, %0, %8, 0\n v_fma_mixlo_f16 %1, %1, %8, 0\n v_fma_mixlo_f16 %2, %2, %8, 0\n v_fma_mixlo_f16 %3, %3, %8, 0\n v_fma_mixlo_f16 %4, %4, %8, 0\n v_fma_mixlo_f16 %5, %5, %8, 0\n v_fma_mixlo_f16 %6, %6, %8, 0\n v_fma_mixlo_f16 %7, %7, %8, 0")
+BODY(k_mixhi, "v_fma_mixhi_f16 %0, %0, %8, 0\n v_fma_mixhi_f16 %1, %1, %8, 0\n v_fma_mixhi_f16 %2, %2, %8, 0\n v_fma_mixhi_f16 %3, %3, %8, 0\n v_fma_mixhi_f16 %4, %4, %8, 0\n v_fma_mixhi_f16 %5, %5, %8, 0\n v_fma_mixhi_f16 %6, %6, %8, 0\n v_fma_mixhi_f16 %7, %7, %8, 0")
+BODY(k_mix32, "v_fma_mix_f32 %0, %0, %8, -%9 op_sel_hi:[0,0,1]\n v_fma_mix_f32 %1, %1, %8, -%9 op_sel_hi:[0,0,1]\n v_fma_mix_f32 %2, %2, %8, -%9 op_sel_hi:[0,0,1]\n v_fma_mix_f32 %3, %3, %8, -%9 op_sel_hi:[0,0,1]\n v_fma_mix_f32 %4, %4, %8, -%9 op_sel_hi:[0,0,1]\n v_fma_mix_f32 %5, %5, %8, -%9 op_sel_hi:[0,0,1]\n v_fma_mix_f32 %6, %6, %8, -%9 op_sel_hi:[0,0,1]\n v_fma_mix_f32 %7, %7, %8, -%9 op_sel_hi:[0,0,1]")
+BODY(k_cvtf16, "v_cvt_pk_f16_f32 %0, %0, %8\n v_cvt_pk_f16_f32 %1, %1, %8\n v_cvt_pk_f16_f32 %2, %2, %8\n v_cvt_pk_f16_f32 %3, %3, %8\n v_cvt_pk_f16_f32 %4, %4, %8\n v_cvt_pk_f16_f32 %5, %5, %8\n v_cvt_pk_f16_f32 %6, %6, %8\n v_cvt_pk_f16_f32 %7, %7, %8")
+BODY(k_fma, "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9")
+BODY(k_cvt1f16, "v_cvt_f16_f32 %0, %0\n v_cvt_f16_f32 %1, %1\n v_cvt_f16_f32 %2, %2\n v_cvt_f16_f32 %3, %3\n v_cvt_f16_f32 %4, %4\n v_cvt_f16_f32 %5, %5\n v_cvt_f16_f32 %6, %6\n v_cvt_f16_f32 %7, %7")
+BODY(k_cvt32f16, "v_cvt_f32_f16 %0, %0\n v_cvt_f32_f16 %1, %1\n v_cvt_f32_f16 %2, %2\n v_cvt_f32_f16 %3, %3\n v_cvt_f32_f16 %4, %4\n v_cvt_f32_f16 %5, %5\n v_cvt_f32_f16 %6, %6\n v_cvt_f32_f16 %7, %7")
+BODY(k_mul, "v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8")
 __global__ __launch_bounds__(64) void k_pkadd(unsigned* out, unsigned long long* cyc, int iters) {
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 a0 = {1.f * threadIdx.x, 2.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, b = {1.0001f, 0.5f};
@@ -40,6 +49,6 @@ int main() {
   unsigned* out; unsigned long long* cyc; hipMalloc(&out, 1024 * 64 * 4); hipMalloc(&cyc, 8);
   const int iters = 2000;
 #define RUN(K) { hipLaunchKernelGGL(K, dim3(1024), dim3(64), 0, 0, out, cyc, iters); hipDeviceSynchronize(); hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0); hipLaunchKernelGGL(K, dim3(1024), dim3(64), 0, 0, out, cyc, iters); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); printf("%-10s %.3f ms  -> %.2f ns per instruction per wave (counter %.2f per instr)\n", #K, ms, ms * 1e6 / (iters * 64.0), (double)c / (iters * 64.0)); }
-  RUN(k_and) RUN(k_sub) RUN(k_lshl) RUN(k_cvt) RUN(k_perm) RUN(k_pkadd) RUN(k_cnd) RUN(k_dpp) RUN(k_rowdpp) RUN(k_cnddpp)
+  RUN(k_and) RUN(k_sub) RUN(k_lshl) RUN(k_cvt) RUN(k_perm) RUN(k_pkadd) RUN(k_cnd) RUN(k_dpp) RUN(k_rowdpp) RUN(k_cnddpp) RUN(k_mul) RUN(k_fma) RUN(k_mixlo) RUN(k_mixhi) RUN(k_mix32) RUN(k_cvtf16) RUN(k_cvt1f16) RUN(k_cvt32f16)
   return 0;
 }
