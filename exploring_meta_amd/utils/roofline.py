@@ -20,7 +20,7 @@ SPLIT_BF16_OPS = ('conv_fwd_stats', 'dgrad', 'tangent_conv_fwd', 'tangent_dgrad'
 SPLIT_BF16_WGRAD_OPS = ('wgrad', 'tangent_wgrad')      # csrc/wgrad_bf16.hip: maps at least 16 wide (the 10 x 10 block keeps the fp32 kernel)
 
 
-def mfma_peak(spec, op, layer, form=2):
+def mfma_peak(spec, op, layer, form=1):
     """(peak TFLOP/s in algorithmic fp32 FLOPs, pipe) of the matrix pipe `op` on block `layer` runs on.  form: the operand form of the
     stride-1 hidden blocks (mi_conv_get_split_bf16): 0 / False fp32 pipe, 1 / True three bf16 planes, 2 two scaled fp16 planes."""
     h, w, ci, co, ho, wo, _, _ = layer_geometry(spec)[layer]

@@ -407,9 +407,10 @@ int mi_debug_conv_stamps(void* buf);
  * tensor from the tensor's largest magnitude (the producing kernels record it; standalone operator entries run a reduction launch),
  * three v_mfma_f32_32x32x16_f16 products per K = 16, the scales multiplied out of the fp32 sums exactly: 22 bits of every operand, an
  * absolute floor 2^-39 below the tensor's maximum, per-kernel errors against fp64 at or below those of the fp32 pipe; a launch whose
- * operands come without a recorded magnitude takes form 1.  0: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  Default 2 (environment
- * variable MI_CONV_BF16X3=0 / 1 starts with another); returns the previous setting.  All three forms meet the same fp32 parity bars
- * (tests run all three).  Values above 0xff (0x100 * variant mask + form) select single kernel variants for bisecting
+ * operands come without a recorded magnitude takes form 1.  Form 2 is an OPT-IN: its operands are narrower than the reference's fp32
+ * (22 bits), so benchmark lines that use it say so and it is never the default.  0: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+ * Default 1 (environment variable MI_CONV_BF16X3=0 / 2 starts with another); returns the previous setting.  All three forms meet the
+ * same fp32 parity bars (tests run all three).  Values above 0xff (0x100 * variant mask + form) select single kernel variants for bisecting
  * (tools/wgrad_probe.py, csrc/conv_mfma.hip) and are not part of the interface. */
 int mi_conv_set_split_bf16(int on);
 /* The operand form in force (2 scaled fp16 planes, 1 split-bf16, 0 fp32 matrix pipe) read without side effects; mask_out (may be NULL)

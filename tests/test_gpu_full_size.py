@@ -228,8 +228,9 @@ def test_cfg4_full_T_batched_looped_oracle(T):
     # envelope.  Per step: every checked task agrees with the fp64 arithmetic to ADJ_G / ADJ_H once the decisions with an fp64
     # margin below TAU (3e-6) are allowed to fall either way.
     # (batched against one-task calls: the launch geometry -- weight-gradient chunks, statistics partials -- follows the task count, so the
-    # last bits differ and, in at most a task or two of the seventeen, a near-tied decision with them: the same one-decision envelope)
-    assert max(el) < 1e-6 and np.median(eg) < 1e-5 and sum(e > 1e-5 for e in eg) <= 2 and max(eg) < 0.3, eg
+    # last bits differ and, with them, near-tied decisions: small ones (below 5e-3 of the task's gradient) in several tasks of the 256-task
+    # leg, a larger one in at most a task or two of the seventeen checked -- the same one-decision envelope as against the oracle)
+    assert max(el) < 1e-6 and np.median(eg) < 1e-5 and sum(e > 5e-3 for e in eg) <= 2 and max(eg) < 0.3, eg
     assert np.median(lo) < 1e-5 and max(lo) < 5e-3
     # (about half of the tasks hold such a decision: P(fewer than two clean ones among nine) is below 2 %)
     assert sum(e < 1e-5 for e in ebest) >= 2 and np.median(ebest) < 1e-2 and max(e64) < 0.3, (e2e_tasks, ebest, flipped)

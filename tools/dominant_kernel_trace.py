@@ -4,7 +4,7 @@ files under profiles/ alone (the --stats summary aggregates every launch of a te
 name and differ only in their grid).
 
     rocprofv3 --kernel-trace --stats --output-format csv -d DIR -- python3 bench.py --no-dist --no-clock --no-cpu-baseline --no-overlap ...
-    python3 tools/dominant_kernel_trace.py DIR --kernel 'conv3x3_s1_mfma_kernel<32, 2, 2, 0, true, true>' [--bench bench.json] > profiles/rN/rocprofv3_dominant_kernel_*.txt
+    python3 tools/dominant_kernel_trace.py DIR --kernel 'conv3x3_s1_mfma_kernel<32, 2, 2, 0, true, false>' [--bench bench.json] > profiles/rN/rocprofv3_dominant_kernel_*.txt
 
 Launches are grouped by grid shape (x = threads, y = tasks, z) and, with --cycle N, by their position in the repeating launch order
 (the two-term tangent convolution runs once per hidden block and Hessian-vector pass: blocks 2, 3, 4, 2, 3, 4, ... so --cycle 3; blocks

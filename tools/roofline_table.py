@@ -26,17 +26,17 @@ def costs(op, l, images):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if a not in ('--fp32-pipe', '--bf16')]
-    # the operand form the hidden convolutions ran in: two scaled fp16 planes (default), three bf16 planes, or the fp32 pipe
-    split = 0 if '--fp32-pipe' in sys.argv[1:] else (1 if '--bf16' in sys.argv[1:] else 2)
+    args = [a for a in sys.argv[1:] if a not in ('--fp32-pipe', '--fp16')]
+    # the operand form the hidden convolutions ran in: three bf16 planes (default), the opt-in two scaled fp16 planes, or the fp32 pipe
+    split = 0 if '--fp32-pipe' in sys.argv[1:] else (2 if '--fp16' in sys.argv[1:] else 1)
     path = args[0]
     images = int(args[1]) if len(args) > 1 else 32 * 25
     rows = [r for r in csv.reader(open(path)) if r and not r[0].startswith('#')]
     hdr, rows = rows[0], rows[1:]
     total = sum(float(r[3]) for r in rows)
     print(f'Per-kernel roofline, {path} ({images} images per launch, one meta-iteration = {total:.2f} ms of kernel time)\n')
-    print('FLOPs are algorithmic fp32 FLOPs.  Matrix peak per kernel: 157.3 TFLOP/s on the fp32 pipe; 833.3 (= dense 16-bit MFMA 2500 / 3 products '
-          'per multiply-add) for the kernels on the two-plane fp16 operand form (marked fp16x3); 416.7 (/ 6) on the three-plane bf16 form (bf16x6).\n')
+    print('FLOPs are algorithmic fp32 FLOPs.  Matrix peak per kernel: 157.3 TFLOP/s on the fp32 pipe; 416.7 (= dense bf16 2500 / 6 products per '
+          'multiply-add) for the kernels on the split-bf16 operand form (marked bf16x6); 833.3 (/ 3) on the opt-in two-plane fp16 form (fp16x3).\n')
     print('| op | block | launches | avg ms | share | GFLOP/launch | MB/launch | TFLOP/s (% of its matrix peak) | GB/s (% of 8000) | bound |')
     print('|---|---|---|---|---|---|---|---|---|---|')
     for r in rows:
