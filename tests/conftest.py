@@ -36,3 +36,15 @@ def golden_fa():
 def golden_refinit():
     import numpy as np
     return np.load(os.path.join(REPO, 'tests', 'golden', 'golden_refinit.npz'), allow_pickle=False)
+
+
+@pytest.fixture(params=['split_f16', 'split_bf16', 'fp32_pipe'])
+def conv_form(request):
+    """Operand form of the 32- / 64-channel stride-1 convolutions and weight gradients (mi_conv_set_split_bf16) for the duration of one test:
+    the exact three-plane bf16 form (the default), the fp32 matrix pipe, and the opt-in two-plane fp16 form -- every bar holds for each form on
+    its own, so a regression in one is not absorbed by another's envelope."""
+    from exploring_meta_amd import _lib
+    lb = _lib.load()
+    was = lb.mi_conv_set_split_bf16({'split_f16': 2, 'split_bf16': 1, 'fp32_pipe': 0}[request.param])
+    yield request.param
+    lb.mi_conv_set_split_bf16(was)

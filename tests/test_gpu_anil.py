@@ -23,7 +23,7 @@ def _params():
 
 
 @pytest.mark.parametrize('K', [1, 5])
-def test_anil_engine_vs_golden_and_oracle(golden_fa, K):
+def test_anil_engine_vs_golden_and_oracle(golden_fa, conv_form, K):
     ways, shots, lr, tasks = 5, 5, 0.5, [0, 1]
     base, tf, th = _params()
     theta = torch.cat([R.flatten_params(tf), R.flatten_params(th)]).float().cuda()

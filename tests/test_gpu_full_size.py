@@ -45,17 +45,6 @@ pytestmark = pytest.mark.gpu
 RAW_MAX, RAW_MAX_T256, OUTLIER_SHARE, ADJ_G, ADJ_H = 3e-2, 1e-1, 0.15, 2e-5, 2e-4
 
 
-@pytest.fixture(params=['split_f16', 'split_bf16', 'fp32_pipe'])
-def conv_form(request):
-    """Operand form of the 32-channel stride-1 convolutions and weight gradients (mi_conv_set_split_bf16) for one test: the per-step
-    bars below hold for each form separately, so a regression in one is not absorbed by the other's envelope."""
-    from exploring_meta_amd import _lib
-    lb = _lib.load()
-    was = lb.mi_conv_set_split_bf16({'split_f16': 2, 'split_bf16': 1, 'fp32_pipe': 0}[request.param])
-    yield request.param
-    lb.mi_conv_set_split_bf16(was)
-
-
 def _ref_theta(spec, seed=11):
     return OrderedDict((k, torch.from_numpy(v)) for k, v in synthetic.ref_init_weights(R.param_shapes(spec), seed).items())
 
