@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "bf16_split.h"
 #include "fold.h"
+#include <type_traits>
 
 // Ablation build (timing / energy experiment, wrong results, not shipped): -DMI_CONV_ABLATE_LOW compiles out the three products of a K
 // step that a two-plane operand form would not have (DESIGN.md 8c lead 5); build to another file name and select it with MI_MAML_LIB.
@@ -851,6 +852,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
   CV_STAMP(4);
 }
 
+#include "conv_b16.h"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // First-layer conv: CI0 in {1,3}.  K = 9*CI0 padded to an even KP; lane half h takes k in [h*KP/2, (h+1)*KP/2).
 template <int CI0, int EPI, int STRIDE>
@@ -1269,10 +1272,31 @@ static hipError_t launch_conv_s1_bf(hipStream_t st, ConvArgs& a, dim3 grid) {
   hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS, true, F16>::value * 64), lds, st, a);
   return hipGetLastError();
 }
+// the split-bf16 form on 16x16x32 MFMAs with one accumulator per horizontal tap (conv_b16.h): same LDS, workgroup shape and grid
+template <int CI, int NTERMS, int EPI, int MODE>
+static hipError_t launch_conv_s1_b16(hipStream_t st, ConvArgs& a, dim3 grid) {
+  const size_t lds = (size_t)NTERMS * 9 * CI * 32 * 6;
+  auto k = conv3x3_s1_b16_kernel<CI, NTERMS, EPI, MODE>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS, true, false>::value * 64), lds, st, a);
+  return hipGetLastError();
+}
+static int g_conv_b16 = -1;
+int conv_b16() {
+  if (g_conv_b16 < 0) { const char* e = getenv("MI_CONV_B16"); g_conv_b16 = e ? (atoi(e) != 0) : MI_CONV_B16_DEFAULT; }
+  return g_conv_b16;
+}
+extern "C" int mi_conv_set_b16(int on) { const int was = conv_b16(); if (on >= 0) g_conv_b16 = on != 0; return was; }
 template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
   if constexpr (CI == 32 || (CI == 64 && NTERMS == 1)) {
     if (a.split_bf16 == 2) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE, true>(st, a, grid);
+    if (a.split_bf16 && conv_b16()) return launch_conv_s1_b16<CI, NTERMS, EPI, MODE>(st, a, grid);
     if (a.split_bf16) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE, false>(st, a, grid);
   }
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);

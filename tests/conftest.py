@@ -38,13 +38,38 @@ def golden_refinit():
     return np.load(os.path.join(REPO, 'tests', 'golden', 'golden_refinit.npz'), allow_pickle=False)
 
 
-@pytest.fixture(params=['split_f16', 'split_bf16', 'fp32_pipe'])
+# Operand form / kernel of the 32- / 64-channel stride-1 convolutions and weight gradients: name -> (mi_conv_set_split_bf16, mi_conv_set_b16).
+# 'split_bf16' is the default (exact three-plane bf16 operands on 16x16x32 MFMAs, csrc/conv_b16.h), 'split_bf16_32x32' the same operand
+# form on the 32x32x16 kernel of rounds 3-4, 'fp32_pipe' the fp32 matrix pipe, 'split_f16' the opt-in two-plane fp16 form.
+CONV_FORMS = {'split_f16': (2, -1), 'split_bf16': (1, 1), 'split_bf16_32x32': (1, 0), 'fp32_pipe': (0, -1)}
+
+
+def apply_conv_form(lb, name):
+    """Select a form; returns a callable that restores the previous selection."""
+    form, b16 = CONV_FORMS[name]
+    was = lb.mi_conv_set_split_bf16(form)
+    was16 = lb.mi_conv_set_b16(b16)
+
+    def restore():
+        lb.mi_conv_set_split_bf16(was)
+        lb.mi_conv_set_b16(was16)
+    return restore
+
+
+@pytest.fixture(params=['split_f16', 'split_bf16', 'split_bf16_32x32', 'fp32_pipe'])
 def conv_form(request):
-    """Operand form of the 32- / 64-channel stride-1 convolutions and weight gradients (mi_conv_set_split_bf16) for the duration of one test:
-    the exact three-plane bf16 form (the default), the fp32 matrix pipe, and the opt-in two-plane fp16 form -- every bar holds for each form on
-    its own, so a regression in one is not absorbed by another's envelope."""
+    """Operand form of the 32- / 64-channel stride-1 convolutions and weight gradients for the duration of one test: every bar holds for
+    each form on its own, so a regression in one is not absorbed by another's envelope."""
     from exploring_meta_amd import _lib
-    lb = _lib.load()
-    was = lb.mi_conv_set_split_bf16({'split_f16': 2, 'split_bf16': 1, 'fp32_pipe': 0}[request.param])
+    restore = apply_conv_form(_lib.load(), request.param)
     yield request.param
-    lb.mi_conv_set_split_bf16(was)
+    restore()
+
+
+@pytest.fixture(params=['split_f16', 'split_bf16', 'fp32_pipe'])
+def conv_form_full(request):
+    """The forms the full-size tests run (their oracle legs take minutes of CPU): the default kernel of each operand form."""
+    from exploring_meta_amd import _lib
+    restore = apply_conv_form(_lib.load(), request.param)
+    yield request.param
+    restore()

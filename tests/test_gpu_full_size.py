@@ -58,7 +58,8 @@ def _unflatten(flat, shapes):
     return out
 
 
-def test_cfg2_T32_teacher_forced_per_step(conv_form):
+def test_cfg2_T32_teacher_forced_per_step(conv_form_full):
+    conv_form = conv_form_full
     """BASELINE config 2 exactly as benchmarked (32 tasks, 5-way 5-shot, K = 5, lr 0.5, second order, the bench's synthetic
     tasks and initial parameters): every inner-step gradient and every Hessian-vector product of ALL 32 tasks against the
     oracle at the engine's own theta_k (oracle legs in CPU worker processes); the theta recursion and the adjoint recursion

@@ -15,13 +15,14 @@ from gpu_utils import dev, ptr, stream, rel_err, max_err, report
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['split_f16', 'split_bf16', 'fp32_pipe'])
+@pytest.fixture(scope='module', params=['split_f16', 'split_bf16', 'split_bf16_32x32', 'fp32_pipe'])
 def lib(request):
     """Every case runs with both operand forms of the 32-channel stride-1 convolutions (mi_conv_set_split_bf16): same bars."""
     lb = _lib.load()
-    was = lb.mi_conv_set_split_bf16({'split_f16': 2, 'split_bf16': 1, 'fp32_pipe': 0}[request.param])
+    from conftest import apply_conv_form
+    restore = apply_conv_form(lb, request.param)
     yield lb
-    lb.mi_conv_set_split_bf16(was)
+    restore()
 
 
 def _rand(seed, shape, lo=-1.0, hi=1.0):

@@ -98,10 +98,14 @@ def walk(path, preds=None):
                         findings.add(f'{os.path.basename(path)}: {kernel}: MFMA "{t[:70]}" reads an operand that inline assembly "{h_txt[:50]}" wrote {back} wait states earlier')
                         break
             if inasm and not is_mfma:
-                for back, (_, h_mfma, h_dst, h_txt) in enumerate(reversed(hist[-WAIT_MFMA_READ:])):
-                    if h_mfma and (h_dst & src):
-                        findings.add(f'{os.path.basename(path)}: {kernel}: inline assembly "{t[:60]}" reads the result of "{h_txt[:50]}" after {back} wait states')
-                        break
+                # per source register, the NEAREST earlier writer decides: a register an MFMA wrote and an ordinary instruction has
+                # redefined since (accumulator registers are re-used for temporaries once a tile's sums are out) is not a matrix result
+                for r in src:
+                    for back, (_, h_mfma, h_dst, h_txt) in enumerate(reversed(hist[-WAIT_MFMA_READ:])):
+                        if r in h_dst:
+                            if h_mfma:
+                                findings.add(f'{os.path.basename(path)}: {kernel}: inline assembly "{t[:60]}" reads the result of "{h_txt[:50]}" after {back} wait states')
+                            break
         push((inasm, is_mfma, dst, t))
         if len(hists) > 1:       # alternatives that have become equal over the window that matters collapse into one
             uniq = []

@@ -1,12 +1,16 @@
-cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r4_pmc2; mkdir -p $O
+#!/bin/bash
+# Issue counters of the block-1 kernels and the dominant convolutions (run on the GPU box: bash tools/pmc_issue.sh [out dir]).
+set -u
+ROOT=${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}
+cd $ROOT
+O=$ROOT/${1:-gpurun_out/pmc_issue}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --list-avail > $O/avail.txt 2>&1
 grep -o "SQ_[A-Z0-9_]*" $O/avail.txt | sort -u | grep -E "INSTS_VALU|MFMA|BUSY_CYCLES|WAVE_CYCLES|ACTIVE_INST|INSTS_LDS|INSTS_VMEM|INSTS_SALU|WAIT_INST|INST_CYCLES" | tr '\n' ' ' > $O/sq_names.txt
 cat $O/sq_names.txt
 for SET in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; do
   T=$(echo $SET | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/p_$T -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --no-secondary --pool 2 > $O/log_$T.txt 2>&1; echo "pass $T rc=$?"
+  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/p_$T -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --no-secondary --pool 2 > $O/log_$T.txt 2>&1; echo "pass $T rc=$?"
   f=$(find $O/p_$T -name "*counter_collection.csv" | head -n 1)
   [ -n "$f" ] && python3 - "$f" > $O/table_$T.txt <<'PY'
 import csv, sys, collections
