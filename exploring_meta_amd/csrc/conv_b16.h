@@ -36,6 +36,12 @@ __device__ __forceinline__ void buf_st2_untracked(mi_u32x4 rsrc, unsigned off, f
 __device__ __forceinline__ floatx2 buf_ld8(mi_rsrc r, unsigned off) {
   return __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
 }
+// -1 where bit `bit` (a compile-time constant after unrolling) of v is set; assembly, so that the merge that uses it stays a bit operation
+__device__ __forceinline__ int lane_mask_bit_rt(unsigned v, int bit) {
+  int r;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(v), "i"(bit));
+  return r;
+}
 __device__ __forceinline__ float bf16_sub_v(float a, float b) {
   float r;
   asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -234,7 +240,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
   read_chunk(1);
   const unsigned lane_out = (unsigned)((cbase + 2 * n) * 4);
   const unsigned addr_dn = (unsigned)(((lane - 16) & 63) * 4), addr_up = (unsigned)(((lane + 16) & 63) * 4);
-  const int g0 = g == 0 ? -1 : 0, g3 = g == 3 ? -1 : 0;          // lane-group masks
+  int g0 = g == 0 ? -1 : 0, g3 = g == 3 ? -1 : 0;                // lane-group masks (opaque: merges stay v_bfi / v_and, never compare + v_cndmask)
+  asm volatile("" : "+v"(g0), "+v"(g3));
 
   // One tile.  PAR: which plane buffer holds the tile's first row-step (the buffers alternate per row-step; NS may be odd).
   auto tile_body = [&](auto par_c) {
@@ -338,11 +345,18 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
     // register of the lane group below (above): a rotation of the wave by 16 lanes, block 1's group 0 taking block 0's group 3
     float o[2][2][4];
     const bool masked = (cur.bmf | cur.bml) != 0u;              // wave-uniform: an image row begins / ends inside the tile
-    const unsigned vf = cur.bmf >> (4 * g), vl = cur.bml >> (4 * g);   // bit 16 mb + r: this lane's pixel row (mb, r)
+    int mf[2][4], ml[2][4];                                     // -1 where this lane's pixel row (mb, r) sits in the image's first / last column
+    if (masked) {
+      const unsigned vf = cur.bmf >> (4 * g), vl = cur.bml >> (4 * g);   // bit 16 mb + r: this lane's pixel row (mb, r)
+#define MI_B16_ROWMASK(MB, R) mf[MB][R] = lane_mask_bit<16 * MB + R>(vf); ml[MB][R] = lane_mask_bit<16 * MB + R>(vl);
+      MI_B16_ROWMASK(0, 0) MI_B16_ROWMASK(0, 1) MI_B16_ROWMASK(0, 2) MI_B16_ROWMASK(0, 3)
+      MI_B16_ROWMASK(1, 0) MI_B16_ROWMASK(1, 1) MI_B16_ROWMASK(1, 2) MI_B16_ROWMASK(1, 3)
+#undef MI_B16_ROWMASK
+    }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       float am[2][4], bp[2][4];
-      const float s_dn1 = lane_select(g3, acc[0][0][nb][3], acc[0][1][nb][3]);      // source lanes of group 3 send block 0's row 15 + ... (block 1, group 0 <- block 0, group 3)
+      const float s_dn1 = lane_select(g3, acc[0][0][nb][3], acc[0][1][nb][3]);      // block 1, group 0 <- block 0, group 3 (the SOURCE lanes of group 3 send block 0's row)
       const float s_up0 = lane_select(g0, acc[2][1][nb][0], acc[2][0][nb][0]);      // block 0, group 3 <- block 1, group 0
       // (the rotated values go through an opaque copy first: handed a matrix accumulator's element directly, hipcc 7.2 rotated element 0
       // of the accumulator instead of the one named -- found by tools/conv_b16_debug.py, checked in the ISA)
@@ -367,9 +381,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int first = (int)(vf << (31 - (16 * mb + r))) >> 31, last = (int)(vl << (31 - (16 * mb + r))) >> 31;   // -1 where the bit is set
-            am[mb][r] = lane_zero_where(first, am[mb][r]);
-            bp[mb][r] = lane_zero_where(last, bp[mb][r]);
+            am[mb][r] = lane_zero_where(mf[mb][r], am[mb][r]);
+            bp[mb][r] = lane_zero_where(ml[mb][r], bp[mb][r]);
           }
       }
 #pragma unroll
@@ -380,53 +393,58 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
     if (EPI == EPI_BRED) {
       // block 1's pooled-resolution tensors at this lane's 16 output positions: "ReLU on" from the argmax byte (below 4) or from p > 0;
       //   1 term : sum [on] out zh, sum [on] out        2 terms: sum [on] (out zh + dp zhd), sum [on] out
-      constexpr int GR = NTERMS == 2 ? 2 : 4;                    // pixel rows per group in flight
-      struct Grp { floatx2 pp[GR], zz[GR], zd[GR], dq[GR]; };
-      auto fetch = [&](int grp, Grp& gq) {
+      // One code path per source of "ReLU on" (a wave-uniform choice per launch, not per element); all of a group's loads are issued
+      // before anything of it is used (the argmax bytes are unpacked where they are consumed).
+      auto bred = [&](auto arg_c) {
+        constexpr bool ARG = decltype(arg_c)::value;
+        constexpr int GR = NTERMS == 2 ? 2 : 4;                  // pixel rows per group in flight
+        struct Grp { floatx2 pp[GR], zz[GR], zd[GR], dq[GR]; unsigned pb[GR]; };
+        auto fetch = [&](int grp, Grp& gq) {
 #pragma unroll
-        for (int rr = 0; rr < GR; ++rr) {
-          const int e = grp * GR + rr, mb = e >> 2, r = e & 3;
-          const unsigned of = row_off(mb, r);
-          if (bred_arg) {                                         // two bytes (channels 2n, 2n + 1), as integers in float registers
-            const unsigned short b2 = __builtin_amdgcn_raw_buffer_load_b16(rbp, of >> 2, 0, 0);
-            gq.pp[rr] = floatx2{__builtin_bit_cast(float, (unsigned)(b2 & 0xffu)), __builtin_bit_cast(float, (unsigned)(b2 >> 8))};
-          } else gq.pp[rr] = buf_ld8(rbp, of);
-          gq.zz[rr] = buf_ld8(rbzh, of);
-          if (NTERMS == 2) { gq.zd[rr] = buf_ld8(rbzhd, of); gq.dq[rr] = buf_ld8(rbdp, of); }
-        }
-      };
-      auto consume = [&](int grp, const Grp& gq) {
-#pragma unroll
-        for (int rr = 0; rr < GR; ++rr) {
-          const int e = grp * GR + rr, mb = e >> 2, r = e & 3;
-          const int keep = keep_mask(mb, r);
-          buf_st2_untracked(rout_raw, keep ? row_off(mb, r) : MI_OOB, o[mb][0][r], o[mb][1][r]);
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const float v = o[mb][nb][r];
-            int on = bred_arg ? ((int)__builtin_bit_cast(unsigned, gq.pp[rr][nb]) - 4) >> 31 : lane_mask_negative(0.f - gq.pp[rr][nb]);
-            on &= keep;
-            const float vv = lane_keep_where(on, v);
-            if (NTERMS == 1) {
-              s[nb] = fma((double)vv, (double)gq.zz[rr][nb], s[nb]);
-            } else {
-              const float dv = lane_keep_where(on, gq.dq[rr][nb]);
-              s[nb] += (double)vv * (double)gq.zz[rr][nb] + (double)dv * (double)gq.zd[rr][nb];
-            }
-            q[nb] += (double)vv;
+          for (int rr = 0; rr < GR; ++rr) {
+            const int e = grp * GR + rr, mb = e >> 2, r = e & 3;
+            const unsigned of = row_off(mb, r);
+            if constexpr (ARG) gq.pb[rr] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rbp, of >> 2, 0, 0);    // two bytes: channels 2n, 2n + 1
+            else gq.pp[rr] = buf_ld8(rbp, of);
+            gq.zz[rr] = buf_ld8(rbzh, of);
+            if (NTERMS == 2) { gq.zd[rr] = buf_ld8(rbzhd, of); gq.dq[rr] = buf_ld8(rbdp, of); }
           }
+        };
+        auto consume = [&](int grp, const Grp& gq) {
+#pragma unroll
+          for (int rr = 0; rr < GR; ++rr) {
+            const int e = grp * GR + rr, mb = e >> 2, r = e & 3;
+            const int keep = keep_mask(mb, r);
+            buf_st2_untracked(rout_raw, keep ? row_off(mb, r) : MI_OOB, o[mb][0][r], o[mb][1][r]);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+              const float v = o[mb][nb][r];
+              // -1 where the ReLU is on: the byte is below 4 (bits 2 and 10 of the pair clear) / p > 0 (0 - p carries a sign bit)
+              int on = ARG ? ~lane_mask_bit_rt(gq.pb[rr], nb ? 10 : 2) : lane_mask_negative(0.f - gq.pp[rr][nb]);
+              on &= keep;
+              const float vv = lane_keep_where(on, v);
+              if (NTERMS == 1) {
+                s[nb] = fma((double)vv, (double)gq.zz[rr][nb], s[nb]);
+              } else {
+                const float dv = lane_keep_where(on, gq.dq[rr][nb]);
+                s[nb] += (double)vv * (double)gq.zz[rr][nb] + (double)dv * (double)gq.zd[rr][nb];
+              }
+              q[nb] += (double)vv;
+            }
+          }
+        };
+        constexpr int NG = 8 / GR;
+        Grp ga, gb;
+        fetch(0, ga);
+#pragma unroll
+        for (int grp = 0; grp < NG; grp += 2) {
+          if (grp + 1 < NG) fetch(grp + 1, gb);
+          consume(grp, ga);
+          if (grp + 2 < NG) fetch(grp + 2, ga);
+          if (grp + 1 < NG) consume(grp + 1, gb);
         }
       };
-      constexpr int NG = 8 / GR;
-      Grp ga, gb;
-      fetch(0, ga);
-#pragma unroll
-      for (int grp = 0; grp < NG; grp += 2) {
-        if (grp + 1 < NG) fetch(grp + 1, gb);
-        consume(grp, ga);
-        if (grp + 2 < NG) fetch(grp + 2, ga);
-        if (grp + 1 < NG) consume(grp + 1, gb);
-      }
+      if (bred_arg) bred(std::true_type{}); else bred(std::false_type{});
     } else {
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
