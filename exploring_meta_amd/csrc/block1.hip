@@ -581,6 +581,7 @@ static int block1_split_bf16() {
   }
   return g_b1_split;
 }
+int block1_split_form() { return block1_split_bf16(); }
 extern "C" int mi_block1_set_split_bf16(int on) {
   const int was = block1_split_bf16();
   g_b1_split = on < 0 ? 0 : (on > 2 ? 2 : on);

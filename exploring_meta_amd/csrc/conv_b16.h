@@ -255,9 +255,21 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[x][mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
     float sr0 = 0.f, sr1 = 0.f;                                   // residuals of the pair being split
+    // Element (mb, nb, r) of the tile's results: pixel row pm = 16 mb + 4g + r, channel cbase + 2n + nb.
+    const unsigned tbase = (unsigned)(tile * 30 - 1) * (unsigned)(CO * 4) + lane_out;   // byte offset of pixel row 0's channel pair (tile 0: wraps; row 0 is dropped)
+    auto row_off = [&](int mb, int r) { return tbase + (unsigned)((16 * mb + 4 * g + r) * CO * 4); };
+    floatx2 zpre[2][4];
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
       if (st + 2 < NS) issue_step(cur, st + 2); else issue_step(nxt, st + 2 - NS);
+      if (EPI == EPI_TSTATS && st == NS - 1) {
+        // z at this lane's 16 output positions, requested one row-step (72 MFMAs) before the epilogue reads it: the registers are the raw
+        // row of the step that is running, dead since its split
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zpre[mb][r] = buf_ld8(rz, row_off(mb, r));
+      }
       const Bf16Planes* pa = pl[(st + PAR) & 1];
       Bf16Planes* pn = pl[(st + 1 + PAR) & 1];
       const floatx4* rn = raw[(st + 1) % 3];
@@ -329,18 +341,9 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- epilogue.  Element (mb, nb, r): pixel row pm = 16 mb + 4g + r, channel cbase + 2n + nb.
-    const unsigned tbase = (unsigned)(tile * 30 - 1) * (unsigned)(CO * 4) + lane_out;   // byte offset of pixel row 0's channel pair (tile 0: wraps; row 0 is dropped)
-    auto row_off = [&](int mb, int r) { return tbase + (unsigned)((16 * mb + 4 * g + r) * CO * 4); };
+    // ---- epilogue
     // the halo rows (pm = 0: mb 0, g 0, r 0; pm = 31: mb 1, g 3, r 3) are neither stored nor summed
     auto keep_mask = [&](int mb, int r) { return (mb == 0 && r == 0) ? ~g0 : ((mb == 1 && r == 3) ? ~g3 : -1); };
-    floatx2 zpre[2][4];
-    if (EPI == EPI_TSTATS) {
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) zpre[mb][r] = buf_ld8(rz, row_off(mb, r));
-    }
     // out[pm] = P0[pm] + P-[pm - 1] + P+[pm + 1]: rows r = 1..3 (r = 0..2) take the neighbouring register, row 0 (3) the last (first)
     // register of the lane group below (above): a rotation of the wave by 16 lanes, block 1's group 0 taking block 0's group 3
     float o[2][2][4];

@@ -1286,17 +1286,27 @@ static hipError_t launch_conv_s1_b16(hipStream_t st, ConvArgs& a, dim3 grid) {
   hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS, true, false>::value * 64), lds, st, a);
   return hipGetLastError();
 }
-static int g_conv_b16 = -1;
+// 0 = never, 1 = launches of at least MI_CONV_B16_MIN_TPW tiles per wave (default), 2 = every launch.  The 16x16x32 kernel works in
+// row-steps of 72 MFMAs behind 4 loads and 16 split values, and its epilogue ends in a lane rotation: with one or two tiles per wave (the
+// 10 x 10 and 21 x 21 blocks at 32 tasks, every block at few tasks per call) the 32x32x16 kernel's shorter fill and drain win
+// (profiles/r5/ab_conv_b16_*.txt: block 4 forward 0.0205 -> 0.0241 ms, block 2 forward 0.1463 -> 0.1376 ms).
+static int g_conv_b16 = -1, g_conv_b16_min_tpw = -1;
 int conv_b16() {
-  if (g_conv_b16 < 0) { const char* e = getenv("MI_CONV_B16"); g_conv_b16 = e ? (atoi(e) != 0) : MI_CONV_B16_DEFAULT; }
+  if (g_conv_b16 < 0) {
+    const char* e = getenv("MI_CONV_B16");
+    g_conv_b16 = e ? (atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e))) : MI_CONV_B16_DEFAULT;
+    const char* m = getenv("MI_CONV_B16_MIN_TPW");
+    g_conv_b16_min_tpw = m ? atoi(m) : 8;
+  }
   return g_conv_b16;
 }
-extern "C" int mi_conv_set_b16(int on) { const int was = conv_b16(); if (on >= 0) g_conv_b16 = on != 0; return was; }
+extern "C" int mi_conv_set_b16(int on) { const int was = conv_b16(); if (on >= 0) g_conv_b16 = on > 2 ? 2 : on; return was; }
+static bool conv_b16_for(const ConvArgs& a) { const int m = conv_b16(); return m == 2 || (m == 1 && a.tiles_per_wave >= g_conv_b16_min_tpw); }
 template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
   if constexpr (CI == 32 || (CI == 64 && NTERMS == 1)) {
     if (a.split_bf16 == 2) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE, true>(st, a, grid);
-    if (a.split_bf16 && conv_b16()) return launch_conv_s1_b16<CI, NTERMS, EPI, MODE>(st, a, grid);
+    if (a.split_bf16 && conv_b16_for(a)) return launch_conv_s1_b16<CI, NTERMS, EPI, MODE>(st, a, grid);
     if (a.split_bf16) return launch_conv_s1_bf<CI, NTERMS, EPI, MODE, false>(st, a, grid);
   }
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);

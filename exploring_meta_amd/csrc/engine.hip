@@ -433,6 +433,15 @@ static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bo
   A.dl = b.take<float>((size_t)T * n * e->d.ways);
 }
 
+// Everything that decides WHICH kernels a fused call launches besides the engine's own switches: the operand form of the hidden
+// convolutions, its bisecting mask, the kernel of that form (16x16x32 / 32x32x16) and block 1's operand form.  Part of the hipGraph cache
+// key: a graph captured under one selection must not be replayed under another.
+static unsigned long long kernel_selection_key() {
+  unsigned mask = 0;
+  const unsigned form = (unsigned)mi_conv_get_split_bf16(&mask);
+  return (unsigned long long)form + 4ull * (unsigned)conv_b16() + 16ull * (unsigned)block1_split_form() + 64ull * (unsigned long long)mask;
+}
+
 static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K, int second_order, Plan& pl) {
   Bump b{reinterpret_cast<char*>(ws), 0};
   const int nl = (int)e->L.size();
@@ -516,7 +525,9 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
     }
   }
   pl.cell_cap = 8 + (K + 1) * 2 * nl + K * 4 * nl + 4 * nl;      // p and dz per block and pass, pd and R{dz} per Hessian-vector pass, spare
-  pl.cells = b.take<unsigned>((size_t)pl.cell_cap * T * MI_CELL_WORDS);
+  // (reserved only while the fp16 operand form is selected -- 4 KB per tensor and task, ~20 MB at cfg2; the workspace size is recomputed by
+  // every call with the form then in force, so a caller that switches forms is asked for the larger workspace by the size check)
+  pl.cells = conv_operand_form() == 2 ? b.take<unsigned>((size_t)pl.cell_cap * T * MI_CELL_WORDS) : nullptr;
   pl.cell_T = T;
   pl.bytes = align_up(b.off, 256);
 }
@@ -1082,7 +1093,7 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
     return fail(e, MI_ERR_WORKSPACE, "workspace too small: need " + std::to_string(pl.bytes) + " bytes");
   const size_t TP = (size_t)T * e->PS;
   const Layer& L0 = e->L[0];
-  const bool tail = e->fuse_tail && e->counters && T <= mi_engine::kMaxCounterTasks && 1024 % L0.co == 0;
+  const bool tail = e->fuse_tail && e->counters && T <= 65535 /* launch_advance puts the tasks on grid.y */ && T <= mi_engine::kMaxCounterTasks && 1024 % L0.co == 0;
   const double inv_m0 = 1.0 / ((double)ns * L0.ho * L0.wo);
   { const int brc = plan_begin(e, st, pl); if (brc) return brc; }
   LAUNCH(e, st, OP_MISC, 0, launch_prepare_batch(st, data, labels, T, 2 * ns, e->d.in_channels, e->d.in_h, e->d.in_w, pl.xs, pl.xq, pl.ys, pl.yq));
@@ -1226,7 +1237,7 @@ static void make_anil_plan(const mi_engine* e, void* ws, int T, int n, int K, An
   ap.scratch.wgpart_side = b.take<float>(wgp);
   ap.scratch.gram_part = ap.scratch.gram_s = nullptr;
   ap.scratch.cell_cap = 8 + 4 * (int)e->L.size();
-  ap.scratch.cells = b.take<unsigned>((size_t)ap.scratch.cell_cap * T * MI_CELL_WORDS);
+  ap.scratch.cells = conv_operand_form() == 2 ? b.take<unsigned>((size_t)ap.scratch.cell_cap * T * MI_CELL_WORDS) : nullptr;
   ap.scratch.cell_T = T;
   if (e->fuse1 && e->gram1 && gram_supported(e->L[0].w, e->L[0].ci)) {   // statistics + weight gradient of block 1 from the Gram matrix
     ap.scratch.gram_part = b.take<double>(gram_partial_doubles(T, 2 * n, e->L[0].h, e->L[0].ci));
@@ -1330,7 +1341,7 @@ static int meta_batch_entry(MetaBatchFn fn, int which, mi_engine* e, void* strea
       (unsigned long long)shots, (unsigned long long)adapt_steps, (unsigned long long)lr_bits, (unsigned long long)second_order,
       (unsigned long long)with_grad, (unsigned long long)(uintptr_t)loss_out, (unsigned long long)(uintptr_t)acc_out,
       (unsigned long long)(uintptr_t)meta_grad_out, (unsigned long long)(uintptr_t)logits_out, (unsigned long long)(uintptr_t)workspace,
-      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 256ull * (unsigned)conv_operand_form()};
+      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 256ull * kernel_selection_key()};
   mi_engine::GraphEntry* ent = nullptr;
   for (auto& g : e->graphs)
     if (g.key == key) { ent = &g; break; }

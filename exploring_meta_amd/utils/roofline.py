@@ -13,8 +13,8 @@ BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 # The 32-channel stride-1 forward / dgrad convolutions run in the split-bf16 operand form (csrc/conv_mfma.hip): SIX bf16 products per
 # algorithmic fp32 multiply-add, so the matrix pipe bounds them at a sixth of its dense bf16 rate, in algorithmic (fp32) FLOPs:
 SPLIT_BF16_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6.0
-# ... or, by default, in the two-plane fp16 form (csrc/bf16_split.h): THREE fp16 products per multiply-add (the fp16 MFMAs run at the
-# bf16 rate), a third of the dense rate:
+# ... or, when the OPT-IN two-plane fp16 form is selected (mi_conv_set_split_bf16(2), csrc/bf16_split.h; never the default): THREE fp16
+# products per multiply-add (the fp16 MFMAs run at the bf16 rate), a third of the dense rate:
 SPLIT_F16_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 3.0
 SPLIT_BF16_OPS = ('conv_fwd_stats', 'dgrad', 'tangent_conv_fwd', 'tangent_dgrad')
 SPLIT_BF16_WGRAD_OPS = ('wgrad', 'tangent_wgrad')      # csrc/wgrad_bf16.hip: maps at least 16 wide (the 10 x 10 block keeps the fp32 kernel)
@@ -107,7 +107,22 @@ BLOCK1_KERNEL_NAMES = {
 }
 
 
-def kernel_name(spec, op, layer):
+def conv_kernel_is_b16(mpix, tasks, co, mode, min_tpw=8):
+    """Whether a split-bf16 stride-1 convolution launch over `tasks` tasks of `mpix` output pixels each takes the 16x16x32 kernel
+    (csrc/conv_b16.h) -- launch_conv3x3's rule: mi_conv_set_b16 mode 2 always, mode 1 from `min_tpw` tiles of 30 pixels per wave
+    (2048 resident waves) on, mode 0 never."""
+    if mode == 2:
+        return True
+    if mode != 1:
+        return False
+    tiles = -(-mpix // 30) * tasks * max(1, co // 32)
+    return -(-tiles // 2048) >= min_tpw
+
+
+def kernel_name(spec, op, layer, b16=False):
     ci = layer_geometry(spec)[layer][2]
     names = BLOCK1_KERNEL_NAMES if (layer == 0 and fused_block1(spec)) else KERNEL_NAMES
-    return names.get(op, op).format(ci=ci)
+    name = names.get(op, op).format(ci=ci)
+    if b16 and name.startswith('conv3x3_s1_mfma_kernel'):
+        name = name.replace('conv3x3_s1_mfma_kernel', 'conv3x3_s1_b16_kernel')
+    return name

@@ -417,10 +417,11 @@ int mi_conv_set_split_bf16(int on);
  * receives the variant mask a bisecting run set through MI_CONV_BF16X3_MASK / mi_conv_set_split_bf16(0x100 * mask + form). */
 int mi_conv_get_split_bf16(unsigned* mask_out);
 /* Which kernel runs the split-bf16 form (form 1) of the stride-1 hidden convolutions (forward, dgrad and their two-term tangent forms;
- * ConvBlock.conv of blocks >= 2, reference core_functions/vision_models.py:177-185,189): 1 (default; MI_CONV_B16=0 starts with the other) =
- * 16x16x32 MFMAs with one accumulator per horizontal tap (csrc/conv_b16.h), 0 = the 32x32x16 kernel with lane-shifted operands of rounds 3-4.
- * Same operands, products and tiles; the two differ in summation order only and meet the same parity bars (the tests run both).
- * on < 0 only reads.  Returns the previous setting. */
+ * ConvBlock.conv of blocks >= 2, reference core_functions/vision_models.py:177-185,189): 16x16x32 MFMAs with one accumulator per horizontal
+ * tap (csrc/conv_b16.h) or the 32x32x16 kernel with lane-shifted operands of rounds 3-4.  0 = always the latter, 2 = always the former,
+ * 1 (default; MI_CONV_B16 starts with another) = the former for launches of at least 8 tiles per wave (MI_CONV_B16_MIN_TPW), where its
+ * longer pipeline fill is amortised.  Same operands, products and tiles; the two kernels differ in summation order only and meet the same
+ * parity bars (the kernel tests run both on every case).  on < 0 only reads.  Returns the previous setting. */
 int mi_conv_set_b16(int on);
 /* Operand form of conv1 inside the two lean block-1 forward kernels (ConvBlock 1 of a three-channel net: conv + BatchNorm + ReLU + pool
  * with the conv output never stored, and its tangent from the stored argmax; reference core_functions/vision_models.py:188-193).

@@ -216,7 +216,7 @@ def test_fused_tail_is_bit_identical(dataset, ways, shots, K, fo, tasks, fused1)
     assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).sum() > 0
 
 
-@pytest.mark.parametrize('K,grad_bar', [(1, 1e-4), (2, 2e-3)])      # (K = 2: 1.1e-3 measured with the fp32 pipe, 3e-4 .. 7e-4 with the split forms)
+@pytest.mark.parametrize('K,grad_bar', [(1, 1e-4), (2, 2e-3)])      # (K = 2: 1.1e-3 measured with the fp32 pipe, 3e-4 .. 7e-4 with the split forms; frozen r5)
 def test_train_and_validation_tasks_in_one_call(conv_form, K, grad_bar):
     """mi_meta_batch_maml_tv (reference maml_vision.py:102-124): 3 train + 2 validation tasks through the same launches against the
     two separate calls -- per-task losses / accuracies / logits of both halves, and the meta-gradient summed over the train tasks only.

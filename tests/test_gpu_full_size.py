@@ -42,7 +42,23 @@ pytestmark = pytest.mark.gpu
 # re-routed element worth 3.3e-2 of a one-shot step's gradient at lr 0.5 -- and carries its own bar, RAW_MAX_T256.  Both are draws,
 # bounded here and explained decision by decision in part (2).  OUTLIER_SHARE is asserted against the fp64 leg: the reference's fp32
 # leg is itself a draw of near-ties that depends on the host's thread count and BLAS, so its share is reported, not asserted.)
-RAW_MAX, RAW_MAX_T256, OUTLIER_SHARE, ADJ_G, ADJ_H = 3e-2, 1e-1, 0.15, 2e-5, 2e-4
+# FROZEN in round 5: RAW_MAX, RAW_MAX_T256, the one-decision envelope ENVELOPE of the batched-vs-looped comparison and the share
+# bar against the reference's fp32 leg stay as they are; any further widening has to come with the offending decision (task, block, window,
+# margin) in the failure output, which the assertions below now print.
+RAW_MAX, RAW_MAX_T256, OUTLIER_SHARE, ADJ_G, ADJ_H = 3e-2, 1e-1, 0.15, 2e-5, 2e-4      # frozen r5
+ENVELOPE, SHARE_FP32_LEG = 0.3, 0.3                                                     # frozen r5
+
+
+def _decisions(res, worst=6):
+    """The flipped near-tied decisions of a teacher-forced result list, as text for a failure message: (task, pass, block, window, kind,
+    margin), largest margin first."""
+    rows = []
+    for r in res:
+        flips = r['flips'] if r['flips'] and isinstance(r['flips'][0], list) else [r['flips']]
+        for k, step in enumerate(flips):
+            for fl in step:
+                rows.append((abs(fl['margin']), f"task {r['t']} pass {k} block {fl['block']} at {tuple(fl['at'])} {fl['kind']} margin {fl['margin']:.2e}"))
+    return [t for _, t in sorted(rows, reverse=True)[:worst]]
 
 
 def _ref_theta(spec, seed=11):
@@ -105,26 +121,40 @@ def test_cfg2_T32_teacher_forced_per_step(conv_form_full):
         report(f'cfg2_T32_teacher_forced[{conv_form}][all {T} tasks, leg fp{leg}]', grad_median=float(np.median(g)), grad_max=float(g.max()),
                grad_share_above_1e4=float((g > 1e-4).mean()), hvp_median=float(np.median(h)), hvp_max=float(h.max()),
                hvp_share_above_1e4=float((h > 1e-4).mean()), query_max=float(q.max()))
-        share = OUTLIER_SHARE if leg == '64' else 1.0
-        assert np.median(g) < 1e-5 and g.max() < RAW_MAX and (g > 1e-4).mean() <= share, sorted(g)[-8:]
-        assert np.median(h) < 1e-4 and h.max() < RAW_MAX and (h > 1e-4).mean() <= share, sorted(h)[-8:]
+        share = OUTLIER_SHARE if leg == '64' else SHARE_FP32_LEG
+        assert np.median(g) < 1e-5 and g.max() < RAW_MAX and (g > 1e-4).mean() <= share, (sorted(g)[-8:], _decisions(res))
+        assert np.median(h) < 1e-4 and h.max() < RAW_MAX and (h > 1e-4).mean() <= share, (sorted(h)[-8:], _decisions(res))
         assert np.median(q) < 1e-5 and q.max() < RAW_MAX, sorted(q)[-4:]
     # (2) near-tie adjusted: every step, every task
     gx, hx, qx = (np.array(legs[k]) for k in ('gx', 'hx', 'qx'))
     margins = [abs(fl['margin']) for fl in flips]
     report(f'cfg2_T32_teacher_forced[{conv_form}][all {T} tasks, near-tie adjusted]', grad_max=float(gx.max()), hvp_max=float(hx.max()),
            query_max=float(qx.max()), flipped_decisions=len(flips), largest_flipped_margin=max(margins) if margins else 0.0)
-    assert gx.max() < ADJ_G and qx.max() < ADJ_G, (sorted(gx)[-4:], sorted(qx)[-4:])
-    assert hx.max() < ADJ_H, sorted(hx)[-4:]
-    assert all(m < TF.TAU for m in margins)
+    assert gx.max() < ADJ_G and qx.max() < ADJ_G, (sorted(gx)[-4:], sorted(qx)[-4:], _decisions(res))
+    assert hx.max() < ADJ_H, (sorted(hx)[-4:], _decisions(res))
+    assert all(m < TF.TAU for m in margins), _decisions(res)
 
 
-def test_cfg2_T32_batched_vs_one_task_at_a_time():
-    """The batched launch against the same engine looped over single tasks (different launch geometry: one tile per wave,
+@pytest.mark.parametrize('kernel', ['split_bf16_16x16', 'split_bf16_32x32'])
+def test_cfg2_T32_batched_vs_one_task_at_a_time(kernel):
+    """(Once per kernel of the default operand form, the SAME kernel in both runs -- conftest.CONV_FORMS: the engine's default picks the
+    16x16x32 kernel by tiles per wave, i.e. for block 2 of the 32-task call only, and two kernels agree to fp32 rounding, not to the
+    last bit: what this test pins is that ONE kernel's results do not depend on the launch geometry.)
+    The batched launch against the same engine looped over single tasks (different launch geometry: one tile per wave,
     other partial-sum groupings).  Step 0 -- one forward/backward from identical parameters -- must agree to rounding for
     every task; after that the fp32 difference in partial-sum order (1e-7) is amplified by the chaotic inner loop exactly as
     the reference's own 1-thread-vs-8-thread difference is, so later steps are held to the teacher-forced
     test above and only reported here."""
+    from conftest import apply_conv_form
+    from exploring_meta_amd import _lib
+    restore = apply_conv_form(_lib.load(), kernel)
+    try:
+        _batched_vs_one_task(kernel)
+    finally:
+        restore()
+
+
+def _batched_vs_one_task(kernel):
     ways, shots, K, lr, T = 5, 5, 5, 0.5, 32
     spec, mspec = R.mini_imagenet_spec(ways), ModelSpec.mini_imagenet(ways)
     theta = R.flatten_params(_ref_theta(spec, 42)).float().cuda().contiguous()
@@ -145,17 +175,26 @@ def test_cfg2_T32_batched_vs_one_task_at_a_time():
         dl.append(abs(float(l1[0]) - float(loss[t])) / abs(float(loss[t])))
         accs_equal += int(float(a1[0]) == float(acc[t]))
     eng.set_trace(0)
-    report('cfg2_T32_batched_vs_looped', step0_grad_rel_max=max(e0), final_loss_rel_median=float(np.median(dl)),
+    report(f'cfg2_T32_batched_vs_looped[{kernel}]', step0_grad_rel_max=max(e0), final_loss_rel_median=float(np.median(dl)),
            final_loss_rel_max=max(dl), acc_equal=accs_equal)
     assert max(e0) < 1e-5
     assert accs_equal >= T - 4 and float(np.median(dl)) < 5e-2
 
 
 @pytest.mark.parametrize('T', [32, 256])
-def test_cfg4_full_T_batched_looped_oracle(T):
-    """BASELINE config 4 (5-way 1-shot, one second-order step, 32 tasks per GPU; 256 = the whole meta-batch on one GPU) with
+def test_cfg4_full_T_batched_looped_oracle(conv_form_full, T):
+    """(Every operand form at 32 tasks per GPU -- the benched size; the 256-task leg runs the default form only: its oracle legs take
+    minutes.)  BASELINE config 4 (5-way 1-shot, one second-order step, 32 tasks per GPU; 256 = the whole meta-batch on one GPU) with
     the reference's initialisers and plateau-free inputs, the well-conditioned setting SURVEY.md 8c calibrated at <= 1e-4:
     per-task meta-gradients (from the trace) batched vs looped vs fp64 oracle."""
+    if T == 256 and conv_form_full != 'split_bf16':
+        pytest.skip('the 256-task leg runs the default operand form')
+    if T == 256:
+        # one kernel for the batched call and the one-task calls (the default picks by tiles per wave: the 16x16x32 kernel for block 2 of the
+        # 256-task call only -- see test_cfg2_T32_batched_vs_one_task_at_a_time); restored by the fixture's own restore on exit
+        from conftest import apply_conv_form
+        from exploring_meta_amd import _lib
+        apply_conv_form(_lib.load(), 'split_bf16_16x16')
     ways, shots, K, lr = 5, 1, 1, 0.5
     spec, mspec = R.mini_imagenet_spec(ways), ModelSpec.mini_imagenet(ways)
     th64 = _ref_theta(spec, 11)
@@ -170,7 +209,7 @@ def test_cfg4_full_T_batched_looped_oracle(T):
     assert rel_err(grad.double().cpu().numpy(), per_task.sum(dim=0).numpy()) < 1e-6
     trace_all = {k: v.clone() for k, v in trace.items()}
     tr1 = eng.set_trace(1, K)
-    eg, el = [], []
+    eg, el, looped_traces = [], [], {}
     check = sorted(set(range(0, T, max(1, T // 16))) | {T - 1})
     for t in check:
         l1, a1, g1, _ = eng.meta_batch(theta, d[t:t + 1], l[t:t + 1], shots, K, lr)
@@ -178,6 +217,8 @@ def test_cfg4_full_T_batched_looped_oracle(T):
         eg.append(rel_err(per_task[t].numpy(), g1.double().cpu().numpy()))
         el.append(abs(float(l1[0]) - float(loss[t])) / abs(float(loss[t])))
         assert float(a1[0]) == float(acc[t])
+        if eg[-1] > 5e-3:                       # kept for the near-tie analysis of the ONE-TASK run below
+            looped_traces[t] = {k: v.clone() for k, v in tr1.items()}
     eng.set_trace(0)
     eo, lo = [], []
     for t in sorted(set(range(0, T, max(1, T // 8))) | {T - 1}):
@@ -203,7 +244,7 @@ def test_cfg4_full_T_batched_looped_oracle(T):
     adj_h = np.array([r['hx'][0] for r in res])
     margins = [abs(fl['margin']) for r in res for step in r['flips'] for fl in step]
     flipped = sorted(int(r['t']) for r in res if any(len(step) for step in r['flips']))
-    report(f'cfg4_T{T}', end_to_end_tasks=e2e_tasks, tasks_with_near_tied_decisions=flipped, batched_vs_looped_grad_rel_median=float(np.median(eg)), batched_vs_looped_grad_rel_max=max(eg),
+    report(f'cfg4_T{T}[{conv_form_full}]', end_to_end_tasks=e2e_tasks, tasks_with_near_tied_decisions=flipped, batched_vs_looped_grad_rel_median=float(np.median(eg)), batched_vs_looped_grad_rel_max=max(eg),
            batched_vs_looped_loss_rel=max(el), vs_fp64_grad_rel=e64, vs_fp64_or_ref_fp32_grad_rel=ebest, vs_fp64_loss_rel=lo,
            teacher_forced_tasks=len(res), teacher_forced_raw_max_vs_fp64=float(raw.max()), teacher_forced_raw_max_vs_fp32=float(raw32.max()),
            teacher_forced_adjusted_grad_max=float(adj_g.max()), teacher_forced_adjusted_hvp_max=float(adj_h.max()),
@@ -220,20 +261,33 @@ def test_cfg4_full_T_batched_looped_oracle(T):
     # (batched against one-task calls: the launch geometry -- weight-gradient chunks, statistics partials -- follows the task count, so the
     # last bits differ and, with them, near-tied decisions: small ones (below 5e-3 of the task's gradient) in several tasks of the 256-task
     # leg, a larger one in at most a task or two of the seventeen checked -- the same one-decision envelope as against the oracle)
-    assert max(el) < 1e-6 and np.median(eg) < 1e-5 and sum(e > 5e-3 for e in eg) <= 2 and max(eg) < 0.3, eg
+    assert max(el) < 1e-6 and np.median(eg) < 1e-5 and sum(e > 5e-3 for e in eg) <= 2 and max(eg) < ENVELOPE, eg
+    # ... and a task above 5e-3 has to come with the decision that explains it: a near-tied (margin < TAU) pooling / ReLU decision that the
+    # fp64 arithmetic needs flipped to reproduce the batched run or the one-task run of that task -- otherwise the difference is a
+    # launch-geometry-dependent error, not a draw (round 4 advisor)
+    by_task = {int(r['t']): r for r in res}
+    for t, e in zip(check, eg):
+        if e <= 5e-3:
+            continue
+        own = [by_task[t]] if t in by_task else TF.teacher_forced_all(trace_all, data, labels, shots, ways, [t])
+        one = TF.teacher_forced_all(looped_traces[t], data[t:t + 1], labels[t:t + 1], shots, ways, [0])
+        found = [fl for r in own + one for step in r['flips'] for fl in step]
+        report(f'cfg4_T{T}[{conv_form_full}] batched-vs-looped outlier', task=int(t), grad_rel=float(e), decisions=_decisions(own + one))
+        assert found and all(abs(fl['margin']) < TF.TAU for fl in found), \
+            f'task {t}: batched vs one-task gradient differs by {e:.2e} without a near-tied decision to explain it: {_decisions(own + one)}'
     assert np.median(lo) < 1e-5 and max(lo) < 5e-3
     # (about half of the tasks hold such a decision: P(fewer than two clean ones among nine) is below 2 %)
-    assert sum(e < 1e-5 for e in ebest) >= 2 and np.median(ebest) < 1e-2 and max(e64) < 0.3, (e2e_tasks, ebest, flipped)
+    assert sum(e < 1e-5 for e in ebest) >= 2 and np.median(ebest) < 1e-2 and max(e64) < ENVELOPE, (e2e_tasks, ebest, flipped, _decisions(res))
     raw_max = RAW_MAX_T256 if T == 256 else RAW_MAX
     # (against the reference's fp32 leg the one-shot envelope RAW_MAX_T256 at either task count: there the draw is the REFERENCE's -- with
     # the fp16 operand form a task at 1.3e-6 from the fp64 leg sat at 3.8e-2 from the fp32 leg, whose own arithmetic re-routed an element)
     assert np.median(raw) < 1e-5 and raw.max() < raw_max and raw32.max() < RAW_MAX_T256
-    assert adj_g.max() < ADJ_G and adj_h.max() < ADJ_H, (sorted(adj_g)[-4:], sorted(adj_h)[-4:])
-    assert all(m < TF.TAU for m in margins)
+    assert adj_g.max() < ADJ_G and adj_h.max() < ADJ_H, (sorted(adj_g)[-4:], sorted(adj_h)[-4:], _decisions(res))
+    assert all(m < TF.TAU for m in margins), _decisions(res)
 
 
-def test_cfg3_anil_T32_batched_looped_oracle():
-    """BASELINE config 3 (ANIL, 64-filter trunk on all 50 rows of a task, head-only inner loop, K = 1) at 32 tasks: the batched
+def test_cfg3_anil_T32_batched_looped_oracle(conv_form_full):
+    """(Every operand form of the 64-filter trunk's stride-1 convolutions.)  BASELINE config 3 (ANIL, 64-filter trunk on all 50 rows of a task, head-only inner loop, K = 1) at 32 tasks: the batched
     call vs the sum of single-task calls, and nine single-task calls vs the oracle in fp64 and fp32."""
     ways, shots, K, lr, T = 5, 5, 1, 0.5, 32
     base = R.convbase_spec(hidden=64, channels=3, max_pool=True)
@@ -265,13 +319,13 @@ def test_cfg3_anil_T32_batched_looped_oracle():
     e64, e32, ex = (np.array([r[k] for r in res]) for k in ('e64', 'e32', 'ex'))
     lo = [abs(per[r['t']][0] - r['loss64']) / abs(r['loss64']) for r in res]
     margins = [abs(fl['margin']) for r in res for fl in r['flips']]
-    report('cfg3_anil_T32', batched_vs_looped_sum_grad_rel=e_sum, batched_vs_looped_loss_rel=max(el), tasks_vs_oracle=len(res),
+    report(f'cfg3_anil_T32[{conv_form_full}]', batched_vs_looped_sum_grad_rel=e_sum, batched_vs_looped_loss_rel=max(el), tasks_vs_oracle=len(res),
            vs_fp64_grad_rel=[float(x) for x in e64], vs_ref_fp32_grad_rel=[float(x) for x in e32], near_tie_adjusted_grad_rel=[float(x) for x in ex],
            vs_oracle_loss_rel=max(lo), flipped_decisions=len(margins), largest_flipped_margin=max(margins) if margins else 0.0)
     # batched vs looped: identical arithmetic per task (measured 1e-7)
     assert max(el) < 1e-5 and e_sum < 1e-4
     assert max(lo) < 1e-4 and e64.max() < RAW_MAX and e32.max() < RAW_MAX and np.median(np.minimum(e64, e32)) < 1e-4
-    assert ex.max() < ADJ_G and all(m < TF.TAU for m in margins), sorted(ex)[-4:]
+    assert ex.max() < ADJ_G and all(m < TF.TAU for m in margins), (sorted(ex)[-4:], _decisions(res))
     assert all(float(acc[r['t']]) == r['acc64'] for r in res)
 
 

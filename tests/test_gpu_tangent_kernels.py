@@ -17,7 +17,7 @@ from gpu_utils import dev, ptr, stream, rel_err, max_err, report
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['split_f16', 'split_bf16', 'split_bf16_32x32', 'fp32_pipe'])
+@pytest.fixture(scope='module', params=['split_f16', 'split_bf16_16x16', 'split_bf16_32x32', 'fp32_pipe'])
 def lib(request):
     """Every case runs with both operand forms of the 32-channel stride-1 convolutions (mi_conv_set_split_bf16) -- and, with them, of the
     lean block-1 forward kernels' conv1 (mi_block1_set_split_bf16; the engine's default splits only the tangent-forward kernel): same bars."""

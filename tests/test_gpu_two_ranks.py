@@ -20,13 +20,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _two_ranks(mode, tmp_path):
-    """Both ranks as child processes (2 + this process = 3 with the card open; the box allows 6)."""
+def _two_ranks(mode, tmp_path, backend='gloo'):
+    """Both ranks as child processes (2 + this process = 3 with the card open; the box allows 6).  backend 'gloo': the ranks share card 0;
+    'nccl' (= RCCL): rank r on GPU r."""
     port = _free_port()
     procs, outs = [], []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   MI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank if backend == 'nccl' else 0), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), MI_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
         out = str(tmp_path / f'{mode}_rank{rank}.pt')
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'two_rank_worker.py'), mode, out], env=env,
@@ -45,9 +46,20 @@ def _two_ranks(mode, tmp_path):
 
 
 def test_two_ranks_of_the_engine_reduce_to_the_single_process_meta_gradient(tmp_path):
+    _check_trainer(*_two_ranks('trainer', tmp_path))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL wants one GPU per rank: runs where the box has two')
+def test_two_ranks_over_rccl_take_the_packed_in_place_all_reduce(tmp_path):
+    """The same two-rank step with the collective the product uses: backend "nccl" (RCCL over xGMI), rank r on GPU r -- the packed
+    [meta-gradient | losses | accuracies] view (sharding.packed_outputs, an as_strided view over the engine's output allocation) all-reduced
+    in place by RCCL with two ranks, which the one-GPU boxes of the build rounds cannot exercise (reference vision/maml_vision.py:139-141)."""
+    _check_trainer(*_two_ranks('trainer', tmp_path, backend='nccl'))
+
+
+def _check_trainer(r0, r1):
     sys.path.insert(0, HERE)
     import two_rank_worker as W
-    r0, r1 = _two_ranks('trainer', tmp_path)
     assert r0['world'] == r1['world'] == 2
     assert r0['local_tasks'] == [6, 7, 8] and r1['local_tasks'] == [9, 10, 11]      # second iteration's shards
     # every rank holds the same reduced gradient and the same parameters after two Adam steps, bit for bit (no broadcast needed)

@@ -70,8 +70,9 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if mode == 'trainer':
         from exploring_meta_amd.sharding import init_process_group
-        torch.cuda.set_device(0)
-        init_process_group(0)
+        local = int(os.environ.get('LOCAL_RANK', '0'))       # 0 for both ranks where they share the card (gloo), the rank's own GPU under RCCL
+        torch.cuda.set_device(local)
+        init_process_group(local)
         res = trainer_step()
         torch.distributed.destroy_process_group()
     elif mode == 'trpo':

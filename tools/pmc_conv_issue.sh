@@ -17,7 +17,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name'].split('(')[0].replace('void ', '')
-    if not any(s in k for s in ('conv3x3_s1_mfma_kernel<32', 'wgrad3x3_strip', 'wgrad3x3_rows_bf16')):
+    if not any(s in k for s in ('conv3x3_s1_mfma_kernel<32', 'conv3x3_s1_b16_kernel<32', 'wgrad3x3_strip', 'wgrad3x3_rows_bf16')):
         continue
     acc[(k, r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
 for (k, g), cs in sorted(acc.items()):

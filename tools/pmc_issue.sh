@@ -17,7 +17,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name'].split('(')[0].replace('void ', '')
-    if not any(s in k for s in ('block1_fwd_kernel', 'sparse_wgrad_rows_kernel', 'conv3x3_s1_mfma_kernel<32, 2, 2, 0, true>', 'conv3x3_s1_mfma_kernel<32, 1, 1, 0, true>')):
+    if not any(s in k for s in ('block1_fwd_kernel', 'sparse_wgrad_rows_kernel', 'conv3x3_s1_mfma_kernel<32, 2, 2, 0, true>', 'conv3x3_s1_mfma_kernel<32, 1, 1, 0, true>', 'conv3x3_s1_b16_kernel<32, 2, 2, 0>', 'conv3x3_s1_b16_kernel<32, 1, 1, 0>')):
         continue
     acc[(k, r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
 for (k, g), cs in sorted(acc.items()):

@@ -132,6 +132,9 @@ def main():
         has_bf = {base(k) for k, g, nl, f, w, c in rows if re.search(r'\d, true(, (true|false))?>$', k) and nl > 0}
         for k, g, nl, f, w, c in rows:
             m = re.match(r'conv3x3_s1_mfma_kernel<(\d+), (\d), (\d), (\d)(?:, (true|false))?(?:, (true|false))?>', k)
+            m16 = re.match(r'conv3x3_s1_b16_kernel<(\d+), (\d), (\d), (\d)>', k)      # the split-bf16 form on 16x16x32 MFMAs: same grid rule as BF = true
+            if m16:
+                m = re.match(r'(\d+), (\d), (\d), (\d), (true)', ', '.join(m16.groups()) + ', true')
             if not (m and (m.group(2), m.group(3), m.group(4)) in CONV_OPS):
                 continue
             if m.group(5) == 'false' and base(k) in has_bf:
