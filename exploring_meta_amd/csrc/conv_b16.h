@@ -259,6 +259,24 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
     const unsigned tbase = (unsigned)(tile * 30 - 1) * (unsigned)(CO * 4) + lane_out;   // byte offset of pixel row 0's channel pair (tile 0: wraps; row 0 is dropped)
     auto row_off = [&](int mb, int r) { return tbase + (unsigned)((16 * mb + 4 * g + r) * CO * 4); };
     floatx2 zpre[2][4];
+    // (block-below reduction) block 1's tensors at this lane's output positions travel in groups of BGR pixel rows.  (Requesting the first
+    // group one row-step early, like z, was measured and is not kept: one-term dgrad -0.1 % instead of -2.4 % against the 32x32x16 kernel,
+    // two-term -6.2 % instead of -8.0 % -- 16 more live registers in the loop cost more than the latency they hide.)
+    constexpr int BGR = NTERMS == 2 ? 2 : 4;
+    struct Grp { floatx2 pp[BGR], zz[BGR], zd[BGR], dq[BGR]; unsigned pb[BGR]; };
+    auto bred_fetch = [&](auto arg_c, int grp, Grp& gq) {
+      constexpr bool ARG = decltype(arg_c)::value;
+#pragma unroll
+      for (int rr = 0; rr < BGR; ++rr) {
+        const int e = grp * BGR + rr, mb = e >> 2, r = e & 3;
+        const unsigned of = row_off(mb, r);
+        if constexpr (ARG) gq.pb[rr] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rbp, of >> 2, 0, 0);    // two bytes: channels 2n, 2n + 1
+        else gq.pp[rr] = buf_ld8(rbp, of);
+        gq.zz[rr] = buf_ld8(rbzh, of);
+        if (NTERMS == 2) { gq.zd[rr] = buf_ld8(rbzhd, of); gq.dq[rr] = buf_ld8(rbdp, of); }
+      }
+    };
+    Grp ga;
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
       if (st + 2 < NS) issue_step(cur, st + 2); else issue_step(nxt, st + 2 - NS);
@@ -400,19 +418,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
       // before anything of it is used (the argmax bytes are unpacked where they are consumed).
       auto bred = [&](auto arg_c) {
         constexpr bool ARG = decltype(arg_c)::value;
-        constexpr int GR = NTERMS == 2 ? 2 : 4;                  // pixel rows per group in flight
-        struct Grp { floatx2 pp[GR], zz[GR], zd[GR], dq[GR]; unsigned pb[GR]; };
-        auto fetch = [&](int grp, Grp& gq) {
-#pragma unroll
-          for (int rr = 0; rr < GR; ++rr) {
-            const int e = grp * GR + rr, mb = e >> 2, r = e & 3;
-            const unsigned of = row_off(mb, r);
-            if constexpr (ARG) gq.pb[rr] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rbp, of >> 2, 0, 0);    // two bytes: channels 2n, 2n + 1
-            else gq.pp[rr] = buf_ld8(rbp, of);
-            gq.zz[rr] = buf_ld8(rbzh, of);
-            if (NTERMS == 2) { gq.zd[rr] = buf_ld8(rbzhd, of); gq.dq[rr] = buf_ld8(rbdp, of); }
-          }
-        };
+        constexpr int GR = BGR;
+        auto fetch = [&](int grp, Grp& gq) { bred_fetch(arg_c, grp, gq); };
         auto consume = [&](int grp, const Grp& gq) {
 #pragma unroll
           for (int rr = 0; rr < GR; ++rr) {
@@ -437,7 +444,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
           }
         };
         constexpr int NG = 8 / GR;
-        Grp ga, gb;
+        Grp gb;
         fetch(0, ga);
 #pragma unroll
         for (int grp = 0; grp < NG; grp += 2) {
