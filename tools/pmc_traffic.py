@@ -130,7 +130,11 @@ def main():
         # (template arguments <CI, NTERMS, EPI, MODE, BF, F16>: BF = a split operand form, F16 = its two-plane fp16 variant)
         base = lambda k: re.sub(r'(, (true|false)){1,2}>$', '', k)
         has_bf = {base(k) for k, g, nl, f, w, c in rows if re.search(r'\d, true(, (true|false))?>$', k) and nl > 0}
-        for k, g, nl, f, w, c in rows:
+        # (the split-bf16 form runs on two kernels since round 5 -- the 16x16x32 one for launches of >= 8 tiles per wave, the 32x32x16 one below
+        # that, the same grid rule for both: a layer the first has taken is not a candidate for the second, whose size classes then count
+        # through the remaining layers of that grid)
+        taken = {}
+        for k, g, nl, f, w, c in sorted(rows, key=lambda r: 0 if 'conv3x3_s1_b16_kernel' in r[0] else 1):
             m = re.match(r'conv3x3_s1_mfma_kernel<(\d+), (\d), (\d), (\d)(?:, (true|false))?(?:, (true|false))?>', k)
             m16 = re.match(r'conv3x3_s1_b16_kernel<(\d+), (\d), (\d), (\d)>', k)      # the split-bf16 form on 16x16x32 MFMAs: same grid rule as BF = true
             if m16:
@@ -141,9 +145,12 @@ def main():
                 continue
             op = CONV_OPS[(m.group(2), m.group(3), m.group(4))]
             same_grid = [layer for layer in range(1, len(geo))       # blocks launched with this grid, largest maps first
-                         if geo[layer][2] == int(m.group(1)) and grid_threads(layer, int(m.group(2)), m.group(5) == 'true') == g]
+                         if geo[layer][2] == int(m.group(1)) and grid_threads(layer, int(m.group(2)), m.group(5) == 'true') == g
+                         and (m16 or layer not in taken.get(op, ()))]
             if c < len(same_grid):
                 out[f'{args.workload},{op},{same_grid[c]}'] = int((f + w) * 1e6)
+                if m16:
+                    taken.setdefault(op, set()).add(same_grid[c])
         json.dump(out, open(args.json, 'w'), indent=1)
 
 
