@@ -26,6 +26,7 @@ struct Layer {
   size_t off_gamma, off_beta, off_w, off_b;
 };
 
+static bool fork_once_env() { static const bool v = getenv("MI_FORK_ONCE") && atoi(getenv("MI_FORK_ONCE")) != 0; return v; }
 struct mi_engine {
   mi_model_desc d;
   int device;
@@ -40,6 +41,7 @@ struct mi_engine {
   // Weight gradients of blocks >= 2 run on a side stream: they depend only on dz_l and the block input, nothing downstream of
   // them until the parameter update, and they are matrix-bound while the BatchNorm kernels of the next block are HBM-bound.
   bool overlap = true;
+  bool fork_once = fork_once_env();   // false (default): one fork / join of the side stream per hidden block; true: ONE per backward pass (mi_engine_set_overlap(e, 3), MI_FORK_ONCE=1; measured slower)
   // BatchNorm statistic / reduction partials are folded by the last workgroup of the producing kernel (finalize.h) instead of a
   // bn_finalize launch; counters: one zero-initialised arrival counter per task, owned by the engine.
   bool fuse_fin = true;
@@ -283,6 +285,7 @@ extern "C" int mi_engine_set_fused_tail(mi_engine* e, int on) {
 extern "C" int mi_engine_set_overlap(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->overlap = on != 0;
+  e->fork_once = on == 3 || fork_once_env();
   return MI_OK;
 }
 
@@ -300,6 +303,8 @@ static hipStream_t pool_stream(const mi_engine* e, int which) {
   }
   return g_pool[d][which];
 }
+// (hipEventReleaseToDevice instead of the default system-scope release was measured in round 5: no difference -- the ~7 us the caller's stream
+// idles behind an event record are the marker packet itself, not its cache write-back; profiles/r5/overlap_fork_ab.txt)
 static bool make_event(hipEvent_t* ev) { return *ev || hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; }
 
 // fork = the side stream waits for everything issued on `st` so far; join = `st` waits for everything issued on the side stream
@@ -310,6 +315,8 @@ static hipStream_t side_fork(mi_engine* e, hipStream_t st, int half) {
     c.side = pool_stream(e, 0);
     if (!c.side || !make_event(&c.fork) || !make_event(&c.join)) { e->overlap = false; return st; }
   }
+  // (stream memory operations instead of the event -- hipStreamWriteValue32 on the caller's stream, hipStreamWaitValue32 on the side stream --
+  // were tried in round 5 as a cheaper fork: they fail on this stack with "invalid argument")
   if (hipEventRecord(c.fork, st) != hipSuccess || hipStreamWaitEvent(c.side, c.fork, 0) != hipSuccess) return st;
   return c.side;
 }
@@ -680,7 +687,8 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
                           float* g, const double* gram = nullptr, AdvanceArgs* adv = nullptr) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;
-  bool forked = false, red_done[9] = {false, false, false, false, false, false, false, false, false};   // [l]: block l's sums rode in block l+1's dgrad
+  bool forked = false, red_done[9] = {false, false, false, false, false, false, false, false, false};
+  WgradArgs held[9]; int held_l[9], nheld = 0;                  // weight gradients held back for the pass's one fork of the side stream   // [l]: block l's sums rode in block l+1's dgrad
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
     const int mpix = n * L.ho * L.wo;
@@ -745,15 +753,35 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
       CELL(wa.x[0], (size_t)n * L.h * L.w * L.ci, wa.amax_x[0]);
       CELL(wa.dz[0], (size_t)n * L.ho * L.wo * L.co, wa.amax_dz[0]);
     }
-    hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
-    if (ws != st) forked = true;
-    wa.partial = adv ? pl.wgpart_l[l] : (ws != st ? pl.wgpart_side : pl.wgpart);
     wa.g = geom(L, n);
     wa.mpix = mpix;
-    int nch = 0;
-    LAUNCH(e, ws, OP_WGRAD, l, launch_wgrad3x3(ws, wa, T, 1, &nch));
-    if (adv) adv_add_seg(adv, L.off_w, 9 * L.ci * L.co, wa.partial, nch);
-    else LAUNCH(e, ws, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(ws, wa.partial, nch, 9 * L.ci * L.co, T, g + L.off_w, P));
+    // The weight gradients of the hidden blocks run on the side stream beside the dgrad chain.  One fork per PASS (default): they are held
+    // back until the last hidden block's dz exists and then issued together -- they overlap that block's dgrad and block 1's kernels --
+    // because every fork is an event record on the caller's stream, which idles it for ~7 us (tools/launch_floor.py: 25 such gaps per
+    // meta-iteration with one fork per block, at every task count; profiles/r5/launch_floor_cfg2_T*.txt).
+    auto issue_wgrad = [&](hipStream_t ws, WgradArgs& w, int wl) -> int {
+      const Layer& Lw = e->L[wl];
+      w.partial = adv ? pl.wgpart_l[wl] : (ws != st ? pl.wgpart_side : pl.wgpart);
+      int nch = 0;
+      LAUNCH(e, ws, OP_WGRAD, wl, launch_wgrad3x3(ws, w, T, 1, &nch));
+      if (adv) adv_add_seg(adv, Lw.off_w, 9 * Lw.ci * Lw.co, w.partial, nch);
+      else LAUNCH(e, ws, OP_WGRAD_REDUCE, wl, launch_wgrad_reduce(ws, w.partial, nch, 9 * Lw.ci * Lw.co, T, g + Lw.off_w, P));
+      return MI_OK;
+    };
+    if (l > 0 && e->overlap && e->fork_once) {
+      held[nheld] = wa; held_l[nheld++] = l;
+      if (l == 1) {
+        hipStream_t ws = side_fork(e, st, pl.half);
+        if (ws != st) forked = true;
+        for (int q = 0; q < nheld; ++q) { const int rc = issue_wgrad(ws, held[q], held_l[q]); if (rc) return rc; }
+        nheld = 0;
+      }
+    } else {
+      hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
+      if (ws != st) forked = true;
+      const int rc = issue_wgrad(ws, wa, l);
+      if (rc) return rc;
+    }
     if (l > 0) {
       ConvArgs ca{};
       ca.in[0] = A.dz[l];
@@ -928,6 +956,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   }
   int cur = 0;
   bool forked = false, red_done[9] = {false, false, false, false, false, false, false, false, false};
+  WgradArgs held[9]; int held_l[9], nheld = 0;                  // weight gradients held back for the pass's one fork of the side stream
   HeadArgs ha{};
   ha.f = A.f; ha.fd = fd;
   ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
@@ -1017,15 +1046,32 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
       CELL(wa.x[1], (size_t)n * L.h * L.w * L.ci, wa.amax_x[1]);
       CELL(wa.dz[1], (size_t)n * L.ho * L.wo * L.co, wa.amax_dz[1]);
     }
-    hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
-    if (ws != st) forked = true;
-    wa.partial = adv ? pl.wgpart_l[l] : (ws != st ? pl.wgpart_side : pl.wgpart);
     wa.g = geom(L, n);
     wa.mpix = mpix;
-    int nch = 0;
-    LAUNCH(e, ws, OP_TAN_WGRAD, l, launch_wgrad3x3(ws, wa, T, l > 0 ? 2 : 1, &nch));
-    if (adv) adv_add_seg(adv, L.off_w, 9 * L.ci * L.co, wa.partial, nch);
-    else LAUNCH(e, ws, OP_WGRAD_REDUCE, l, launch_wgrad_reduce(ws, wa.partial, nch, 9 * L.ci * L.co, T, hv + L.off_w, P));
+    // (one fork of the side stream per pass, as in the primal backward pass above)
+    auto issue_wgrad = [&](hipStream_t ws, WgradArgs& w, int wl) -> int {
+      const Layer& Lw = e->L[wl];
+      w.partial = adv ? pl.wgpart_l[wl] : (ws != st ? pl.wgpart_side : pl.wgpart);
+      int nch = 0;
+      LAUNCH(e, ws, OP_TAN_WGRAD, wl, launch_wgrad3x3(ws, w, T, wl > 0 ? 2 : 1, &nch));
+      if (adv) adv_add_seg(adv, Lw.off_w, 9 * Lw.ci * Lw.co, w.partial, nch);
+      else LAUNCH(e, ws, OP_WGRAD_REDUCE, wl, launch_wgrad_reduce(ws, w.partial, nch, 9 * Lw.ci * Lw.co, T, hv + Lw.off_w, P));
+      return MI_OK;
+    };
+    if (l > 0 && e->overlap && e->fork_once) {
+      held[nheld] = wa; held_l[nheld++] = l;
+      if (l == 1) {
+        hipStream_t ws = side_fork(e, st, pl.half);
+        if (ws != st) forked = true;
+        for (int q = 0; q < nheld; ++q) { const int rc = issue_wgrad(ws, held[q], held_l[q]); if (rc) return rc; }
+        nheld = 0;
+      }
+    } else {
+      hipStream_t ws = l > 0 ? side_fork(e, st, pl.half) : st;
+      if (ws != st) forked = true;
+      const int rc = issue_wgrad(ws, wa, l);
+      if (rc) return rc;
+    }
     if (l > 0) {
       ConvArgs ca{};
       ca.in[0] = X.rdz[l]; ca.wt[0] = theta + L.off_w;

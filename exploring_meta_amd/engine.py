@@ -130,7 +130,8 @@ class MetaEngine:
         _lib.check(self.lib.mi_engine_set_fused_block1(self._h, int(on)), self._h)
 
     def set_overlap(self, on):
-        """Side-stream execution of the weight gradients of blocks >= 2 (default on); results do not depend on it."""
+        """Side-stream execution of the weight gradients of blocks >= 2 (default on: one fork of the side stream per hidden block; 3: one
+        per backward pass, measured slower); results do not depend on it."""
         _lib.check(self.lib.mi_engine_set_overlap(self._h, int(on)), self._h)
 
     def set_fused_finalize(self, on):

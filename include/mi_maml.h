@@ -57,8 +57,10 @@ int mi_engine_set_fused_block1(mi_engine* e, int on);
 
 /* 1 (default): the weight gradients of blocks >= 2 run on an engine-owned side stream, forked from the caller's stream once
  * dz of the block is written and joined before the pass's gradients are used (they are matrix-bound, the BatchNorm kernels
- * that follow on the main stream are HBM-bound).  0: every kernel on the caller's stream.  Results are identical either way
- * (per-launch times from mi_profile_* are only additive with 0). */
+ * that follow on the main stream are HBM-bound).  0: every kernel on the caller's stream.  1 (default): one fork of the side stream per
+ * hidden block.  3: ONE fork per backward pass (the weight gradients issued together once the last hidden block's dz exists): saves two
+ * event records per pass -- each idles the caller's stream for ~7 us -- but loses more overlap than that (measured: +2.9 % on cfg2).
+ * Results are identical in every mode (per-launch times from mi_profile_* are only additive with 0). */
 int mi_engine_set_overlap(mi_engine* e, int on);
 
 /* 1: a call of mi_meta_batch_maml / mi_meta_batch_anil whose arguments (every pointer, size and scalar, the stream included) equal

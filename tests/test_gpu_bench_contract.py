@@ -69,3 +69,9 @@ def test_bench_starts_its_own_ranks():
     co = d['collective']
     assert co['world_size'] == 2 and co['backend'].startswith('gloo') and co['rccl_version'] is None
     assert co['theta_checksum_identical_on_all_ranks'] is True
+    # N > 1 under the default weak scaling: the line also carries the strong-scaling reading (global meta-batch kept, each rank its share)
+    st = d['strong_scaling']
+    assert st['scaling'] == 'strong' and st['global_meta_batch'] == 4 and st['tasks_per_rank'] == 2 and st['n_gpus'] == 2
+    assert st['ms_per_iteration'] > 0 and abs(st['tasks_per_s'] - 4 * 1e3 / st['ms_per_iteration']) < 1e-2 * st['tasks_per_s']
+    assert d['secondary']['strong_scaling'] == st
+    assert 0.0 <= d['secondary']['valid_acc_mean'] <= 1.0          # (the in-place all-reduce sums the ranks' accuracies: divided by the world size)

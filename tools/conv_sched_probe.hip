@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
   const unsigned lane_in = (unsigned)(h * 64);
   const int tile_base = blockIdx.x * NW * tiles_per_wave;
   auto tile_off = [&](int tl) { return (FLAGS & 2) ? lane_in + (unsigned)(j * 128) + (unsigned)wci : (unsigned)((tl * 30 + j) * (CI * 4)) + lane_in + (unsigned)wci; };
-  floatx4 rawc[HRING][2];
+  floatx4 rawc[HRING][2], rawd[HRING][2];                        // (rawd, pd, accd: the second tile of LAYOUT 7)
   auto issue_hg = [&](unsigned base, int i) {
     const int ddy = (i % 6) / 2 - 1;
     const unsigned o = base + (unsigned)(ddy * wci) + (unsigned)((i & 1) * 32);
@@ -83,9 +83,22 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
   unsigned cur = tile_off(tile);
 #pragma unroll
   for (int i = 0; i < HRING; ++i) issue_hg(cur, i);
-  Bf16Planes pc[2], opm[2], opp[2];
+  // LAYOUT 7: the wave owns TWO tiles (64 pixel rows) and every weight read serves both -- half the LDS bytes per MFMA
+  constexpr unsigned T2 = 30u * 128u * 4096u;                     // the second tile: 4096 tiles further (another part of the tensor)
+  auto issue_hg2 = [&](unsigned base, int i) {
+    const int ddy = (i % 6) / 2 - 1;
+    const unsigned o = base + T2 + (unsigned)(ddy * wci) + (unsigned)((i & 1) * 32);
+    rawd[i % HRING][0] = buf_ld16(rin, o);
+    rawd[i % HRING][1] = buf_ld16(rin, o + 16);
+  };
+  if (LAYOUT == 7) {
+#pragma unroll
+    for (int i = 0; i < HRING; ++i) issue_hg2(cur, i);
+  }
+  Bf16Planes pc[2], opm[2], opp[2], pd[2];
   mi_u32x4 pb[2][3];
   split_pair<0>(rawc[0][0], pc[0]); split_pair<1>(rawc[0][0], pc[0]); split_pair<2>(rawc[0][1], pc[0]); split_pair<3>(rawc[0][1], pc[0]);
+  if (LAYOUT == 7) { split_pair<0>(rawd[0][0], pd[0]); split_pair<1>(rawd[0][0], pd[0]); split_pair<2>(rawd[0][1], pd[0]); split_pair<3>(rawd[0][1], pd[0]); }
   unsigned selm = 0xffffffffu, selp = (j == 17) ? 0u : 0xffffffffu;
   asm volatile("" : "+v"(selm), "+v"(selp));
 #define SHIFTR(dst, src, P, R, CTRL, SEL) dst.P[R] = (FLAGS & 1) ? (src.P[R] & SEL) : ((unsigned)__builtin_amdgcn_mov_dpp((int)src.P[R], CTRL, 0xf, 0xf, true) & SEL);
@@ -97,9 +110,9 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
   if (LAYOUT != 0 && LAYOUT != 6 && NACC == 1) { SHIFT6(opm[0], pc[0], 0x138, selm) SHIFT6B(opm[0], pc[0], 0x138, selm) SHIFT6(opp[0], pc[0], 0x130, selp) SHIFT6B(opp[0], pc[0], 0x130, selp) }
   READB(pb[0], unit_of(0, 0));
   typedef AccT<SHAPE> Acc;
-  Acc acc[3];
+  Acc acc[3], accd[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) acc[a].zero();
+  for (int a = 0; a < 3; ++a) { acc[a].zero(); accd[a].zero(); }
   float sink = 0.f;
   if (LAYOUT == 3 && wave >= 4) asm volatile("s_barrier" ::: "memory");
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -108,6 +121,7 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
       if (i + HRING < NH) issue_hg(cur, i + HRING); else issue_hg(nxt, i + HRING - NH);
+      if (LAYOUT == 7) { if (i + HRING < NH) issue_hg2(cur, i + HRING); else issue_hg2(nxt, i + HRING - NH); }
       const Bf16Planes& pc_ = pc[i & 1];
       Bf16Planes& nc = pc[(i + 1) & 1];
       const floatx4* rc = rawc[(i + 1) % HRING];
@@ -131,6 +145,19 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
           READB(pb[(3 * i + 3) & 1], unit_of((i + 1) % NH, 0));
           SIX(pc_, pb[(3 * i + 2) & 1], a2, (void)0, (void)0, (void)0, (void)0)
         }
+      } else if constexpr (LAYOUT == 7) {
+        const Bf16Planes& pd_ = pd[i & 1];
+        Bf16Planes& nd = pd[(i + 1) & 1];
+        const floatx4* rd = rawd[(i + 1) % HRING];
+        READB(pb[(3 * i + 1) & 1], unit_of(i, -1));
+        SIX(pc_, pb[(3 * i) & 1], acc[0], (void)0, split_pair<0>(rc[0], nc), (void)0, split_pair<1>(rc[0], nc))
+        SIX(pd_, pb[(3 * i) & 1], accd[0], (void)0, split_pair<0>(rd[0], nd), (void)0, split_pair<1>(rd[0], nd))
+        READB(pb[(3 * i + 2) & 1], unit_of(i, 1));
+        SIX(pc_, pb[(3 * i + 1) & 1], acc[1], (void)0, split_pair<2>(rc[1], nc), (void)0, split_pair<3>(rc[1], nc))
+        SIX(pd_, pb[(3 * i + 1) & 1], accd[1], (void)0, split_pair<2>(rd[1], nd), (void)0, split_pair<3>(rd[1], nd))
+        READB(pb[(3 * i + 3) & 1], unit_of((i + 1) % NH, 0));
+        SIX(pc_, pb[(3 * i + 2) & 1], acc[2], (void)0, (void)0, (void)0, (void)0)
+        SIX(pd_, pb[(3 * i + 2) & 1], accd[2], (void)0, (void)0, (void)0, (void)0)
       } else if constexpr (LAYOUT == 6) {
         // one split stage / four shifts behind every MFMA (the split of a pair is three dependent stages; written as whole pairs every third slot)
         Bf16Planes& om = opm[0]; Bf16Planes& op = opp[0];
@@ -193,7 +220,8 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   if (LAYOUT == 3 && wave < 4) asm volatile("s_barrier" ::: "memory");
 #pragma unroll
-  for (int a = 0; a < 3; ++a) sink += acc[a].sum();
+  for (int a = 0; a < 3; ++a) sink += acc[a].sum() + accd[a].sum();
+  sink += __uint_as_float(pd[0].h[1] ^ pd[1].l[2]);
   sink += __uint_as_float(pc[0].h[0] ^ pc[1].l[3] ^ opm[0].m[1] ^ opp[0].l[2] ^ opm[1].h[2] ^ opp[1].m[3]);
   out[(size_t)blockIdx.x * 512 + tid] = sink;
   if (lane == 0) { stamps[(blockIdx.x * 8 + wave) * 2] = t1 - t0; stamps[(blockIdx.x * 8 + wave) * 2 + 1] = r1 - r0; }
@@ -289,6 +317,11 @@ int main(int argc, char** argv) {
   RUN(5, 3, 0); RUN(0, 3, 0); RUN(1, 3, 0); RUN(3, 3, 0); RUN(6, 3, 0);
   RUN16(4, 1, 0); RUN16(0, 1, 0); RUN16(0, 3, 0); RUN16(6, 3, 0); RUN16(3, 3, 0);
   RUN(4, 1, 2); RUN(0, 1, 2); RUN(0, 3, 2); RUN(5, 1, 2);
+  // two tiles per wave sharing every weight read, one wave per SIMD (4-wave workgroups): 216 MFMAs per loop trip and wave
+  run("layout 7 (2 tiles/wave) 32x32x16, 1 wave/SIMD", probe<7, 3, 0, 0>, 256, tpw, mpw * 2, false);
+  run("layout 7 (2 tiles/wave) 16x16x32, 1 wave/SIMD", probe<7, 3, 0, 1>, 256, tpw, mpw * 2, false);
+  run("layout 7 (2 tiles/wave) 16x16x32, 2 waves/SIMD", probe<7, 3, 0, 1>, 512, tpw, mpw * 2, false);
+  run("layout 0 acc 3 16x16x32, 1 wave/SIMD", probe<0, 3, 0, 1>, 256, tpw, mpw, false);
   RUN(0, 1, 0);                                                          // (repeat of the shipped order: drift check)
   const int it = 140; const double fm = it * 18.0;
 #define RUNF(NV) run("fma sweep NV=" #NV " 2 waves", fma_sweep<NV>, 512, it, fm, true); run("fma sweep NV=" #NV " 1 wave", fma_sweep<NV>, 256, it, fm, true)
