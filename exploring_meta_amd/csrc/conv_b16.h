@@ -73,6 +73,15 @@ __device__ __forceinline__ void stats_block_reduce_pairs(double s0, double q0, d
   mi_finalize_last(fin, partial_task, gridDim.x, co_total, task, gridDim.x * gridDim.z, ldsd);
 }
 
+// Diagnostic build only (-DMI_B16_STAMPS, another file name, selected with MI_MAML_LIB; tools/conv_b16_stamps.py): waves 0 and 4 of workgroup
+// (0, 0, 0) -- SIMD partners in an 8-wave workgroup -- write shader-clock totals to the buffer of mi_debug_conv_stamps:
+// [8 w4 + 0] kernel start, [1] weights staged, [2] sum over tiles of the epilogue's first part (the combination of the three accumulators), [3] of the K loops (with the tile head), [4] of the epilogues,
+// [5] last tile done, [6] kernel end, [7] tiles.  No stamp executes in the production build.
+#ifdef MI_B16_STAMPS
+#define B16_ST(...) __VA_ARGS__
+#else
+#define B16_ST(...)
+#endif
 template <int CI, int NTERMS, int EPI, int MODE>
 __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2) void conv3x3_s1_b16_kernel(ConvArgs a) {
   constexpr int NW = ConvWaves<CI, NTERMS, true, false>::value, NT = NW * 64, CO = CI;
@@ -96,6 +105,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
   }
   const int H = a.g.h, W = a.g.w;
   const int cbase = ct * 32;
+  B16_ST(unsigned long long* stp = (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0 && lane == 0 && g_conv_stamps) ? g_conv_stamps + (wave >> 2) * 8 : nullptr;
+         unsigned long long st_head = 0, st_k = 0, st_epi = 0, st_n = 0, st_a = 0, st_b = 0, st_comb = 0; if (stp) stp[0] = __builtin_amdgcn_s_memtime();)
 
   // ---- stage this task's weights as bf16 planes in operand order (all of a thread's loads first, then the splits)
   {
@@ -233,11 +244,27 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
   issue_step(cur, 0);
   issue_step(cur, 1);
   __syncthreads();                                               // weights staged (the first operand loads are already in flight)
+  B16_ST(if (stp) stp[1] = __builtin_amdgcn_s_memtime();)
   Bf16Planes pl[2][2];                                           // [buffer][mb]
   bf16_split_pair<0>(raw[0][0], pl[0][0]); bf16_split_pair<1>(raw[0][0], pl[0][0]); bf16_split_pair<2>(raw[0][1], pl[0][0]); bf16_split_pair<3>(raw[0][1], pl[0][0]);
   bf16_split_pair<0>(raw[0][2], pl[0][1]); bf16_split_pair<1>(raw[0][2], pl[0][1]); bf16_split_pair<2>(raw[0][3], pl[0][1]); bf16_split_pair<3>(raw[0][3], pl[0][1]);
   read_chunk(0);
   read_chunk(1);
+  // Stagger (MI355X_MICROARCH.md, "Two waves per SIMD" 9).  The two waves of a SIMD run the same program on equal work and start together, so
+  // they stay in LOCKSTEP: both in the K loop (sharing the matrix pipe), then both in their epilogues -- lane rotations, 100+ vector
+  // instructions, 64 fp64 operations, stores -- with the pipe idle (SQ counters of the two-term forward: matrix pipe busy 62 % of the launch
+  // where the K loop alone sustains 86 %).  A phase offset between the partners is neutrally stable (whichever wave is in its epilogue, the
+  // other has the pipe to itself for exactly that long), so ONE delay of half a tile's matrix time at the start keeps one wave's epilogue
+  // under the other's K loop for the rest of the launch.  Partners: waves w and w + 4 of an 8-wave workgroup; with 4-wave workgroups (two
+  // per CU) the workgroups of the second half of the launch order, which land on the CUs the first half already occupies.
+  const unsigned total_wg = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned lin_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const bool late = NW == 8 ? wave >= 4 : lin_wg >= (total_wg >> 1);     // the second (younger) wave of its SIMD
+  int prio_phase = late ? 1 : 0;
+  if (a.stagger & 1) {
+    // one tile's matrix time, NS x 72 MFMAs x 16 cycles = half the period of two waves that share the pipe; s_sleep counts units of 64 cycles
+    if (late) __builtin_amdgcn_s_sleep(NS * 18 > 127 ? 127 : NS * 18);
+  }
   const unsigned lane_out = (unsigned)((cbase + 2 * n) * 4);
   const unsigned addr_dn = (unsigned)(((lane - 16) & 63) * 4), addr_up = (unsigned)(((lane + 16) & 63) * 4);
   int g0 = g == 0 ? -1 : 0, g3 = g == 3 ? -1 : 0;                // lane-group masks (opaque: merges stay v_bfi / v_and, never compare + v_cndmask)
@@ -246,6 +273,14 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
   // One tile.  PAR: which plane buffer holds the tile's first row-step (the buffers alternate per row-step; NS may be odd).
   auto tile_body = [&](auto par_c) {
     constexpr int PAR = decltype(par_c)::value;
+    // (a.stagger & 2) issue priority alternates between the SIMD's two waves from tile to tile: at equal priority the older wave's vector
+    // instructions go first every time, its K loop runs 10.3k cycles per two-term tile against the younger wave's 14.5k, it finishes a quarter
+    // of the launch early and the SIMD ends on one wave (tools/conv_b16_stamps.py) -- taking turns, both finish together
+    if (a.stagger & 2) {
+      if (prio_phase & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+      ++prio_phase;
+    }
+    B16_ST(st_a = __builtin_amdgcn_s_memtime();)
     const TileSt nxt = decode(tile + NW);
     floatx4 acc[3][2][2];
 #pragma unroll
@@ -259,6 +294,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
     const unsigned tbase = (unsigned)(tile * 30 - 1) * (unsigned)(CO * 4) + lane_out;   // byte offset of pixel row 0's channel pair (tile 0: wraps; row 0 is dropped)
     auto row_off = [&](int mb, int r) { return tbase + (unsigned)((16 * mb + 4 * g + r) * CO * 4); };
     floatx2 zpre[2][4];
+    B16_ST(st_b = st_a;)
     // (block-below reduction) block 1's tensors at this lane's output positions travel in groups of BGR pixel rows.  (Requesting the first
     // group one row-step early, like z, was measured and is not kept: one-term dgrad -0.1 % instead of -2.4 % against the 32x32x16 kernel,
     // two-term -6.2 % instead of -8.0 % -- 16 more live registers in the loop cost more than the latency they hide.)
@@ -358,6 +394,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    B16_ST(st_a = __builtin_amdgcn_s_memtime(); st_k += st_a - st_b;)
 
     // ---- epilogue
     // the halo rows (pm = 0: mb 0, g 0, r 0; pm = 31: mb 1, g 3, r 3) are neither stored nor summed
@@ -411,6 +448,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[mb][nb][r] = acc[1][mb][nb][r] + (am[mb][r] + bp[mb][r]);
     }
+    B16_ST(const unsigned long long st_c = __builtin_amdgcn_s_memtime(); st_comb += st_c - st_a;)
     if (EPI == EPI_BRED) {
       // block 1's pooled-resolution tensors at this lane's 16 output positions: "ReLU on" from the argmax byte (below 4) or from p > 0;
       //   1 term : sum [on] out zh, sum [on] out        2 terms: sum [on] (out zh + dp zhd), sum [on] out
@@ -478,6 +516,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
         }
     }
     cur = nxt;
+    B16_ST(st_b = __builtin_amdgcn_s_memtime(); st_epi += st_b - st_a; ++st_n;)
   };
 
   // plane-buffer parity of a tile's first row-step: alternates from tile to tile when NS is odd
@@ -491,8 +530,10 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
       tile -= NW;
     }
   }
+  B16_ST(if (stp) { stp[2] = st_comb; stp[3] = st_k; stp[4] = st_epi; stp[5] = __builtin_amdgcn_s_memtime(); stp[7] = st_n; })
   if (EPI != EPI_NONE) {
     double* pb = a.partial + (size_t)task * gridDim.x * 2 * CO;
     stats_block_reduce_pairs(s[0], q[0], s[1], q[1], reinterpret_cast<double*>(lds), lane, wave, NW, pb, CO, cbase, a.fin, task, bx);
   }
+  B16_ST(if (stp) stp[6] = __builtin_amdgcn_s_memtime();)
 }

@@ -1301,6 +1301,12 @@ int conv_b16() {
   return g_conv_b16;
 }
 extern "C" int mi_conv_set_b16(int on) { const int was = conv_b16(); if (on >= 0) g_conv_b16 = on > 2 ? 2 : on; return was; }
+// Experiments of round 5 on how the two waves of a SIMD share it in the 16x16x32 kernel, both OFF by default (MI_CONV_STAGGER bit 0: the second
+// wave starts half a tile late; bit 1: issue priority alternates between the two from tile to tile).  tools/conv_b16_stamps.py: at equal
+// priority the older wave's K loop takes 10.3k cycles per two-term tile and the younger's 14.5k, so the older finishes a quarter of the launch
+// early; alternating priority balances them (12.6k / 13.6k, launch cycles -5 %), but the wall time moves by -2 % on the forward kernel and +2 %
+// on the dgrad: the SIMD's issue port, not the partner's phase, is what is short (an MFMA of this shape holds it 8 of its 16 cycles).
+static int conv_stagger() { static const int v = getenv("MI_CONV_STAGGER") ? atoi(getenv("MI_CONV_STAGGER")) : 0; return v; }
 static bool conv_b16_for(const ConvArgs& a) { const int m = conv_b16(); return m == 2 || (m == 1 && a.tiles_per_wave >= g_conv_b16_min_tpw); }
 template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
@@ -1362,6 +1368,7 @@ hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int
   conv_grid(a.mpix, tasks, cot, nw, a.g.ci, nterms, ntiles, tpw, grid, a.split_bf16 ? 30 : 32, a.split_bf16 == 2 && MI_F16_WIDE && epi != EPI_TSTATS);
   a.ntiles = ntiles;
   a.tiles_per_wave = tpw;
+  a.stagger = conv_stagger();
   if (blocks_per_task) *blocks_per_task = grid.x;
   if (a.g.co % 32 != 0) return hipErrorInvalidValue;
   const int s = a.g.stride;

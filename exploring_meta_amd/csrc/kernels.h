@@ -23,6 +23,7 @@ struct ConvArgs {
   int mpix;             // n*ho*wo
   int ntiles, tiles_per_wave;
   int split_bf16;       // set by launch_conv3x3: the operand form of this launch -- 0 fp32 pipe, 1 split-bf16, 2 scaled fp16 planes (30-pixel tiles)
+  int stagger;          // set by launch_conv3x3 (conv_b16.h): delay the second wave of every SIMD by half a tile once, so that the partners' epilogues do not coincide
   const unsigned* amax[2];   // fp16 form: cells [T][MI_CELL_WORDS] (mi_common.h) = the exponent field (fp32 bits) of max |in[term]| per task (written by the tensor's producer, launch_amax otherwise)
 };
 

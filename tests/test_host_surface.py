@@ -118,3 +118,23 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f'{f} imports the oracle'
+
+
+def test_roofline_names_the_kernel_a_conv_launch_takes():
+    """utils/roofline.py mirrors launch_conv3x3's rule for the split-bf16 form's two kernels (csrc/conv_mfma.hip: conv_b16_for): the 16x16x32
+    kernel from 8 tiles of 30 pixels per wave (2048 resident waves) on in mode 1, always / never in modes 2 / 0 -- bench.py names the
+    dominant kernel with it."""
+    from exploring_meta_amd.engine import ModelSpec
+    from exploring_meta_amd.utils import roofline as RF
+    # cfg2, 32 tasks x 25 images: block 2 (42 x 42) 23 tiles per wave, block 3 (21 x 21) 5.7, block 4 (10 x 10) 1.3
+    assert RF.conv_kernel_is_b16(25 * 42 * 42, 32, 32, 1) and not RF.conv_kernel_is_b16(25 * 21 * 21, 32, 32, 1)
+    assert not RF.conv_kernel_is_b16(25 * 10 * 10, 32, 32, 1)
+    # few tasks per call stay on the 32x32x16 kernel; cfg4 (5 images per task) too; modes 0 / 2 do not look at the size
+    assert not RF.conv_kernel_is_b16(25 * 42 * 42, 4, 32, 1) and not RF.conv_kernel_is_b16(5 * 42 * 42, 32, 32, 1)
+    assert RF.conv_kernel_is_b16(5 * 10 * 10, 1, 32, 2) and not RF.conv_kernel_is_b16(25 * 42 * 42, 32, 32, 0)
+    # 64 filters: two channel tiles per pixel tile
+    assert RF.conv_kernel_is_b16(50 * 21 * 21, 32, 64, 1)
+    spec = ModelSpec.mini_imagenet(5)
+    assert RF.kernel_name(spec, 'tangent_conv_fwd', 1, b16=True).startswith('conv3x3_s1_b16_kernel<32,2,EPI_TSTATS')
+    assert RF.kernel_name(spec, 'tangent_conv_fwd', 1).startswith('conv3x3_s1_mfma_kernel<32,2,EPI_TSTATS')
+    assert RF.kernel_name(spec, 'wgrad', 1, b16=True).startswith('wgrad3x3')          # only the forward / dgrad family has the second kernel

@@ -81,8 +81,10 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
   auto unit_of = [](int i, int ddx) { return ((((i % 6) / 2) * 3 + (ddx + 1)) * 2 + (i & 1)); };   // 0..17
   int tile = tile_base + wave;
   unsigned cur = tile_off(tile);
+  if (LAYOUT != 8) {
 #pragma unroll
-  for (int i = 0; i < HRING; ++i) issue_hg(cur, i);
+    for (int i = 0; i < HRING; ++i) issue_hg(cur, i);
+  }
   // LAYOUT 7: the wave owns TWO tiles (64 pixel rows) and every weight read serves both -- half the LDS bytes per MFMA
   constexpr unsigned T2 = 30u * 128u * 4096u;                     // the second tile: 4096 tiles further (another part of the tensor)
   auto issue_hg2 = [&](unsigned base, int i) {
@@ -96,6 +98,36 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
     for (int i = 0; i < HRING; ++i) issue_hg2(cur, i);
   }
   Bf16Planes pc[2], opm[2], opp[2], pd[2];
+  // LAYOUT 8: the tile's rows through LDS in FULL lines -- 4 coalesced 16-byte loads per row (1 KB each: 8 pixels x 128 B), stored to a
+  // per-wave ring of three 4-KB row images with the 16-byte chunk index XOR-ed with the pixel (conflict-free 16-byte reads at a 128-byte
+  // pitch), the A operand of a half-group read back as 2 x ds_read_b128 -- instead of 64 lane-accesses per fragment-shaped load
+  floatx4 rrow[2][4];
+  unsigned char* stage = smem + 54 * 1024 + wave * 12 * 1024;
+  auto row_base = [&](int tl, int ddy) { return (unsigned)(tl * 30 * 128 + 42 * 128) + (unsigned)(ddy * wci) + (unsigned)(lane * 16); };
+  auto load_row = [&](unsigned base, int slot) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rrow[slot][q] = buf_ld16(rin, base + (unsigned)(q * 1024));
+  };
+  auto write_row = [&](int slot, int lslot) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int px = q * 8 + (lane >> 3), c = lane & 7;
+      *reinterpret_cast<floatx4*>(stage + lslot * 4096 + px * 128 + ((c ^ (px & 7)) * 16)) = rrow[slot][q];
+    }
+  };
+  auto read_op = [&](int lslot, int kb, floatx4* dst) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = h * 4 + kb * 2 + e;
+      dst[e] = *reinterpret_cast<const floatx4*>(stage + lslot * 4096 + j * 128 + ((c ^ (j & 7)) * 16));
+    }
+  };
+  if (LAYOUT == 8) {
+    load_row(row_base(tile, -1), 0);
+    write_row(0, 0);
+    load_row(row_base(tile, 0), 1);
+    read_op(0, 0, rawc[0]);
+  }
   mi_u32x4 pb[2][3];
   split_pair<0>(rawc[0][0], pc[0]); split_pair<1>(rawc[0][0], pc[0]); split_pair<2>(rawc[0][1], pc[0]); split_pair<3>(rawc[0][1], pc[0]);
   if (LAYOUT == 7) { split_pair<0>(rawd[0][0], pd[0]); split_pair<1>(rawd[0][0], pd[0]); split_pair<2>(rawd[0][1], pd[0]); split_pair<3>(rawd[0][1], pd[0]); }
@@ -120,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
     const unsigned nxt = tile_off(tile + NW);
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-      if (i + HRING < NH) issue_hg(cur, i + HRING); else issue_hg(nxt, i + HRING - NH);
+      if (LAYOUT != 8) { if (i + HRING < NH) issue_hg(cur, i + HRING); else issue_hg(nxt, i + HRING - NH); }
       if (LAYOUT == 7) { if (i + HRING < NH) issue_hg2(cur, i + HRING); else issue_hg2(nxt, i + HRING - NH); }
       const Bf16Planes& pc_ = pc[i & 1];
       Bf16Planes& nc = pc[(i + 1) & 1];
@@ -145,6 +177,23 @@ __global__ __launch_bounds__(512, 1) void probe(const float* __restrict__ stream
           READB(pb[(3 * i + 3) & 1], unit_of((i + 1) % NH, 0));
           SIX(pc_, pb[(3 * i + 2) & 1], a2, (void)0, (void)0, (void)0, (void)0)
         }
+      } else if constexpr (LAYOUT == 8) {
+        // half-group i = (row R = i / 2, k half i & 1); rows are counted through the tiles: 3 per tile, ring slots by row number
+        const int R = i >> 1, kb = i & 1;
+        if (kb == 0) {
+          // the row after next into the registers of this row; the next row (loaded one row ago) into its LDS slot
+          const int r2 = R + 2;
+          load_row(r2 < 3 ? row_base(tile, r2 - 1) : row_base(tile + NW, r2 - 4), R & 1);
+          write_row((R + 1) & 1, (R + 1) % 3);
+        }
+        // the operand of half-group i + 1 from LDS, split between this half-group's MFMAs
+        { const int i1 = (i + 1) % NH; read_op(((i + 1) >> 1) % 3, i1 & 1, rawc[(i + 1) % HRING]); }
+        READB(pb[(3 * i + 1) & 1], unit_of(i, -1));
+        SIX(pc_, pb[(3 * i) & 1], a0, (void)0, split_pair<0>(rc[0], nc), (void)0, split_pair<1>(rc[0], nc))
+        READB(pb[(3 * i + 2) & 1], unit_of(i, 1));
+        SIX(pc_, pb[(3 * i + 1) & 1], a1, (void)0, split_pair<2>(rc[1], nc), (void)0, split_pair<3>(rc[1], nc))
+        READB(pb[(3 * i + 3) & 1], unit_of((i + 1) % NH, 0));
+        SIX(pc_, pb[(3 * i + 2) & 1], a2, (void)0, (void)0, (void)0, (void)0)
       } else if constexpr (LAYOUT == 7) {
         const Bf16Planes& pd_ = pd[i & 1];
         Bf16Planes& nd = pd[(i + 1) & 1];
@@ -276,11 +325,11 @@ static float* g_stream; static unsigned g_bytes; static mi_u32x4* g_w; static fl
 // SIMD, and the in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz.
 template <class K> static void run(const char* name, K kern, int threads, int tpw, double mfma_per_wave, bool is_fma, int nwarm = 600, int nt = 200) {
   const int grid = 256;
-  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (is_fma) hipLaunchKernelGGL(((void (*)(float*, unsigned long long*, int))kern), dim3(grid), dim3(threads), 96 * 1024, 0, g_out, g_st, tpw);
-    else hipLaunchKernelGGL(((void (*)(const float*, unsigned, const mi_u32x4*, float*, unsigned long long*, int))kern), dim3(grid), dim3(threads), 96 * 1024, 0, g_stream, g_bytes, g_w, g_out, g_st, tpw);
+    if (is_fma) hipLaunchKernelGGL(((void (*)(float*, unsigned long long*, int))kern), dim3(grid), dim3(threads), 152 * 1024, 0, g_out, g_st, tpw);
+    else hipLaunchKernelGGL(((void (*)(const float*, unsigned, const mi_u32x4*, float*, unsigned long long*, int))kern), dim3(grid), dim3(threads), 152 * 1024, 0, g_stream, g_bytes, g_w, g_out, g_st, tpw);
   };
   for (int i = 0; i < nwarm; ++i) launch();
   CK(hipEventRecord(e0));
@@ -322,6 +371,9 @@ int main(int argc, char** argv) {
   run("layout 7 (2 tiles/wave) 16x16x32, 1 wave/SIMD", probe<7, 3, 0, 1>, 256, tpw, mpw * 2, false);
   run("layout 7 (2 tiles/wave) 16x16x32, 2 waves/SIMD", probe<7, 3, 0, 1>, 512, tpw, mpw * 2, false);
   run("layout 0 acc 3 16x16x32, 1 wave/SIMD", probe<0, 3, 0, 1>, 256, tpw, mpw, false);
+  run("layout 8 (rows through LDS) 32x32x16", probe<8, 3, 0, 0>, 512, tpw, mpw, false);
+  run("layout 8 (rows through LDS) 16x16x32", probe<8, 3, 0, 1>, 512, tpw, mpw, false);
+  run("layout 0 acc 3 16x16x32 (again)", probe<0, 3, 0, 1>, 512, tpw, mpw, false);
   RUN(0, 1, 0);                                                          // (repeat of the shipped order: drift check)
   const int it = 140; const double fm = it * 18.0;
 #define RUNF(NV) run("fma sweep NV=" #NV " 2 waves", fma_sweep<NV>, 512, it, fm, true); run("fma sweep NV=" #NV " 1 wave", fma_sweep<NV>, 256, it, fm, true)
