@@ -77,6 +77,9 @@ __device__ __forceinline__ void stats_block_reduce_pairs(double s0, double q0, d
 // (0, 0, 0) -- SIMD partners in an 8-wave workgroup -- write shader-clock totals to the buffer of mi_debug_conv_stamps:
 // [8 w4 + 0] kernel start, [1] weights staged, [2] sum over tiles of the epilogue's first part (the combination of the three accumulators), [3] of the K loops (with the tile head), [4] of the epilogues,
 // [5] last tile done, [6] kernel end, [7] tiles.  No stamp executes in the production build.
+#ifndef MI_B16_EXP
+#define MI_B16_EXP 0           // (diagnostic builds only: bit 0 drops the epilogue's stores, bit 1 its statistics -- what each costs; results are then wrong)
+#endif
 #ifdef MI_B16_STAMPS
 #define B16_ST(...) __VA_ARGS__
 #else
@@ -106,7 +109,7 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
   const int H = a.g.h, W = a.g.w;
   const int cbase = ct * 32;
   B16_ST(unsigned long long* stp = (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0 && lane == 0 && g_conv_stamps) ? g_conv_stamps + (wave >> 2) * 8 : nullptr;
-         unsigned long long st_head = 0, st_k = 0, st_epi = 0, st_n = 0, st_a = 0, st_b = 0, st_comb = 0; if (stp) stp[0] = __builtin_amdgcn_s_memtime();)
+         unsigned long long st_k = 0, st_epi = 0, st_n = 0, st_a = 0, st_b = 0, st_comb = 0; if (stp) stp[0] = __builtin_amdgcn_s_memtime();)
 
   // ---- stage this task's weights as bf16 planes in operand order (all of a thread's loads first, then the splits)
   {
@@ -449,6 +452,11 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
         for (int r = 0; r < 4; ++r) o[mb][nb][r] = acc[1][mb][nb][r] + (am[mb][r] + bp[mb][r]);
     }
     B16_ST(const unsigned long long st_c = __builtin_amdgcn_s_memtime(); st_comb += st_c - st_a;)
+    // The statistics: this lane's 8 values per channel are summed in fp32 and the tile's two partial sums go into the fp64 accumulators -- 4
+    // double-precision instructions per tile instead of 48 to 128.  While the partner wave of the SIMD is in its K loop an fp64 instruction
+    // costs this wave about 16 cycles (tools/conv_b16_stamps.py with -DMI_B16_EXP: the statistics were 1400-1700 cycles of a tile's epilogue).
+    // A partial sum of 8 terms carries a rounding of a few 2^-24 of itself, below that of the 288 products behind each term.
+    float ts[2] = {0.f, 0.f}, tq[2] = {0.f, 0.f};
     if (EPI == EPI_BRED) {
       // block 1's pooled-resolution tensors at this lane's 16 output positions: "ReLU on" from the argmax byte (below 4) or from p > 0;
       //   1 term : sum [on] out zh, sum [on] out        2 terms: sum [on] (out zh + dp zhd), sum [on] out
@@ -472,12 +480,12 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
               on &= keep;
               const float vv = lane_keep_where(on, v);
               if (NTERMS == 1) {
-                s[nb] = fma((double)vv, (double)gq.zz[rr][nb], s[nb]);
+                ts[nb] = __builtin_fmaf(vv, gq.zz[rr][nb], ts[nb]);
               } else {
                 const float dv = lane_keep_where(on, gq.dq[rr][nb]);
-                s[nb] += (double)vv * (double)gq.zz[rr][nb] + (double)dv * (double)gq.zd[rr][nb];
+                ts[nb] = __builtin_fmaf(dv, gq.zd[rr][nb], __builtin_fmaf(vv, gq.zz[rr][nb], ts[nb]));
               }
-              q[nb] += (double)vv;
+              tq[nb] += vv;
             }
           }
         };
@@ -499,21 +507,31 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, true, false>::value * 64), 2
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int keep = keep_mask(mb, r);
+#if !(MI_B16_EXP & 1)
           buf_st2_untracked(rout_raw, keep ? row_off(mb, r) : MI_OOB, o[mb][0][r], o[mb][1][r]);
+#endif
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             const float v = lane_keep_where(keep, o[mb][nb][r]);
+#if MI_B16_EXP & 2
+            asm volatile("" :: "v"(v));
+            if (EPI == EPI_TSTATS) asm volatile("" :: "v"(zpre[mb][r][nb]));
+            continue;
+#endif
             if (EPI == EPI_STATS) {
-              const double dv = (double)v;
-              s[nb] += dv;
-              q[nb] = fma(dv, dv, q[nb]);
+              ts[nb] += v;
+              tq[nb] = __builtin_fmaf(v, v, tq[nb]);
             } else if (EPI == EPI_TSTATS) {
               const float zh = bn_zh(zpre[mb][r][nb], mu_c[nb], r_c[nb]);
-              s[nb] += (double)v;
-              q[nb] = fma((double)zh, (double)v, q[nb]);
+              ts[nb] += v;
+              tq[nb] = __builtin_fmaf(zh, v, tq[nb]);
             }
           }
         }
+    }
+    if (EPI != EPI_NONE) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) { s[nb] += (double)ts[nb]; q[nb] += (double)tq[nb]; }
     }
     cur = nxt;
     B16_ST(st_b = __builtin_amdgcn_s_memtime(); st_epi += st_b - st_a; ++st_n;)
