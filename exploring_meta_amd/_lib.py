@@ -90,7 +90,11 @@ _SIGS = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'mi_cg_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double]),
     'mi_cg_update_checked': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double]),
+    'mi_cg_init': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'mi_trpo_scale_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
     'mi_gae_max_rows': (C.c_int, [C.c_int]),
+    'mi_upload_i32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    'mi_copy_segments': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'mi_gae_advantages': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     'mi_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float,

@@ -60,9 +60,24 @@ class DiagNormalPolicy(nn.Module):
         return torch.cat([p.detach().reshape(-1) for p in self._engine_params()]).float().contiguous()
 
     def load_flat(self, theta):
+        params = self._engine_params()
+        f32 = torch.float32
+        if (theta.is_cuda and theta.dtype is f32 and theta.is_contiguous() and
+                all(p.is_cuda and p.dtype is f32 and p.is_contiguous() and p.get_device() == theta.get_device() for p in params)):
+            # one mi_copy_segments launch scatters the vector into the parameter tensors (one copy launch per parameter otherwise)
+            from ..engine import copy_segments
+            base, srcs, cnts, off = theta.data_ptr(), [], [], 0
+            for p in params:
+                srcs.append(base + 4 * off)
+                cnts.append(p.numel())
+                off += p.numel()
+            if off != theta.numel():
+                raise ValueError(f'load_flat: {theta.numel()} values for {off} parameters')
+            copy_segments(srcs, [p.data_ptr() for p in params], cnts, cnts, theta.device)      # (like a write through `.data`: no autograd version bump)
+            return
         off = 0
         with torch.no_grad():
-            for p in self._engine_params():
+            for p in params:
                 p.copy_(theta[off:off + p.numel()].view_as(p))
                 off += p.numel()
 

@@ -134,6 +134,13 @@ def _device_batch(replay_list, S, A, dev):
     lens = [int(r['states'].shape[0]) for r in replay_list]
     B = max(lens)
 
+    # fast path: every field of every replay already a contiguous fp32 tensor on the device -- mi_copy_segments packs all five fields of all
+    # replays (padding rows zeroed) in one launch per 128 arrays, the host collects 5 R addresses (the concatenate / pad / gather per field
+    # of the general path below is 0.5 ms of host time for the 40 ragged replays of a 20-task meta-iteration)
+    packed = _device_batch_packed(replay_list, lens, B, S, A, dev)
+    if packed is not None:
+        return packed
+
     ragged = any(n != B for n in lens)
     if ragged:          # one row index for all fields: replay r's rows, then the appended zero row for its padding
         total = sum(lens)
@@ -143,9 +150,6 @@ def _device_batch(replay_list, S, A, dev):
             idx[i, :n] = np.arange(off, off + n)
             off += n
         idx = torch.from_numpy(idx.reshape(-1)).to(dev)
-
-    # fast path: every field of every replay already an fp32 tensor on the device, equal lengths -- one stack per field, no per-replay
-    # conversion chain (200 small tensor operations = 0.4 ms of host time for the 40 replays of a 20-task meta-iteration)
     first = replay_list[0]['states']
     plain = (not ragged and torch.is_tensor(first) and first.device == torch.device(dev) and
              all(torch.is_tensor(r[k]) and r[k].dtype == torch.float32 and r[k].device == first.device and r[k].is_contiguous()
@@ -174,6 +178,77 @@ def _device_batch(replay_list, S, A, dev):
     out = dict(states=field('states', S), actions=field('actions', A), next_states=field('next_states', S),
                rewards=field('rewards', 1).reshape(len(lens), B), dones=field('dones', 1).reshape(len(lens), B))
     out['count'] = torch.tensor(lens, dtype=torch.int32, device=dev)
+    return out
+
+
+_FIELDS = ('states', 'actions', 'next_states', 'rewards', 'dones')
+
+
+def _device_batch_packed(replay_list, lens, B, S, A, dev):
+    """_device_batch through mi_copy_segments, or None when a field is not a contiguous fp32 tensor on ``dev`` (the general path converts)."""
+    dev = torch.device(dev)
+    if dev.type != 'cuda':
+        return None
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    R = len(lens)
+    widths = (S, A, S, 1, 1)
+    f32, Tensor, didx = torch.float32, torch.Tensor, dev.index
+    srcs, cnts = [], []
+    for r, n in zip(replay_list, lens):           # (attribute reads only: this loop is the host time of the call, ~0.5 us per array)
+        for k, w in zip(_FIELDS, widths):
+            t = r[k]
+            if not (isinstance(t, Tensor) and t.dtype is f32 and t.is_cuda and t.get_device() == didx and t.is_contiguous() and t.numel() == n * w):
+                return None
+            srcs.append(t.data_ptr())
+            cnts.append(n * w)
+    out = dict(states=torch.empty(R, B, S, dtype=f32, device=dev), actions=torch.empty(R, B, A, dtype=f32, device=dev),
+               next_states=torch.empty(R, B, S, dtype=f32, device=dev), rewards=torch.empty(R, B, dtype=f32, device=dev),
+               dones=torch.empty(R, B, dtype=f32, device=dev))
+    base = [out[k].data_ptr() for k in _FIELDS]
+    dsts, pads = [], []
+    for i in range(R):
+        for b, w in zip(base, widths):
+            dsts.append(b + 4 * i * B * w)
+            pads.append(B * w)
+    from ..engine import copy_segments, upload_int32
+    copy_segments(srcs, dsts, cnts, pads, dev)
+    if all(n == B for n in lens):
+        out['count'] = torch.full((R,), B, dtype=torch.int32, device=dev)
+    else:
+        out['count'] = upload_int32(lens, dev)
+    return out
+
+
+def _stacked_flat_parameters(policies, dev):
+    """[len(policies), P] fp32: every policy's parameters in the engine's order (sigma first), gathered by mi_copy_segments from the
+    parameter tensors where they lie; None when one of them is not a contiguous fp32 tensor on ``dev``."""
+    dev = torch.device(dev)
+    if dev.type != 'cuda':
+        return None
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    f32, didx = torch.float32, dev.index
+    srcs, cnts, offs, P = [], [], [], None
+    for p in policies:
+        off = 0
+        for q in p._engine_params():
+            if not (q.dtype is f32 and q.is_cuda and q.get_device() == didx and q.is_contiguous()):
+                return None
+            n = q.numel()
+            srcs.append(q.data_ptr())
+            cnts.append(n)
+            offs.append(off)
+            off += n
+        if P is None:
+            P = off
+        elif off != P:
+            return None
+    out = torch.empty(len(policies), P, dtype=f32, device=dev)
+    base, per = out.data_ptr(), len(offs) // len(policies)
+    dsts = [base + 4 * ((i // per) * P + o) for i, o in enumerate(offs)]
+    from ..engine import copy_segments
+    copy_segments(srcs, dsts, cnts, cnts, dev)
     return out
 
 
@@ -329,7 +404,9 @@ class _SurrogateContext:
         # the stored old policies' parameters as ONE gather ([tasks, P], engine order: sigma first) and their scales from its first columns
         # (per-policy flat() / clamp / exp launches were ~80 of the ~100 launches of this constructor)
         if all(hasattr(p, '_engine_params') for p in iter_policies):
-            thetas = torch.cat([q.detach().reshape(-1).float() for p in iter_policies for q in p._engine_params()]).view(len(iter_policies), -1)
+            thetas = _stacked_flat_parameters(iter_policies, dev)
+            if thetas is None:
+                thetas = torch.cat([q.detach().reshape(-1).float() for p in iter_policies for q in p._engine_params()]).view(len(iter_policies), -1)
         else:                                                       # any object with the policy protocol (flat(), sigma first)
             thetas = torch.stack([p.flat() for p in iter_policies])
         self.old_loc = self.engine.forward(thetas, self.qry['states'])
@@ -415,11 +492,19 @@ def _conjugate_gradient_device(Ax, b, num_iterations, tol, eps):
     from ..engine import _ptr, _stream
     lib = _lib.load()
     dev, n = b.device, b.numel()
-    r = b.detach().to(torch.float64, copy=True).reshape(-1).contiguous()      # a copy: mi_cg_update overwrites r in place
-    x, p = torch.zeros_like(r), r.clone()
-    p32 = r.float()
-    rr = torch.zeros(3, dtype=torch.float64, device=dev)          # r.r, last step length, "converged" latch
-    rr[0] = torch.dot(r, r)
+    if b.dtype == torch.float32:
+        b32 = b.detach().reshape(-1).contiguous()
+        x, r, p = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+        p32 = torch.empty(n, dtype=torch.float32, device=dev)
+        rr = torch.empty(3, dtype=torch.float64, device=dev)      # r.r, last step length, "converged" latch
+        with torch.cuda.device(dev):                              # x = 0, r = p = b, rr = (b.b, 0, 0): one launch
+            _lib.check(lib.mi_cg_init(_stream(dev), _ptr(b32), _ptr(x), _ptr(r), _ptr(p), _ptr(p32), _ptr(rr), n))
+    else:
+        r = b.detach().to(torch.float64, copy=True).reshape(-1).contiguous()      # a copy: mi_cg_update overwrites r in place
+        x, p = torch.zeros_like(r), r.clone()
+        p32 = r.float()
+        rr = torch.zeros(3, dtype=torch.float64, device=dev)
+        rr[0] = torch.dot(r, r)
     for _ in range(num_iterations):
         # the reference's `if r_dot_new < tol: break` is taken on the device (mi_cg_update_checked): after the break every later
         # recurrence is a no-op, so the loop needs no host synchronisation per iteration and x is exactly the x at the break
@@ -443,13 +528,24 @@ def meta_optimize_trpo(params, policy, baseline, iter_replays, iter_policies, an
         ctx.prepare_general_kl(theta)
     Fvp = lambda v: ctx.fvp(theta, v)
     step = conjugate_gradient(Fvp, grad)
-    shs = 0.5 * torch.dot(step, Fvp(step))
-    lagrange_multiplier = torch.sqrt(shs / params['max_kl'])
-    step = step / lagrange_multiplier
+    if step.is_cuda and step.dtype == torch.float32:
+        # shs = 0.5 step . F step, lagrange = sqrt(shs / max_kl), step / lagrange (rl.py:419-421) as one launch
+        from .. import _lib
+        from ..engine import _ptr, _stream
+        step, fstep = step.contiguous(), Fvp(step).detach().float().reshape(-1).contiguous()
+        scaled = torch.empty_like(step)
+        with torch.cuda.device(step.device):
+            _lib.check(_lib.load().mi_trpo_scale_step(_stream(step.device), _ptr(step), _ptr(fstep), step.numel(), float(params['max_kl']),
+                                                      _ptr(scaled), None))
+        step = scaled
+    else:
+        shs = 0.5 * torch.dot(step, Fvp(step))
+        lagrange_multiplier = torch.sqrt(shs / params['max_kl'])
+        step = step / lagrange_multiplier
     accepted, new_loss, kl = None, None, None
     for ls_step in range(params['ls_max_steps']):
         stepsize = params['backtrack_factor'] ** ls_step * params['outer_lr']
-        cand = (theta - stepsize * step).contiguous()
+        cand = torch.add(theta, step, alpha=-stepsize).contiguous()
         new_loss, kl, _ = ctx.evaluate(cand)
         if new_loss.item() < old_loss.item() and kl.item() < params['max_kl']:
             policy.load_flat(cand)

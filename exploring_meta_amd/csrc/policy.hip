@@ -758,6 +758,62 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(double* __restrict__ x,
   if (tid == 0) { rr[0] = rr_new; rr[1] = alpha; if (tol >= 0.0 && rr_new < tol) rr[2] = 1.0; }
 }
 
+// The start of a solve as one launch: r = p = b (fp64), x = 0, p32 = b, rr = (b . b, 0, 0) -- seven tensor-library launches otherwise.
+__global__ __launch_bounds__(1024) void cg_init_kernel(const float* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
+                                                       double* __restrict__ p, float* __restrict__ p32, double* __restrict__ rr, size_t n) {
+  __shared__ double red[16];
+  const int tid = threadIdx.x;
+  double q = 0.0;
+  for (size_t i = tid; i < n; i += 1024) {
+    const float bf = b[i];
+    const double bi = (double)bf;
+    x[i] = 0.0; r[i] = bi; p[i] = bi; p32[i] = bf;
+    q += bi * bi;
+  }
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[tid >> 6] = q;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int k = 0; k < 16; ++k) s += red[k];
+    rr[0] = s; rr[1] = 0.0; rr[2] = 0.0;
+  }
+}
+extern "C" int mi_cg_init(void* stream, const float* b, double* x, double* r, double* p, float* p32, double* rr, size_t n) {
+  if (!b || !x || !r || !p || !p32 || !rr || n == 0) return MI_ERR_ARG;
+  hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), b, x, r, p, p32, rr, n);
+  return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
+}
+
+// The step of a trust-region update from the solve's direction s and F s (reference rl.py:419-421): shs = 0.5 s . F s (summed in fp64),
+// lagrange = sqrt(shs / max_kl), out = s / lagrange -- five tensor-library launches otherwise.  A negative shs gives NaN, as there.
+__global__ __launch_bounds__(1024) void trpo_scale_step_kernel(const float* __restrict__ s, const float* __restrict__ fs, size_t n, float max_kl,
+                                                               float* __restrict__ out, float* __restrict__ lagrange) {
+  __shared__ double red[16];
+  __shared__ float lm_s;
+  const int tid = threadIdx.x;
+  double q = 0.0;
+  for (size_t i = tid; i < n; i += 1024) q += (double)s[i] * (double)fs[i];
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[tid >> 6] = q;
+  __syncthreads();
+  if (tid == 0) {
+    double d = 0.0;
+    for (int k = 0; k < 16; ++k) d += red[k];
+    const float shs = 0.5f * (float)d;
+    lm_s = sqrtf(shs / max_kl);
+    if (lagrange) *lagrange = lm_s;
+  }
+  __syncthreads();
+  const float lm = lm_s;
+  for (size_t i = tid; i < n; i += 1024) out[i] = s[i] / lm;
+}
+extern "C" int mi_trpo_scale_step(void* stream, const float* step, const float* fstep, size_t n, float max_kl, float* out, float* lagrange_out) {
+  if (!step || !fstep || !out || n == 0 || !(max_kl > 0.f)) return MI_ERR_ARG;
+  hipLaunchKernelGGL(trpo_scale_step_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), step, fstep, n, max_kl, out, lagrange_out);
+  return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
+}
+
 extern "C" int mi_cg_update(void* stream, double* x, double* r, double* p, const float* ap, double* rr, float* p32, size_t n, double eps) {
   if (!x || !r || !p || !ap || !rr || !p32 || n == 0) return MI_ERR_ARG;
   hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), x, r, p, ap, rr, p32, n, eps, -1.0);

@@ -98,7 +98,47 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     const float* th = a.theta + (size_t)t * a.tstride;
     const float* dv = PRIMAL ? th : a.dir + (size_t)t * a.dstride;      // primal sweep: the "direction" tables hold theta's own W1, b1, b2, b3
     typedef float floatx2 __attribute__((ext_vector_type(2)));
+    // Every global load of the task's tables is requested BEFORE the first LDS store waits for one: the small tables first (into
+    // registers), then the two matrices.  Table by table (load, wait, store) the cold start of a sweep paid five memory latencies in a
+    // row -- 26k cycles of every launch (tools/sweep_stamps.py), a ninth of a five-slab workgroup's time.
+    if constexpr (PRIMAL) {        // (the primal variant sits at the register limit and runs 4 of a step's 38 sweeps: table by table, as before)
+#pragma unroll 20
+      for (int e = tid; e < HH; e += 256) W2s[e] = th[a.o_w2 + e];
+      for (int e = tid; e < H * S; e += 256) W1d[(e / S) * SW_MAX_S + e % S] = dv[a.o_w1 + e];
+      for (int e = tid; e < H; e += 256) { b1d[e] = dv[a.o_b1 + e]; b2d[e] = dv[a.o_b2 + e]; }
+      for (int e = tid; e < A * H; e += 256) { W3s[e] = th[a.o_w3 + e]; W3d[e] = dv[a.o_w3 + e]; }
+      if (tid < A) {
+        b3d[tid] = dv[a.o_b3 + tid]; rho[tid] = th[a.o_sigma + tid];
+        rhod[tid] = a.surrogate ? a.old_scale[(size_t)t * A + tid] : 1.f;       // the OLD policy's scale
+      }
+      return;
+    }
+    constexpr int N1 = (H * SW_MAX_S + 255) / 256, N3 = (SW_MAX_A * H + 255) / 256;
+    float w1r[N1], w3sr[N3], w3dr[N3], b1r = 0.f, b2r = 0.f, b3r = 0.f, rhor = 0.f, rhodr = 0.f;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) { const int e = tid + 256 * i; w1r[i] = e < H * S ? dv[a.o_w1 + e] : 0.f; }
+    if (tid < H) { b1r = dv[a.o_b1 + tid]; b2r = dv[a.o_b2 + tid]; }
+#pragma unroll
+    for (int i = 0; i < N3; ++i) {
+      const int e = tid + 256 * i;
+      w3sr[i] = e < A * H ? th[a.o_w3 + e] : 0.f;
+      w3dr[i] = PRIMAL ? 0.f : (e < A * H ? dv[a.o_w3 + e] : 0.f);      // (primal: the same table)
+    }
+    if (tid < A) {
+      b3r = dv[a.o_b3 + tid]; rhor = th[a.o_sigma + tid];
+      rhodr = PRIMAL ? (a.surrogate ? a.old_scale[(size_t)t * A + tid] : 1.f) : dv[a.o_sigma + tid];      // primal: the OLD policy's scale
+    }
+    auto store_small = [&]() {
+#pragma unroll
+      for (int i = 0; i < N1; ++i) { const int e = tid + 256 * i; if (e < H * S) W1d[(e / S) * SW_MAX_S + e % S] = w1r[i]; }
+      if (tid < H) { b1d[tid] = b1r; b2d[tid] = b2r; }
+#pragma unroll
+      for (int i = 0; i < N3; ++i) { const int e = tid + 256 * i; if (e < A * H) { W3s[e] = w3sr[i]; W3d[e] = PRIMAL ? w3sr[i] : w3dr[i]; } }
+      if (tid < A) { b3d[tid] = b3r; rho[tid] = rhor; rhod[tid] = rhodr; }
+    };
+    __builtin_amdgcn_sched_barrier(0);
     if (PRIMAL) {
+      store_small();                                  // (the primal variant sits at the register limit: its small tables do not stay live under the matrix)
 #pragma unroll 20
       for (int e = tid; e < HH; e += 256) W2s[e] = th[a.o_w2 + e];
     } else if ((((size_t)(th + a.o_w2) | (size_t)(dv + a.o_w2)) & 7) == 0) {      // 8-byte loads where both matrices are 8-byte aligned
@@ -111,13 +151,8 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 #pragma unroll 16
       for (int e = tid; e < HH; e += 256) { W2s[e] = th[a.o_w2 + e]; W2d[e] = dv[a.o_w2 + e]; }
     }
-    for (int e = tid; e < H * S; e += 256) W1d[(e / S) * SW_MAX_S + e % S] = dv[a.o_w1 + e];
-    for (int e = tid; e < H; e += 256) { b1d[e] = dv[a.o_b1 + e]; b2d[e] = dv[a.o_b2 + e]; }
-    for (int e = tid; e < A * H; e += 256) { W3s[e] = th[a.o_w3 + e]; W3d[e] = dv[a.o_w3 + e]; }
-    if (tid < A) {
-      b3d[tid] = dv[a.o_b3 + tid]; rho[tid] = th[a.o_sigma + tid];
-      rhod[tid] = PRIMAL ? (a.surrogate ? a.old_scale[(size_t)t * A + tid] : 1.f) : dv[a.o_sigma + tid];      // primal: the OLD policy's scale
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!PRIMAL) store_small();
   };
 
   // one partial [P] per (workgroup, task): slot = this workgroup's position among the workgroups that touch the task

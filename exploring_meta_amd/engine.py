@@ -425,6 +425,28 @@ def gae_advantages(states, next_states, rewards, dones, count, gamma, tau, reg, 
     return (adv, wts) if want_weights else adv
 
 
+def copy_segments(src_ptrs, dst_ptrs, nfloat, npad, dev):
+    """mi_copy_segments: segment k = nfloat[k] floats from device address src_ptrs[k] to dst_ptrs[k], zeros up to npad[k] floats (lists of
+    ints).  The caller keeps the tensors alive and has checked them (fp32, contiguous, on ``dev``)."""
+    n = len(src_ptrs)
+    if n == 0:
+        return
+    vp, u32 = C.c_void_p * n, C.c_uint32 * n
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mi_copy_segments(_stream(dev), vp(*src_ptrs), vp(*dst_ptrs), u32(*nfloat), u32(*npad), n))
+
+
+def upload_int32(values, dev):
+    """A short list of ints as an int32 device tensor through mi_upload_i32: the values travel in kernel arguments (a pageable
+    host-to-device copy of a few bytes blocks the host for ~50 us on this stack)."""
+    n = len(values)
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    if n:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mi_upload_i32(_stream(dev), _ptr(out), (C.c_int32 * n)(*values), n))
+    return out
+
+
 def flatten_parameters(module):
     """Flat fp32 vector in module.parameters() order (what the C ABI calls theta)."""
     return torch.cat([p.detach().reshape(-1) for p in module.parameters()]).float().contiguous()

@@ -192,6 +192,15 @@ int mi_cg_update(void* stream, double* x, double* r, double* p, const float* ap,
 int mi_cg_update_checked(void* stream, double* x, double* r, double* p, const float* ap, double* rr, float* p32, size_t n, double eps,
                          double tol);
 
+/* The start of that solve as one launch: r = p = b (fp64), x = 0, p32 = b, rr = (b . b, 0, 0)  (rl.py:418; cherry's conjugate_gradient
+ * begins with x = 0, r = p = b). */
+int mi_cg_init(void* stream, const float* b, double* x, double* r, double* p, float* p32, double* rr, size_t n);
+
+/* The trust-region step from the solve's direction and its Fisher-vector product (reference rl.py:419-421), one launch:
+ *   shs = 0.5 step . fstep (summed in fp64);  lagrange = sqrt(shs / max_kl);  out = step / lagrange;  *lagrange_out = lagrange (or NULL).
+ * A negative shs yields NaN, as in the reference. */
+int mi_trpo_scale_step(void* stream, const float* step, const float* fstep, size_t n, float max_kl, float* out, float* lagrange_out);
+
 /* Generalised advantage estimation with cherry's LinearValue baseline for a list of replays, one launch (reference
  * core_functions/rl.py:95-110 compute_advantages: ch.td.discount, LinearValue.fit / __call__ (features [s, s^2, t, t^2, t^3, 1],
  * t = row/100, ridge normal equations with `reg`; rl/maml_trpo.py:85 passes env.action_size as reg), bootstraps,
@@ -205,6 +214,16 @@ int mi_gae_max_rows(int state_dim);
 int mi_gae_advantages(void* stream, const float* states, const float* next_states, const float* rewards, const float* dones,
                       const int32_t* count, const double* weight_in, int replays, int rows, int state_dim, double gamma, double tau,
                       double reg, int normalize, float* adv_out, double* weight_out);
+
+/* Assembly of a padded device batch from a list of contiguous fp32 device arrays -- the fields of the replays a meta-iteration collected
+ * (reference core_functions/rl.py:444-465 walks them task by task, replay by replay) and the parameters of the stored adapted policies
+ * (rl.py:447-449): segment k copies nfloat[k] floats from src[k] to dst[k] and writes zeros up to npad[k] (>= nfloat[k]) floats.
+ * src, dst, nfloat, npad are HOST arrays of nseg entries holding DEVICE pointers; the pointers travel in kernel arguments, one launch per
+ * 128 segments. */
+int mi_copy_segments(void* stream, const void* const* src, void* const* dst, const uint32_t* nfloat, const uint32_t* npad, int nseg);
+/* n int32 values from HOST memory to the device array dst, carried in kernel arguments (512 per launch): the per-replay row counts of
+ * the batch above without a staging copy. */
+int mi_upload_i32(void* stream, int32_t* dst, const int32_t* host_values, int n);
 
 /* Adam step on the flat meta-parameters with torch.optim.Adam defaults (maml_vision.py:85,139-141):
  * grad is first scaled by grad_scale (= 1/meta_batch_size). step is the 1-based step count after increment. */

@@ -560,6 +560,100 @@ def test_gae_kernel_matches_oracle(S, lens, ep_len, truncated, normalize):
     assert worst < 5e-7                               # fp32 output rounding
 
 
+@pytest.mark.parametrize('lens', [[85, 60, 17, 1], [64, 64, 64], [2000] * 27 + [1731] * 110])
+def test_packed_device_batch_matches_the_general_path(lens, monkeypatch):
+    """_device_batch of replays whose fields already lie on the device as fp32 tensors (what the runners produce): mi_copy_segments packs
+    all fields of all replays in one launch per 128 arrays, the row counts travel in kernel arguments (mi_upload_i32) -- against the
+    general path (conversion chain per field, concatenate / pad / gather): identical tensors, zero padding rows; ragged and equal
+    lengths, more than 128 arrays (685: six launches), and the same for the stacked parameters of the old policies."""
+    from exploring_meta_amd.core_functions import rl as prl
+    dev = torch.device('cuda', torch.cuda.current_device())
+    S, A = 3, 2
+    eps = [{k: v.float().to(dev) for k, v in _random_replay(7 + i, n, S, 16, False).items()} for i, n in enumerate(lens)]
+    for e in eps:
+        e['actions'] = torch.randn(e['states'].shape[0], A, device=dev)
+    packed = prl._device_batch(eps, S, A, dev)
+    assert prl._device_batch_packed(eps, lens, max(lens), S, A, dev) is not None          # the fast path is the one that ran
+    monkeypatch.setattr(prl, '_device_batch_packed', lambda *a: None)
+    plain = prl._device_batch(eps, S, A, dev)
+    torch.cuda.synchronize()
+    for k in ('states', 'actions', 'next_states', 'rewards', 'dones', 'count'):
+        assert packed[k].shape == plain[k].shape and packed[k].dtype == plain[k].dtype and torch.equal(packed[k], plain[k]), k
+    for i, n in enumerate(lens):
+        assert float(packed['states'][i, n:].abs().sum()) == 0.0 and float(packed['rewards'][i, n:].abs().sum()) == 0.0
+    # a field that is not fp32 / contiguous / on the device sends the whole call down the general path
+    eps[1]['rewards'] = eps[1]['rewards'].double()
+    monkeypatch.undo()
+    assert prl._device_batch_packed(eps, lens, max(lens), S, A, dev) is None
+    # the stored policies' parameters, [tasks, P] in the engine's order
+    pols = [cf.DiagNormalPolicy(2, 2).to(dev) for _ in range(min(len(lens), 30))]
+    for i, q in enumerate(pols):
+        with torch.no_grad():
+            q.sigma.fill_(0.1 * i)
+    got = prl._stacked_flat_parameters(pols, dev)
+    assert got is not None and torch.equal(got, torch.stack([q.flat() for q in pols]))
+    th = torch.randn(got.shape[1], device=dev)               # and back: load_flat scatters a vector into the parameters in one launch
+    pols[1].load_flat(th)
+    assert torch.equal(pols[1].flat(), th) and torch.equal(pols[1].sigma.detach(), th[:2])
+    with pytest.raises(ValueError):
+        pols[1].load_flat(th[:-1].contiguous())
+    pols[0].double()
+    assert prl._stacked_flat_parameters(pols, dev) is None
+
+
+def test_fused_conjugate_gradient_update_on_long_vectors():
+    """mi_cg_update against the recurrences in torch fp64 on vectors of the 2 x 100 policy's length (10,604) and longer ones (more
+    elements than threads, lengths that are not multiples of the workgroup)."""
+    from exploring_meta_amd import _lib
+    from exploring_meta_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(3)
+    for n in (10604, 12288, 12289, 40000):
+        r0 = torch.randn(n, generator=g, dtype=torch.float64)
+        ap = (2.0 * r0 + 0.3 * torch.roll(r0, 1)).float()
+        x, r, p = torch.zeros(n, dtype=torch.float64, device=dev), r0.to(dev), r0.to(dev)
+        rr = torch.zeros(3, dtype=torch.float64, device=dev)
+        rr[0] = torch.dot(r, r)
+        p32 = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(lib.mi_cg_update(_stream(dev), _ptr(x), _ptr(r), _ptr(p), _ptr(ap.to(dev)), _ptr(rr), _ptr(p32), n, 1e-8))
+        torch.cuda.synchronize()
+        rr_old = torch.dot(r0, r0)
+        alpha = rr_old / (torch.dot(r0, ap.double()) + 1e-8)
+        x_ref, r_ref = alpha * r0, r0 - alpha * ap.double()
+        rr_new = torch.dot(r_ref, r_ref)
+        p_ref = r_ref + (rr_new / rr_old) * r0
+        assert torch.allclose(x.cpu(), x_ref, rtol=1e-12, atol=1e-14) and torch.allclose(r.cpu(), r_ref, rtol=1e-12, atol=1e-14), n
+        assert torch.allclose(p.cpu(), p_ref, rtol=1e-12, atol=1e-13) and torch.equal(p32.cpu(), p.cpu().float()), n
+        assert abs(float(rr[0]) - float(rr_new)) <= 1e-12 * float(rr_new) and abs(float(rr[1]) - float(alpha)) <= 1e-12 * abs(float(alpha)), n
+
+
+def test_solve_start_and_step_scaling_kernels():
+    """mi_cg_init (x = 0, r = p = b, rr = (b.b, 0, 0)) and mi_trpo_scale_step (shs = 0.5 s.Fs, lagrange = sqrt(shs / max_kl), s / lagrange;
+    reference rl.py:419-421) against the tensor expressions they replace."""
+    from exploring_meta_amd import _lib
+    from exploring_meta_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(5)
+    for n in (10604, 3, 40001):
+        b = torch.randn(n, generator=g).to(dev)
+        x, r, p = (torch.full((n,), 7.0, dtype=torch.float64, device=dev) for _ in range(3))
+        p32, rr = torch.full((n,), 7.0, device=dev), torch.full((3,), 7.0, dtype=torch.float64, device=dev)
+        _lib.check(lib.mi_cg_init(_stream(dev), _ptr(b), _ptr(x), _ptr(r), _ptr(p), _ptr(p32), _ptr(rr), n))
+        assert float(x.abs().sum()) == 0.0 and torch.equal(r, b.double()) and torch.equal(p, b.double()) and torch.equal(p32, b)
+        assert abs(float(rr[0]) - float(torch.dot(b.double(), b.double()))) <= 1e-12 * float(rr[0]) and float(rr[1]) == 0.0 and float(rr[2]) == 0.0
+        fs = (2.0 * b + 0.1 * torch.roll(b, 1)).contiguous()
+        out, lm = torch.empty_like(b), torch.empty(1, device=dev)
+        _lib.check(lib.mi_trpo_scale_step(_stream(dev), _ptr(b), _ptr(fs), n, 0.01, _ptr(out), _ptr(lm)))
+        lm_ref = torch.sqrt(0.5 * torch.dot(b.double(), fs.double()) / 0.01)
+        assert abs(float(lm) - float(lm_ref)) <= 1e-6 * float(lm_ref)
+        assert torch.allclose(out, (b.double() / lm_ref).float(), rtol=1e-6, atol=0)
+    # a direction of negative curvature: NaN, as torch.sqrt of a negative number in the reference
+    _lib.check(lib.mi_trpo_scale_step(_stream(dev), _ptr(b), _ptr((-fs).contiguous()), n, 0.01, _ptr(out), _ptr(lm)))
+    assert torch.isnan(lm).all() and torch.isnan(out).all()
+
+
 def test_surrogate_context_on_device_matches_host_path(monkeypatch):
     """_SurrogateContext built on the device (one mi_gae_advantages launch, no host round trip) == built by the host numpy walk."""
     from exploring_meta_amd.core_functions import rl as prl

@@ -42,14 +42,18 @@ def main():
         sync()
         return (time.perf_counter() - t0) / n * 1e3, r
 
+    def whole():
+        policy.load_flat(theta)
+        return cf.meta_optimize_trpo(p, policy, baseline, replays, olds)
+    if '--whole-only' in sys.argv:                # for a kernel trace of the step alone (tools/trpo_trace.py delimits steps by gae_kernel)
+        t_all, _ = timed(whole, 6)
+        print(f'whole step {t_all:.2f} ms')
+        return
     t_ctx, ctx = timed(lambda: prl._SurrogateContext(replays, olds, policy, baseline, p))
     t_eval, _ = timed(lambda: ctx.evaluate(theta, want_grad=True))
     v = torch.randn_like(theta)
     t_fvp, _ = timed(lambda: ctx.fvp(theta, v), 20)
     t_ls, _ = timed(lambda: ctx.evaluate(theta))
-    def whole():
-        policy.load_flat(theta)
-        return cf.meta_optimize_trpo(p, policy, baseline, replays, olds)
     t_all, _ = timed(whole)
     print(f'context (host GAE / fits / upload) {t_ctx:.2f} ms | surrogate+grad {t_eval:.2f} | fvp {t_fvp:.3f} x 11 = {11 * t_fvp:.2f} | '
           f'line-search evaluation {t_ls:.2f} | whole step {t_all:.2f} ms')
