@@ -1,6 +1,9 @@
 // Kernels of the fused Fisher-vector-product sweeps: see policy_sweep.h for the design.
 #include "policy_sweep.h"
 
+#ifndef SW_EXP
+#define SW_EXP 0        // (diagnostic builds, tools/sweep_exp.sh: 1 = the first slab's rows requested AFTER the weights, 2 / 3 = without the direction's / both W2 loads -- wrong results)
+#endif
 #define SW_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[nstamp++] = ((unsigned long long)(k) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); } while (0)
 __device__ __forceinline__ floatx4 lds4(const float* p) { return *reinterpret_cast<const floatx4*>(p); }
 
@@ -81,9 +84,9 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     for (int r = 0; r < 16; ++r) accW2[m][r] = 0.f;
   // vector-stage mapping: thread = (column col of the hidden layer, half of the slab's rows)
   const int col = tid & 127, rb = (tid >> 7) * 16;
-  float accW3[SW_MAX_A], accb3 = 0.f, accb2 = 0.f, accb1 = 0.f, accW1[SW_MAX_S], accrho[SW_MAX_A], accloss = 0.f, acckl = 0.f;
+  float accW3[SW_MAX_A], accb3r[SW_MAX_A], accb2 = 0.f, accb1 = 0.f, accW1[SW_MAX_S], accrho[SW_MAX_A], accloss = 0.f, acckl = 0.f;
 #pragma unroll
-  for (int d = 0; d < SW_MAX_A; ++d) accW3[d] = 0.f;
+  for (int d = 0; d < SW_MAX_A; ++d) { accW3[d] = 0.f; accb3r[d] = 0.f; }
 #pragma unroll
   for (int s = 0; s < SW_MAX_S; ++s) accW1[s] = 0.f;
 #pragma unroll
@@ -97,7 +100,6 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
   auto load_weights = [&](int t) {
     const float* th = a.theta + (size_t)t * a.tstride;
     const float* dv = PRIMAL ? th : a.dir + (size_t)t * a.dstride;      // primal sweep: the "direction" tables hold theta's own W1, b1, b2, b3
-    typedef float floatx2 __attribute__((ext_vector_type(2)));
     // Every global load of the task's tables is requested BEFORE the first LDS store waits for one: the small tables first (into
     // registers), then the two matrices.  Table by table (load, wait, store) the cold start of a sweep paid five memory latencies in a
     // row -- 26k cycles of every launch (tools/sweep_stamps.py), a ninth of a five-slab workgroup's time.
@@ -142,10 +144,33 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 #pragma unroll 20
       for (int e = tid; e < HH; e += 256) W2s[e] = th[a.o_w2 + e];
     } else if ((((size_t)(th + a.o_w2) | (size_t)(dv + a.o_w2)) & 7) == 0) {      // 8-byte loads where both matrices are 8-byte aligned
-#pragma unroll 20
-      for (int e = 2 * tid; e < HH; e += 512) {       // H = 100: all 20 + 20 loads of a thread in flight at once
-        *reinterpret_cast<floatx2*>(W2s + e) = *reinterpret_cast<const floatx2*>(th + a.o_w2 + e);
-        *reinterpret_cast<floatx2*>(W2d + e) = *reinterpret_cast<const floatx2*>(dv + a.o_w2 + e);
+      // Chunks of W2_CH + W2_CH loads issued together, then their LDS stores.  Written as one loop of load / store pairs hipcc keeps two
+      // or three loads in flight (s_waitcnt vmcnt(0) in front of every store: it schedules for register pressure), and the two matrices
+      // cost 13k cycles of round trips at the start of every sweep (tools/sweep_exp.sh).  Raw buffer loads: the range check ends the
+      // matrix, no predicated load.
+      constexpr int W2_CH = 10, W2_N = (HH / 2 + 255) / 256;      // H = 100: 20 pairs of floats per thread and matrix
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      const mi_rsrc rws = __builtin_amdgcn_make_buffer_rsrc((void*)(th + a.o_w2), 0, (unsigned)(HH * 4), 0x00020000);
+      const mi_rsrc rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(dv + a.o_w2), 0, (unsigned)(HH * 4), 0x00020000);
+#pragma unroll
+      for (int c0 = 0; c0 < W2_N; c0 += W2_CH) {
+        u32x2 vs[W2_CH], vd[W2_CH];
+#pragma unroll
+        for (int k = 0; k < W2_CH; ++k) {
+          const unsigned off = (unsigned)(8 * tid + 2048 * (c0 + k));
+          if (c0 + k < W2_N && SW_EXP != 3) vs[k] = __builtin_amdgcn_raw_buffer_load_b64(rws, off, 0, 0);
+          if (c0 + k < W2_N && SW_EXP != 2 && SW_EXP != 3) vd[k] = __builtin_amdgcn_raw_buffer_load_b64(rwd, off, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < W2_CH; ++k) {
+          const int e = 2 * tid + 512 * (c0 + k);
+          if (c0 + k < W2_N && e < HH) {
+            if (SW_EXP != 3) *reinterpret_cast<u32x2*>(W2s + e) = vs[k];
+            if (SW_EXP != 2 && SW_EXP != 3) *reinterpret_cast<u32x2*>(W2d + e) = vd[k];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll 16
@@ -173,8 +198,6 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
         if (orel + 4 * hh < H && icol < H) pw[orel * H] = accW2[m][r];
         accW2[m][r] = 0.f;
       }
-    if (tid < A) pv[a.o_b3 + tid] = accb3;
-    accb3 = 0.f;
     // W1 / b1 partials sit per lane half (16 rows each), rho partials per row-thread: fold through LDS (the slab arrays are free)
     float* t1 = h1s;                                   // [2][H][S + 1]
     if (icol < H) {
@@ -188,10 +211,10 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       for (int d = 0; d < SW_MAX_A; ++d) t3[((tid >> 7) * (SW_MAX_A + 1) + d) * 128 + col] = accW3[d];
       t3[((tid >> 7) * (SW_MAX_A + 1) + SW_MAX_A) * 128 + col] = accb2;
     }
-    float* t2 = h1d;                                   // [32][A], then [32][2] loss / KL partials of the primal sweep
+    float* t2 = h1d;                                   // [32][A] rho partials, [32][2] loss / KL partials of the primal sweep, [32][A] b3 partials
     if (tid < 32) {
 #pragma unroll
-      for (int d = 0; d < SW_MAX_A; ++d) if (d < A) t2[tid * SW_MAX_A + d] = accrho[d];
+      for (int d = 0; d < SW_MAX_A; ++d) if (d < A) { t2[tid * SW_MAX_A + d] = accrho[d]; t2[32 * SW_MAX_A + 64 + tid * SW_MAX_A + d] = accb3r[d]; }
       if (PRIMAL) { t2[32 * SW_MAX_A + 2 * tid] = accloss; t2[32 * SW_MAX_A + 2 * tid + 1] = acckl; }
     }
     __syncthreads();
@@ -203,6 +226,9 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       float s = 0.f;
       for (int r = 0; r < 32; ++r) s += t2[r * SW_MAX_A + tid];
       pv[a.o_sigma + tid] = s;
+      float b = 0.f;
+      for (int r = 0; r < 32; ++r) b += t2[32 * SW_MAX_A + 64 + r * SW_MAX_A + tid];
+      pv[a.o_b3 + tid] = b;
     }
     if (PRIMAL && tid >= 64 && tid < 66) {
       float s = 0.f;
@@ -217,7 +243,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     __syncthreads();
     accb1 = 0.f; accb2 = 0.f; accloss = 0.f; acckl = 0.f;
 #pragma unroll
-    for (int d = 0; d < SW_MAX_A; ++d) accW3[d] = 0.f;
+    for (int d = 0; d < SW_MAX_A; ++d) { accW3[d] = 0.f; accb3r[d] = 0.f; }
 #pragma unroll
     for (int s = 0; s < SW_MAX_S; ++s) accW1[s] = 0.f;
 #pragma unroll
@@ -265,8 +291,9 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     const int t = slab / spt, row0 = (slab - t * spt) * 32;
     if (t != cur) {
       if (cur >= 0) flush(cur);
-      if (cur < 0) fetch(slab, pf);                 // the first slab's rows fly under the weight load
+      if (cur < 0 && SW_EXP != 1) fetch(slab, pf);  // the first slab's rows fly under the weight load
       if (cur < 0 || a.tstride != 0 || a.dstride != 0) load_weights(t);
+      if (cur < 0 && SW_EXP == 1) fetch(slab, pf);
       cur = t;
     }
     SW_STAMP(1);
@@ -474,10 +501,12 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     // ---- head weight gradient, then r2 = [h2 > 0] (rdmu W3 + dmu W3d) in place of h2d: a thread owns one column and 16 rows, reads
     // its own h2d element before overwriting it (no barrier in between), and sums its rows of r2 for the bias gradient
     const bool bwd = !(PRIMAL && a.fwd_only);        // uniform: a forward-only primal sweep stops after the loss
-    if (bwd && tid < A) {
-      float s = 0.f;
-      for (int r = 0; r < 32; ++r) s += rdmus[r * SW_MAX_A + tid];
-      accb3 += s;
+    // (the head bias gradient: every row thread of the Gaussian stage keeps the sum of its row's cotangents, folded at the flush like the
+    // rho partials -- one thread per action dimension summing the slab's 32 rows here was 32 dependent LDS reads, 2k cycles of wave 0 in
+    // front of the stage's barrier)
+    if (bwd && tid < 32) {
+#pragma unroll
+      for (int d = 0; d < SW_MAX_A; ++d) if (d < A) accb3r[d] += rdmus[tid * SW_MAX_A + d];
     }
     if (bwd && col < H) {
       float w3[SW_MAX_A], w3d[SW_MAX_A];

@@ -138,3 +138,15 @@ def test_roofline_names_the_kernel_a_conv_launch_takes():
     assert RF.kernel_name(spec, 'tangent_conv_fwd', 1, b16=True).startswith('conv3x3_s1_b16_kernel<32,2,EPI_TSTATS')
     assert RF.kernel_name(spec, 'tangent_conv_fwd', 1).startswith('conv3x3_s1_mfma_kernel<32,2,EPI_TSTATS')
     assert RF.kernel_name(spec, 'wgrad', 1, b16=True).startswith('wgrad3x3')          # only the forward / dgrad family has the second kernel
+
+
+def test_time_feature_without_division_is_the_quotient():
+    """csrc/gae.hip::gae_time: t / 100.0 as q = RN(t * 0.01), r = fma(-q, 100, t), fma(r, 0.01, q) -- the LinearValue time features
+    (reference rl.py:95-110 via cherry's LinearValue: t = row / 100) must be bit for bit those of the division.  Exact rational arithmetic
+    for every row index a replay can hold (mi_gae_max_rows is below 6000) and well beyond."""
+    from fractions import Fraction
+    fma = lambda a, b, c: float(Fraction(a) * Fraction(b) + Fraction(c))     # one rounding, like the hardware FMA
+    for t in list(range(0, 20000)) + [2 ** k + d for k in range(15, 24) for d in (-1, 0, 1, 37)]:
+        td = float(t)
+        q = td * 0.01
+        assert fma(fma(-q, 100.0, td), 0.01, q) == td / 100.0, t
