@@ -517,10 +517,10 @@ struct TrpoPlan {
 // geometry of the fused sweeps: slabs of 32 rows, a contiguous run of slabs per workgroup, one round of workgroups on 256 CUs
 static void sweep_geometry(int T, int B, int& spt, int& spw, int& slots, int& grid) {
   spt = ceil_div(B, 32);
-  const int total = T * spt;
+  const int total = T * (spt + 1);      // virtual slabs: a marker in front of every task's slabs (policy_sweep.hip: what entering a task costs)
   spw = ceil_div(total, 256);
   grid = ceil_div(total, spw);
-  slots = ceil_div(spt, spw) + 1;
+  slots = ceil_div(spt + 1, spw) + 1;
 }
 static bool sweep_supported(const mi_policy* p) {
   return policy_sweep_supported(p->act == ACT_RELU, p->H1, p->H2, p->S, p->A);

@@ -47,7 +47,7 @@ struct SweepArgs {
   int surrogate;         // 0: L = -mean(logp adv) (rl.py:358); 1: L = -mean(exp(logp - logp_old) adv), KL(new || old) (rl.py:459-469)
   int fwd_only;          // loss / KL only (line-search evaluations of the query pass): no backward, gradient partials are zero
   float *h1_out, *h2_out, *mu_out, *dmu_out, *d2_out, *coef_out;     // [T][B][.] stores of the pass (null: not kept)
-  int T, B, S, A, spt, spw, slots;      // spt = slabs per task, spw = slabs per workgroup
+  int T, B, S, A, spt, spw, slots;      // spt = slabs per task, spw = VIRTUAL slabs per workgroup (a marker in front of every task's slabs: policy_sweep.hip)
   int o_sigma, o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, P;
   unsigned long long* stamps;   // debug: shader-clock stamps of workgroup 0's stages (null in production)
 };

@@ -74,7 +74,13 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, hh = lane >> 5;
   const int B = a.B, spt = a.spt;
-  const int slab0 = blockIdx.x * a.spw, slab1 = min(slab0 + a.spw, a.T * spt);
+  // A workgroup takes a.spw consecutive VIRTUAL slabs of the stream [task 0: marker, slab 0 .. spt-1][task 1: marker, ...]: the marker in
+  // front of every task's slabs stands for what entering a task costs (flushing the previous task's partial, loading the new task's
+  // tables: about half a slab's time), so a workgroup whose run crosses a task boundary gets one slab less than the others instead of
+  // being the straggler every other workgroup waits for (with plain runs of 5 slabs 16 of cfg5's 252 workgroups crossed a boundary and
+  // the launch took their 227k cycles against 210k).
+  const int vspt = spt + 1;
+  const int v0 = blockIdx.x * a.spw, v1 = min(v0 + a.spw, a.T * vspt);
 
   // ---- accumulators that live across the slabs of one task
   floatx16 accW2[MT];
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 
   // one partial [P] per (workgroup, task): slot = this workgroup's position among the workgroups that touch the task
   auto flush = [&](int t) {
-    const int slot = blockIdx.x - (t * spt) / a.spw;
+    const int slot = blockIdx.x - (t * vspt + 1) / a.spw;       // position among the workgroups that hold slabs of task t
     float* pv = a.partial + ((size_t)t * a.slots + slot) * a.pitch;
     const int icol = 32 * wave + n;
     // the 64 store addresses hang off ONE lane offset that the compiler cannot see through: otherwise it hoists 64 loop-invariant
@@ -253,8 +259,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
   // the NEXT slab's global data travels in registers under this slab's last two matrix stages
   constexpr int NPF = (SL + 1023) / 1024;
   struct Prefetch { floatx4 v1[NPF], v2[NPF], v3[NPF]; float x, act, mu, dmu, coef; } pf;
-  auto fetch = [&](int slab, Prefetch& f) {
-    const int t = slab / spt, row0 = (slab - t * spt) * 32;
+  auto fetch = [&](int t, int row0, Prefetch& f) {
     const int nv = min(32, B - row0);
     const size_t rbase = (size_t)t * B + row0;
     if (!PRIMAL) {
@@ -287,13 +292,16 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
   int cur = -1;
   int nstamp = 0;
   SW_STAMP(0);
-  for (int slab = slab0; slab < slab1; ++slab) {
-    const int t = slab / spt, row0 = (slab - t * spt) * 32;
+  int t = v0 / vspt, vr = v0 - t * vspt;               // (task, position in the task's virtual slabs) of v, carried along: no division per slab
+  for (int v = v0; v < v1; ++v, ++vr) {
+    if (vr == vspt) { vr = 0; ++t; }
+    if (vr == 0) continue;                             // a task's marker
+    const int row0 = (vr - 1) * 32;
     if (t != cur) {
       if (cur >= 0) flush(cur);
-      if (cur < 0 && SW_EXP != 1) fetch(slab, pf);  // the first slab's rows fly under the weight load
+      if (cur < 0 && SW_EXP != 1) fetch(t, row0, pf);  // the first slab's rows fly under the weight load
       if (cur < 0 || a.tstride != 0 || a.dstride != 0) load_weights(t);
-      if (cur < 0 && SW_EXP == 1) fetch(slab, pf);
+      if (cur < 0 && SW_EXP == 1) fetch(t, row0, pf);
       cur = t;
     }
     SW_STAMP(1);
@@ -540,7 +548,10 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     }
     __syncthreads();
     SW_STAMP(8);
-    if (slab + 1 < slab1) fetch(slab + 1, pf);       // the next slab's data flies under the two matrix stages below
+    {                                                 // the next slab's data flies under the two matrix stages below
+      const bool last_of_task = vr + 1 == vspt;        // then the next slab is the next task's first, behind its marker
+      if (v + (last_of_task ? 2 : 1) < v1) fetch(last_of_task ? t + 1 : t, last_of_task ? 0 : row0 + 32, pf);
+    }
     const float* r2 = h2d;
     // ---- r1 = [h1 > 0] (r2 W2 + d2 W2d) on the matrix pipe; its products with the states (W1, b1 gradients) from the accumulators
     if (bwd) {
@@ -616,7 +627,8 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 }
 
 __device__ __forceinline__ float sweep_fold_sum(const FoldArgs& f, int t, int p) {
-  const int first = (t * f.spt) / f.spw, last = (t * f.spt + f.spt - 1) / f.spw;
+  const int vspt = f.spt + 1;                          // (the sweep's virtual slab stream: one marker in front of every task's slabs)
+  const int first = (t * vspt + 1) / f.spw, last = (t * vspt + f.spt) / f.spw;
   const float* pp = f.partial + (size_t)t * f.slots * f.pitch + p;
   float s = 0.f;
   const int ns = last - first + 1;
