@@ -371,6 +371,8 @@ struct mi_policy {
   int act;   // ACT_RELU / ACT_TANH between the dense layers (policies.py:32-37,76)
   size_t o_sigma, o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, P;
   std::string err;
+  unsigned* fold_counters = nullptr;   // device, one per 256-parameter block: arrival counters of the fold that also takes the mean over tasks
+                                       // (policy_sweep.h FoldArgs::counter; zero between launches).  Allocated at the first fused product.
 };
 static thread_local std::string g_perr;
 static int pfail(mi_policy* p, int code, const std::string& m) {
@@ -407,7 +409,10 @@ extern "C" int mi_policy_create(const mi_policy_desc* d, int device, mi_policy**
   *out = p;
   return MI_OK;
 }
-extern "C" void mi_policy_destroy(mi_policy* p) { delete p; }
+extern "C" void mi_policy_destroy(mi_policy* p) {
+  if (p && p->fold_counters) (void)hipFree(p->fold_counters);
+  delete p;
+}
 extern "C" int mi_policy_param_count(const mi_policy* p, size_t* n) {
   if (!p || !n) return MI_ERR_ARG;
   *n = p->P;
@@ -851,6 +856,16 @@ static int fused_fvp(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B, c
   hs.dir = pl.w; hs.dstride = P;
   PCHK(p, launch_policy_sweep(st, hs, pl.sweep_grid, SW_HVP));
   f.mode = 2; f.out = pl.tmpP; f.w = pl.w;
+  if (!p->fold_counters) {               // (once per policy object: the fold leaves the counters zero again)
+    const size_t nb = (size_t)ceil_div(P, 256) * sizeof(unsigned);
+    if (hipMalloc(reinterpret_cast<void**>(&p->fold_counters), nb) != hipSuccess) { p->fold_counters = nullptr; (void)hipGetLastError(); }
+    else PCHK(p, hipMemsetAsync(p->fold_counters, 0, nb, st));
+  }
+  if (p->fold_counters) {                // the mean over tasks + damping v by the last workgroup of every parameter block: no launch of its own
+    f.counter = p->fold_counters; f.mean_out = out; f.inv_T = 1.f / (float)T;
+    PCHK(p, launch_policy_sweep_fold(st, f, T));
+    return MI_OK;
+  }
   PCHK(p, launch_policy_sweep_fold(st, f, T));
   hipLaunchKernelGGL(mean_tasks_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, pl.tmpP, T, P, 1.f / (float)T, v, damping, out);
   PCHK(p, hipGetLastError());

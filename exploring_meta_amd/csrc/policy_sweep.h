@@ -55,7 +55,8 @@ struct SweepArgs {
 // Fold the per-workgroup partials of a sweep in slot order (deterministic) and finish the phase:
 //   mode 0 (after A): out[t][p] = v[p] - lr sum                          (u_t)
 //   mode 1 (after B): out[t][p] = sum; sigma slots: the Gaussian Fisher's 2 u / D where sigma is not clamped   (w_t)
-//   mode 2 (after C): out[t][p] = w[t][p] - lr sum    (the caller takes the mean over tasks and adds damping v)
+//   mode 2 (after C): out[t][p] = w[t][p] - lr sum    (then the mean over tasks + damping v: by the last workgroup of a parameter block
+//                     when FoldArgs::counter is set, by the caller's mean_tasks launch otherwise)
 //   mode 3 (primal)  : out[t][p] = sum (the pass's gradient); loss_t[t], kl_t[t] = the two extra slots
 struct FoldArgs {
   const float* partial; int slots, spt, spw, T, P, pitch;
@@ -68,6 +69,10 @@ struct FoldArgs {
   int o_sigma, A;
   float* out;
   int mode;
+  // mode 2 with a counter: the workgroup of a parameter block that finishes LAST among the T tasks also forms
+  //   mean_out[p] = inv_T sum_t out[t][p] + damping v[p]   (tasks in order: the value does not depend on who is last)
+  // -- the mean over tasks without its own launch.  counter: one unsigned per parameter block, zero on entry, zero again on exit.
+  unsigned* counter; float* mean_out; float inv_T;
 };
 // launchers (policy_sweep.hip, built WITHOUT -amdgpu-mfma-vgpr-form: the sweep keeps its 80 accumulator registers in the AGPR half
 // of the register file, where only MFMAs reach them, and all 256 architectural VGPRs for operands, prefetch and vector work)

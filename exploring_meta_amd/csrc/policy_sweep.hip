@@ -640,6 +640,40 @@ __device__ __forceinline__ float sweep_fold_sum(const FoldArgs& f, int t, int p)
   for (; k < ns; ++k) s += pp[(size_t)k * f.pitch];
   return s;
 }
+// mode 2 with the mean over tasks folded in (FoldArgs::counter): the arrival protocol of finalize.h -- write-through stores, acknowledged,
+// workgroup barrier, one relaxed agent-scope increment per workgroup; the workgroup that arrives last reads the T values back with
+// agent-scope loads, in task order
+__global__ __launch_bounds__(256) void policy_sweep_fold_mean_kernel(FoldArgs f) {
+  __shared__ int last_s;
+  const int p = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+  const bool act = p < f.P;
+  if (act) {
+    const float s = sweep_fold_sum(f, t, p);
+    __hip_atomic_store(f.out + (size_t)t * f.P + p, f.w[(size_t)t * f.P + p] - f.lr * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(f.counter + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev + 1u == (unsigned)f.T;
+    if (last) __hip_atomic_store(f.counter + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = last;
+  }
+  __syncthreads();
+  if (!last_s || !act) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float s = 0.f;
+  int k = 0;
+  for (; k + 4 <= f.T; k += 4) {                        // four tasks in flight, summed in task order (as mean_tasks_kernel does)
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __hip_atomic_load(f.out + (size_t)(k + u) * f.P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s += v[0]; s += v[1]; s += v[2]; s += v[3];
+  }
+  for (; k < f.T; ++k) s += __hip_atomic_load(f.out + (size_t)k * f.P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  f.mean_out[p] = s * f.inv_T + f.damping * f.v[p];
+}
+
 __global__ __launch_bounds__(256) void policy_sweep_fold_kernel(FoldArgs f) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= f.P) {
@@ -695,6 +729,11 @@ hipError_t launch_policy_sweep(hipStream_t st, const SweepArgs& a, int grid, int
   return hipErrorInvalidValue;
 }
 hipError_t launch_policy_sweep_fold(hipStream_t st, const FoldArgs& f, int tasks) {
+  if (f.mode == 2 && f.counter) {
+    if (!f.mean_out || !f.v || f.T != tasks) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(policy_sweep_fold_mean_kernel, dim3(ceil_div(f.P, 256), tasks), dim3(256), 0, st, f);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(policy_sweep_fold_kernel, dim3(ceil_div(f.P + 2, 256), tasks), dim3(256), 0, st, f);
   return hipGetLastError();
 }
