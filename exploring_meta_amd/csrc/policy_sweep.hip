@@ -393,6 +393,46 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     __syncthreads();
     SW_STAMP(4);
     // ---- head tangent (A-wide): mud = h2 W3d^T + h2d W3^T + b3d; partial dot products per (row, eighth of the columns)
+    // Two action dimensions (the reference's tasks: 2D navigation, rl/maml_trpo.py) take a copy of the stage with the dimension count as a
+    // constant: with the run-time count every dimension is a branch region, and the stage was a chain of 16 LDS latencies (2.8k cycles).
+    if (!PRIMAL && A == 2) {                         // (the primal variant sits at the register limit: it keeps the general form)
+      constexpr int AA = 2;
+      const int r = tid & 31, q = tid >> 5;
+      float sacc[AA] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < (H / 4 + 7) / 8; ++j) {
+        const int kq = q + 8 * j;
+        const bool okq = kq < H / 4;
+        const int kc = okq ? kq : H / 4 - 1;          // (a chunk past the row reads the row's last chunk and is zeroed: no branch)
+        floatx4 hv = lds4(h2s + r * H + 4 * kc);
+        floatx4 hd = PRIMAL ? hv : lds4(h2d + r * H + 4 * kc);
+        floatx4 ws[AA], wd[AA];
+#pragma unroll
+        for (int d = 0; d < AA; ++d) {
+          ws[d] = lds4(W3s + d * H + 4 * kc);
+          wd[d] = PRIMAL ? ws[d] : lds4(W3d + d * H + 4 * kc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          hd[c] = (okq && hv[c] > 0.f) ? hd[c] : 0.f;
+          hv[c] = okq ? hv[c] : 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < AA; ++d) {
+          if (PRIMAL) {                                // mu = h2 W3^T + b3
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sacc[d] = fmaf(hv[c], ws[d][c], sacc[d]);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sacc[d] = fmaf(hv[c], wd[d][c], fmaf(hd[c], ws[d][c], sacc[d]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int d = 0; d < AA; ++d) red[(d * 8 + q) * 32 + r] = sacc[d];
+    } else
     {
       const int r = tid & 31, q = tid >> 5;
       float sacc[SW_MAX_A];
