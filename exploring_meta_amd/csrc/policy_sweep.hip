@@ -560,6 +560,28 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       float w3[SW_MAX_A], w3d[SW_MAX_A];
 #pragma unroll
       for (int d = 0; d < SW_MAX_A; ++d) { w3[d] = W3s[d * H + col]; w3d[d] = W3d[d * H + col]; }     // rows past A are zero
+      if (!PRIMAL && A == 2) {                       // (two action dimensions: one pair, no branch per pair -- as the head-tangent stage)
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
+#pragma unroll 8
+        for (int j = 0; j < 16; ++j) {
+          const int r = rb + j;
+          const float h2v = h2s[r * H + col], h2raw = h2d[r * H + col];
+          const floatx2 rm = *reinterpret_cast<const floatx2*>(rdmus + r * SW_MAX_A);
+          floatx2 dm = {0.f, 0.f};
+          if (HVP) dm = *reinterpret_cast<const floatx2*>(dmus + r * SW_MAX_A);
+          const float h2dv = h2v > 0.f ? h2raw : 0.f;
+          float v = 0.f;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            accW3[e] = fmaf(rm[e], h2v, accW3[e]);
+            v = fmaf(rm[e], w3[e], v);
+            if (HVP) { accW3[e] = fmaf(dm[e], h2dv, accW3[e]); v = fmaf(dm[e], w3d[e], v); }
+          }
+          v = h2v > 0.f ? v : 0.f;
+          h2d[r * H + col] = v;
+          accb2 += v;
+        }
+      } else {
 #pragma unroll 8
       for (int j = 0; j < 16; ++j) {
         const int r = rb + j;
@@ -584,6 +606,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
         h2d[r * H + col] = v;
         if (PRIMAL && a.d2_out && r < nv) a.d2_out[(rbase + r) * H + col] = v;      // dz2 of the pass, for its Hessian-vector sweeps
         accb2 += v;
+      }
       }
     }
     __syncthreads();
