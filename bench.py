@@ -751,7 +751,7 @@ def run_trpo(args, wl, rank, world, local, dist):
     if os.path.exists(tpath):            # HBM bytes of ONE Hessian-vector sweep launch (the dominant kernel of a product: two of its three sweeps)
         traffic = json.load(open(tpath)).get('cfg5,fisher_vector_product,0')
     roofline = dict(kernel='mi_trpo_fvp = 3 fused sweeps (policy_sweep_kernel: H_t v over the support pass, F_t u over the query pass, H_t w over the '
-                           'support pass) + 3 folds + the mean over tasks: 7 launches',
+                           'support pass) + 3 folds, the last of which also takes the mean over tasks: 6 launches',
                     op='fisher_vector_product', bound='mfma', achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TF, unit='TFLOP/s',
                     frac=round(achieved / FP32_MFMA_PEAK_TF, 5), traffic=traffic, launches=nf, avg_launch_ms=round(fvp_ms, 4),
                     flops_per_launch=flops, traffic_note='counter bytes of one policy_sweep_kernel<HVP> launch (a product = 2 such sweeps + 1 Fisher sweep)',
