@@ -184,6 +184,52 @@ def _device_batch(replay_list, S, A, dev):
 _FIELDS = ('states', 'actions', 'next_states', 'rewards', 'dones')
 
 
+class Replay(dict):
+    """A replay as the runners of this package return it: a dict of tensors that remembers the device addresses of its five fields once
+    ``_device_batch_packed`` has checked them (fp32, contiguous, on the device), so the meta-step that gathers the same replays again
+    reads one tuple per replay instead of inspecting five tensors.  Any change of the dict's entries forgets it; plain dicts work as before."""
+    __slots__ = ('_mi_pack',)
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._mi_pack = None
+
+    def _forget(self):
+        self._mi_pack = None
+
+    def __setitem__(self, k, v):
+        self._mi_pack = None
+        super().__setitem__(k, v)
+
+    def __delitem__(self, k):
+        self._mi_pack = None
+        super().__delitem__(k)
+
+    def update(self, *a, **k):
+        self._mi_pack = None
+        super().update(*a, **k)
+
+    def pop(self, *a):
+        self._mi_pack = None
+        return super().pop(*a)
+
+    def popitem(self):
+        self._mi_pack = None
+        return super().popitem()
+
+    def clear(self):
+        self._mi_pack = None
+        super().clear()
+
+    def setdefault(self, *a):
+        self._mi_pack = None
+        return super().setdefault(*a)
+
+    def __ior__(self, other):
+        self._mi_pack = None
+        return super().__ior__(other)
+
+
 def _device_batch_packed(replay_list, lens, B, S, A, dev):
     """_device_batch through mi_copy_segments, or None when a field is not a contiguous fp32 tensor on ``dev`` (the general path converts)."""
     dev = torch.device(dev)
@@ -195,13 +241,24 @@ def _device_batch_packed(replay_list, lens, B, S, A, dev):
     widths = (S, A, S, 1, 1)
     f32, Tensor, didx = torch.float32, torch.Tensor, dev.index
     srcs, cnts = [], []
-    for r, n in zip(replay_list, lens):           # (attribute reads only: this loop is the host time of the call, ~0.5 us per array)
+    key = (didx, S, A)
+    for r, n in zip(replay_list, lens):           # (attribute reads only: this loop is the host time of the call, ~0.8 us per array)
+        memo = r._mi_pack if type(r) is Replay else None
+        if memo is not None and memo[0] == key and memo[1] == n:
+            srcs.extend(memo[2])                  # (checked before; the tensors are held by the replay, so the addresses are theirs)
+            cnts.extend(memo[3])
+            continue
+        ps, cs = [], []
         for k, w in zip(_FIELDS, widths):
             t = r[k]
             if not (isinstance(t, Tensor) and t.dtype is f32 and t.is_cuda and t.get_device() == didx and t.is_contiguous() and t.numel() == n * w):
                 return None
-            srcs.append(t.data_ptr())
-            cnts.append(n * w)
+            ps.append(t.data_ptr())
+            cs.append(n * w)
+        if type(r) is Replay:
+            r._mi_pack = (key, n, tuple(ps), tuple(cs))
+        srcs.extend(ps)
+        cnts.extend(cs)
     out = dict(states=torch.empty(R, B, S, dtype=f32, device=dev), actions=torch.empty(R, B, A, dtype=f32, device=dev),
                next_states=torch.empty(R, B, S, dtype=f32, device=dev), rewards=torch.empty(R, B, dtype=f32, device=dev),
                dones=torch.empty(R, B, dtype=f32, device=dev))
@@ -547,7 +604,9 @@ def meta_optimize_trpo(params, policy, baseline, iter_replays, iter_policies, an
         stepsize = params['backtrack_factor'] ** ls_step * params['outer_lr']
         cand = torch.add(theta, step, alpha=-stepsize).contiguous()
         new_loss, kl, _ = ctx.evaluate(cand)
-        if new_loss.item() < old_loss.item() and kl.item() < params['max_kl']:
+        # (one host read for the three scalars of the test: each .item() is a copy and a synchronisation of its own, ~25 us)
+        nl, ol, klv = torch.cat([new_loss.reshape(-1)[:1], old_loss.reshape(-1)[:1], kl.reshape(-1)[:1]]).tolist()
+        if nl < ol and klv < params['max_kl']:
             policy.load_flat(cand)
             accepted = ls_step
             break
@@ -760,4 +819,4 @@ class Particles2DRunner:
         R, D, M = torch.stack(R, 1), torch.stack(D, 1), torch.stack(M, 1)
         keep = M.reshape(-1)
         flat = lambda x: x.reshape(E * L, -1)[keep]
-        return dict(states=flat(S), actions=flat(A), rewards=flat(R), dones=flat(D), next_states=flat(NS))
+        return Replay(states=flat(S), actions=flat(A), rewards=flat(R), dones=flat(D), next_states=flat(NS))
