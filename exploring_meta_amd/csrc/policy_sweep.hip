@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const int ocol = min(32 * wave + n, H - 1);
-#pragma unroll 1
+#pragma unroll
       for (int term = 0; term < (PRIMAL ? 1 : 2); ++term) {
         const float* arow = (term == 0 ? h1s : h1d) + n * H + hh * KH0;
         const float* brow = ((term == 0 && !PRIMAL) ? W2d : W2s) + ocol * H + hh * KH0;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
       float gate[16];                                  // [h1 > 0] of this lane's 16 output elements, in flight under the products
 #pragma unroll
       for (int r = 0; r < 16; ++r) gate[r] = h1s[((r & 3) + 8 * (r >> 2) + 4 * hh) * H + icol];
-#pragma unroll 1
+#pragma unroll
       for (int term = 0; term < (HVP ? 2 : 1); ++term) {
         const float* arow = (term == 0 ? r2 : d2s) + n * H + hh * KH0;
         const float* bcol = (term == 0 ? W2s : W2d) + icol + hh * KH0 * H;

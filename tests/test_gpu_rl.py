@@ -581,6 +581,18 @@ def test_packed_device_batch_matches_the_general_path(lens, monkeypatch):
         assert packed[k].shape == plain[k].shape and packed[k].dtype == plain[k].dtype and torch.equal(packed[k], plain[k]), k
     for i, n in enumerate(lens):
         assert float(packed['states'][i, n:].abs().sum()) == 0.0 and float(packed['rewards'][i, n:].abs().sum()) == 0.0
+    # a Replay (what the runners return) remembers its checked addresses: a second gather reads them back, a changed entry forgets them
+    monkeypatch.undo()
+    reps = [prl.Replay(e) for e in eps]
+    first = prl._device_batch(reps, S, A, dev)
+    assert all(r._mi_pack is not None for r in reps)
+    again = prl._device_batch(reps, S, A, dev)
+    for k in ('states', 'actions', 'next_states', 'rewards', 'dones', 'count'):
+        assert torch.equal(first[k], packed[k]) and torch.equal(again[k], packed[k]), k
+    reps[0]['rewards'] = reps[0]['rewards'] * 2.0
+    assert reps[0]._mi_pack is None
+    changed = prl._device_batch(reps, S, A, dev)
+    assert torch.equal(changed['rewards'][0, :lens[0]], 2.0 * packed['rewards'][0, :lens[0]]) and torch.equal(changed['rewards'][1:], packed['rewards'][1:])
     # a field that is not fp32 / contiguous / on the device sends the whole call down the general path
     eps[1]['rewards'] = eps[1]['rewards'].double()
     monkeypatch.undo()

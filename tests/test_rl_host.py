@@ -30,3 +30,20 @@ def test_advantages_match_oracle():
 def test_discount_matches_oracle():
     ep = _replay(1)
     assert np.allclose(PR.discount(0.9, ep['rewards'].numpy(), ep['dones'].numpy()), RL.discount(0.9, ep['rewards'], ep['dones']).numpy())
+
+
+def test_replay_forgets_its_addresses_when_an_entry_changes():
+    """core_functions.rl.Replay: the dict the runners return; every way of changing its entries drops the remembered device addresses
+    (copies start without them)."""
+    import copy
+    from exploring_meta_amd.core_functions.rl import Replay
+    r = Replay(states=1, actions=2)
+    assert r._mi_pack is None and dict(r) == {'states': 1, 'actions': 2}
+    for change in (lambda d: d.__setitem__('states', 3), lambda d: d.update(actions=4), lambda d: d.pop('actions'), lambda d: d.setdefault('x', 0),
+                   lambda d: d.__delitem__('x'), lambda d: d.popitem(), lambda d: d.clear(), lambda d: d.__ior__({'y': 1})):
+        r._mi_pack = ('memo',)
+        change(r)
+        assert r._mi_pack is None
+    r['states'] = 5
+    r._mi_pack = ('memo',)
+    assert copy.copy(r)._mi_pack is None and copy.deepcopy(r)._mi_pack is None and dict(copy.deepcopy(r)) == dict(r)
