@@ -666,11 +666,11 @@ __global__ __launch_bounds__(256) void policy_sweep_kernel(SweepArgs a) {
     // ---- dW2[o][i] += sum_rows r2[row][o] h1[row][i] + d2[row][o] h1d[row][i]: M = o (MT tiles), N = this wave's columns, K = rows
     if (bwd) {
       const int icol = 32 * wave + n;                  // columns past H read the next row: finite, never stored
-#pragma unroll 1
+#pragma unroll
       for (int term = 0; term < (HVP ? 2 : 1); ++term) {
         const float* am = (term == 0 ? r2 : d2s) + (16 * hh) * H + n;
         const float* bm = (term == 0 ? h1s : h1d) + (16 * hh) * H + icol;
-#pragma unroll 8
+#pragma unroll
         for (int s = 0; s < 16; ++s) {
           const float bv = bm[s * H];
           float avv[MT];
