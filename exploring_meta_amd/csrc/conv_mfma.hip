@@ -779,13 +779,17 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
       // BF: accumulator rows 0 (r = 0 of lane half 0) and 31 (r = 15 of lane half 1) belong to the halo lanes: not stored, not summed
       auto dropped = [&](int r) { return BF && ((r == 0 && h == 0) || (r == 15 && h == 1)); };
       const int keep_lo = h == 0 ? 0 : -1, keep_hi = h == 1 ? 0 : -1;
+      // One code path per source of "ReLU on" (a wave-uniform property of the launch): as a branch per row the choice fenced every row's
+      // loads behind the previous row's (conv_b16.h, where the same hoist took the one-term dgrad from +39 % to -2 %).
+      auto bred_path = [&](auto arg_c) {
+      constexpr bool ARG = decltype(arg_c)::value;
       auto fetch = [&](int grp, Grp& gq) {
 #pragma unroll
         for (int rr = 0; rr < GR; ++rr) {
           const unsigned o = row_off(grp * GR + rr);
-          // (uniform branch; the byte as an integer in a float register: 0..3 = the window's argmax position, 4 = its ReLU is off;
+          // (the byte as an integer in a float register: 0..3 = the window's argmax position, 4 = its ReLU is off;
           // a row past the end of the task reads 0 = "on", and contributes nothing: its accumulators and cotangents are exact zeros)
-          if (bred_arg) gq.pp[rr] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rbp, o >> 2, 0, 0));
+          if (ARG) gq.pp[rr] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rbp, o >> 2, 0, 0));
           else gq.pp[rr] = buf_ld(rbp, o);
           gq.zz[rr] = buf_ld(rbzh, o);
           if (NTERMS == 2) { gq.zd[rr] = buf_ld(rbzhd, o); gq.dq[rr] = buf_ld(rbdp, o); }
@@ -800,8 +804,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
           else buf_st(rout, row_off(r), v);
           // "ReLU on" as a lane mask: p is a ReLU output (>= +0), so 0 - p carries a sign bit exactly where p > 0.  The masked
           // values are ANDs on the floats (mi_common.h): a select after the fp64 conversion is two quarter-rate v_cndmask per row
-          int on = bred_arg ? ((int)__builtin_bit_cast(unsigned, gq.pp[rr]) - 4) >> 31      // -1 where the byte is below 4
-                            : lane_mask_negative(0.f - gq.pp[rr]);
+          int on = ARG ? ((int)__builtin_bit_cast(unsigned, gq.pp[rr]) - 4) >> 31      // -1 where the byte is below 4
+                       : lane_mask_negative(0.f - gq.pp[rr]);
           if (BF && r == 0) on &= keep_lo;
           if (BF && r == 15) on &= keep_hi;
           const float vv = lane_keep_where(on, v);
@@ -824,6 +828,8 @@ __global__ __launch_bounds__((ConvWaves<CI, NTERMS, BF, F16>::value * 64), (Conv
         if (grp + 2 < NG) fetch(grp + 2, ga);
         if (grp + 1 < NG) consume(grp + 1, gb);
       }
+      };
+      if (bred_arg) bred_path(std::true_type{}); else bred_path(std::false_type{});
       continue;
     }
 #pragma unroll
