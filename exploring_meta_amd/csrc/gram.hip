@@ -60,15 +60,49 @@ __global__ __launch_bounds__(256) void input_gram_kernel(const float* __restrict
 
   const int nrows = n * H;
   const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
-  for (int row = row0; row < row0 + rows_per_wave && row < nrows; ++row) {
+  const int row1 = min(row0 + rows_per_wave, nrows);
+  // Rows of at most 256 floats (84 x 3, 28 x 1): the three input rows of an output row are REQUESTED as 12 unconditional loads (clamped
+  // addresses, zero selected afterwards) one output row ahead, under the matrix work of the current row.  As a loop of predicated
+  // load / convert / store triples the staging was twelve memory round trips per output row against one microsecond of MFMAs
+  // (the kernel ran at a quarter of the fp64 matrix rate).
+  const bool narrow = ROWF <= 256;
+  float pre[3][4];
+  auto fetch_rows = [&](int row) {
+    const int img = row / H, y = row - img * H;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int yy = y - 1 + r;
+      const bool rv = (unsigned)yy < (unsigned)H;
+      const float* src = x_t + (size_t)(img * H + (rv ? yy : 0)) * ROWF;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = lane + 64 * k;
+        const float f = src[e < ROWF ? e : ROWF - 1];
+        pre[r][k] = rv ? f : 0.f;
+      }
+    }
+  };
+  if (narrow && row0 < row1) fetch_rows(row0);
+  for (int row = row0; row < row1; ++row) {
     const int img = row / H, y = row - img * H;
     // stage input rows y-1, y, y+1 (coalesced), converted to fp64 once; rows outside the image are zeros
+    if (narrow) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = lane + 64 * k;
+          if (e < ROWF) rows[r * RPD + CI0 + e] = (double)pre[r][k];
+        }
+      if (row + 1 < row1) fetch_rows(row + 1);              // in flight under this row's products
+    } else {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int yy = y - 1 + r;
       const bool rv = (unsigned)yy < (unsigned)H;
       const float* src = x_t + (size_t)(img * H + (rv ? yy : 0)) * ROWF;
       for (int e = lane; e < ROWF; e += 64) rows[r * RPD + CI0 + e] = rv ? (double)src[e] : 0.0;
+    }
     }
     for (int x0 = 0; x0 < W; x0 += 4) {
       const bool pv = x0 + kpix < W;
