@@ -405,7 +405,9 @@ int mi_trpo_surrogate(mi_policy* p, void* stream, const float* theta, const floa
                       int batch, float inner_lr, float* loss_out, float* kl_out, float* grad_out, void* workspace,
                       size_t workspace_bytes);
 /* trpo.hessian_vector_product(old_kl, params, damping)(v) (rl.py:417) at the parameters mi_trpo_surrogate was last called
- * with on this workspace (where the adapted policies equal the stored old policies). */
+ * with on this workspace (where the adapted policies equal the stored old policies).
+ * Calls on ONE mi_policy are ordered by the caller (one stream at a time): the fused product keeps a few arrival counters in device
+ * memory owned by the policy object (its last fold also takes the mean over tasks; they are zero between launches). */
 int mi_trpo_fvp(mi_policy* p, void* stream, const float* theta, const float* s_states, const float* s_actions,
                 const int32_t* s_count, const float* q_states, const int32_t* q_count, int tasks, int batch, float inner_lr,
                 float damping, const float* v, float* out, void* workspace, size_t workspace_bytes);
