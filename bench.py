@@ -481,7 +481,7 @@ def run_vision(args, wl, rank, world, local, dist):
             a1, p1 = (fl / sec1 / 1e12, pk1) if b1 == 'mfma' else (by / sec1 / 1e9, HBM_PEAK_GBS)
             iso.append(dict(op=op, block=layer + 1, launches=int(cnt1), avg_launch_ms=round(ms1 / cnt1, 4), bound=b1, pipe=pipe1,
                             achieved=round(a1, 1), frac=round(a1 / p1, 3), tflops=round(fl / sec1 / 1e12, 1) if fl else None))
-        # (which kernel of the split-bf16 form this launch takes: 16x16x32 MFMAs from 8 tiles per wave on, csrc/conv_b16.h)
+        # (which kernel of the split-bf16 form this launch takes: 16x16x32 MFMAs from 6 tiles per wave on, csrc/conv_b16.h)
         dom_b16 = bool(split == 1 and dom[0] in RF.SPLIT_BF16_OPS and dom[1] >= 1 and
                        RF.conv_kernel_is_b16(n_img // max(T, 1) * h * w, T, co, eng.lib.mi_conv_set_b16(-1)))
         roofline = dict(kernel=f'{RF.kernel_name(spec, dom[0], dom[1], b16=dom_b16)}, block {dom[1] + 1} ({h}x{w}, {ci}->{co} filters)', op=dom[0],

@@ -107,7 +107,7 @@ BLOCK1_KERNEL_NAMES = {
 }
 
 
-def conv_kernel_is_b16(mpix, tasks, co, mode, min_tpw=8):
+def conv_kernel_is_b16(mpix, tasks, co, mode, min_tpw=6):
     """Whether a split-bf16 stride-1 convolution launch over `tasks` tasks of `mpix` output pixels each takes the 16x16x32 kernel
     (csrc/conv_b16.h) -- launch_conv3x3's rule: mi_conv_set_b16 mode 2 always, mode 1 from `min_tpw` tiles of 30 pixels per wave
     (2048 resident waves) on, mode 0 never."""

@@ -39,7 +39,7 @@ def golden_refinit():
 
 
 # Operand form / kernel of the 32- / 64-channel stride-1 convolutions and weight gradients: name -> (mi_conv_set_split_bf16, mi_conv_set_b16).
-# 'split_bf16' is the engine's default (exact three-plane bf16 operands; the 16x16x32 kernel of csrc/conv_b16.h for launches of >= 8 tiles
+# 'split_bf16' is the engine's default (exact three-plane bf16 operands; the 16x16x32 kernel of csrc/conv_b16.h for launches of >= 6 tiles
 # per wave, the 32x32x16 kernel of rounds 3-4 below that -- what bench.py times), 'split_bf16_16x16' / 'split_bf16_32x32' the same operand
 # form with EVERY launch on one of the two kernels (small test shapes reach the 16x16x32 kernel only this way), 'fp32_pipe' the fp32 matrix
 # pipe, 'split_f16' the opt-in two-plane fp16 form.

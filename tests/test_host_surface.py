@@ -122,15 +122,17 @@ def test_product_does_not_import_oracle():
 
 def test_roofline_names_the_kernel_a_conv_launch_takes():
     """utils/roofline.py mirrors launch_conv3x3's rule for the split-bf16 form's two kernels (csrc/conv_mfma.hip: conv_b16_for): the 16x16x32
-    kernel from 8 tiles of 30 pixels per wave (2048 resident waves) on in mode 1, always / never in modes 2 / 0 -- bench.py names the
-    dominant kernel with it."""
+    kernel from 6 tiles of 30 pixels per wave (rounded up; 2048 resident waves) on in mode 1, always / never in modes 2 / 0 -- bench.py names
+    the dominant kernel with it."""
     from exploring_meta_amd.engine import ModelSpec
     from exploring_meta_amd.utils import roofline as RF
     # cfg2, 32 tasks x 25 images: block 2 (42 x 42) 23 tiles per wave, block 3 (21 x 21) 5.7, block 4 (10 x 10) 1.3
-    assert RF.conv_kernel_is_b16(25 * 42 * 42, 32, 32, 1) and not RF.conv_kernel_is_b16(25 * 21 * 21, 32, 32, 1)
+    assert RF.conv_kernel_is_b16(25 * 42 * 42, 32, 32, 1) and RF.conv_kernel_is_b16(25 * 21 * 21, 32, 32, 1)
     assert not RF.conv_kernel_is_b16(25 * 10 * 10, 32, 32, 1)
-    # few tasks per call stay on the 32x32x16 kernel; cfg4 (5 images per task) too; modes 0 / 2 do not look at the size
-    assert not RF.conv_kernel_is_b16(25 * 42 * 42, 4, 32, 1) and not RF.conv_kernel_is_b16(5 * 42 * 42, 32, 32, 1)
+    # few tasks per call stay on the 32x32x16 kernel (4 tasks: block 2 at 2.9 tiles per wave; 8 tasks: 5.7 -> 6: the new kernel); cfg4
+    # (5 images per task: block 2 at 4.6 -> 5) stays too; modes 0 / 2 do not look at the size
+    assert not RF.conv_kernel_is_b16(25 * 42 * 42, 4, 32, 1) and RF.conv_kernel_is_b16(25 * 42 * 42, 8, 32, 1)
+    assert not RF.conv_kernel_is_b16(5 * 42 * 42, 32, 32, 1)
     assert RF.conv_kernel_is_b16(5 * 10 * 10, 1, 32, 2) and not RF.conv_kernel_is_b16(25 * 42 * 42, 32, 32, 0)
     # 64 filters: two channel tiles per pixel tile
     assert RF.conv_kernel_is_b16(50 * 21 * 21, 32, 64, 1)

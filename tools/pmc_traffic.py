@@ -130,7 +130,7 @@ def main():
         # (template arguments <CI, NTERMS, EPI, MODE, BF, F16>: BF = a split operand form, F16 = its two-plane fp16 variant)
         base = lambda k: re.sub(r'(, (true|false)){1,2}>$', '', k)
         has_bf = {base(k) for k, g, nl, f, w, c in rows if re.search(r'\d, true(, (true|false))?>$', k) and nl > 0}
-        # (the split-bf16 form runs on two kernels since round 5 -- the 16x16x32 one for launches of >= 8 tiles per wave, the 32x32x16 one below
+        # (the split-bf16 form runs on two kernels since round 5 -- the 16x16x32 one for launches of >= 6 tiles per wave, the 32x32x16 one below
         # that, the same grid rule for both: a layer the first has taken is not a candidate for the second, whose size classes then count
         # through the remaining layers of that grid)
         taken = {}
