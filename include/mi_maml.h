@@ -442,7 +442,7 @@ int mi_conv_get_split_bf16(unsigned* mask_out);
 /* Which kernel runs the split-bf16 form (form 1) of the stride-1 hidden convolutions (forward, dgrad and their two-term tangent forms;
  * ConvBlock.conv of blocks >= 2, reference core_functions/vision_models.py:177-185,189): 16x16x32 MFMAs with one accumulator per horizontal
  * tap (csrc/conv_b16.h) or the 32x32x16 kernel with lane-shifted operands of rounds 3-4.  0 = always the latter, 2 = always the former,
- * 1 (default; MI_CONV_B16 starts with another) = the former for launches of at least 8 tiles per wave (MI_CONV_B16_MIN_TPW), where its
+ * 1 (default; MI_CONV_B16 starts with another) = the former for launches of at least 6 tiles per wave, rounded up (MI_CONV_B16_MIN_TPW), where its
  * longer pipeline fill is amortised.  Same operands, products and tiles; the two kernels differ in summation order only and meet the same
  * parity bars (the kernel tests run both on every case).  on < 0 only reads.  Returns the previous setting. */
 int mi_conv_set_b16(int on);
