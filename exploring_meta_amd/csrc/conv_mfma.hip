@@ -1312,12 +1312,12 @@ int conv_b16() {
   return g_conv_b16;
 }
 extern "C" int mi_conv_set_b16(int on) { const int was = conv_b16(); if (on >= 0) g_conv_b16 = on > 2 ? 2 : on; return was; }
-// Experiments of round 5 on how the two waves of a SIMD share it in the 16x16x32 kernel, both OFF by default (MI_CONV_STAGGER bit 0: the second
-// wave starts half a tile late; bit 1: issue priority alternates between the two from tile to tile).  tools/conv_b16_stamps.py: at equal
-// priority the older wave's K loop takes 10.3k cycles per two-term tile and the younger's 14.5k, so the older finishes a quarter of the launch
-// early; alternating priority balances them (12.6k / 13.6k, launch cycles -5 %), but the wall time moves by -2 % on the forward kernel and +2 %
-// on the dgrad: the SIMD's issue port, not the partner's phase, is what is short (an MFMA of this shape holds it 8 of its 16 cycles).
-static int conv_stagger() { static const int v = getenv("MI_CONV_STAGGER") ? atoi(getenv("MI_CONV_STAGGER")) : 0; return v; }
+// How the two waves of a SIMD share it in the 16x16x32 kernel (MI_CONV_STAGGER; bit 0: the second wave starts half a tile late -- no effect,
+// off; bit 1, the DEFAULT: issue priority alternates between the two from tile to tile).  tools/conv_b16_stamps.py: at equal priority the older
+// wave's K loop takes 10.3k cycles per two-term tile and the younger's 14.5k, so the older finishes a quarter of the launch early; alternating
+// priority balances them (12.6k / 13.6k, launch cycles -5 %).  Isolated launches move by -2 % (forward) / +2 % (dgrad); inside the meta-iteration
+// (tools/r5_ab_env.sh, six alternating pairs on two boxes) it is -0.3 ... -1.0 % on cfg2 (16.33 against 16.41 ms) and -0.7 % on cfg3: on.
+static int conv_stagger() { static const int v = getenv("MI_CONV_STAGGER") ? atoi(getenv("MI_CONV_STAGGER")) : 2; return v; }
 static bool conv_b16_for(const ConvArgs& a) { const int m = conv_b16(); return m == 2 || (m == 1 && a.tiles_per_wave >= g_conv_b16_min_tpw); }
 template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
