@@ -11,7 +11,7 @@ declare -A PICK
 PICK[cfg1]='conv3x3_mfma_kernel<64, 1, 1, 0, 2>::conv_fwd_stats,1'
 PICK[cfg3]='conv3x3_s1_(mfma_kernel<64, 1, 1, 0, true|b16_kernel<64, 1, 1, 0>)::conv_fwd_stats,1'
 PICK[cfg4]='conv3x3_s1_(mfma_kernel<32, 2, 2, 0, true|b16_kernel<32, 2, 2, 0>)::tangent_conv_fwd,1;;sparse_wgrad_rows_kernel<3, false::wgrad,0;;sparse_wgrad_rows_kernel<3, true::tangent_wgrad,0;;block1_fwd_kernel<3, false[,>]::bn_relu_pool_fwd,0;;block1_fwd_kernel<3, true[,>]::bn_tangent_fwd,0'
-PICK[cfg5]='policy_sweep_kernel<100, true>::fisher_vector_product,0'
+PICK[cfg5]='policy_sweep_kernel<100, 0>::fisher_vector_product,0'
 PICK[cfg2]='conv3x3_s1_(mfma_kernel<32, 2, 2, 0, true|b16_kernel<32, 2, 2, 0>)::tangent_conv_fwd,1;;sparse_wgrad_rows_kernel<3, false::wgrad,0;;sparse_wgrad_rows_kernel<3, true::tangent_wgrad,0;;block1_fwd_kernel<3, false[,>]::bn_relu_pool_fwd,0;;block1_fwd_kernel<3, true[,>]::bn_tangent_fwd,0'
 for W in ${WORKLOADS:-cfg2 cfg1 cfg3 cfg4 cfg5}; do
   for C in FETCH_SIZE WRITE_SIZE; do
