@@ -16,6 +16,13 @@ Pinning status
 * The learn2learn pieces the reference calls but does not vendor (``MAML.clone/adapt``, ``clone_module``, ``maml_update``;
   version unpinned, not in requirements.txt) are restated from their published semantics (reference
   ``vision/README.md:59-80``, call sites ``core_functions/rl.py:368-374``): PARITY UNPINNED at that boundary.
-* cherry-rl pieces (``td.discount``, ``pg.generalized_advantage``, ``normalize``, ``LinearValue``, TRPO helpers; unpinned in
-  ``requirements.txt:6``) likewise restated from published semantics: PARITY UNPINNED (``rl_ref.py``).
+* RL path (``rl_ref.py``): COMPOSITION PINNED, cherry / learn2learn LEAVES UNPINNED.  ``tests/golden/make_golden_rl.py`` imports the
+  reference's ``core_functions/rl.py`` (same stub recipe) and EXECUTES its ``compute_advantages`` (:95-110), ``trpo_a2c_loss``
+  (:346-358), ``trpo_update`` (:361-374), ``fast_adapt_trpo`` (:377-406), ``meta_surrogate_loss`` (:441-473) and
+  ``meta_optimize_trpo`` (:409-438) on seeded replays (MAML-TRPO small / two inner steps / ANIL-TRPO / BASELINE config 5 at full
+  size), with ``rl_ref.py``'s leaf restatements installed where the reference calls cherry / learn2learn; ``tests/test_oracle_rl.py``
+  holds ``rl_ref.py``'s own composition to those records at 1e-9.  The leaves themselves (``td.discount``,
+  ``pg.generalized_advantage``, ``normalize``, ``LinearValue``, ``a2c/trpo.policy_loss``, ``trpo.hessian_vector_product``,
+  ``trpo.conjugate_gradient``, ``clone_module``, ``maml_update``; unpinned in ``requirements.txt:6`` / absent from it) are restated
+  from published semantics: PARITY UNPINNED at the leaves.
 """

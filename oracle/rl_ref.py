@@ -2,7 +2,11 @@
 core_functions/policies.py, rl/maml_trpo.py) for BASELINE config 5 (Particles2D, 2x100 MLP policy).
 
 Pinned: ``DiagNormalPolicy`` / ``DiagNormalPolicyANIL`` density and log_prob against fixtures produced by the reference's own
-classes (tests/golden G5).  PARITY UNPINNED (third-party code absent from /root/reference, versions unpinned in
+classes (tests/golden G5).  COMPOSITION PINNED (round 6): ``compute_advantages``, ``trpo_a2c_loss``, ``trpo_update``, ``fast_adapt_trpo``,
+``meta_surrogate_loss`` and ``meta_optimize_trpo`` below are held to 1e-9 (fp64) against ``tests/golden/golden_rl.npz``, which
+``tests/golden/make_golden_rl.py`` records by EXECUTING the reference's own rl.py:95-110,346-473 with this file's leaf restatements
+installed in place of the absent cherry / learn2learn leaves (``tests/test_oracle_rl.py::test_composition_matches_the_reference``).
+LEAVES PARITY UNPINNED (third-party code absent from /root/reference, versions unpinned in
 requirements.txt:6): cherry-rl's ``td.discount``, ``pg.generalized_advantage``, ``normalize``, ``models.robotics.LinearValue``,
 ``a2c.policy_loss``, ``trpo.policy_loss``, ``trpo.hessian_vector_product``, ``trpo.conjugate_gradient``, and learn2learn's
 ``Particles2D`` / ``clone_module`` / ``maml_update`` -- restated below from their published behaviour, anchored on the
@@ -286,6 +290,28 @@ def fast_adapt_trpo(env, p, baseline, params, generator, first_order=False, acti
     replay.append(q)
     valid_loss = trpo_a2c_loss(q, p, baseline, params['gamma'], params['tau'], update_vf=False, activation=activation)
     return p, valid_loss, replay, q['rewards'].sum().item() / params['adapt_batch_size']
+
+
+def get_ep_successes(success, path_length):
+    """rl.py:59-72: ``success`` = the replay's per-step success flags; reshape(path_length, -1).T lays one episode per row (the
+    reference's runner interleaves its workers' steps), an episode counts when any of its flags is 1."""
+    if success is None:                                   # AttributeError branch (rl.py:69-71): 'No success metric registered!'
+        return 0
+    return int(sum(1 for ep in success.reshape(path_length, -1).T if 1. in ep))
+
+
+def fast_adapt_trpo_replayed(replays, p, baseline, params, first_order=False, activation=torch.relu, anil=False, success=None):
+    """rl.py:377-406 on GIVEN replays (``task.run`` hands out replays[0..K-1] as the support episodes, replays[K] as the query):
+    K x trpo_update (head-only under anil: the body grads are off, :381-382), the validation loss WITHOUT refitting the baseline
+    (:401), mean query reward (:403), success rate (:404)."""
+    for k in range(params['adapt_steps']):
+        p = trpo_update(replays[k], p, baseline, params['inner_lr'], params['gamma'], params['tau'], first_order=first_order,
+                        activation=activation, head_only=anil)
+    q = replays[params['adapt_steps']]
+    valid_loss = trpo_a2c_loss(q, p, baseline, params['gamma'], params['tau'], update_vf=False, activation=activation)
+    rew = q['rewards'].sum().item() / params['adapt_batch_size']
+    suc = get_ep_successes(success, params['max_path_length']) / params['adapt_batch_size']
+    return p, valid_loss, rew, suc
 
 
 def meta_surrogate_loss(iter_replays, iter_policies, p, baseline, params, activation=torch.relu):

@@ -33,6 +33,13 @@ def golden_fa():
 
 
 @pytest.fixture(scope='session')
+def golden_rl():
+    """Records of the REFERENCE's rl.py:95-110,346-473 executed on seeded replays (tests/golden/make_golden_rl.py)."""
+    import numpy as np
+    return np.load(os.path.join(REPO, 'tests', 'golden', 'golden_rl.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
 def golden_refinit():
     import numpy as np
     return np.load(os.path.join(REPO, 'tests', 'golden', 'golden_refinit.npz'), allow_pickle=False)

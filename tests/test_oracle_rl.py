@@ -129,3 +129,111 @@ def test_dice_restatement_equals_the_literal_in_place_loop():
     assert torch.allclose(M @ lp, values)
     assert torch.allclose(g, M.t() @ k)
     assert M[0, n - 1] != 0                                                          # the wrap-around term is there
+
+
+# ------------------------------------------------------------------------------------ composition pinned to the reference's own lines
+import pytest                                                                    # noqa: E402
+import rl_cases                                                                  # noqa: E402
+
+
+def _flat(p):
+    return torch.cat([v.detach().reshape(-1) for v in (p.values() if hasattr(p, 'values') else p)]).numpy()
+
+
+def _close(a, b, tol=1e-9):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.max(np.abs(a - b)) <= tol * max(1.0, float(np.max(np.abs(b)))), float(np.max(np.abs(a - b)))
+
+
+@pytest.mark.parametrize('name', list(rl_cases.CASES))
+def test_composition_matches_the_reference(golden_rl, name, monkeypatch):
+    """oracle/rl_ref.py against tests/golden/golden_rl.npz = the REFERENCE's compute_advantages (rl.py:95-110), trpo_a2c_loss
+    (:346-358), trpo_update (:361-374), fast_adapt_trpo (:377-406), meta_surrogate_loss (:441-473), meta_optimize_trpo (:409-438)
+    executed in the build container with this oracle's leaf restatements standing in for cherry / learn2learn: every detach,
+    refit, mean, KL direction, step scaling and line-search test of those lines, to 1e-9 in fp64."""
+    g = golden_rl
+    case = rl_cases.load_case(g, name)
+    params, theta, replays, olds, act, anil = (case[k] for k in ('params', 'theta', 'replays', 'olds', 'activation', 'anil'))
+    pre = f'rl_{name}_f64'
+    leaf = lambda: OrderedDict((k, v.clone().requires_grad_(True)) for k, v in theta.items())
+
+    # rl.py:95-110
+    bl = RL.LinearValue(2, 2)
+    _close(RL.compute_advantages(bl, params['tau'], params['gamma'], replays[0][0]).numpy(), g[f'{pre}_adv_fit'])
+    _close(RL.compute_advantages(bl, params['tau'], params['gamma'], replays[0][-1], update_vf=False).numpy(), g[f'{pre}_adv_nofit'])
+    _close(bl.weight.numpy(), g[f'{pre}_vf_weight'], 1e-7)          # (normal equations: the solution itself is conditioned ~1e7)
+
+    # rl.py:346-374
+    p = leaf()
+    loss = RL.trpo_a2c_loss(replays[0][0], p, RL.LinearValue(2, 2), params['gamma'], params['tau'], activation=act)
+    _close([loss.item()], g[f'{pre}_inner_loss'])
+    _close(_flat(torch.autograd.grad(loss, list(p.values()))), g[f'{pre}_inner_grad'])
+    new = RL.trpo_update(replays[0][0], leaf(), RL.LinearValue(2, 2), params['inner_lr'], params['gamma'], params['tau'], first_order=True,
+                         activation=act)
+    _close(_flat(new), g[f'{pre}_adapted_theta'])
+
+    # rl.py:377-406 (head-only inner steps under anil; validation loss without a refit; success rate from the success flags)
+    n_q = replays[0][-1]['states'].shape[0]
+    has = bool(g[f'{pre}_fa_has_success'][0])
+    succ = rl_cases.success_flags(n_q) if has else None
+    if has:
+        assert np.array_equal(succ.numpy(), g[f'{pre}_fa_success_flags'])
+    adapted, vloss, rew, suc = RL.fast_adapt_trpo_replayed(replays[0], leaf(), RL.LinearValue(2, 2), params, first_order=True, activation=act,
+                                                           anil=anil, success=succ)
+    _close(_flat(adapted), g[f'{pre}_fa_theta'])
+    _close([vloss.item()], g[f'{pre}_fa_valid_loss'])
+    _close([rew, suc], g[f'{pre}_fa_reward_success'])
+    if anil:                                                         # the body did not move (rl.py:381-382 + allow_unused)
+        body = slice(2, 2 + 100 * 2 + 100 + 100 * 100 + 100)
+        assert np.array_equal(_flat(adapted)[body], _flat(theta)[body])
+
+    # rl.py:441-473 and the gradient of :413-416
+    p = leaf()
+    sl, kl = RL.meta_surrogate_loss(replays, olds, p, RL.LinearValue(2, 2), params, act)
+    _close([sl.item(), kl.item()], g[f'{pre}_surr_loss_kl'])
+    _close(_flat(torch.autograd.grad(sl, list(p.values()), retain_graph=True)), g[f'{pre}_surr_grad'])
+    cand = OrderedDict((k, (v.detach() + 0.01 * torch.sin(torch.arange(v.numel(), dtype=torch.float64)).view_as(v)).requires_grad_(True))
+                       for k, v in theta.items())
+    sl2, kl2 = RL.meta_surrogate_loss(replays, olds, cand, RL.LinearValue(2, 2), params, act)
+    _close([sl2.item(), kl2.item()], g[f'{pre}_surr_displaced_loss_kl'])
+
+    # rl.py:409-438: every Fisher-vector product (10 CG iterations + shs) and every evaluation of the line search
+    fin, fout, evals = [], [], []
+    hvp0, msl0 = RL.hessian_vector_product, RL.meta_surrogate_loss
+
+    def hvp_rec(loss_, ps_, **k):
+        f = hvp0(loss_, ps_, **k)
+        def call(v):
+            r = f(v)
+            fin.append(v.detach().clone())
+            fout.append(r.detach().clone())
+            return r
+        return call
+
+    def msl_rec(*a, **k):
+        l_, k_ = msl0(*a, **k)
+        evals.append((l_.item(), k_.item()))
+        return l_, k_
+    monkeypatch.setattr(RL, 'hessian_vector_product', hvp_rec)
+    monkeypatch.setattr(RL, 'meta_surrogate_loss', msl_rec)
+    p = leaf()
+    out = RL.meta_optimize_trpo(params, p, RL.LinearValue(2, 2), replays, olds, act)
+    tol = 1e-7 if anil else 1e-9        # (ANIL: ten CG iterations on the indefinite exact KL Hessian amplify the last bits ~1e3-fold)
+    assert len(fout) == int(g[f'{pre}_opt_n_fvp'][0]) == 11
+    assert (-1 if out['accepted'] is None else out['accepted']) == int(g[f'{pre}_opt_accepted'][0])
+    _close(np.array(evals), g[f'{pre}_opt_evals'], tol)
+    _close(np.array([[torch.dot(a, b).item(), b.norm().item()] for a, b in zip(fin, fout)]), g[f'{pre}_opt_fvp_dots'], tol)
+    _close(fout[0].numpy(), g[f'{pre}_opt_fvp_first'])
+    _close(fout[-1].numpy(), g[f'{pre}_opt_fvp_last'], tol)
+    _close(fin[-1].numpy(), g[f'{pre}_opt_cg_step'], tol)
+    _close(_flat(p), g[f'{pre}_opt_theta_new'], tol)
+
+
+def test_reference_fp32_run_is_recorded_next_to_its_fp64_run(golden_rl):
+    """What "fp32 parity" can mean on this path: the reference's OWN fp32 run against its fp64 run (advantages, inner gradient,
+    surrogate gradient, CG step, new parameters).  At config-5 size the fp32 normal equations of the baseline fit (features up to
+    t^3 = 8000) lose the advantages altogether; the HIP path fits in fp64 on the device and is held to the fp64 record."""
+    small = golden_rl['rl_small_relu_f32_rel_to_f64']
+    assert small[:3].max() < 1e-4
+    assert golden_rl['rl_cfg5_f32_rel_to_f64'][0] > 0.05
