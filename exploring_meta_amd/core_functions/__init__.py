@@ -6,4 +6,4 @@ from ..utils.data_pre import prepare_batch
 from .policies import DiagNormalPolicy, DiagNormalPolicyANIL
 from .rl import (fast_adapt_trpo, meta_optimize_trpo, meta_surrogate_loss, trpo_update, trpo_a2c_loss, fast_adapt_vpg, fast_adapt_ppo,
                  evaluate_vpg, evaluate_ppo, evaluate_trpo,
-                 compute_advantages, set_device, LinearValue, Particles2DRunner)
+                 compute_advantages, set_device, LinearValue, Particles2DRunner, Particles2DEnv, EnvRunner, get_ep_successes)

@@ -1,6 +1,8 @@
 """MAML-TRPO functions with the reference's names (core_functions/rl.py TRPO part, lines 95-110 and 346-473) on the batched
-HIP policy engine.  Replays are plain dicts of tensors (the reference uses cherry ExperienceReplay objects, out of scope):
-``states [N,S], actions [N,A], rewards [N,1], dones [N,1], next_states [N,S]`` with episodes concatenated.
+HIP policy engine.  Replays are either dicts of tensors ``states [N,S], actions [N,A], rewards [N,1], dones [N,1], next_states
+[N,S]`` (episodes concatenated; what this package's runners return) or any object with cherry ExperienceReplay's accessors
+``state() action() reward() done() next_state()`` (+ ``success()`` where the runner records it) -- what the reference's own call
+sites pass (rl.py:49-56, rl/maml_trpo.py:106-134); ``_as_replay`` reads either.
 Host side (tiny): discounting, the LinearValue least-squares baseline, GAE, normalisation.
 Device side: policy forward, the inner ``trpo_update``, the meta surrogate loss / KL, its gradient, and the Fisher-vector
 products inside conjugate gradient -- for ALL tasks of the meta-batch per call.
@@ -17,6 +19,54 @@ def set_device(dev):
     """reference rl.py:44-46"""
     global device
     device = dev
+
+
+# ---------------------------------------------------------------------------------------------- replays
+_ACCESSORS = (('states', 'state'), ('actions', 'action'), ('rewards', 'reward'), ('dones', 'done'), ('next_states', 'next_state'))
+
+
+def _as_replay(episodes):
+    """A replay as the dict the rest of this module reads.  Dicts pass through; an object with cherry ExperienceReplay's accessors
+    (reference rl.py:49-56 ``get_episode_values``: ``state() action() reward() done() next_state()``) is read ONCE into a ``Replay``
+    that is remembered on the object (``_mi_replay``), so the meta-step that walks the same replays again (rl.py:444-465) finds the same
+    tensors -- and the device addresses already checked for them.  ``success()`` (rl.py:59-72), where present, rides along."""
+    if isinstance(episodes, dict):
+        return episodes
+    memo = getattr(episodes, '_mi_replay', None)
+    if memo is not None:
+        return memo
+    try:
+        fields = {k: getattr(episodes, a)() for k, a in _ACCESSORS}
+    except AttributeError as e:
+        raise TypeError(f'a replay must be a dict of tensors or offer state() / action() / reward() / done() / next_state(): {e}') from None
+    n = fields['states'].shape[0]
+    fields['rewards'], fields['dones'] = fields['rewards'].reshape(n, 1), fields['dones'].reshape(n, 1)
+    suc = getattr(episodes, 'success', None)
+    if callable(suc):
+        fields['success'] = suc()
+    out = Replay(fields)
+    try:
+        episodes._mi_replay = out
+    except Exception:                                      # (objects without a __dict__: converted again next time)
+        pass
+    return out
+
+
+_warned_no_success = [False]
+
+
+def get_ep_successes(episodes, path_length):
+    """reference rl.py:59-72: the number of episodes of the replay with at least one success flag; ``success`` reshaped
+    (path_length, -1).T puts one episode per row (the reference's runner interleaves its workers' steps).  Without a success
+    record the reference prints 'No success metric registered!' and counts 0 -- here the notice is printed once per process."""
+    suc = _as_replay(episodes).get('success')
+    if suc is None:
+        if not _warned_no_success[0]:
+            _warned_no_success[0] = True
+            print('No success metric registered!')
+        return 0
+    suc = torch.as_tensor(suc).detach().reshape(path_length, -1).T
+    return int((suc == 1.).any(dim=1).sum().item())
 
 
 # ---------------------------------------------------------------------------------------------- host-side pieces (cherry semantics)
@@ -229,6 +279,10 @@ class Replay(dict):
         self._mi_pack = None
         return super().__ior__(other)
 
+    def __reduce_ex__(self, protocol):
+        # pickling (torch.save, multiprocessing) must not carry the remembered device ADDRESSES: the restored tensors live elsewhere
+        return (Replay, (dict(self),))
+
 
 def _device_batch_packed(replay_list, lens, B, S, A, dev):
     """_device_batch through mi_copy_segments, or None when a field is not a contiguous fp32 tensor on ``dev`` (the general path converts)."""
@@ -287,7 +341,7 @@ def _stacked_flat_parameters(policies, dev):
         dev = torch.device('cuda', torch.cuda.current_device())
     f32, didx = torch.float32, dev.index
     srcs, cnts, offs, P = [], [], [], None
-    for p in policies:
+    for row, p in enumerate(policies):
         off = 0
         for q in p._engine_params():
             if not (q.dtype is f32 and q.is_cuda and q.get_device() == didx and q.is_contiguous()):
@@ -295,15 +349,15 @@ def _stacked_flat_parameters(policies, dev):
             n = q.numel()
             srcs.append(q.data_ptr())
             cnts.append(n)
-            offs.append(off)
+            offs.append((row, off))                        # (the row travels with the segment: policies may split P differently)
             off += n
         if P is None:
             P = off
         elif off != P:
             return None
     out = torch.empty(len(policies), P, dtype=f32, device=dev)
-    base, per = out.data_ptr(), len(offs) // len(policies)
-    dsts = [base + 4 * ((i // per) * P + o) for i, o in enumerate(offs)]
+    base = out.data_ptr()
+    dsts = [base + 4 * (row * P + o) for row, o in offs]
     from ..engine import copy_segments
     copy_segments(srcs, dsts, cnts, cnts, dev)
     return out
@@ -365,13 +419,14 @@ def _pad(eps_list, advs, S, A, dev):
 # ---------------------------------------------------------------------------------------------- reference functions
 def trpo_a2c_loss(episodes, learner, baseline, gamma, tau, update_vf=True):
     """reference rl.py:346-358: -mean(log_prob * normalised advantages) (value only; the gradient path is trpo_update)."""
+    episodes = _as_replay(episodes)
     dev = learner.sigma.device
     if _gae_on_device(dev, learner.input_size, int(episodes['states'].shape[0])):
         b = _replay_on_device(episodes, baseline, gamma, tau, learner.input_size, learner.output_size, dev, update_vf=update_vf)
         lp = learner.log_prob(b['states'][0], b['actions'][0])
         return -(lp * b['adv'][0].reshape(-1, 1).to(lp)).mean()
     adv = _advantages(episodes, baseline, gamma, tau, update_vf)
-    lp = learner.log_prob(episodes['states'].to(device), episodes['actions'].to(device))
+    lp = learner.log_prob(episodes['states'].to(dev), episodes['actions'].to(dev))
     return -(lp * torch.from_numpy(adv).to(lp)).mean()
 
 
@@ -380,6 +435,7 @@ def trpo_update(episodes, learner, baseline, inner_lr, gamma, tau, anil=False, f
     second-order dependence on the original parameters is handled inside meta_optimize_trpo's fused calls)."""
     # anil only sets allow_unused (rl.py:371): which parameters move is decided by the policy's own switch -- with
     # DiagNormalPolicyANIL.turn_off_body_grads() the body's gradients are None and maml_update leaves it unchanged.
+    episodes = _as_replay(episodes)
     head_only = bool(getattr(learner, 'features_no_grad', False))
     eng = learner.engine()
     dev = learner.sigma.device
@@ -395,22 +451,25 @@ def trpo_update(episodes, learner, baseline, inner_lr, gamma, tau, anil=False, f
 
 
 def fast_adapt_trpo(task, learner, baseline, params, anil=False, first_order=False, render=False):
-    """reference rl.py:377-406.  ``task.run(policy, episodes=n)`` returns a replay dict."""
+    """reference rl.py:377-406.  ``task.run(policy, episodes=n)`` returns a replay (dict or cherry-style object, ``_as_replay``).
+    ``learner``: the policy itself or a ``MAML`` wrapper around it (rl/anil_trpo.py:84 wraps; rl.py:382,396 reach the policy as
+    ``learner.module``)."""
     task_replay = []
     if anil:                                                   # rl.py:381-382
-        learner.turn_off_body_grads()
+        _unwrap(learner).turn_off_body_grads()
     for step in range(params['adapt_steps']):
         support_episodes = task.run(learner, episodes=params['adapt_batch_size'])
         task_replay.append(support_episodes)
         learner = trpo_update(support_episodes, learner, baseline, params['inner_lr'], params['gamma'], params['tau'],
                               anil=anil, first_order=first_order)
     if anil:                                                   # rl.py:395-396
-        learner.turn_on_body_grads()
+        _unwrap(learner).turn_on_body_grads()
     query_episodes = task.run(learner, episodes=params['adapt_batch_size'])
     task_replay.append(query_episodes)
     valid_loss = trpo_a2c_loss(query_episodes, learner, baseline, params['gamma'], params['tau'], update_vf=False)
-    query_rew = query_episodes['rewards'].sum().item() / params['adapt_batch_size']
-    return learner, valid_loss, task_replay, query_rew, 0.0
+    query_rew = _as_replay(query_episodes)['rewards'].sum().item() / params['adapt_batch_size']                    # rl.py:403
+    query_success_rate = get_ep_successes(query_episodes, params['max_path_length']) / params['adapt_batch_size']  # rl.py:404
+    return learner, valid_loss, task_replay, query_rew, query_success_rate
 
 
 class _SurrogateContext:
@@ -419,6 +478,7 @@ class _SurrogateContext:
 
     def __init__(self, iter_replays, iter_policies, policy, baseline, params):
         S, A, dev = policy.input_size, policy.output_size, policy.sigma.device
+        iter_replays = [[_as_replay(r) for r in task] for task in iter_replays]
         K = len(iter_replays[0]) - 1
         if K < 1 or any(len(r) != K + 1 for r in iter_replays):
             raise ValueError('every task needs the same number (>= 1) of support replays plus one query replay')
@@ -696,7 +756,7 @@ def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order
         pol.turn_off_body_grads()
     support, sup_adv, current = [], [], pol
     for step in range(params['adapt_steps']):
-        ep = task.run(current, episodes=params['adapt_batch_size'])
+        ep = _as_replay(task.run(current, episodes=params['adapt_batch_size']))
         support.append(ep)
         sup_adv.append(adv_of(ep))
         # parameters after the updates so far (the rollouts of the next step / the query need them); value of the loss unused
@@ -705,7 +765,7 @@ def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order
         current.load_flat(theta_k)
     if anil:
         pol.turn_on_body_grads()
-    query = task.run(current, episodes=params['adapt_batch_size'])
+    query = _as_replay(task.run(current, episodes=params['adapt_batch_size']))
     need = torch.is_grad_enabled() and any(q.requires_grad for q in pol.parameters())
     lt, _, grad = _replay_meta(pol, support, sup_adv, query, adv_of(query), params['inner_lr'], kind, clip, epochs, anil, first_order, need)
     if need:
@@ -714,13 +774,14 @@ def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order
     else:
         valid_loss = lt[0]
     rew = query['rewards'].sum().item() / params['adapt_batch_size']
+    suc = get_ep_successes(query, params['max_path_length']) / params['adapt_batch_size']                          # rl.py:252,315
     # learn2learn's learner.adapt updates the learner in place; here the base module is shared by every clone, so the adapted
     # parameters are handed over on the side (evaluate() below acts with them)
     try:
         learner._adapted_policy = current
     except Exception:
         pass
-    return valid_loss, rew, 0.0
+    return valid_loss, rew, suc
 
 
 def fast_adapt_vpg(task, learner, baseline, params, anil=False, first_order=False, render=False, dice=False):
@@ -734,6 +795,7 @@ def fast_adapt_vpg(task, learner, baseline, params, anil=False, first_order=Fals
 def vpg_a2c_loss(episodes, learner, baseline, gamma, tau, dice=False):
     """reference rl.py:208-228, value only (the gradient path is the fused fast_adapt_vpg): -mean(log_prob * advantages), or with
     ``dice`` -mean(magic_box(weighted_cumsum(log_probs, weights)) * advantages) = -mean(advantages) (magic_box evaluates to 1)."""
+    episodes = _as_replay(episodes)
     adv = compute_advantages(baseline, tau, gamma, episodes['rewards'], episodes['dones'], episodes['states'], episodes['next_states'])
     adv_t = torch.from_numpy(adv).to(device=device, dtype=torch.float32)
     if dice:
@@ -747,15 +809,42 @@ def fast_adapt_ppo(task, learner, baseline, params, anil=False, render=False):
     return _adapt_and_validate(task, learner, baseline, params, 'ppo', anil, False)
 
 
-def evaluate(algo, goals, policy, baseline, params, anil=False, render=False, generator=None):
-    """reference rl.py:142-196 for Particles2D: adapt a copy of the policy to every evaluation task with `algo` in
-    {'vpg', 'ppo', 'trpo'}, then roll out `adapt_batch_size` query episodes with the adapted policy.
-    `goals`: the evaluation tasks (the reference draws env.sample_tasks(params['n_tasks'])).
+def _eval_tasks(env, params, goals):
+    """The evaluation tasks and a runner factory for them.  ``env`` as the reference passes it (rl.py:142-196: an environment NAME handed to
+    make_env, whose result offers ``sample_tasks / set_task / reset``): 'Particles2D-v1' (or any name containing 'Particles2D') builds this
+    package's ``Particles2DEnv``; an env-like object is used as it is -- ``Particles2DEnv`` through the device-vectorised
+    ``Particles2DRunner``, anything else through the host loop of ``EnvRunner``; a sequence of goals (this package's earlier signature, also
+    the ``goals=`` keyword) is taken as the task list itself."""
+    if goals is None and not isinstance(env, str) and not hasattr(env, 'sample_tasks'):
+        goals, env = env, None
+    if isinstance(env, str):
+        if 'Particles2D' not in env:
+            raise NotImplementedError(f'environment {env!r}: this package ships Particles2D (Meta-World / MuJoCo are out of scope); pass an '
+                                      'env-like object with sample_tasks / set_task / reset / step instead of a name')
+        env = Particles2DEnv(seed=params.get('seed', 42))
+    if goals is not None:
+        tasks = [{'goal': g} for g in goals]
+        env = env if env is not None else Particles2DEnv(seed=params.get('seed', 42))
+    else:
+        tasks = env.sample_tasks(params['n_tasks'])                                    # rl.py:162
+    return env, tasks
+
+
+def evaluate(algo, env, policy, baseline, params, anil=False, render=False, generator=None, goals=None):
+    """reference rl.py:142-196: adapt a copy of the policy to every evaluation task with `algo` in {'vpg', 'ppo', 'trpo'}, then roll out
+    `adapt_batch_size` query episodes with the adapted policy.  ``env``: see ``_eval_tasks`` (name, env-like, or the task goals).
     Returns (tasks_rewards, mean reward, mean success rate)."""
+    env, tasks = _eval_tasks(env, params, goals)
+    dev = _unwrap(policy).sigma.device
     tasks_rewards, tasks_success = [], []
-    for goal in goals:
+    for task_desc in tasks:
         learner = deepcopy(policy)
-        task = Particles2DRunner(goal, params['max_path_length'], generator, _unwrap(policy).sigma.device)
+        env.set_task(task_desc)                                                        # rl.py:166-167
+        env.reset()
+        if isinstance(env, Particles2DEnv):
+            task = Particles2DRunner(env.goal, params['max_path_length'], generator, dev)
+        else:
+            task = EnvRunner(env, params['max_path_length'], dev)
         with torch.no_grad():
             if algo == 'vpg':
                 fast_adapt_vpg(task, learner, baseline, params, anil=anil)
@@ -765,26 +854,28 @@ def evaluate(algo, goals, policy, baseline, params, anil=False, render=False, ge
                 adapted = learner._adapted_policy
             else:
                 adapted, _, _, _, _ = fast_adapt_trpo(task, _unwrap(learner), baseline, params, anil=anil)
-        query = task.run(adapted, episodes=params['adapt_batch_size'])
+        query = _as_replay(task.run(adapted, episodes=params['adapt_batch_size']))    # rl.py:181-184
         tasks_rewards.append(query['rewards'].sum().item() / params['adapt_batch_size'])
-        tasks_success.append(0.0)                             # Particles2D reports no success signal (extra_info only for Meta-World)
+        tasks_success.append(get_ep_successes(query, params['max_path_length']) / params['adapt_batch_size'])
     n = params.get('n_tasks', len(tasks_rewards))
+    if isinstance(n, str):                                                             # (rl.py:158-159: an explicit task name)
+        n = len(tasks_rewards)
     return tasks_rewards, sum(tasks_rewards) / n, sum(tasks_success) / n
 
 
-def evaluate_vpg(goals, policy, baseline, eval_params, anil=False, render=False, generator=None):
+def evaluate_vpg(env, policy, baseline, eval_params, anil=False, render=False, generator=None, goals=None):
     """reference rl.py:258-259"""
-    return evaluate('vpg', goals, policy, baseline, eval_params, anil, render, generator)
+    return evaluate('vpg', env, policy, baseline, eval_params, anil, render, generator, goals)
 
 
-def evaluate_ppo(goals, policy, baseline, eval_params, anil=False, render=False, generator=None):
+def evaluate_ppo(env, policy, baseline, eval_params, anil=False, render=False, generator=None, goals=None):
     """reference rl.py:340-341"""
-    return evaluate('ppo', goals, policy, baseline, eval_params, anil, render, generator)
+    return evaluate('ppo', env, policy, baseline, eval_params, anil, render, generator, goals)
 
 
-def evaluate_trpo(goals, policy, baseline, eval_params, anil=False, render=False, generator=None):
+def evaluate_trpo(env, policy, baseline, eval_params, anil=False, render=False, generator=None, goals=None):
     """reference rl.py:476-477"""
-    return evaluate('trpo', goals, policy, baseline, eval_params, anil, render, generator)
+    return evaluate('trpo', env, policy, baseline, eval_params, anil, render, generator, goals)
 
 
 # ---------------------------------------------------------------------------------------------- Particles2D rollouts (host loop, device math)
@@ -820,3 +911,72 @@ class Particles2DRunner:
         keep = M.reshape(-1)
         flat = lambda x: x.reshape(E * L, -1)[keep]
         return Replay(states=flat(S), actions=flat(A), rewards=flat(R), dones=flat(D), next_states=flat(NS))
+
+
+class Particles2DEnv:
+    """learn2learn's Particles2D as the reference's drivers use it (rl/maml_trpo.py:100-108: ``sample_tasks / set_task / reset``; out of
+    scope as a dependency): state in R^2 from the origin, goal ~ U(-0.5, 0.5)^2, action clipped to +-0.1,
+    reward = -||state - goal||_2, done when both |state - goal| < 0.01.  Episodes are rolled out on the device by ``Particles2DRunner``
+    (``runner()``); ``step`` is the same arithmetic one step at a time on the host, for callers that drive the env themselves."""
+    state_size, action_size = 2, 2
+
+    def __init__(self, seed=42):
+        self.rng = np.random.RandomState(seed)
+        self.goal = np.zeros(2, dtype=np.float32)
+        self.state = np.zeros(2, dtype=np.float32)
+
+    def sample_tasks(self, num_tasks):
+        return [{'goal': g} for g in self.rng.uniform(-0.5, 0.5, size=(num_tasks, 2))]
+
+    def set_task(self, task):
+        self.goal = np.asarray(task['goal'], dtype=np.float32)
+
+    def reset(self):
+        self.state = np.zeros(2, dtype=np.float32)
+        return self.state.copy()
+
+    def step(self, action):
+        self.state = self.state + np.clip(np.asarray(action, dtype=np.float32).reshape(2), -0.1, 0.1)
+        diff = self.state - self.goal
+        return self.state.copy(), -float(np.sqrt((diff * diff).sum())), bool((np.abs(diff) < 0.01).all()), {}
+
+    def runner(self, max_path_length, generator=None, dev=None):
+        return Particles2DRunner(self.goal, max_path_length, generator, dev)
+
+
+class EnvRunner:
+    """``task.run(policy, episodes=n)`` for ANY env-like object (``reset() -> state``, ``step(action) -> (state, reward, done, info)``):
+    the host loop of the reference's core_functions/runner.py for one environment, the policy evaluated on the device one state at a
+    time.  ``info['success']`` (Meta-World's signal, runner.py's ``extra_info``) is recorded as the replay's ``success`` when present.
+    Slow by construction (an environment step per policy call); Particles2D has its own vectorised runner."""
+
+    def __init__(self, env, max_path_length, dev=None):
+        self.env, self.max_path_length, self.dev = env, max_path_length, dev or device
+
+    def run(self, policy, episodes, render=False):
+        S, A, R, D, NS, SU = [], [], [], [], [], []
+        any_success = False
+        for _ in range(episodes):
+            state = np.asarray(self.env.reset(), dtype=np.float32).reshape(-1)
+            for t in range(self.max_path_length):
+                st = torch.from_numpy(state).to(self.dev).reshape(1, -1)
+                action = policy(st)[0]
+                nxt, reward, done, info = self.env.step(action.detach().cpu().numpy())
+                nxt = np.asarray(nxt, dtype=np.float32).reshape(-1)
+                last = bool(done) or t == self.max_path_length - 1
+                S.append(st[0]); A.append(action.detach().float()); R.append(float(reward)); D.append(1.0 if last else 0.0)
+                NS.append(torch.from_numpy(nxt).to(self.dev))
+                if isinstance(info, dict) and 'success' in info:
+                    any_success = True
+                    SU.append(float(info['success']))
+                else:
+                    SU.append(0.0)
+                state = nxt
+                if done:
+                    break
+        col = lambda x: torch.tensor(x, dtype=torch.float32, device=self.dev).reshape(-1, 1)
+        out = Replay(states=torch.stack(S).contiguous(), actions=torch.stack(A).contiguous(), rewards=col(R), dones=col(D),
+                     next_states=torch.stack(NS).contiguous())
+        if any_success:
+            out['success'] = col(SU)
+        return out

@@ -208,6 +208,30 @@ def test_trpo_path_matches_the_reference_records(golden_rl, name):
     assert out['accepted'] == int(G('opt_accepted')[0]) and et < 5e-3
 
 
+def test_cherry_style_replay_objects_take_the_same_path_as_dicts():
+    """Replays as objects with cherry ExperienceReplay's accessors over CUDA tensors (what the reference's call sites hand over,
+    rl.py:49-56) against the same replays as dicts: bit-identical step, same packed device batch (the object is read once)."""
+    theta, replays, olds = _replays()
+
+    class Episodes:
+        def __init__(self, d): self._d = {k: v.float().cuda().contiguous() for k, v in d.items()}
+        def state(self): return self._d['states']
+        def action(self): return self._d['actions']
+        def reward(self): return self._d['rewards']
+        def done(self): return self._d['dones']
+        def next_state(self): return self._d['next_states']
+    objs = [[Episodes(r) for r in task] for task in replays]
+    dicts = [[dict(e._d) for e in task] for task in objs]
+    outs = []
+    for reps in (objs, dicts):
+        pol = _policy(theta)
+        out = cf.meta_optimize_trpo(PARAMS, pol, cf.LinearValue(2, 2), reps, [_policy(o) for o in olds])
+        outs.append((out['accepted'], out['step'].clone(), pol.flat().clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    from exploring_meta_amd.core_functions.rl import _as_replay, Replay
+    assert type(_as_replay(objs[0][0])) is Replay and _as_replay(objs[0][0]) is _as_replay(objs[0][0])
+
+
 def test_runner_and_fast_adapt_trpo_shapes():
     pol = _policy(_theta64())
     gen = torch.Generator(device='cuda').manual_seed(0)
