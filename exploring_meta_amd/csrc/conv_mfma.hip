@@ -1252,16 +1252,25 @@ int conv_max_blocks_per_task(const ConvGeom& g) {  // tiles_per_wave == 1 is the
   return ceil_div(ceil_div(g.n * g.ho * g.wo, 30), 4);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for kernels that stage more than 64 KB, once per (kernel, device): a process that drives a
+// second GPU launches that device's copy of the kernel, which needs the attribute too.
+static inline hipError_t ensure_dynamic_lds(const void* k, size_t lds, unsigned* done_mask) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  const unsigned bit = 1u << (dev & 31);
+  if (*done_mask & bit) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+  *done_mask |= bit;
+  return hipSuccess;
+}
+
 template <int CI, int NTERMS, int EPI, int MODE, int STRIDE>
 static hipError_t launch_conv_t(hipStream_t st, ConvArgs& a, dim3 grid) {
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);
   auto k = conv3x3_mfma_kernel<CI, NTERMS, EPI, MODE, STRIDE>;
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static unsigned attr_done = 0;             // one bit per device: the attribute belongs to the device's copy of the kernel
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, &attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS>::value * 64), lds, st, a);
   return hipGetLastError();
 }
@@ -1269,12 +1278,8 @@ template <int CI, int NTERMS, int EPI, int MODE, bool F16>
 static hipError_t launch_conv_s1_bf(hipStream_t st, ConvArgs& a, dim3 grid) {
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * (F16 ? 4 : 6) + (F16 ? 64 : 0);   // three bf16 planes / two fp16 planes + the weight maxima
   auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE, true, F16>;
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static unsigned attr_done = 0;             // one bit per device: the attribute belongs to the device's copy of the kernel
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, &attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS, true, F16>::value * 64), lds, st, a);
   return hipGetLastError();
 }
@@ -1283,12 +1288,8 @@ template <int CI, int NTERMS, int EPI, int MODE>
 static hipError_t launch_conv_s1_b16(hipStream_t st, ConvArgs& a, dim3 grid) {
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * 6;
   auto k = conv3x3_s1_b16_kernel<CI, NTERMS, EPI, MODE>;
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static unsigned attr_done = 0;             // one bit per device: the attribute belongs to the device's copy of the kernel
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, &attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS, true, false>::value * 64), lds, st, a);
   return hipGetLastError();
 }
@@ -1328,12 +1329,8 @@ static hipError_t launch_conv_s1(hipStream_t st, ConvArgs& a, dim3 grid) {
   }
   const size_t lds = (size_t)NTERMS * 9 * CI * 32 * sizeof(float);
   auto k = conv3x3_s1_mfma_kernel<CI, NTERMS, EPI, MODE>;
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static unsigned attr_done = 0;             // one bit per device: the attribute belongs to the device's copy of the kernel
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, &attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, dim3(ConvWaves<CI, NTERMS>::value * 64), lds, st, a);
   return hipGetLastError();
 }

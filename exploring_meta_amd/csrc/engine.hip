@@ -755,7 +755,8 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     }
     wa.g = geom(L, n);
     wa.mpix = mpix;
-    // The weight gradients of the hidden blocks run on the side stream beside the dgrad chain.  One fork per PASS (default): they are held
+    // The weight gradients of the hidden blocks run on the side stream beside the dgrad chain.  One fork per BLOCK is the default
+    // (fork_once = false); with one fork per PASS (mi_engine_set_overlap(e, 3); measured slower, profiles/r5/overlap_fork_ab.txt) they are held
     // back until the last hidden block's dz exists and then issued together -- they overlap that block's dgrad and block 1's kernels --
     // because every fork is an event record on the caller's stream, which idles it for ~7 us (tools/launch_floor.py: 25 such gaps per
     // meta-iteration with one fork per block, at every task count; profiles/r5/launch_floor_cfg2_T*.txt).
@@ -1387,7 +1388,7 @@ static int meta_batch_entry(MetaBatchFn fn, int which, mi_engine* e, void* strea
       (unsigned long long)shots, (unsigned long long)adapt_steps, (unsigned long long)lr_bits, (unsigned long long)second_order,
       (unsigned long long)with_grad, (unsigned long long)(uintptr_t)loss_out, (unsigned long long)(uintptr_t)acc_out,
       (unsigned long long)(uintptr_t)meta_grad_out, (unsigned long long)(uintptr_t)logits_out, (unsigned long long)(uintptr_t)workspace,
-      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 256ull * kernel_selection_key()};
+      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 64ull * e->fork_once + 256ull * kernel_selection_key()};
   mi_engine::GraphEntry* ent = nullptr;
   for (auto& g : e->graphs)
     if (g.key == key) { ent = &g; break; }

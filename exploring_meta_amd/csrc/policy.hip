@@ -372,6 +372,7 @@ struct mi_policy {
   size_t o_sigma, o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, P;
   std::string err;
   unsigned* fold_counters = nullptr;   // device, one per 256-parameter block: arrival counters of the fold that also takes the mean over tasks
+  bool fold_dirty = false;             // a counted fold was issued and not seen to launch cleanly: re-zero the counters before the next one
                                        // (policy_sweep.h FoldArgs::counter; zero between launches).  Allocated at the first fused product.
 };
 static thread_local std::string g_perr;
@@ -862,8 +863,14 @@ static int fused_fvp(mi_policy* p, hipStream_t st, TrpoPlan& pl, int T, int B, c
     else PCHK(p, hipMemsetAsync(p->fold_counters, 0, nb, st));
   }
   if (p->fold_counters) {                // the mean over tasks + damping v by the last workgroup of every parameter block: no launch of its own
+    // The protocol needs the counters at zero when the fold starts; its last workgroup leaves them at zero.  A fold whose launch was
+    // refused leaves the flag set, and the next product re-zeroes (stream-ordered, 4 * ceil(P / 256) bytes) instead of waiting for a
+    // "last" workgroup that can no longer exist.  One stream per mi_policy at a time (include/mi_maml.h).
+    if (p->fold_dirty) PCHK(p, hipMemsetAsync(p->fold_counters, 0, (size_t)ceil_div(P, 256) * sizeof(unsigned), st));
+    p->fold_dirty = true;
     f.counter = p->fold_counters; f.mean_out = out; f.inv_T = 1.f / (float)T;
     PCHK(p, launch_policy_sweep_fold(st, f, T));
+    p->fold_dirty = false;
     return MI_OK;
   }
   PCHK(p, launch_policy_sweep_fold(st, f, T));
