@@ -468,7 +468,7 @@ def fast_adapt_trpo(task, learner, baseline, params, anil=False, first_order=Fal
     task_replay.append(query_episodes)
     valid_loss = trpo_a2c_loss(query_episodes, learner, baseline, params['gamma'], params['tau'], update_vf=False)
     query_rew = _as_replay(query_episodes)['rewards'].sum().item() / params['adapt_batch_size']                    # rl.py:403
-    query_success_rate = get_ep_successes(query_episodes, params['max_path_length']) / params['adapt_batch_size']  # rl.py:404
+    query_success_rate = get_ep_successes(query_episodes, params.get('max_path_length')) / params['adapt_batch_size']  # rl.py:404
     return learner, valid_loss, task_replay, query_rew, query_success_rate
 
 
@@ -774,7 +774,7 @@ def _adapt_and_validate(task, learner, baseline, params, algo, anil, first_order
     else:
         valid_loss = lt[0]
     rew = query['rewards'].sum().item() / params['adapt_batch_size']
-    suc = get_ep_successes(query, params['max_path_length']) / params['adapt_batch_size']                          # rl.py:252,315
+    suc = get_ep_successes(query, params.get('max_path_length')) / params['adapt_batch_size']                          # rl.py:252,315
     # learn2learn's learner.adapt updates the learner in place; here the base module is shared by every clone, so the adapted
     # parameters are handed over on the side (evaluate() below acts with them)
     try:
@@ -856,7 +856,7 @@ def evaluate(algo, env, policy, baseline, params, anil=False, render=False, gene
                 adapted, _, _, _, _ = fast_adapt_trpo(task, _unwrap(learner), baseline, params, anil=anil)
         query = _as_replay(task.run(adapted, episodes=params['adapt_batch_size']))    # rl.py:181-184
         tasks_rewards.append(query['rewards'].sum().item() / params['adapt_batch_size'])
-        tasks_success.append(get_ep_successes(query, params['max_path_length']) / params['adapt_batch_size'])
+        tasks_success.append(get_ep_successes(query, params.get('max_path_length')) / params['adapt_batch_size'])
     n = params.get('n_tasks', len(tasks_rewards))
     if isinstance(n, str):                                                             # (rl.py:158-159: an explicit task name)
         n = len(tasks_rewards)
