@@ -358,6 +358,57 @@ def run_vision(args, wl, rank, world, local, dist):
         if not wl.get('anil'):
             del tv
 
+    # Sampled leg: every step DRAWS its meta-batch -- learn2learn TaskDataset semantics (NWays / KShots(2 * shots) /
+    # RemapLabels / ConsecutiveLabels, utils/data_pre.py:70-112; the reference calls tasks.sample() per task on the host, maml_vision.py:103) --
+    # from a dataset resident in HBM: the host draws image indices, one mi_sample_tasks launch gathers the pixels, then the same step.
+    sampled = None
+    if not args.no_sampled and not wl.get('anil') and wl['dataset'] == 'min':
+        from exploring_meta_amd.utils.task_sampler import ResidentDataset, TaskSampler
+        k2 = 2 * wl['shots']
+        imgs = torch.cat([d.reshape(-1, *d.shape[2:]) for d, _ in pool[:2]])          # [batches * T * 2SW, C, H, W]: class c = (batch, task, way)
+        cls = np.repeat(np.arange(imgs.shape[0] // k2), k2)
+        sampler = TaskSampler(ResidentDataset(imgs, cls, device=imgs.device), wl['ways'], wl['shots'], seed=1234 + rank)
+        draw = {'host_s': 0.0}
+
+        def compute_sampled(th, _task_ids):
+            t_h = time.perf_counter()
+            index, lab, rot = sampler.sample_indices(T)
+            draw['host_s'] += time.perf_counter() - t_h
+            d = sampler.gather(index, rot)
+            l = torch.from_numpy(lab).to(d.device)
+            loss, acc, grad, _ = run_batch(th, d, l, wl['shots'], wl['steps'], wl['lr'], first_order=wl['first_order'])
+            return loss, acc, grad
+
+        trainer_smp = MetaTrainer(compute_sampled, adam_fn, global_T)
+        keep_theta, keep_adam = theta.clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in adam.items()}
+        for _ in range(2):
+            trainer_smp.step(theta)
+        draw['host_s'] = 0.0
+        nsm = max(3, min(10, args.steps))
+        fence()
+        t_s0 = time.perf_counter()
+        for _ in range(nsm):
+            sl, sa, _ = trainer_smp.step(theta)
+        fence()
+        d_sm = (time.perf_counter() - t_s0) / nsm
+        if dist is not None:
+            tm = torch.tensor([d_sm], device='cuda', dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            d_sm = tm.item()
+        sampled = {'metric': 'tasks/sec with the meta-batch drawn every step from a resident dataset', 'value': round(global_T / d_sm, 2),
+                   'ms_per_step': round(d_sm * 1e3, 3), 'steps': nsm, 'host_index_draw_ms_per_step': round(draw['host_s'] / nsm * 1e3, 3),
+                   'dataset': f'{imgs.shape[0]} images in {imgs.shape[0] // k2} classes ({k2} per class), fp32, resident in HBM',
+                   'how': 'TaskSampler.sample_indices on the host (numpy), mi_sample_tasks gathers [T, 2*shots*ways, C, H, W] on the device, '
+                          'then the step of the timed region (fused call, all-reduce, Adam)',
+                   'query_acc_mean_last_step': round(float(sa), 5)}
+        theta.copy_(keep_theta)
+        for k, v in keep_adam.items():
+            if torch.is_tensor(v):
+                adam[k].copy_(v)
+            else:
+                adam[k] = v
+        del imgs, sampler, trainer_smp
+
     hbm_copy_gbps = measure_stream_copy(eng)
     collective = collective_record(dist, world, theta, eng.param_count + 2 * T,
                                    'one in-place all-reduce per meta-iteration of [meta-gradient | per-task losses | accuracies]')
@@ -542,7 +593,7 @@ def run_vision(args, wl, rank, world, local, dist):
                    'shots': wl['shots'], 'adapt_steps': wl['steps'], 'inner_lr': wl['lr'],
                    'second_order': not wl['first_order'], 'parallelism': f'task-sharded dp{world}, 1 all-reduce/iter',
                    'task_hardness': HARDNESS[wl['dataset']]},
-        'post_adapt': post, 'secondary': secondary, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline,
+        'post_adapt': post, 'secondary': secondary, 'sampled': sampled, 'hbm_stream_copy_GBps': round(hbm_copy_gbps, 1), 'roofline': roofline,
         'cpu_baseline': cpu, 'collective': collective, 'arithmetic': arithmetic_note(eng, T), 'fp32_pipe': fp32_pipe, 'fp16_planes': fp16_planes, 'strong_scaling': strong, 'clock': clock,
     }
 
@@ -562,6 +613,13 @@ def clock_record(step, world, seconds=3.0, ms_per_step=None):
     if 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
         return None
     samples, t_end = [], time.perf_counter() + seconds
+    torch.cuda.synchronize()
+    n_steps, t_loop = [0], time.perf_counter()
+    step_inner = step
+
+    def step():                                              # (counted: the loop below is also the line's `sustained` figure)
+        step_inner()
+        n_steps[0] += 1
     try:
         while time.perf_counter() < t_end:
             with subprocess.Popen(['rocm-smi', '-c', '-P'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) as p:
@@ -582,6 +640,7 @@ def clock_record(step, world, seconds=3.0, ms_per_step=None):
     except OSError:
         pass
     torch.cuda.synchronize()
+    loop_s = time.perf_counter() - t_loop
     samples = samples[1:] or samples                     # the first sample may still see the clock ramp
     if not samples:
         return None
@@ -590,7 +649,10 @@ def clock_record(step, world, seconds=3.0, ms_per_step=None):
     power = sorted(watts)[len(watts) // 2] if watts else None
     return {'sclk_mhz': sclk, 'nominal_mhz': 2400, 'socket_power_w': power,
             'joules_per_step': (round(power * ms_per_step * 1e-3, 3) if power and ms_per_step else None),    # at the cap, time follows energy
-            'samples': len(samples), 'how': 'rocm-smi -c -P while the step loop runs, after the timed region'}
+            'samples': len(samples), 'how': 'rocm-smi -c -P while the step loop runs, after the timed region',
+            # the same step loop over >= 3 s (an observer that samples the GPU every few seconds sees this leg; the headline's timed region is the
+            # K steps the command line asks for)
+            'sustained': {'steps': n_steps[0], 'seconds': round(loop_s, 3), 'ms_per_step': round(loop_s / max(1, n_steps[0]) * 1e3, 3)}}
 
 
 def arithmetic_note(eng, tasks_per_call=32):
@@ -815,6 +877,30 @@ def cpu_baseline_trpo(p, policy, theta0, replays, olds, gpu_out):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def other_workloads(current, steps=5, warmup=2):
+    """The other BASELINE configurations, 5 timed steps each in a child process of this run (same box, same build, after the headline's timed
+    region): {ms_per_step, tasks_per_s, the dominant kernel's roofline fraction}.  The headline's `value` is untouched by this."""
+    import subprocess
+    out = {}
+    for name in sorted(WORKLOADS):
+        if name == current:
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--steps', str(steps), '--warmup', str(warmup), '--pool', '2',
+               '--no-cpu-baseline', '--no-fp32-pipe', '--no-secondary', '--no-clock', '--no-dist', '--no-other', '--no-sampled']
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=150, env=env)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf = d.get('roofline') or {}
+            out[name] = {'workload': d['config']['workload'], 'ms_per_step': d['ms_per_step'], 'tasks_per_s': d['value'], 'steps': d['steps'],
+                         'roofline': {'kernel': rf.get('kernel'), 'bound': rf.get('bound'), 'frac': rf.get('frac'), 'avg_launch_ms': rf.get('avg_launch_ms')},
+                         'wall_s': round(time.perf_counter() - t0, 1)}
+        except Exception as e:                               # a failed side run must not take the headline with it
+            out[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -835,6 +921,8 @@ def main():
                     'kernels with twice the tasks, which a per-kernel counter table cannot tell from the timed workload)')
     ap.add_argument('--no-fp32-pipe', action='store_true', help='skip the fp32-pipe leg (counter passes: only the shipped operand form is launched)')
     ap.add_argument('--no-dist', action='store_true', help='N = 1 without the single-rank process group (profiler runs)')
+    ap.add_argument('--no-sampled', action='store_true', help='skip the leg that draws every step\'s meta-batch with mi_sample_tasks from a resident dataset')
+    ap.add_argument('--no-other', action='store_true', help='skip the short runs of the other BASELINE configurations (N = 1 only; child processes)')
     ap.add_argument('--launch-check', action='store_true', help='ranks only join the process group, all-reduce one number and rank 0 prints '
                     '{"launch_check": true, "world_size": N}: exercises the self-launch path without a GPU (MI_DIST_BACKEND=gloo)')
     args = ap.parse_args()
@@ -878,6 +966,8 @@ def main():
             dist, dist_note = None, f'single-rank process group failed: {type(e).__name__}: {e}'
     runner = run_trpo if wl.get('kind') == 'trpo' else run_vision
     line = runner(args, wl, rank, world, local, dist)
+    if rank == 0 and world == 1 and line is not None and not args.no_other and not profiled and not args.tasks:
+        line['other_workloads'] = other_workloads(args.workload)
     if rank == 0:
         if dist_note and line is not None:
             line['collective'] = {'error': dist_note}

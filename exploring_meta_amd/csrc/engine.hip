@@ -53,6 +53,9 @@ struct mi_engine {
   // gram_wgrad + axpy + gram_stats launches and a memset per pass.  Same arithmetic in the same order: bit-identical results.
   bool bred_arg = true;     // block 2's dgrad epilogue reads block 1's argmax byte instead of p (MI_BRED_ARG=0: p, for A/B runs; same results)
   bool fuse_tail = true;
+  // the last ConvBlock's BatchNorm + pooling, the head, its backward and that block's BatchNorm backward as ONE launch with one workgroup per
+  // task (tail.hip) instead of five launches per pass (MI_FUSE_LAST=0 / mi_engine_set_fused_last_block(e, 0): the separate launches)
+  bool fuse_last = !(getenv("MI_FUSE_LAST") && atoi(getenv("MI_FUSE_LAST")) == 0);
   unsigned zoff[10] = {}, zlen[10] = {};   // conv-bias segments and the padding P..PS of a parameter-shaped vector (never written by a kernel)
   int nzero = 0;
   unsigned* counters = nullptr;
@@ -277,6 +280,16 @@ extern "C" int mi_engine_set_graph(mi_engine* e, int on) {
 extern "C" int mi_engine_set_fused_tail(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->fuse_tail = on != 0;
+  return MI_OK;
+}
+
+// Ablation / test switch: 1 (default) = the last block's BatchNorm + pooling, the head, its backward and that block's BatchNorm backward (or
+// their tangents) in one launch with one workgroup per task (tail.hip); 0 = the five separate launches per pass.  Same stage bodies: p,
+// logits, loss, accuracy, the head's gradients and df are bit-identical; the BatchNorm-backward sums are the same fp64 terms folded in a
+// different (fixed) order.
+extern "C" int mi_engine_set_fused_last_block(mi_engine* e, int on) {
+  if (!e) return MI_ERR_ARG;
+  e->fuse_last = on != 0;
   return MI_OK;
 }
 
@@ -618,9 +631,18 @@ static B1Args b1_args(const mi_engine* e, Plan& pl, ActSet& A, const float* x0, 
     if (_crc) return _crc;                                                         \
   } while (0)
 
+// The one-launch tail (tail.hip) serves a generic last block (not the conv-recompute block 1) feeding a flattened head, outside the fp16
+// operand form (its producers would have to fold largest-magnitude cells).
+static bool fused_last_ok(const mi_engine* e, const Plan& pl, int n) {
+  const int nl = (int)e->L.size();
+  if (!e->fuse_last || e->d.head_mean_pool || pl.f16 || (nl == 1 && e->fuse1)) return false;
+  return tail_supported(n, e->L[nl - 1].co, e->d.ways);
+}
+
 // Trunk forward: ConvBlocks on n images per task (conv + BN-stat epilogue, finalize, BN+ReLU+pool).
+// skip_last_bn: the last block's BatchNorm + pooling belongs to the caller's tail launch.
 static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
-                         const double* gram = nullptr, bool stats_ready = false) {
+                         const double* gram = nullptr, bool stats_ready = false, bool skip_last_bn = false) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   for (int l = 0; l < nl; ++l) {
@@ -659,6 +681,7 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
     LAUNCH(e, st, OP_CONV_FWD, l, launch_conv3x3(st, ca, T, 1, EPI_STATS, 0, &blk));
     if (!ca.fin.counter)
       LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)ca.mpix, FIN_STATS, A.mu[l], L.co, A.rstd[l], L.co));
+    if (skip_last_bn && l == nl - 1) break;
     BnArgs ba{};
     ba.z = A.z[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
@@ -683,8 +706,9 @@ static void adv_add_seg(AdvanceArgs* adv, size_t off, int nelem, const float* pa
   AdvanceSeg& sg = adv->seg[adv->nseg++];
   sg.off = (unsigned)off; sg.nelem = (unsigned)nelem; sg.partial = partial; sg.nchunks = nchunks;
 }
+// last_bn_done: the caller's tail launch already formed the last block's dgamma / dbeta and dz.
 static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
-                          float* g, const double* gram = nullptr, AdvanceArgs* adv = nullptr) {
+                          float* g, const double* gram = nullptr, AdvanceArgs* adv = nullptr, bool last_bn_done = false) {
   const int nl = (int)e->L.size();
   const size_t P = e->PS;
   bool forked = false, red_done[9] = {false, false, false, false, false, false, false, false, false};
@@ -736,7 +760,8 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
-    if (!red_done[l]) {
+    const bool bn_done = last_bn_done && l == nl - 1;
+    if (!red_done[l] && !bn_done) {
       ba.fin = fin_of(e, T, 1.0, FIN_SUMS, g + L.off_gamma, P, g + L.off_beta, P);
       LAUNCH(e, st, OP_BN_BWD_REDUCE, l, launch_bn_bwd_reduce(st, ba, T, L.pool, &blk));
       if (!ba.fin.counter)
@@ -744,8 +769,10 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     }
     ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
     ba.out = A.dz[l];
-    ba.amax_out = cell_bind(e, pl, ba.out);
-    LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
+    if (!bn_done) {
+      ba.amax_out = cell_bind(e, pl, ba.out);
+      LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
+    }
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = A.dz[l];
@@ -868,12 +895,38 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
                         const double* gram = nullptr, AdvanceArgs* adv = nullptr, bool stats_ready = false, int Tb = -1) {
   const int nl = (int)e->L.size();
   if (Tb < 0) Tb = T;
-  int rc = trunk_forward(e, st, pl, A, x0, n, T, theta, gram, stats_ready);
+  const bool fused_last = fused_last_ok(e, pl, n);
+  int rc = trunk_forward(e, st, pl, A, x0, n, T, theta, gram, stats_ready, fused_last);
   if (rc) return rc;
   rc = export_bn_stats(e, st, A, T);
   if (rc) return rc;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean(st, A.p[nl - 1], A.f, T * n, e->head_hw, e->head_c));
   if (with_grad && !adv) HIPCHK(e, hipMemsetAsync(g, 0, (size_t)T * e->PS * sizeof(float), st));
+  if (fused_last) {   // the last block's BatchNorm + pooling, the head, its backward and that block's BatchNorm backward: one launch (tail.hip)
+    const Layer& L = e->L[nl - 1];
+    const size_t P = e->PS;
+    TailArgs ta{};
+    BnArgs& ba = ta.bn;
+    ba.z = A.z[nl - 1]; ba.mu = A.mu[nl - 1]; ba.rstd = A.rstd[nl - 1];
+    ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
+    ba.dp = A.dp[nl - 1]; ba.out = A.dz[nl - 1];
+    ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
+    ba.inv_m = 1.f / (float)(n * L.ho * L.wo);
+    HeadArgs& ha = ta.hd;
+    ha.f = A.f;
+    ha.wl = theta + e->off_wl; ha.bl = theta + e->off_bl; ha.pstride = P;
+    ha.y = y; ha.loss = loss; ha.acc = acc; ha.logits = logits; ha.prob = A.prob; ha.dl = A.dl;
+    ha.dwl = with_grad ? g + e->off_wl : nullptr; ha.dbl = with_grad ? g + e->off_bl : nullptr; ha.gstride = P;
+    ha.df = with_grad ? A.df : nullptr;
+    ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
+    head_scratch(e, ha, pl.hscr, T, n);
+    ta.pooled = A.p[nl - 1];
+    ta.sum0 = with_grad ? g + L.off_gamma : nullptr; ta.sum1 = with_grad ? g + L.off_beta : nullptr; ta.sum_stride = P;
+    ta.with_grad = with_grad ? 1 : 0; ta.bwd_tasks = Tb;
+    LAUNCH(e, st, OP_HEAD, 0, launch_tail(st, ta, T, L.pool, 0));
+    if (!with_grad || Tb == 0) return MI_OK;
+    return trunk_backward(e, st, pl, A, x0, n, Tb, theta, g, gram, adv, true);
+  }
   rc = head_pass(e, st, pl.hscr, A.f, y, n, T, theta, g, loss, acc, logits, A.prob, A.dl, A.df, with_grad);
   if (rc || !with_grad || Tb == 0) return rc;
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, A.df, A.dp[nl - 1], Tb * n, e->head_hw, e->head_c));
@@ -889,6 +942,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   TanSet& X = pl.tan;
+  const bool fused_last = !dl_fixed && !ld_out && fused_last_ok(e, pl, n);   // tangent tail in one launch (tail.hip)
   if (!adv) HIPCHK(e, hipMemsetAsync(hv, 0, (size_t)T * P * sizeof(float), st));
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
@@ -940,6 +994,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     LAUNCH(e, st, OP_TAN_CONV, l, launch_conv3x3(st, ca, T, l > 0 ? 2 : 1, EPI_TSTATS, 0, &blk));
     if (!ca.fin.counter)
       LAUNCH(e, st, OP_BN_FINALIZE, l, launch_bn_finalize(st, pl.bnpart, blk, T, L.co, 1.0 / (double)mpix, FIN_TSTATS, X.m1[l], L.co, X.m2[l], L.co));
+    if (fused_last && l == nl - 1) break;
     BnArgs ba{};
     ba.z = A.z[l]; ba.zd = X.zd[l]; ba.mu = A.mu[l]; ba.rstd = A.rstd[l]; ba.m1 = X.m1[l]; ba.m2 = X.m2[l];
     ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
@@ -968,7 +1023,25 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   ha.df = e->d.head_mean_pool ? X.rdf : X.dpd[cur];
   ha.n = n; ha.feat = e->feat; ha.ways = e->d.ways;
   head_scratch(e, ha, pl.hscr, T, n);
-  LAUNCH(e, st, OP_HEAD_TAN, 0, launch_head_tangent(st, ha, T));
+  if (fused_last) {   // tangent of the last block's BatchNorm + pooling, the head's tangent and the tangent of that block's BatchNorm backward
+    const Layer& L = e->L[nl - 1];
+    TailArgs ta{};
+    BnArgs& ba = ta.bn;
+    ba.z = A.z[nl - 1]; ba.zd = X.zd[nl - 1]; ba.mu = A.mu[nl - 1]; ba.rstd = A.rstd[nl - 1]; ba.m1 = X.m1[nl - 1]; ba.m2 = X.m2[nl - 1];
+    ba.gamma = theta + L.off_gamma; ba.beta = theta + L.off_beta; ba.pstride = P;
+    ba.gammad = v + L.off_gamma; ba.betad = v + L.off_beta; ba.vstride = P;
+    ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
+    ba.dp = A.dp[nl - 1]; ba.dpd = X.dpd[cur]; ba.out = X.rdz[nl - 1];
+    ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
+    ba.inv_m = 1.f / (float)(n * L.ho * L.wo);
+    ta.hd = ha;
+    ta.pooled = X.pd[nl - 1];
+    ta.sum0 = hv + L.off_gamma; ta.sum1 = hv + L.off_beta; ta.sum_stride = P;
+    ta.with_grad = 1; ta.bwd_tasks = T;
+    LAUNCH(e, st, OP_HEAD_TAN, 0, launch_tail(st, ta, T, L.pool, 1));
+  } else {
+    LAUNCH(e, st, OP_HEAD_TAN, 0, launch_head_tangent(st, ha, T));
+  }
   if (e->d.head_mean_pool) HIPCHK(e, launch_spatial_mean_bwd(st, X.rdf, X.dpd[cur], T * n, e->head_hw, e->head_c));
   for (int l = nl - 1; l >= 0; --l) {
     const Layer& L = e->L[l];
@@ -1027,7 +1100,8 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ba.n = n; ba.ho = L.ho; ba.wo = L.wo; ba.c = L.co;
     ba.inv_m = 1.f / (float)mpix;
     int blk = 0;
-    if (!red_done[l]) {
+    const bool bn_done = fused_last && l == nl - 1;
+    if (!red_done[l] && !bn_done) {
       ba.fin = fin_of(e, T, 1.0, FIN_SUMS, hv + L.off_gamma, P, hv + L.off_beta, P);
       LAUNCH(e, st, OP_BN_TAN_BWD_REDUCE, l, launch_bn_tan_bwd_reduce(st, ba, T, L.pool, &blk));
       if (!ba.fin.counter)
@@ -1035,8 +1109,10 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     }
     ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
     ba.out = X.rdz[l];
-    ba.amax_out = cell_bind(e, pl, ba.out);
-    LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
+    if (!bn_done) {
+      ba.amax_out = cell_bind(e, pl, ba.out);
+      LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
+    }
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = X.rdz[l];
@@ -1388,7 +1464,7 @@ static int meta_batch_entry(MetaBatchFn fn, int which, mi_engine* e, void* strea
       (unsigned long long)shots, (unsigned long long)adapt_steps, (unsigned long long)lr_bits, (unsigned long long)second_order,
       (unsigned long long)with_grad, (unsigned long long)(uintptr_t)loss_out, (unsigned long long)(uintptr_t)acc_out,
       (unsigned long long)(uintptr_t)meta_grad_out, (unsigned long long)(uintptr_t)logits_out, (unsigned long long)(uintptr_t)workspace,
-      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 64ull * e->fork_once + 256ull * kernel_selection_key()};
+      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 64ull * e->fork_once + 128ull * e->fuse_last + 256ull * kernel_selection_key()};
   mi_engine::GraphEntry* ent = nullptr;
   for (auto& g : e->graphs)
     if (g.key == key) { ent = &g; break; }

@@ -217,6 +217,20 @@ hipError_t launch_head_grads(hipStream_t st, const HeadArgs& a, int tasks);   //
 hipError_t launch_spatial_mean(hipStream_t st, const float* p, float* f, int rows, int hw, int c);
 hipError_t launch_spatial_mean_bwd(hipStream_t st, const float* df, float* dp, int rows, int hw, int c);
 
+// tail.hip: the last ConvBlock's BatchNorm + ReLU + MaxPool, the head, the head's backward and that block's BatchNorm backward (or their
+// tangents) for one task per workgroup, in one launch.
+struct TailArgs {
+  BnArgs bn;            // z (zd), mu, rstd (m1, m2), gamma / beta (gammad / betad), dp = the head's df output (dpd = the tangent head's), out = dz (R{dz}),
+                        // n, ho, wo, c, inv_m; tangent: dgamma / dbeta = the primal sums
+  HeadArgs hd;          // f = pooled (primal) / the stored primal features (tangent: fd = pooled)
+  float* pooled;        // [T][n][hp][wp][c]: p (primal) or pd (tangent), written by this launch
+  float* sum0; float* sum1; size_t sum_stride;   // dgamma / dbeta (tangent: R{dgamma} / R{dbeta}) [T][..c], written by this launch
+  int with_grad;        // primal: 0 = forward, loss and accuracy only
+  int bwd_tasks;        // primal: tasks >= bwd_tasks stop after the loss (validation tasks of a fused train + validation call)
+};
+bool tail_supported(int n, int c, int ways);
+hipError_t launch_tail(hipStream_t st, const TailArgs& t, int tasks, int pool, int tangent);
+
 // misc.hip
 hipError_t launch_prepare_batch(hipStream_t st, const float* data, const int64_t* labels, int tasks, int n2, int c, int h,
                                 int w, float* xs, float* xq, int32_t* ys, int32_t* yq);

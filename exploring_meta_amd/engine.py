@@ -147,6 +147,11 @@ class MetaEngine:
         launches; bit-identical results."""
         _lib.check(self.lib.mi_engine_set_fused_tail(self._h, int(on)), self._h)
 
+    def set_fused_last_block(self, on):
+        """The last block's BatchNorm + pooling, the head, its backward and that block's BatchNorm backward (or their tangents) as one launch
+        per pass with one workgroup per task (default on) or the five separate launches (mi_engine_set_fused_last_block)."""
+        _lib.check(self.lib.mi_engine_set_fused_last_block(self._h, int(on)), self._h)
+
     def set_graph(self, on):
         """Replay repeated identical fused calls as one hipGraphLaunch (mi_engine_set_graph).  While on, `meta_batch` /
         `meta_batch_anil` return views of PERSISTENT output buffers (one set per call shape), because a replay writes where the

@@ -137,6 +137,15 @@ int mi_meta_batch_maml_tv(mi_engine* e, void* stream, const float* theta, const 
  * 0 = the separate launches (reduce_partials x3, gram_wgrad, axpy, gram_stats, a memset).  Bit-identical results. */
 int mi_engine_set_fused_tail(mi_engine* e, int on);
 
+/* Ablation / test switch: 1 (default) = the LAST ConvBlock's BatchNorm + ReLU + MaxPool (core_functions/vision_models.py:188-193), the linear
+ * head with its cross-entropy and accuracy (vision_models.py:109, core_functions/vision.py:11,16-18,21-23), the head's backward and that block's
+ * BatchNorm backward -- in the Hessian-vector passes their tangents -- run as ONE launch per pass with one workgroup per task (csrc/tail.hip);
+ * 0 = the five separate launches per pass (bn_fwd, head rows, head grads, bn_bwd_reduce, bn_bwd_apply).  The stage bodies are shared: the pooled
+ * output, logits, loss, accuracy, head gradients and feature cotangents are bit-identical; the BatchNorm-backward sums are the same fp64 terms
+ * folded in a fixed order that no longer depends on the tasks per call.  Applies to nets whose last block is a generic (hidden -> hidden) block
+ * feeding a flattened head (MiniImagenetCNN; not the mean-pooled OmniglotCNN head) outside the opt-in fp16 operand form. */
+int mi_engine_set_fused_last_block(mi_engine* e, int on);
+
 /* One meta-batch of ANIL tasks (vision/anil_vision.py:116-122 with features = Sequential(ConvBase, view(-1, fc_neurons)),
  * head = MAML(Linear(fc_neurons, ways)), :86-94): the trunk runs once per task on all 2*shots*ways images (BatchNorm over
  * support and query together, utils/data_pre.py:118-119), only the head is adapted, and the outer gradient reaches both.

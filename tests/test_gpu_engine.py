@@ -216,6 +216,50 @@ def test_fused_tail_is_bit_identical(dataset, ways, shots, K, fo, tasks, fused1)
     assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).sum() > 0
 
 
+@pytest.mark.parametrize('ways,shots,K,fo,tasks,grad_tasks', [
+    (5, 5, 3, False, [3, 4, 5], None), (5, 1, 1, False, [0, 1, 2, 3, 4, 5, 6], None), (5, 5, 2, True, [1, 2], None), (5, 5, 2, False, [3, 4, 5, 6, 7], 3),
+    (3, 2, 2, False, [8, 9], None), (20, 1, 1, False, [2, 3], None)])
+def test_fused_last_block_matches_the_separate_launches(ways, shots, K, fo, tasks, grad_tasks):
+    """The one-workgroup-per-task tail (csrc/tail.hip: last block's BatchNorm + pooling, head, cross-entropy, the head's backward and that
+    block's BatchNorm backward -- and their tangents in the Hessian-vector passes -- in ONE launch) against the five separate launches per pass.
+    The stage bodies are shared, so the query logits / loss / accuracy of a call WITHOUT adaptation are bit-identical; with inner steps the only
+    difference is the fold order of the BatchNorm-backward fp64 sums (thread partials in a fixed order instead of per-workgroup partials), which
+    leaves dgamma / dbeta equal except within ~1e-16 of an fp32 rounding boundary: everything is held to 1e-6, and whether the whole call came
+    out bit-identical is reported.  Also: two fused calls agree bit for bit (fixed order, no atomics), forward-only calls (with_grad = 0), a train +
+    validation call (the validation tasks stop after the loss), other ways / shots (20-way: 100 logits per task staged)."""
+    spec, mspec = _spec('min', ways)
+    theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
+    data, labels = synthetic.make_meta_batch('min', tasks, ways, shots)
+    d, l = torch.from_numpy(data).cuda().contiguous(), torch.from_numpy(labels).cuda().contiguous()
+    outs = {}
+    for on in (1, 0):
+        eng = MetaEngine(mspec)
+        eng.set_fused_last_block(on)
+        trace = eng.set_trace(len(tasks), K) if (not fo and grad_tasks is None) else None
+        runs = []
+        for _ in range(2 if on else 1):
+            loss, acc, grad, logits = eng.meta_batch(theta, d, l, shots, K, 0.4, first_order=fo, return_logits=True, grad_tasks=grad_tasks)
+            torch.cuda.synchronize()
+            runs.append((loss.cpu().numpy(), acc.cpu().numpy(), grad.cpu().numpy(), logits.cpu().numpy()) +
+                        (tuple(trace[k].cpu().numpy() for k in ('theta', 'g', 'lam_in', 'hv')) if trace else ()))
+        if trace:
+            eng.set_trace(0)
+        l0, a0, _, g0 = eng.meta_batch(theta, d, l, shots, 0, 0.4, with_grad=False, return_logits=True)      # no adaptation: forward only
+        torch.cuda.synchronize()
+        outs[on] = (runs, (l0.cpu().numpy(), a0.cpu().numpy(), g0.cpu().numpy()))
+    fused, sep = outs[1], outs[0]
+    for a, b in zip(fused[0][0], fused[0][1]):
+        assert np.array_equal(a, b)                                  # deterministic
+    for a, b in zip(fused[1], sep[1]):
+        assert np.array_equal(a, b)                                  # forward: same bodies, bit-identical
+    exact = all(np.array_equal(a, b) for a, b in zip(fused[0][0], sep[0][0]))
+    errs = [rel_err(a, b) for a, b in zip(fused[0][0], sep[0][0])]
+    report(f'fused_last_block[{ways}w{shots}s K{K} fo{int(fo)} T{len(tasks)}]', bit_identical=bool(exact), max_rel=max(errs))
+    assert np.array_equal(fused[0][0][1], sep[0][0][1])              # accuracy
+    assert max(errs) < 1e-6, errs
+    assert np.isfinite(fused[0][0][2]).all() and np.abs(fused[0][0][2]).sum() > 0
+
+
 @pytest.mark.parametrize('K,grad_bar', [(1, 1e-4), (2, 2e-3)])      # (K = 2: 1.1e-3 measured with the fp32 pipe, 3e-4 .. 7e-4 with the split forms; frozen r5)
 def test_train_and_validation_tasks_in_one_call(conv_form, K, grad_bar):
     """mi_meta_batch_maml_tv (reference maml_vision.py:102-124): 3 train + 2 validation tasks through the same launches against the

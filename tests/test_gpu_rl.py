@@ -137,6 +137,7 @@ def test_cfg5_full_size_matches_oracle(golden_rl):
     ctx = _SurrogateContext(replays, old_pols, pol, cf.LinearValue(2, 2), PARAMS_CFG5)
     l32, k32, g32 = ctx.evaluate(pol.flat(), want_grad=True)
     f32 = ctx.fvp(pol.flat(), v.float().cuda())
+    f_first = ctx.fvp(pol.flat(), torch.from_numpy(golden_rl['rl_cfg5_f64_surr_grad']).float().cuda()).cpu().numpy()   # F g: the first CG product
     torch.cuda.synchronize()
     eg, ef = rel_err(g32.cpu().numpy(), grad.numpy()), rel_err(f32.cpu().numpy(), fv.detach().numpy())
     p64b = OrderedDict((k, v_.clone().requires_grad_(True)) for k, v_ in theta.items())
@@ -152,8 +153,7 @@ def test_cfg5_full_size_matches_oracle(golden_rl):
     # the reference's own lines on these replays (fp64 record)
     G = lambda k: golden_rl['rl_cfg5_f64_' + k]
     egr = rel_err(g32.cpu().numpy(), G('surr_grad'))
-    g_ref = torch.from_numpy(G('surr_grad'))
-    efr = rel_err(ctx.fvp(torch.cat([v_.reshape(-1) for v_ in theta.values()]).float().cuda(), g_ref.float().cuda()).cpu().numpy(), G('opt_fvp_first'))
+    efr = rel_err(f_first, G('opt_fvp_first'))
     etr = rel_err(pol.flat().cpu().numpy(), G('opt_theta_new'))
     report('cfg5_full_size_vs_reference_record', loss_ref=float(G('surr_loss_kl')[0]), grad_rel=egr, fvp_first_rel=efr, theta_new_rel=etr,
            accepted_ref=int(G('opt_accepted')[0]), reference_fp32_rel_to_its_fp64=golden_rl['rl_cfg5_f32_rel_to_f64'].tolist())

@@ -10,7 +10,7 @@ shift; shift || true
 for R in 1 2 3; do
   for V in base new; do
     if [ $V = base ]; then export MI_MAML_LIB=$BASE; else unset MI_MAML_LIB; fi
-    timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-pipe --no-secondary --no-clock "$@" --breakdown $O/breakdown_${V}_r$R.csv > $O/bench_${V}_r$R.json 2> $O/bench_${V}_r$R.err
+    timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-pipe --no-secondary --no-clock --no-other --no-sampled "$@" --breakdown $O/breakdown_${V}_r$R.csv > $O/bench_${V}_r$R.json 2> $O/bench_${V}_r$R.err
     python - $O/bench_${V}_r$R.json $V $R <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

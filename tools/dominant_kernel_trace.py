@@ -3,7 +3,7 @@
 files under profiles/ alone (the --stats summary aggregates every launch of a template instantiation: blocks 2, 3 and 4 of the net share one
 name and differ only in their grid).
 
-    rocprofv3 --kernel-trace --stats --output-format csv -d DIR -- python3 bench.py --no-dist --no-clock --no-cpu-baseline --no-overlap ...
+    rocprofv3 --kernel-trace --stats --output-format csv -d DIR -- python3 bench.py --no-dist --no-clock --no-other --no-sampled --no-cpu-baseline --no-overlap ...
     python3 tools/dominant_kernel_trace.py DIR --kernel 'conv3x3_s1_mfma_kernel<32, 2, 2, 0, true, false>' [--bench bench.json] > profiles/rN/rocprofv3_dominant_kernel_*.txt
 
 Launches are grouped by grid shape (x = threads, y = tasks, z) and, with --cycle N, by their position in the repeating launch order

@@ -10,7 +10,7 @@ N=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD"; do
   N=$((N + 1))
-  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/p_$N -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --no-secondary --pool 2 > $O/log_$N.txt 2>&1; echo "pass $N ($SET) rc=$?"
+  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/p_$N -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-clock --no-other --no-sampled --no-dist --no-fp32-pipe --no-secondary --pool 2 > $O/log_$N.txt 2>&1; echo "pass $N ($SET) rc=$?"
   f=$(find $O/p_$N -name "*counter_collection.csv" | head -n 1)
   [ -n "$f" ] && python3 - "$f" > $O/table_$N.txt <<'PY'
 import csv, sys, collections

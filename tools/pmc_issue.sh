@@ -10,7 +10,7 @@ grep -o "SQ_[A-Z0-9_]*" $O/avail.txt | sort -u | grep -E "INSTS_VALU|MFMA|BUSY_C
 cat $O/sq_names.txt
 for SET in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; do
   T=$(echo $SET | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/p_$T -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --no-secondary --pool 2 > $O/log_$T.txt 2>&1; echo "pass $T rc=$?"
+  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/p_$T -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-clock --no-other --no-sampled --no-dist --no-fp32-pipe --no-secondary --pool 2 > $O/log_$T.txt 2>&1; echo "pass $T rc=$?"
   f=$(find $O/p_$T -name "*counter_collection.csv" | head -n 1)
   [ -n "$f" ] && python3 - "$f" > $O/table_$T.txt <<'PY'
 import csv, sys, collections

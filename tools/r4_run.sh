@@ -20,7 +20,7 @@ for W in "$@"; do
       done
       timeout -k 10 300 python bench.py --workload cfg5 --steps 10 --warmup 2 > $O/bench_cfg5.json 2> $O/bench_cfg5.err; echo "cfg5 rc=$?" ;;
     trace2)
-      ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg2 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-clock --no-dist --no-overlap --pool 2 > $O/prof_cfg2.log 2>&1; echo "trace2 rc=$?" )
+      ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg2 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-clock --no-other --no-sampled --no-dist --no-overlap --pool 2 > $O/prof_cfg2.log 2>&1; echo "trace2 rc=$?" )
       f=$(find $O/prof_cfg2 -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp $f $O/rocprofv3_kernel_stats_cfg2.csv
       python3 tools/dominant_kernel_trace.py $O/prof_cfg2 --kernel 'conv3x3_s1_mfma_kernel<32, 2, 2, 0, true, false>' --cycle 3 --bench $O/bench_cfg2.json > $O/rocprofv3_dominant_kernel_cfg2.txt 2>&1
       rm -rf $O/prof_cfg2 ;;

@@ -8,7 +8,7 @@ O=$ROOT/${1:-gpurun_out/r5_ab}; mkdir -p $O
 shift || true
 for R in 1 2; do
   for B in 0 1; do
-    MI_CONV_B16=$B timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-pipe --no-secondary --no-clock "$@" --breakdown $O/breakdown_b16_${B}_r$R.csv > $O/bench_b16_${B}_r$R.json 2> $O/bench_b16_${B}_r$R.err
+    MI_CONV_B16=$B timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-pipe --no-secondary --no-clock --no-other --no-sampled "$@" --breakdown $O/breakdown_b16_${B}_r$R.csv > $O/bench_b16_${B}_r$R.json 2> $O/bench_b16_${B}_r$R.err
     python - $O/bench_b16_${B}_r$R.json $B $R <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -7,7 +7,7 @@ O=$ROOT/$1; VAR=$2; VALS=$3; shift 3
 mkdir -p $O
 for R in 1 2; do
   for V in $VALS; do
-    env $VAR=$V timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-pipe --no-secondary --no-clock "$@" > $O/bench_${VAR}_${V}_r$R.json 2> $O/bench_${VAR}_${V}_r$R.err
+    env $VAR=$V timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-pipe --no-secondary --no-clock --no-other --no-sampled "$@" > $O/bench_${VAR}_${V}_r$R.json 2> $O/bench_${VAR}_${V}_r$R.err
     python - $O/bench_${VAR}_${V}_r$R.json $VAR $V $R <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

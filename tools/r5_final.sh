@@ -15,7 +15,7 @@ if [ "$PART" = a ]; then
   timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -n 2 $O/smoke.log
   timeout -k 10 400 python bench.py --steps 20 --warmup 5 --breakdown $O/event_breakdown_cfg2.csv > $O/bench_cfg2.json 2> $O/bench_cfg2.err; echo "bench2 rc=$?"
   python tools/roofline_table.py $O/event_breakdown_cfg2.csv > $O/roofline_table_cfg2.md 2>/dev/null
-  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/prof_cfg2 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-clock --no-dist --no-overlap --pool 2 > $ROOT/$O/prof_cfg2.log 2>&1; echo "trace2 rc=$?" )
+  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/prof_cfg2 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-clock --no-other --no-sampled --no-dist --no-overlap --pool 2 > $ROOT/$O/prof_cfg2.log 2>&1; echo "trace2 rc=$?" )
   f=$(find $O/prof_cfg2 -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp $f $O/rocprofv3_kernel_stats_cfg2.csv
   python3 tools/dominant_kernel_trace.py $O/prof_cfg2 --kernel "$DOM" --cycle 1 --bench $O/bench_cfg2.json > $O/rocprofv3_dominant_kernel_cfg2.txt 2>&1
   rm -rf $O/prof_cfg2
@@ -28,11 +28,11 @@ else
   WORKLOADS="cfg2 cfg3" bash tools/pmc_all.sh gpurun_out/$TAG/pmc r5 > $O/pmc.log 2>&1; echo "pmc rc=$?"
   bash tools/pmc_conv_issue.sh gpurun_out/$TAG/pmc_conv > $O/pmc_conv.log 2>&1; echo "pmc_conv rc=$?"
   for T in 4 1; do
-    timeout -k 10 200 python bench.py --tasks $T --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-dist --no-fp32-pipe --breakdown $O/event_breakdown_cfg2_T$T.csv > $O/bench_cfg2_T$T.json 2> $O/bench_cfg2_T$T.err
+    timeout -k 10 200 python bench.py --tasks $T --steps 20 --warmup 3 --no-cpu-baseline --no-clock --no-other --no-sampled --no-dist --no-fp32-pipe --breakdown $O/event_breakdown_cfg2_T$T.csv > $O/bench_cfg2_T$T.json 2> $O/bench_cfg2_T$T.err
   done
   timeout -k 10 300 python tools/t_sweep.py --workload cfg4 --tasks 8,16,32,64,256 --out $O/t_sweep_cfg4.md > $O/t_sweep_cfg4.log 2>&1
   ( cd /tmp && export TMPDIR=/tmp && for W in cfg1 cfg3 cfg4 cfg5; do
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/prof_$W -- python3 $ROOT/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline --no-clock --no-dist --pool 2 > $ROOT/$O/prof_$W.log 2>&1
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/prof_$W -- python3 $ROOT/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline --no-clock --no-other --no-sampled --no-dist --pool 2 > $ROOT/$O/prof_$W.log 2>&1
     f=$(find $ROOT/$O/prof_$W -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp $f $ROOT/$O/rocprofv3_kernel_stats_$W.csv
     rm -rf $ROOT/$O/prof_$W
   done )

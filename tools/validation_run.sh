@@ -19,7 +19,7 @@ timeout -k 10 300 python tools/t_sweep.py --workload cfg2 --tasks 1,2,4,8,16,32 
 timeout -k 10 300 python tools/t_sweep.py --workload cfg4 --tasks 8,16,32,64,256 --out $O/t_sweep_cfg4.md > $O/t_sweep_cfg4.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 for W in cfg2 cfg5; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$W -- python3 $ROOT/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline --no-clock > $O/prof_$W.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$W -- python3 $ROOT/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline --no-clock --no-other --no-sampled > $O/prof_$W.log 2>&1
   f=$(find $O/prof_$W -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp $f $O/rocprofv3_kernel_stats_$W.csv
   rm -rf $O/prof_$W
 done
