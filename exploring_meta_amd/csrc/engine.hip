@@ -53,8 +53,8 @@ struct mi_engine {
   // gram_wgrad + axpy + gram_stats launches and a memset per pass.  Same arithmetic in the same order: bit-identical results.
   bool bred_arg = true;     // block 2's dgrad epilogue reads block 1's argmax byte instead of p (MI_BRED_ARG=0: p, for A/B runs; same results)
   bool fuse_tail = true;
-  // the last ConvBlock's BatchNorm + pooling, the head, its backward and that block's BatchNorm backward as ONE launch with one workgroup per
-  // task (tail.hip) instead of five launches per pass (MI_FUSE_LAST=0 / mi_engine_set_fused_last_block(e, 0): the separate launches)
+  // the last ConvBlock's BatchNorm + pooling, the head, its backward and that block's BatchNorm-backward sums as ONE launch, four workgroups per
+  // task (tail.hip), instead of four launches per pass (MI_FUSE_LAST=0 / mi_engine_set_fused_last_block(e, 0): the separate launches)
   bool fuse_last = !(getenv("MI_FUSE_LAST") && atoi(getenv("MI_FUSE_LAST")) == 0);
   unsigned zoff[10] = {}, zlen[10] = {};   // conv-bias segments and the padding P..PS of a parameter-shaped vector (never written by a kernel)
   int nzero = 0;
@@ -283,10 +283,10 @@ extern "C" int mi_engine_set_fused_tail(mi_engine* e, int on) {
   return MI_OK;
 }
 
-// Ablation / test switch: 1 (default) = the last block's BatchNorm + pooling, the head, its backward and that block's BatchNorm backward (or
-// their tangents) in one launch with one workgroup per task (tail.hip); 0 = the five separate launches per pass.  Same stage bodies: p,
-// logits, loss, accuracy, the head's gradients and df are bit-identical; the BatchNorm-backward sums are the same fp64 terms folded in a
-// different (fixed) order.
+// Ablation / test switch: 1 (default) = the last block's BatchNorm + pooling, the head, its backward and that block's BatchNorm-backward sums (or
+// their tangents) in one launch, four workgroups per task (tail.hip); 0 = the four separate launches per pass.  Same arithmetic in the same
+// order: p, logits, loss, accuracy, the head's gradients and df are bit-identical; the BatchNorm-backward sums are the same fp64 terms folded
+// in a different (fixed) order.
 extern "C" int mi_engine_set_fused_last_block(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->fuse_last = on != 0;
@@ -415,6 +415,7 @@ struct Plan {
   int half = 0;                 // stream context (engine SideCtx) this plan's side work uses
   float *tmp_loss, *tmp_acc;
   float* hscr;   // head scratch: R{dl} [T][n][ways], row loss [T][n], row hit [T][n]
+  float* tail_wpart = nullptr; double* tail_bpart = nullptr; float* tail_scr = nullptr;   // one-launch tail (tail.hip): row-group partials
   // fp16 operand form (bf16_split.h): largest-magnitude cells [slot][T], one slot per tensor a convolution reads, handed out in launch
   // order (cell_bind: the tensor's producer is about to run; cell_of: a consumer asks) and zeroed once per call (plan_begin)
   unsigned* cells;
@@ -479,6 +480,12 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
   pl.tmp_loss = b.take<float>(T);
   pl.tmp_acc = b.take<float>(T);
   pl.hscr = b.take<float>((size_t)T * (ns > nq ? ns : nq) * (e->d.ways + 2));
+  {
+    const int nmx = ns > nq ? ns : nq;
+    pl.tail_wpart = b.take<float>(tail_wpart_floats(T, e->feat, e->d.ways));
+    pl.tail_bpart = b.take<double>(tail_bpart_doubles(T, e->L.back().co));
+    pl.tail_scr = b.take<float>(tail_scr_floats(T, nmx, e->d.ways));
+  }
   const int nsets = (second_order && K > 0) ? K : 1;
   pl.sup.resize(nsets);
   for (int k = 0; k < nsets; ++k) plan_actset(e, b, pl.sup[k], T, ns, true);
@@ -633,10 +640,16 @@ static B1Args b1_args(const mi_engine* e, Plan& pl, ActSet& A, const float* x0, 
 
 // The one-launch tail (tail.hip) serves a generic last block (not the conv-recompute block 1) feeding a flattened head, outside the fp16
 // operand form (its producers would have to fold largest-magnitude cells).
-static bool fused_last_ok(const mi_engine* e, const Plan& pl, int n) {
+static bool fused_last_ok(const mi_engine* e, const Plan& pl, int n, int T) {
   const int nl = (int)e->L.size();
-  if (!e->fuse_last || e->d.head_mean_pool || pl.f16 || (nl == 1 && e->fuse1)) return false;
-  return tail_supported(n, e->L[nl - 1].co, e->d.ways);
+  if (!e->fuse_last || e->d.head_mean_pool || pl.f16 || (nl == 1 && e->fuse1) || !e->counters || T > mi_engine::kMaxCounterTasks || T > 65535 ||
+      !pl.tail_wpart)
+    return false;
+  const Layer& L = e->L[nl - 1];
+  return tail_supported(n, L.ho, L.wo, L.co, L.pool, e->feat, e->d.ways);
+}
+static void tail_common(const mi_engine* e, const Plan& pl, TailArgs& ta) {
+  ta.wpart = pl.tail_wpart; ta.bpart = pl.tail_bpart; ta.scr = pl.tail_scr; ta.counter = e->counters;
 }
 
 // Trunk forward: ConvBlocks on n images per task (conv + BN-stat epilogue, finalize, BN+ReLU+pool).
@@ -706,7 +719,7 @@ static void adv_add_seg(AdvanceArgs* adv, size_t off, int nelem, const float* pa
   AdvanceSeg& sg = adv->seg[adv->nseg++];
   sg.off = (unsigned)off; sg.nelem = (unsigned)nelem; sg.partial = partial; sg.nchunks = nchunks;
 }
-// last_bn_done: the caller's tail launch already formed the last block's dgamma / dbeta and dz.
+// last_bn_done: the caller's tail launch already formed the last block's dgamma / dbeta (the apply is launched here).
 static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const float* x0, int n, int T, const float* theta,
                           float* g, const double* gram = nullptr, AdvanceArgs* adv = nullptr, bool last_bn_done = false) {
   const int nl = (int)e->L.size();
@@ -769,10 +782,8 @@ static int trunk_backward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, con
     }
     ba.dgamma = g + L.off_gamma; ba.dbeta = g + L.off_beta; ba.gstride = P;
     ba.out = A.dz[l];
-    if (!bn_done) {
-      ba.amax_out = cell_bind(e, pl, ba.out);
-      LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
-    }
+    ba.amax_out = cell_bind(e, pl, ba.out);
+    LAUNCH(e, st, OP_BN_BWD_APPLY, l, launch_bn_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = A.dz[l];
@@ -895,7 +906,7 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
                         const double* gram = nullptr, AdvanceArgs* adv = nullptr, bool stats_ready = false, int Tb = -1) {
   const int nl = (int)e->L.size();
   if (Tb < 0) Tb = T;
-  const bool fused_last = fused_last_ok(e, pl, n);
+  const bool fused_last = fused_last_ok(e, pl, n, T);
   int rc = trunk_forward(e, st, pl, A, x0, n, T, theta, gram, stats_ready, fused_last);
   if (rc) return rc;
   rc = export_bn_stats(e, st, A, T);
@@ -923,6 +934,7 @@ static int pass_fwd_bwd(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const
     ta.pooled = A.p[nl - 1];
     ta.sum0 = with_grad ? g + L.off_gamma : nullptr; ta.sum1 = with_grad ? g + L.off_beta : nullptr; ta.sum_stride = P;
     ta.with_grad = with_grad ? 1 : 0; ta.bwd_tasks = Tb;
+    tail_common(e, pl, ta);
     LAUNCH(e, st, OP_HEAD, 0, launch_tail(st, ta, T, L.pool, 0));
     if (!with_grad || Tb == 0) return MI_OK;
     return trunk_backward(e, st, pl, A, x0, n, Tb, theta, g, gram, adv, true);
@@ -942,7 +954,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
   const int nl = (int)e->L.size();
   const size_t P = e->PS;  // task stride
   TanSet& X = pl.tan;
-  const bool fused_last = !dl_fixed && !ld_out && fused_last_ok(e, pl, n);   // tangent tail in one launch (tail.hip)
+  const bool fused_last = !dl_fixed && !ld_out && fused_last_ok(e, pl, n, T);   // tangent tail in one launch (tail.hip)
   if (!adv) HIPCHK(e, hipMemsetAsync(hv, 0, (size_t)T * P * sizeof(float), st));
   for (int l = 0; l < nl; ++l) {
     const Layer& L = e->L[l];
@@ -1038,6 +1050,7 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     ta.pooled = X.pd[nl - 1];
     ta.sum0 = hv + L.off_gamma; ta.sum1 = hv + L.off_beta; ta.sum_stride = P;
     ta.with_grad = 1; ta.bwd_tasks = T;
+    tail_common(e, pl, ta);
     LAUNCH(e, st, OP_HEAD_TAN, 0, launch_tail(st, ta, T, L.pool, 1));
   } else {
     LAUNCH(e, st, OP_HEAD_TAN, 0, launch_head_tangent(st, ha, T));
@@ -1109,10 +1122,8 @@ static int pass_hvp(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, const flo
     }
     ba.rdgamma = hv + L.off_gamma; ba.rdbeta = hv + L.off_beta; ba.hstride = P;
     ba.out = X.rdz[l];
-    if (!bn_done) {
-      ba.amax_out = cell_bind(e, pl, ba.out);
-      LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
-    }
+    ba.amax_out = cell_bind(e, pl, ba.out);
+    LAUNCH(e, st, OP_BN_TAN_BWD_APPLY, l, launch_bn_tan_bwd_apply(st, ba, T, L.pool));
     WgradArgs wa{};
     wa.x[0] = l == 0 ? x0 : A.p[l - 1];
     wa.dz[0] = X.rdz[l];

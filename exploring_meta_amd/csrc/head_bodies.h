@@ -18,14 +18,13 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ x, const flo
 // One sample row by one wave (lane = 0..63): `ways` dot products over the feature row, softmax, prob / dlogits, row loss, row hit
 // (TANGENT: ld = fd wl^T + f wld^T + bld and R{dl}).  Shared by head_rows_kernel (head.hip) and the per-task tail kernel (tail.hip):
 // the same instructions in the same order, whoever calls it.
+// f_n / fd_n: the row's features (and their tangents), wl_t / wld_t: the task's head weights (and the direction's) -- wherever they live
+// (global memory in head.hip; LDS copies in tail.hip).
 template <bool TANGENT>
-__device__ __forceinline__ void head_row(const HeadArgs& a, int task, int n, int lane) {
+__device__ __forceinline__ void head_row_at(const HeadArgs& a, int task, int n, int lane, const float* f_n, const float* fd_n,
+                                            const float* wl_t, const float* wld_t) {
   const int N = a.n, F = a.feat, WY = a.ways;
-  const float* f_n = a.f + ((size_t)task * N + n) * F;
-  const float* fd_n = (TANGENT && a.fd) ? a.fd + ((size_t)task * N + n) * F : nullptr;
-  const float* wl_t = a.wl + (size_t)task * a.pstride;
   const float* bl_t = a.bl + (size_t)task * a.pstride;
-  const float* wld_t = TANGENT ? a.wld + (size_t)task * a.vstride : nullptr;
   const float* bld_t = TANGENT ? a.bld + (size_t)task * a.vstride : nullptr;
   // lane w (< WY) ends up holding logit w of this row.  All `ways` dot products of the row advance together: one pass over the
   // feature row, 16-byte loads, every load of the pass independent of the others (the former one-dot-at-a-time loop with 4-byte
@@ -131,6 +130,14 @@ __device__ __forceinline__ void head_row(const HeadArgs& a, int task, int n, int
   }
 }
 
+
+template <bool TANGENT>
+__device__ __forceinline__ void head_row(const HeadArgs& a, int task, int n, int lane) {
+  const int N = a.n, F = a.feat;
+  head_row_at<TANGENT>(a, task, n, lane, a.f + ((size_t)task * N + n) * F,
+                       (TANGENT && a.fd) ? a.fd + ((size_t)task * N + n) * F : nullptr, a.wl + (size_t)task * a.pstride,
+                       TANGENT ? a.wld + (size_t)task * a.vstride : nullptr);
+}
 
 // dl (primal) or R{dl} (+ dl, tangent) of one task into LDS: s_a [N][WY], s_b [N][WY] (tangent only).  The caller synchronises.
 template <bool TANGENT>

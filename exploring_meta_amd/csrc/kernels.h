@@ -217,18 +217,24 @@ hipError_t launch_head_grads(hipStream_t st, const HeadArgs& a, int tasks);   //
 hipError_t launch_spatial_mean(hipStream_t st, const float* p, float* f, int rows, int hw, int c);
 hipError_t launch_spatial_mean_bwd(hipStream_t st, const float* df, float* dp, int rows, int hw, int c);
 
-// tail.hip: the last ConvBlock's BatchNorm + ReLU + MaxPool, the head, the head's backward and that block's BatchNorm backward (or their
-// tangents) for one task per workgroup, in one launch.
+// tail.hip: the last ConvBlock's BatchNorm + ReLU + MaxPool, the head, the head's backward and that block's BatchNorm-backward SUMS (or their
+// tangents) in one launch, four workgroups (row groups) per task; cross-workgroup sums by the last arriver (finalize.h protocol).
 struct TailArgs {
-  BnArgs bn;            // z (zd), mu, rstd (m1, m2), gamma / beta (gammad / betad), dp = the head's df output (dpd = the tangent head's), out = dz (R{dz}),
-                        // n, ho, wo, c, inv_m; tangent: dgamma / dbeta = the primal sums
-  HeadArgs hd;          // f = pooled (primal) / the stored primal features (tangent: fd = pooled)
+  BnArgs bn;            // z (zd), mu, rstd (m1, m2), gamma / beta (gammad / betad), n, ho, wo, c; tangent: dp = the primal cotangent of p
+  HeadArgs hd;          // primal: y, loss, acc, logits, prob, dl, rowloss, rowhit, dwl, dbl, df; tangent: f = the stored primal features, prob, dl, rdl, wld, bld
   float* pooled;        // [T][n][hp][wp][c]: p (primal) or pd (tangent), written by this launch
   float* sum0; float* sum1; size_t sum_stride;   // dgamma / dbeta (tangent: R{dgamma} / R{dbeta}) [T][..c], written by this launch
   int with_grad;        // primal: 0 = forward, loss and accuracy only
   int bwd_tasks;        // primal: tasks >= bwd_tasks stop after the loss (validation tasks of a fused train + validation call)
+  float* wpart;         // [T][4][ways][feat] row-group partials of dWl (tail_wpart_floats)
+  double* bpart;        // [T][4][2][c] row-group partials of the BatchNorm-backward sums (tail_bpart_doubles)
+  float* scr;           // [T][4][ceil(n/4)][ways + 2] per-row dlogits / loss / hit for the folding workgroup (tail_scr_floats)
+  unsigned* counter;    // [T] arrival counters, zero on entry, left at zero
 };
-bool tail_supported(int n, int c, int ways);
+bool tail_supported(int n, int ho, int wo, int c, int pool, int feat, int ways);
+size_t tail_wpart_floats(int tasks, int feat, int ways);
+size_t tail_bpart_doubles(int tasks, int c);
+size_t tail_scr_floats(int tasks, int n, int ways);
 hipError_t launch_tail(hipStream_t st, const TailArgs& t, int tasks, int pool, int tangent);
 
 // misc.hip

@@ -1,45 +1,69 @@
-// The tail of a pass, one workgroup per task: the LAST ConvBlock's BatchNorm + ReLU + MaxPool, the classifier head with its
-// cross-entropy, the head's backward and the last block's BatchNorm backward (sums + apply) -- or their tangents -- in ONE launch.
+// The tail of a pass in ONE launch: the LAST ConvBlock's BatchNorm + ReLU + MaxPool, the classifier head with its cross-entropy and accuracy,
+// the head's backward and the last block's BatchNorm-backward sums -- in the Hessian-vector passes their tangents.
 //
 // Replaces (reference): the last `normalize -> relu -> max_pool` of ConvBase (core_functions/vision_models.py:188-193), `self.linear(x.view(-1,
 // 25*hidden))` (:109), `loss(learner(adapt_data), adapt_labels)` / `accuracy` (core_functions/vision.py:11,16-18,21-23) and the autograd backward /
-// double-backward of those ops -- five launches per pass before (bn_fwd, head_rows, head_grads, bn_bwd_reduce, bn_bwd_apply; tangent: bn_tan_fwd,
-// head_rows<T>, head_grads<T>, bn_tan_bwd_reduce, bn_tan_bwd_apply).
+// double-backward of those ops -- four launches per pass before (bn_fwd, head_rows, head_grads, bn_bwd_reduce; tangent: bn_tan_fwd, head_rows<T>,
+// head_grads<T>, bn_tan_bwd_reduce), each a chain of dependent memory round trips on a few hundred kilobytes.
 //
-// Why one workgroup per task and not a cluster with in-kernel barriers: at this end of the net a task's tensors are small (z of the last block:
-// 25 images x 10 x 10 x 32 floats = 320 KB) and every stage needs ALL of the task's rows or columns (the head transposes rows into columns, the
-// BatchNorm sums run over every image), so a cluster would exchange its whole working set through memory at every stage behind a cross-workgroup
-// hand-off that costs what a kernel boundary costs on this chip (MI355X_MICROARCH.md price list: barrier 4-7 us, boundary 1.5-2 us).  Inside ONE
-// workgroup the stages are separated by workgroup barriers (a hundred cycles), everything a stage hands to the next stays in this CU's L1 / the
-// XCD's L2, and nothing depends on dispatch order or placement.  32 tasks keep 32 CUs busy for ~15 us instead of 256 CUs for five latency-bound
-// launches of 7-19 us each; one task per call pays one launch instead of five.
+// Shape: FOUR workgroups per task, workgroup rg owning the sample rows n = rg, rg + 4, ... -- the row groups head_grads_kernel already sums over.
+// A workgroup reads its rows' conv outputs ONCE and keeps everything it derives on chip: the pooled features in LDS (the head's dot products, the
+// weight-gradient partial and the feature cotangents read them there), zhat at the pooling argmax and the ReLU mask in registers (the BatchNorm-backward
+// terms of a pooled element are formed by the thread that pooled it, from the cotangent it has just computed).  What crosses workgroups is sums only
+// -- dWl over rows, dbl, loss, accuracy, dgamma / dbeta over images -- and they cross the way every sum in this library does: one partial per
+// workgroup, written through (sc1), drained, counted; the workgroup that arrives last folds them in a fixed order (finalize.h).  Nobody WAITS for
+// another workgroup: no in-kernel barrier (which costs what a kernel boundary costs on this chip, MI355X_MICROARCH.md price list), no assumption about
+// dispatch order, residency or placement.  The BatchNorm-backward APPLY needs the folded sums and stays the next launch.
 //
-// Arithmetic: the stage bodies are the ones the separate kernels run (bn_window.h, head_bodies.h) -- same instructions, same order -- so p, the
-// logits, prob / dlogits, loss, accuracy, dWl, dbl, df are bit-identical to the separate launches.  The BatchNorm-backward sums (dgamma, dbeta and
-// their tangents) are fp64 sums folded in a FIXED order that does not depend on the number of tasks per call (thread partials over the task's windows,
-// then the threads in order); the separate kernels fold the same fp64 terms per workgroup and then across workgroups, so the two agree to the last
-// bit of the fp64 sum's rounding, i.e. bit-identically in fp32 except where that sum lies within ~1e-16 of a rounding boundary.
+// (Round 6 first built the whole tail, apply included, as ONE workgroup per task: bit-identical and 27 % SLOWER at one task per call, 4 % at 32 -- a
+// single CU pulls a task's 320 KB through five dependent stages at ~100 GB/s.  profiles/r6/ab_fuse_last_v1.txt.)
+//
+// Arithmetic: the stage bodies are the separate kernels' (bn_window.h, head_bodies.h) or the same operations in the same order -- p, logits, prob,
+// dlogits, loss, accuracy, dWl (the four row-group partials are folded ((g0 + g1) + g2) + g3 as head_grads_kernel folds them), dbl, df are
+// bit-identical to the separate launches.  dgamma / dbeta are the same fp64 terms in a fixed order that does not depend on the tasks per call (the
+// separate kernels fold per-workgroup partials whose number does): equal in fp32 except where the fp64 sum lies within ~1e-16 of a rounding boundary.
 #include "mi_common.h"
 #include "kernels.h"
 #include "bn_window.h"
 #include "head_bodies.h"
 
 #define TAIL_THREADS 512
+#define TAIL_GROUPS 4          // row groups = workgroups per task (head_grads_kernel's grouping: rows rg, rg + 4, ...)
+#define TAIL_KMAX 4            // (row, pooling window, channel quad) items per thread
 
-#define TAIL_SETUP(POOL)                                                                          \
-  const BnArgs& a = t.bn;                                                                         \
-  const int tid = threadIdx.x, task = blockIdx.x;                                                 \
-  const int quads = a.c >> 2;                                                                     \
-  const int quad = tid % quads, wl = tid / quads, wpb = TAIL_THREADS / quads;                     \
-  const int c0 = quad * 4;                                                                        \
-  const WinIter<POOL> it(a);                                                                      \
-  const size_t z_task = (size_t)a.n * a.ho * a.wo * a.c;                                          \
-  const size_t p_task = (size_t)a.n * it.hp * it.wp * a.c;                                        \
-  const ChanConst k = load_consts(a, task, c0);                                                   \
-  const float* z_t = a.z + (size_t)task * z_task;
+__device__ __forceinline__ float tail_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double tail_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tail_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tail_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// fp64 reduction of 8 per-thread accumulators (4 channels x 2 quantities) over the workgroup, threads in order -> out0 / out1 [c] as fp32
-__device__ __forceinline__ void tail_reduce_store(const double* acc0, const double* acc1, double* red, int quads, int c, float* out0, float* out1) {
+struct TailLds {
+  double* red;       // [TAIL_THREADS * 8]
+  float *f, *fd;     // [RL][F] pooled features of this workgroup's rows (tangent kernel: the stored primal features, and their tangents)
+  float *wl, *wld;   // [WY][F] the task's head weights (and the direction's)
+  float *a, *b;      // [RL][WY] dlogits (tangent kernel: R{dlogits}, dlogits)
+  int* flag;
+};
+__host__ __device__ inline size_t tail_lds_bytes(int n, int feat, int ways, int tangent) {
+  const size_t rl = (size_t)(n + TAIL_GROUPS - 1) / TAIL_GROUPS;
+  size_t floats = (tangent ? 2 : 1) * (rl * feat + (size_t)ways * feat) + 2 * ((rl * ways + 3) & ~(size_t)3) + 4;
+  return (size_t)TAIL_THREADS * 8 * sizeof(double) + floats * sizeof(float);
+}
+__device__ __forceinline__ TailLds tail_carve(double* smem, int RL, int F, int WY, bool tangent) {
+  TailLds L;
+  L.red = smem;
+  float* p = reinterpret_cast<float*>(smem + TAIL_THREADS * 8);
+  L.f = p; p += (size_t)RL * F;
+  L.fd = tangent ? p : nullptr; if (tangent) p += (size_t)RL * F;
+  L.wl = p; p += (size_t)WY * F;
+  L.wld = tangent ? p : nullptr; if (tangent) p += (size_t)WY * F;
+  L.a = p; p += (RL * WY + 3) & ~3;
+  L.b = p; p += (RL * WY + 3) & ~3;
+  L.flag = reinterpret_cast<int*>(p);
+  return L;
+}
+
+// the workgroup's 8 per-thread fp64 accumulators (4 channels x 2 quantities) -> one partial [2][c] of the task, written through
+__device__ __forceinline__ void tail_partial(const double* acc0, const double* acc1, double* red, int quads, int c, double* part) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int ch = 0; ch < 4; ++ch) {
@@ -54,233 +78,357 @@ __device__ __forceinline__ void tail_reduce_store(const double* acc0, const doub
       s0 += red[(w * quads + q) * 8 + comp];
       s1 += red[(w * quads + q) * 8 + 4 + comp];
     }
-    out0[tid] = (float)s0;
-    out1[tid] = (float)s1;
+    tail_st(part + tid, s0);
+    tail_st(part + c + tid, s1);
   }
 }
 
-// the head's gradient stage for one task by the whole workgroup: two groups of 256 threads take the 64-column chunks alternately
-template <bool TANGENT>
-__device__ __forceinline__ void tail_head_grads(const HeadArgs& h, int task, float* sm) {
-  const int tid = threadIdx.x, N = h.n, WY = h.ways;
-  float* s_a = sm;
-  float* s_b = sm + N * WY;
-  float* s_red = sm + ((2 * N * WY + 63) & ~63) + (tid >> 8) * (3 * 8 * 64);
-  head_stage_dl<TANGENT>(h, task, tid, TAIL_THREADS, s_a, s_b);
+// finalize.h's arrival: every thread of the workgroup calls it after the workgroup's write-through stores; true in the workgroup that arrived last
+__device__ __forceinline__ bool tail_arrive(unsigned* counter, int task, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int nch = (h.feat + 63) / 64, groups = TAIL_THREADS / 256;
-  for (int c = tid >> 8; c < ((nch + groups - 1) / groups) * groups; c += groups) {      // (every thread the same number of trips: barriers inside)
-    head_grads_chunk<TANGENT>(h, task, c, tid & 255, s_a, s_b, s_red);
-    __syncthreads();                                                                     // s_red is rewritten by the next trip
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(counter + task, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (prev + 1u == (unsigned)TAIL_GROUPS);
+    if (last) __hip_atomic_store(counter + task, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
   }
-  head_task_sums<TANGENT>(h, task, tid, TAIL_THREADS, s_a);
+  __syncthreads();
+  const bool last = *flag != 0;
+  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (compiler ordering: the fold's sc1 loads stay below the counter read)
+  return last;
 }
+
+// per-row scalars that the folding workgroup sums in row order: scr[task][rg][rl][WY + 2] = (WY values, row loss, row hit)
+__device__ __forceinline__ float* tail_scr_row(const TailArgs& t, int task, int n, int RL, int WY) {
+  return t.scr + (((size_t)task * TAIL_GROUPS + (n % TAIL_GROUPS)) * RL + n / TAIL_GROUPS) * (WY + 2);
+}
+
+#define TAIL_SETUP(POOL, TANGENT)                                                                 \
+  extern __shared__ double tail_smem[];                                                           \
+  const BnArgs& a = t.bn;                                                                         \
+  const HeadArgs& h = t.hd;                                                                       \
+  const int tid = threadIdx.x, rg = blockIdx.x, task = blockIdx.y;                                \
+  const int N = h.n, F = h.feat, WY = h.ways;                                                     \
+  const int RL = (N + TAIL_GROUPS - 1) / TAIL_GROUPS;                                             \
+  const int rows = N > rg ? (N - rg + TAIL_GROUPS - 1) / TAIL_GROUPS : 0;                         \
+  const TailLds L = tail_carve(tail_smem, RL, F, WY, TANGENT);                                    \
+  const int quads = a.c >> 2, quad = tid % quads, c0 = quad * 4;                                  \
+  const WinIter<POOL> it(a);                                                                      \
+  const int wins = it.hw2 * it.ww2, per_row = wins * quads, items = rows * per_row;               \
+  const size_t z_task = (size_t)a.n * a.ho * a.wo * a.c;                                          \
+  const size_t p_task = (size_t)a.n * it.hp * it.wp * a.c;                                        \
+  const ChanConst k = load_consts(a, task, c0);                                                   \
+  const float* z_t = a.z + (size_t)task * z_task;
 
 template <int POOL>
 __global__ __launch_bounds__(TAIL_THREADS) void tail_fwd_bwd_kernel(TailArgs t) {
-  __shared__ double red[TAIL_THREADS * 8];
-  TAIL_SETUP(POOL)
-  // ---- BatchNorm + ReLU + MaxPool of the last block (bn_fwd_kernel's body)
+  TAIL_SETUP(POOL, false)
+  // the task's head weights into LDS (requested first: in flight under the BatchNorm stage)
+  {
+    const float* wl_t = h.wl + (size_t)task * h.pstride;
+    for (int e = tid; e < WY * F; e += TAIL_THREADS) L.wl[e] = wl_t[e];
+  }
+  // ---- BatchNorm + ReLU + MaxPool of this workgroup's rows (bn_fwd_kernel's arithmetic): p -> memory and LDS, zhat at the argmax / "ReLU on" kept
+  float zh_keep[TAIL_KMAX][4];
+  unsigned on_keep[TAIL_KMAX];
+  int poff_keep[TAIL_KMAX];             // offset of the item's channel quad inside its row's features, -1: no item
   {
     float* out_t = t.pooled + (size_t)task * p_task;
-    Window<POOL> w;
-    for (int win = wl; win < it.nwin; win += wpb) {
-      w.locate(a, it, win, c0);
-      if (!w.pooled) continue;
-      floatx4 umax, zh_at, zd_at;
-      scan_window<POOL, false>(w, z_t, nullptr, k, umax, zh_at, zd_at);
-      floatx4 o;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) o[c] = fmaxf(umax[c], 0.f);
-      *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
+    for (int kk = 0; kk < TAIL_KMAX; ++kk) {
+      const int item = tid + kk * TAIL_THREADS;
+      on_keep[kk] = 0u; poff_keep[kk] = -1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) zh_keep[kk][c] = 0.f;
+      if (item < items) {
+        const int rl = item / per_row, n = rg + TAIL_GROUPS * rl;
+        Window<POOL> w;
+        w.locate(a, it, n * wins + (item - rl * per_row) / quads, c0);
+        if (w.pooled) {
+          floatx4 umax, zh_at, zd_at;
+          scan_window<POOL, false>(w, z_t, nullptr, k, umax, zh_at, zd_at);
+          floatx4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            o[c] = fmaxf(umax[c], 0.f);
+            zh_keep[kk][c] = zh_at[c];
+            on_keep[kk] |= (umax[c] > 0.f ? 1u : 0u) << c;
+          }
+          *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
+          const int fo = (int)(w.poff - (size_t)n * F);
+          *reinterpret_cast<floatx4*>(L.f + (size_t)rl * F + fo) = o;
+          poff_keep[kk] = fo;
+        }
+      }
     }
   }
-  __syncthreads();                                           // p = the head's feature rows: written by this workgroup, read by it
-  // ---- Linear + cross-entropy, one wave per sample row (head_rows_kernel's body)
-  const HeadArgs& h = t.hd;
-  for (int n = tid >> 6; n < h.n; n += TAIL_THREADS / 64) head_row<false>(h, task, n, tid & 63);
   __syncthreads();
-  if (!t.with_grad || task >= t.bwd_tasks) {                 // evaluation / validation task: loss and accuracy, nothing else (head_reduce_kernel)
-    if (tid == 0 && h.loss) {
-      float ls = 0.f, cs = 0.f;
-      for (int r = 0; r < h.n; ++r) { ls += h.rowloss[(size_t)task * h.n + r]; cs += h.rowhit[(size_t)task * h.n + r]; }
-      h.loss[task] = ls / (float)h.n;
-      h.acc[task] = cs / (float)h.n;
-    }
-    return;
+  // ---- Linear + cross-entropy, one wave per row (head_rows_kernel's body on the LDS copies)
+  for (int rl = tid >> 6; rl < rows; rl += TAIL_THREADS / 64)
+    head_row_at<false>(h, task, rg + TAIL_GROUPS * rl, tid & 63, L.f + (size_t)rl * F, nullptr, L.wl, nullptr);
+  __syncthreads();
+  // this workgroup's dlogits into LDS, and -- written through -- where the folding workgroup sums them in row order (with row loss / hit)
+  const bool bwd = t.with_grad && task < t.bwd_tasks;
+  for (int e = tid; e < rows * (WY + 2); e += TAIL_THREADS) {
+    const int rl = e / (WY + 2), w = e - rl * (WY + 2), n = rg + TAIL_GROUPS * rl;
+    float v;
+    if (w < WY) { v = h.dl[((size_t)task * N + n) * WY + w]; L.a[rl * WY + w] = v; }
+    else v = (w == WY ? h.rowloss : h.rowhit)[(size_t)task * N + n];
+    tail_st(tail_scr_row(t, task, n, RL, WY) + w, v);
   }
-  // ---- dWl, dbl, df (= the cotangent of p), loss, accuracy (head_grads_kernel's body)
-  tail_head_grads<false>(h, task, reinterpret_cast<float*>(red));
   __syncthreads();
-  // ---- BatchNorm backward sums: dbeta = sum [u > 0 at the argmax] dp, dgamma = sum [...] dp zhat (bn_bwd_reduce_kernel's terms)
-  const float* dp_t = a.dp + (size_t)task * p_task;
-  {
+  if (bwd) {
+    // ---- this row group's share of dWl (head_grads_kernel: rows rg, rg + 4, ... in order) -> partial, written through
+    float* wp = t.wpart + ((size_t)task * TAIL_GROUPS + rg) * WY * F;
+    for (int i = tid; i < F; i += TAIL_THREADS) {
+      float dw[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) dw[w] = 0.f;
+      for (int rl = 0; rl < rows; ++rl) {
+        const float fv = L.f[(size_t)rl * F + i];
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+          if (w < WY) dw[w] = fmaf(L.a[rl * WY + w], fv, dw[w]);
+      }
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+        if (w < WY) tail_st(wp + (size_t)w * F + i, dw[w]);
+    }
+    // ---- df of this workgroup's rows (= the cotangent of p) and, from it, the BatchNorm-backward terms of the elements this thread pooled
     double dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
-    Window<POOL> w;
-    for (int win = wl; win < it.nwin; win += wpb) {
-      w.locate(a, it, win, c0);
-      if (!w.pooled) continue;
-      floatx4 umax, zh_at, zd_at;
-      scan_window<POOL, false>(w, z_t, nullptr, k, umax, zh_at, zd_at);
-      const floatx4 d = *reinterpret_cast<const floatx4*>(dp_t + w.poff);
+    float* df_t = h.df + (size_t)task * N * F;
+#pragma unroll
+    for (int kk = 0; kk < TAIL_KMAX; ++kk) {
+      if (poff_keep[kk] < 0) continue;
+      const int item = tid + kk * TAIL_THREADS, rl = item / per_row, n = rg + TAIL_GROUPS * rl, fo = poff_keep[kk];
+      floatx4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < WY; ++w) {
+        const floatx4 wv = *reinterpret_cast<const floatx4*>(L.wl + (size_t)w * F + fo);
+        const float dlw = L.a[rl * WY + w];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = fmaf(dlw, wv[c], s[c]);
+      }
+      *reinterpret_cast<floatx4*>(df_t + (size_t)n * F + fo) = s;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float du = umax[c] > 0.f ? d[c] : 0.f;
+        const float du = ((on_keep[kk] >> c) & 1u) ? s[c] : 0.f;
         db[c] += (double)du;
-        dg[c] += (double)du * (double)zh_at[c];
+        dg[c] += (double)du * (double)zh_keep[kk][c];
       }
     }
-    tail_reduce_store(dg, db, red, quads, a.c, t.sum0 + (size_t)task * t.sum_stride, t.sum1 + (size_t)task * t.sum_stride);
+    tail_partial(dg, db, L.red, quads, a.c, t.bpart + ((size_t)task * TAIL_GROUPS + rg) * 2 * a.c);
   }
-  __syncthreads();
-  // ---- BatchNorm backward apply: dz (bn_bwd_apply_kernel's body)
+  if (!tail_arrive(t.counter, task, L.flag)) return;
+  // ---- the workgroup that arrived last: loss, accuracy; dbl; dWl from the four partials; dgamma / dbeta
+  if (tid == 64 && h.loss) {
+    float ls = 0.f, cs = 0.f;
+    for (int n = 0; n < N; ++n) { const float* r = tail_scr_row(t, task, n, RL, WY); ls += tail_ld(r + WY); cs += tail_ld(r + WY + 1); }
+    h.loss[task] = ls / (float)N;
+    h.acc[task] = cs / (float)N;
+  }
+  if (!bwd) return;
+  if (tid < WY) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += tail_ld(tail_scr_row(t, task, n, RL, WY) + tid);
+    h.dbl[(size_t)task * h.gstride + tid] = s;
+  }
   {
-    float* out_t = a.out + (size_t)task * z_task;
-    float dgm[4], dbm[4], gr[4];
-    load4(t.sum0 + (size_t)task * t.sum_stride + c0, dgm);
-    load4(t.sum1 + (size_t)task * t.sum_stride + c0, dbm);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { dgm[c] *= a.inv_m; dbm[c] *= a.inv_m; gr[c] = k.g[c] * k.r[c]; }
-    Window<POOL> w;
-    for (int win = wl; win < it.nwin; win += wpb) {
-      w.locate(a, it, win, c0);
-      w.analyse(z_t, k);
-      float d[4] = {0.f, 0.f, 0.f, 0.f};
-      if (w.pooled) load4(dp_t + w.poff, d);
-#pragma unroll
-      for (int p = 0; p < Window<POOL>::NP; ++p) {
-        if (!w.exists[p]) continue;
-        float o[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float du = (w.pooled && w.arg[c] == p && w.umax[c] > 0.f) ? d[c] : 0.f;
-          o[c] = gr[c] * (du - dbm[c] - w.zh[p][c] * dgm[c]);
-        }
-        store4(out_t + w.off[p], o);
-      }
-    }
+    const float* p0 = t.wpart + (size_t)task * TAIL_GROUPS * WY * F;
+    float* dwl_t = h.dwl + (size_t)task * h.gstride;
+    const int WF = WY * F;
+    for (int e = tid; e < WF; e += TAIL_THREADS)
+      dwl_t[e] = ((tail_ld(p0 + e) + tail_ld(p0 + WF + e)) + tail_ld(p0 + 2 * WF + e)) + tail_ld(p0 + 3 * WF + e);
+  }
+  if (tid >= TAIL_THREADS - a.c) {
+    const int ch = tid - (TAIL_THREADS - a.c);
+    const double* bp = t.bpart + (size_t)task * TAIL_GROUPS * 2 * a.c;
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < TAIL_GROUPS; ++r) { s0 += tail_ld(bp + (size_t)r * 2 * a.c + ch); s1 += tail_ld(bp + (size_t)r * 2 * a.c + a.c + ch); }
+    t.sum0[(size_t)task * t.sum_stride + ch] = (float)s0;
+    t.sum1[(size_t)task * t.sum_stride + ch] = (float)s1;
   }
 }
 
 template <int POOL>
 __global__ __launch_bounds__(TAIL_THREADS) void tail_tangent_kernel(TailArgs t) {
-  __shared__ double red[TAIL_THREADS * 8];
-  TAIL_SETUP(POOL)
+  TAIL_SETUP(POOL, true)
+  {
+    const float* wl_t = h.wl + (size_t)task * h.pstride;
+    const float* wld_t = h.wld + (size_t)task * h.vstride;
+    for (int e = tid; e < WY * F; e += TAIL_THREADS) { L.wl[e] = wl_t[e]; L.wld[e] = wld_t[e]; }
+    // the primal features of this workgroup's rows (stored by the primal pass)
+    for (int e = tid; e < rows * F; e += TAIL_THREADS) {
+      const int rl = e / F;
+      L.f[e] = h.f[((size_t)task * N + rg + TAIL_GROUPS * rl) * F + (e - rl * F)];
+    }
+  }
   const float* zd_t = a.zd + (size_t)task * z_task;
-  float m1[4], m2[4], gd[4];
+  float m1[4], m2[4], gd[4], bd[4];
   load4(a.m1 + (size_t)task * a.c + c0, m1);
   load4(a.m2 + (size_t)task * a.c + c0, m2);
   load4(a.gammad + (size_t)task * a.vstride + c0, gd);
-  // ---- tangent of BatchNorm + ReLU + MaxPool (bn_tan_fwd_kernel's body)
+  load4(a.betad + (size_t)task * a.vstride + c0, bd);
+  // ---- tangent of BatchNorm + ReLU + MaxPool (bn_tan_fwd_kernel's arithmetic): pd -> memory and LDS; zhat, zhat-dot at the argmax and "ReLU on" kept
+  float zh_keep[TAIL_KMAX][4], zhd_keep[TAIL_KMAX][4];
+  unsigned on_keep[TAIL_KMAX];
+  int poff_keep[TAIL_KMAX];
   {
-    float bd[4];
-    load4(a.betad + (size_t)task * a.vstride + c0, bd);
     float* out_t = t.pooled + (size_t)task * p_task;
-    Window<POOL> w;
-    for (int win = wl; win < it.nwin; win += wpb) {
-      w.locate(a, it, win, c0);
-      if (!w.pooled) continue;
-      floatx4 umax, zh_at, zd_at;
-      scan_window<POOL, true>(w, z_t, zd_t, k, umax, zh_at, zd_at);
-      floatx4 o;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float zhd = k.r[c] * (zd_at[c] - m1[c] - zh_at[c] * m2[c]);
-        const float ud = gd[c] * zh_at[c] + k.g[c] * zhd + bd[c];
-        o[c] = (umax[c] > 0.f) ? ud : 0.f;
+    for (int kk = 0; kk < TAIL_KMAX; ++kk) {
+      const int item = tid + kk * TAIL_THREADS;
+      on_keep[kk] = 0u; poff_keep[kk] = -1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { zh_keep[kk][c] = 0.f; zhd_keep[kk][c] = 0.f; }
+      if (item < items) {
+        const int rl = item / per_row, n = rg + TAIL_GROUPS * rl;
+        Window<POOL> w;
+        w.locate(a, it, n * wins + (item - rl * per_row) / quads, c0);
+        if (w.pooled) {
+          floatx4 umax, zh_at, zd_at;
+          scan_window<POOL, true>(w, z_t, zd_t, k, umax, zh_at, zd_at);
+          floatx4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float zhd = k.r[c] * (zd_at[c] - m1[c] - zh_at[c] * m2[c]);
+            const float ud = gd[c] * zh_at[c] + k.g[c] * zhd + bd[c];
+            o[c] = (umax[c] > 0.f) ? ud : 0.f;
+            zh_keep[kk][c] = zh_at[c];
+            zhd_keep[kk][c] = zhd;
+            on_keep[kk] |= (umax[c] > 0.f ? 1u : 0u) << c;
+          }
+          *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
+          const int fo = (int)(w.poff - (size_t)n * F);
+          *reinterpret_cast<floatx4*>(L.fd + (size_t)rl * F + fo) = o;
+          poff_keep[kk] = fo;
+        }
       }
-      *reinterpret_cast<floatx4*>(out_t + w.poff) = o;
     }
   }
   __syncthreads();
-  // ---- logit tangents and R{dlogits} (head_rows_kernel<true>'s body), then R{dWl}, R{dbl}, R{df} (head_grads_kernel<true>'s)
-  const HeadArgs& h = t.hd;
-  for (int n = tid >> 6; n < h.n; n += TAIL_THREADS / 64) head_row<true>(h, task, n, tid & 63);
+  // ---- logit tangents and R{dlogits} (head_rows_kernel<true>'s body on the LDS copies)
+  for (int rl = tid >> 6; rl < rows; rl += TAIL_THREADS / 64)
+    head_row_at<true>(h, task, rg + TAIL_GROUPS * rl, tid & 63, L.f + (size_t)rl * F, L.fd + (size_t)rl * F, L.wl, L.wld);
   __syncthreads();
-  tail_head_grads<true>(h, task, reinterpret_cast<float*>(red));
-  __syncthreads();
-  // ---- tangent BatchNorm backward sums: R{dbeta} = sum dud, R{dgamma} = sum (dud zh + du zhd) (bn_tan_bwd_reduce_kernel's terms)
-  const float* dp_t = a.dp + (size_t)task * p_task;
-  const float* dpd_t = a.dpd + (size_t)task * p_task;
-  {
-    double rg[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
-    Window<POOL> w;
-    for (int win = wl; win < it.nwin; win += wpb) {
-      w.locate(a, it, win, c0);
-      if (!w.pooled) continue;
-      floatx4 umax, zh_at, zd_at;
-      scan_window<POOL, true>(w, z_t, zd_t, k, umax, zh_at, zd_at);
-      const floatx4 d = *reinterpret_cast<const floatx4*>(dp_t + w.poff);
-      const floatx4 dd = *reinterpret_cast<const floatx4*>(dpd_t + w.poff);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bool on = umax[c] > 0.f;
-        const float du = on ? d[c] : 0.f, dud = on ? dd[c] : 0.f;
-        const float zhd = k.r[c] * (zd_at[c] - m1[c] - zh_at[c] * m2[c]);
-        rb[c] += (double)dud;
-        rg[c] += (double)dud * (double)zh_at[c] + (double)du * (double)zhd;
-      }
-    }
-    tail_reduce_store(rg, rb, red, quads, a.c, t.sum0 + (size_t)task * t.sum_stride, t.sum1 + (size_t)task * t.sum_stride);
+  for (int e = tid; e < rows * WY; e += TAIL_THREADS) {
+    const int rl = e / WY, w = e - rl * WY, n = rg + TAIL_GROUPS * rl;
+    const float r = h.rdl[((size_t)task * N + n) * WY + w];
+    L.a[e] = r;
+    L.b[e] = h.dl[((size_t)task * N + n) * WY + w];
+    tail_st(tail_scr_row(t, task, n, RL, WY) + w, r);
   }
   __syncthreads();
-  // ---- tangent BatchNorm backward apply: R{dz} (bn_tan_bwd_apply_kernel's body)
+  // ---- this row group's share of R{dWl} = sum_n R{dl}[n] f[n] + dl[n] fd[n] (head_grads_kernel<true>: per row, in that order)
   {
-    float* out_t = a.out + (size_t)task * z_task;
-    float dgm[4], dbm[4], rgm[4], rbm[4], c1[4], gr[4];
-    load4(a.dgamma + (size_t)task * a.gstride + c0, dgm);
-    load4(a.dbeta + (size_t)task * a.gstride + c0, dbm);
-    load4(t.sum0 + (size_t)task * t.sum_stride + c0, rgm);
-    load4(t.sum1 + (size_t)task * t.sum_stride + c0, rbm);
+    float* wp = t.wpart + ((size_t)task * TAIL_GROUPS + rg) * WY * F;
+    for (int i = tid; i < F; i += TAIL_THREADS) {
+      float dw[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      dgm[c] *= a.inv_m; dbm[c] *= a.inv_m; rgm[c] *= a.inv_m; rbm[c] *= a.inv_m;
-      const float rd = -k.r[c] * k.r[c] * m2[c];
-      c1[c] = gd[c] * k.r[c] + k.g[c] * rd;
-      gr[c] = k.g[c] * k.r[c];
+      for (int w = 0; w < 8; ++w) dw[w] = 0.f;
+      for (int rl = 0; rl < rows; ++rl) {
+        const float fv = L.f[(size_t)rl * F + i], fdv = L.fd[(size_t)rl * F + i];
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+          if (w < WY) {
+            dw[w] = fmaf(L.a[rl * WY + w], fv, dw[w]);
+            dw[w] = fmaf(L.b[rl * WY + w], fdv, dw[w]);
+          }
+      }
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+        if (w < WY) tail_st(wp + (size_t)w * F + i, dw[w]);
     }
-    Window<POOL> w;
-    for (int win = wl; win < it.nwin; win += wpb) {
-      w.locate(a, it, win, c0);
-      w.analyse(z_t, k);
-      float d[4] = {0.f, 0.f, 0.f, 0.f}, dd[4] = {0.f, 0.f, 0.f, 0.f};
-      if (w.pooled) { load4(dp_t + w.poff, d); load4(dpd_t + w.poff, dd); }
+  }
+  // ---- R{df} of this workgroup's rows and the tangent BatchNorm-backward terms: R{dbeta} += dud, R{dgamma} += dud zh + du zhd
+  {
+    double rgm[4] = {0, 0, 0, 0}, rbm[4] = {0, 0, 0, 0};
+    float* df_t = h.df + (size_t)task * N * F;
+    const float* dp_t = a.dp + (size_t)task * p_task;
 #pragma unroll
-      for (int p = 0; p < Window<POOL>::NP; ++p) {
-        if (!w.exists[p]) continue;
-        float zdv[4], o[4];
-        load4(zd_t + w.off[p], zdv);
+    for (int kk = 0; kk < TAIL_KMAX; ++kk) {
+      if (poff_keep[kk] < 0) continue;
+      const int item = tid + kk * TAIL_THREADS, rl = item / per_row, n = rg + TAIL_GROUPS * rl, fo = poff_keep[kk];
+      const floatx4 d = *reinterpret_cast<const floatx4*>(dp_t + (size_t)n * F + fo);
+      floatx4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < WY; ++w) {
+        const floatx4 wv = *reinterpret_cast<const floatx4*>(L.wl + (size_t)w * F + fo);
+        const floatx4 wdv = *reinterpret_cast<const floatx4*>(L.wld + (size_t)w * F + fo);
+        const float ra = L.a[rl * WY + w], rb = L.b[rl * WY + w];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const bool sel = w.pooled && w.arg[c] == p && w.umax[c] > 0.f;
-          const float du = sel ? d[c] : 0.f, dud = sel ? dd[c] : 0.f;
-          const float zh = w.zh[p][c];
-          const float zhd = k.r[c] * (zdv[c] - m1[c] - zh * m2[c]);
-          const float e = du - dbm[c] - zh * dgm[c];
-          o[c] = c1[c] * e + gr[c] * (dud - rbm[c] - zhd * dgm[c] - zh * rgm[c]);
+          s[c] = fmaf(ra, wv[c], s[c]);
+          s[c] = fmaf(rb, wdv[c], s[c]);
         }
-        store4(out_t + w.off[p], o);
+      }
+      *reinterpret_cast<floatx4*>(df_t + (size_t)n * F + fo) = s;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool on = (on_keep[kk] >> c) & 1u;
+        const float du = on ? d[c] : 0.f, dud = on ? s[c] : 0.f;
+        rbm[c] += (double)dud;
+        rgm[c] += (double)dud * (double)zh_keep[kk][c] + (double)du * (double)zhd_keep[kk][c];
       }
     }
+    tail_partial(rgm, rbm, L.red, quads, a.c, t.bpart + ((size_t)task * TAIL_GROUPS + rg) * 2 * a.c);
+  }
+  if (!tail_arrive(t.counter, task, L.flag)) return;
+  if (tid < WY) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += tail_ld(tail_scr_row(t, task, n, RL, WY) + tid);
+    h.dbl[(size_t)task * h.gstride + tid] = s;
+  }
+  {
+    const float* p0 = t.wpart + (size_t)task * TAIL_GROUPS * WY * F;
+    float* dwl_t = h.dwl + (size_t)task * h.gstride;
+    const int WF = WY * F;
+    for (int e = tid; e < WF; e += TAIL_THREADS)
+      dwl_t[e] = ((tail_ld(p0 + e) + tail_ld(p0 + WF + e)) + tail_ld(p0 + 2 * WF + e)) + tail_ld(p0 + 3 * WF + e);
+  }
+  if (tid >= TAIL_THREADS - a.c) {
+    const int ch = tid - (TAIL_THREADS - a.c);
+    const double* bp = t.bpart + (size_t)task * TAIL_GROUPS * 2 * a.c;
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < TAIL_GROUPS; ++r) { s0 += tail_ld(bp + (size_t)r * 2 * a.c + ch); s1 += tail_ld(bp + (size_t)r * 2 * a.c + a.c + ch); }
+    t.sum0[(size_t)task * t.sum_stride + ch] = (float)s0;
+    t.sum1[(size_t)task * t.sum_stride + ch] = (float)s1;
   }
 }
 
-// The stage bodies assume: 4 | c, (c / 4) | TAIL_THREADS, c <= TAIL_THREADS, and the staged dlogits + the two groups' fold buffers inside
-// the reduction buffer (TAIL_THREADS * 8 doubles).
-bool tail_supported(int n, int c, int ways) {
-  if (c < 4 || c % 4 || TAIL_THREADS % (c / 4) || c > TAIL_THREADS || ways < 1 || ways > 64 || n < 1) return false;
-  const size_t floats = (size_t)((2 * n * ways + 63) & ~63) + (size_t)(TAIL_THREADS / 256) * 3 * 8 * 64;
-  return floats * sizeof(float) <= (size_t)TAIL_THREADS * 8 * sizeof(double);
+// What the kernels assume: 4 | c, (c / 4) | TAIL_THREADS, c <= TAIL_THREADS / 2; 4 | feat; ways <= 8; a row group's (row, window, quad) items within
+// TAIL_KMAX per thread; the LDS of the tangent kernel within the CU's 160 KB.
+bool tail_supported(int n, int ho, int wo, int c, int pool, int feat, int ways) {
+  if (c < 4 || c % 4 || TAIL_THREADS % (c / 4) || c > TAIL_THREADS / 2 || feat % 4 || ways < 1 || ways > 8 || n < 1) return false;
+  const int wins = pool ? ((ho + 1) / 2) * ((wo + 1) / 2) : ho * wo;
+  const int hp = pool ? ho / 2 : ho, wp = pool ? wo / 2 : wo;
+  if (hp * wp * c != feat) return false;
+  const long items = (long)((n + TAIL_GROUPS - 1) / TAIL_GROUPS) * wins * (c / 4);
+  if (items > (long)TAIL_KMAX * TAIL_THREADS) return false;
+  return tail_lds_bytes(n, feat, ways, 1) <= 150 * 1024;
+}
+size_t tail_wpart_floats(int tasks, int feat, int ways) { return (size_t)tasks * TAIL_GROUPS * ways * feat; }
+size_t tail_bpart_doubles(int tasks, int c) { return (size_t)tasks * TAIL_GROUPS * 2 * c; }
+size_t tail_scr_floats(int tasks, int n, int ways) { return (size_t)tasks * TAIL_GROUPS * ((n + TAIL_GROUPS - 1) / TAIL_GROUPS) * (ways + 2); }
+
+template <class K>
+static hipError_t tail_launch(K kern, hipStream_t st, const TailArgs& t, int tasks, size_t lds, unsigned* attr_done) {
+  if (lds > 64 * 1024) {
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (!(*attr_done & (1u << (dev & 31)))) {
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+      *attr_done |= 1u << (dev & 31);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(TAIL_GROUPS, tasks), dim3(TAIL_THREADS), lds, st, t);
+  return hipGetLastError();
 }
 
 hipError_t launch_tail(hipStream_t st, const TailArgs& t, int tasks, int pool, int tangent) {
-  if (!tail_supported(t.bn.n, t.bn.c, t.hd.ways)) return hipErrorInvalidValue;
-  if (tangent) {
-    if (pool) hipLaunchKernelGGL(tail_tangent_kernel<1>, dim3(tasks), dim3(TAIL_THREADS), 0, st, t);
-    else hipLaunchKernelGGL(tail_tangent_kernel<0>, dim3(tasks), dim3(TAIL_THREADS), 0, st, t);
-  } else {
-    if (pool) hipLaunchKernelGGL(tail_fwd_bwd_kernel<1>, dim3(tasks), dim3(TAIL_THREADS), 0, st, t);
-    else hipLaunchKernelGGL(tail_fwd_bwd_kernel<0>, dim3(tasks), dim3(TAIL_THREADS), 0, st, t);
-  }
-  return hipGetLastError();
+  if (!tail_supported(t.bn.n, t.bn.ho, t.bn.wo, t.bn.c, pool, t.hd.feat, t.hd.ways) || !t.counter || !t.wpart || !t.bpart || !t.scr || tasks > 65535)
+    return hipErrorInvalidValue;
+  const size_t lds = tail_lds_bytes(t.hd.n, t.hd.feat, t.hd.ways, tangent);
+  static unsigned done[4] = {0, 0, 0, 0};
+  if (tangent) return pool ? tail_launch(tail_tangent_kernel<1>, st, t, tasks, lds, &done[0]) : tail_launch(tail_tangent_kernel<0>, st, t, tasks, lds, &done[1]);
+  return pool ? tail_launch(tail_fwd_bwd_kernel<1>, st, t, tasks, lds, &done[2]) : tail_launch(tail_fwd_bwd_kernel<0>, st, t, tasks, lds, &done[3]);
 }

@@ -139,10 +139,10 @@ int mi_engine_set_fused_tail(mi_engine* e, int on);
 
 /* Ablation / test switch: 1 (default) = the LAST ConvBlock's BatchNorm + ReLU + MaxPool (core_functions/vision_models.py:188-193), the linear
  * head with its cross-entropy and accuracy (vision_models.py:109, core_functions/vision.py:11,16-18,21-23), the head's backward and that block's
- * BatchNorm backward -- in the Hessian-vector passes their tangents -- run as ONE launch per pass with one workgroup per task (csrc/tail.hip);
- * 0 = the five separate launches per pass (bn_fwd, head rows, head grads, bn_bwd_reduce, bn_bwd_apply).  The stage bodies are shared: the pooled
- * output, logits, loss, accuracy, head gradients and feature cotangents are bit-identical; the BatchNorm-backward sums are the same fp64 terms
- * folded in a fixed order that no longer depends on the tasks per call.  Applies to nets whose last block is a generic (hidden -> hidden) block
+ * BatchNorm-backward sums -- in the Hessian-vector passes their tangents -- run as ONE launch per pass, four workgroups (row groups) per task whose
+ * sums meet in the last-arriving workgroup (csrc/tail.hip); 0 = the four separate launches per pass (bn_fwd, head rows, head grads,
+ * bn_bwd_reduce).  Same arithmetic in the same order: the pooled output, logits, loss, accuracy, head gradients and feature cotangents are
+ * bit-identical; the BatchNorm-backward sums are the same fp64 terms folded in a fixed order that no longer depends on the tasks per call.  Applies to nets whose last block is a generic (hidden -> hidden) block
  * feeding a flattened head (MiniImagenetCNN; not the mean-pooled OmniglotCNN head) outside the opt-in fp16 operand form. */
 int mi_engine_set_fused_last_block(mi_engine* e, int on);
 

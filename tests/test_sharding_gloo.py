@@ -51,7 +51,7 @@ def _run(rank, world, port, out_path, meta_batch, packed=False):
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     import torch.distributed as dist
     from exploring_meta_amd.sharding import MetaTrainer
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     if world > 1:
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     compute, theta, R = _compute_factory()
@@ -100,6 +100,27 @@ def test_two_ranks_match_single_process(tmp_path, meta_batch):
     g = a['outs'][-1][2].abs()
     live = g > 1e-9 * g.max()
     assert live.float().mean() > 0.9
+    assert torch.allclose(a['theta'][live], b['theta'][live], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('meta_batch,packed', [(32, True), (20, False)])
+def test_eight_ranks_match_single_process(tmp_path, meta_batch, packed):
+    """World size 8 (the node the scaling bench runs on; gloo here): a 32-task meta-batch (4 tasks per rank: the in-place all-reduce of the
+    packed [grad | loss | acc] buffer) and a 20-task one (config 5's split over 8 ranks: 3/3/3/3/2/2/2/2, the gather path).  theta is
+    bit-identical on all eight ranks after two iterations (asserted inside every rank) and equal to the single-process run up to the order
+    of the fp64 sums."""
+    from exploring_meta_amd.sharding import shard_range
+    sizes = [b - a for a, b in (shard_range(meta_batch, r, 8) for r in range(8))]
+    assert sizes == ([4] * 8 if meta_batch == 32 else [3, 3, 3, 3, 2, 2, 2, 2])
+    single, multi = str(tmp_path / 'single.pt'), str(tmp_path / 'multi.pt')
+    _run(0, 1, 0, single, meta_batch, packed)
+    mp.spawn(_run, args=(8, _free_port(), multi, meta_batch, packed), nprocs=8, join=True)
+    a, b = torch.load(single), torch.load(multi)
+    for (la, aa, ga), (lb, ab, gb) in zip(a['outs'], b['outs']):
+        assert la == pytest.approx(lb, rel=1e-12) and aa == pytest.approx(ab, rel=1e-12)
+        assert float((ga - gb).norm() / ga.norm()) < 1e-12
+    g = a['outs'][-1][2].abs()
+    live = g > 1e-9 * g.max()
     assert torch.allclose(a['theta'][live], b['theta'][live], rtol=1e-9, atol=1e-12)
 
 
