@@ -75,6 +75,7 @@ _SIGS = {
                                         C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'mi_engine_set_fused_tail': (C.c_int, [C.c_void_p, C.c_int]),
     'mi_engine_set_fused_last_block': (C.c_int, [C.c_void_p, C.c_int]),
+    'mi_debug_tail_stamps': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mi_anil_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     'mi_meta_batch_anil': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

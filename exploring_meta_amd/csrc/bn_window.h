@@ -111,14 +111,16 @@ struct Window {
 
 // Streaming scan of one window: running maximum of u and the values of zh (and zd) AT the running maximum, carried as
 // plain SSA values (no per-position arrays: selecting among stored positions by index makes LLVM spill them to scratch).
+// scan_values: the scan on values already in registers (a caller that issues the loads of several windows before it waits for any);
+// scan_window: loads + the same scan.
 template <int POOL, bool WITH_ZD>
-__device__ __forceinline__ void scan_window(const Window<POOL>& w, const float* __restrict__ z_t, const float* __restrict__ zd_t,
-                                            const ChanConst& k, floatx4& umax, floatx4& zh_at, floatx4& zd_at) {
+__device__ __forceinline__ void scan_values(const floatx4* zv, const floatx4* zdv, const ChanConst& k, floatx4& umax, floatx4& zh_at,
+                                            floatx4& zd_at) {
 #pragma unroll
   for (int p = 0; p < Window<POOL>::NP; ++p) {
-    const floatx4 z = *reinterpret_cast<const floatx4*>(z_t + w.off[p]);
+    const floatx4 z = zv[p];
     floatx4 zd = {0.f, 0.f, 0.f, 0.f};
-    if (WITH_ZD) zd = *reinterpret_cast<const floatx4*>(zd_t + w.off[p]);
+    if (WITH_ZD) zd = zdv[p];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float zh = bn_zh(z[c], k.mu[c], k.r[c]);
@@ -134,4 +136,14 @@ __device__ __forceinline__ void scan_window(const Window<POOL>& w, const float* 
     }
   }
 }
-
+template <int POOL, bool WITH_ZD>
+__device__ __forceinline__ void scan_window(const Window<POOL>& w, const float* __restrict__ z_t, const float* __restrict__ zd_t,
+                                            const ChanConst& k, floatx4& umax, floatx4& zh_at, floatx4& zd_at) {
+  floatx4 zv[Window<POOL>::NP], zdv[Window<POOL>::NP];
+#pragma unroll
+  for (int p = 0; p < Window<POOL>::NP; ++p) {
+    zv[p] = *reinterpret_cast<const floatx4*>(z_t + w.off[p]);
+    if (WITH_ZD) zdv[p] = *reinterpret_cast<const floatx4*>(zd_t + w.off[p]);
+  }
+  scan_values<POOL, WITH_ZD>(zv, zdv, k, umax, zh_at, zd_at);
+}

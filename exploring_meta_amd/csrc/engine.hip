@@ -56,6 +56,7 @@ struct mi_engine {
   // the last ConvBlock's BatchNorm + pooling, the head, its backward and that block's BatchNorm-backward sums as ONE launch, four workgroups per
   // task (tail.hip), instead of four launches per pass (MI_FUSE_LAST=0 / mi_engine_set_fused_last_block(e, 0): the separate launches)
   bool fuse_last = !(getenv("MI_FUSE_LAST") && atoi(getenv("MI_FUSE_LAST")) == 0);
+  unsigned long long* tail_stamps = nullptr;   // debug (mi_debug_tail_stamps)
   unsigned zoff[10] = {}, zlen[10] = {};   // conv-bias segments and the padding P..PS of a parameter-shaped vector (never written by a kernel)
   int nzero = 0;
   unsigned* counters = nullptr;
@@ -649,7 +650,14 @@ static bool fused_last_ok(const mi_engine* e, const Plan& pl, int n, int T) {
   return tail_supported(n, L.ho, L.wo, L.co, L.pool, e->feat, e->d.ways);
 }
 static void tail_common(const mi_engine* e, const Plan& pl, TailArgs& ta) {
-  ta.wpart = pl.tail_wpart; ta.bpart = pl.tail_bpart; ta.scr = pl.tail_scr; ta.counter = e->counters;
+  ta.wpart = pl.tail_wpart; ta.bpart = pl.tail_bpart; ta.scr = pl.tail_scr; ta.counter = e->counters; ta.stamps = e->tail_stamps;
+}
+// Debug aid: while set, every launch of the one-launch tail (tail.hip) writes the 100 MHz wall clock at its stage boundaries, thread 0 of each of
+// its workgroups: buf [tasks][4][16] 64-bit words (device memory; the LAST tail launch of a call is what remains).  NULL switches it off.
+extern "C" int mi_debug_tail_stamps(mi_engine* e, unsigned long long* buf) {
+  if (!e) return MI_ERR_ARG;
+  e->tail_stamps = buf;
+  return MI_OK;
 }
 
 // Trunk forward: ConvBlocks on n images per task (conv + BN-stat epilogue, finalize, BN+ReLU+pool).

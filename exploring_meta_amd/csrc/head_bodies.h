@@ -21,11 +21,12 @@ __device__ __forceinline__ float wave_dot(const float* __restrict__ x, const flo
 // f_n / fd_n: the row's features (and their tangents), wl_t / wld_t: the task's head weights (and the direction's) -- wherever they live
 // (global memory in head.hip; LDS copies in tail.hip).
 template <bool TANGENT>
+// row_copy (optional, LDS): the row's dlogits (TANGENT: R{dlogits}) [WY], then -- primal only -- its loss and hit, for a caller that keeps working on them.
+// bl_t / bld_t: the task's head bias (the direction's); y: the row's label (primal).
 __device__ __forceinline__ void head_row_at(const HeadArgs& a, int task, int n, int lane, const float* f_n, const float* fd_n,
-                                            const float* wl_t, const float* wld_t) {
+                                            const float* wl_t, const float* wld_t, const float* bl_t, const float* bld_t, int y,
+                                            float* row_copy = nullptr) {
   const int N = a.n, F = a.feat, WY = a.ways;
-  const float* bl_t = a.bl + (size_t)task * a.pstride;
-  const float* bld_t = TANGENT ? a.bld + (size_t)task * a.vstride : nullptr;
   // lane w (< WY) ends up holding logit w of this row.  All `ways` dot products of the row advance together: one pass over the
   // feature row, 16-byte loads, every load of the pass independent of the others (the former one-dot-at-a-time loop with 4-byte
   // loads waited for memory once per 64 features and dot product: 57 us for a 5-way tangent row kernel).
@@ -105,18 +106,20 @@ __device__ __forceinline__ void head_row_at(const HeadArgs& a, int task, int n, 
     const int am = __ffsll((long long)eq) - 1;
     const float ex = act ? expf(mine - mx) : 0.f;
     const float se = wave_sum(ex);
-    const int y = a.y[(size_t)task * N + n];
     const float ly = __shfl(mine, y, 64);
     if (act) {
       const float p = ex / se;
       const float dl = (p - (lane == y ? 1.f : 0.f)) * invn;
       if (a.prob) a.prob[o + lane] = p;
       if (a.dl) a.dl[o + lane] = dl;
+      if (row_copy) row_copy[lane] = dl;
       if (a.logits) a.logits[o + lane] = mine;
     }
     if (lane == 0) {
-      a.rowloss[(size_t)task * N + n] = (mx + logf(se)) - ly;
-      a.rowhit[(size_t)task * N + n] = (am == y) ? 1.f : 0.f;
+      const float rl_ = (mx + logf(se)) - ly, rh_ = (am == y) ? 1.f : 0.f;
+      a.rowloss[(size_t)task * N + n] = rl_;
+      a.rowhit[(size_t)task * N + n] = rh_;
+      if (row_copy) { row_copy[WY] = rl_; row_copy[WY + 1] = rh_; }
     }
   } else {
     if (a.ld_out && act) a.ld_out[o + lane] = mine;
@@ -125,7 +128,11 @@ __device__ __forceinline__ void head_row_at(const HeadArgs& a, int task, int n, 
     } else {
       const float pr = act ? a.prob[o + lane] : 0.f;
       const float dot = wave_sum(pr * mine);
-      if (act) a.rdl[o + lane] = pr * (mine - dot) * invn;
+      if (act) {
+        const float r_ = pr * (mine - dot) * invn;
+        a.rdl[o + lane] = r_;
+        if (row_copy) row_copy[lane] = r_;
+      }
     }
   }
 }
@@ -136,7 +143,8 @@ __device__ __forceinline__ void head_row(const HeadArgs& a, int task, int n, int
   const int N = a.n, F = a.feat;
   head_row_at<TANGENT>(a, task, n, lane, a.f + ((size_t)task * N + n) * F,
                        (TANGENT && a.fd) ? a.fd + ((size_t)task * N + n) * F : nullptr, a.wl + (size_t)task * a.pstride,
-                       TANGENT ? a.wld + (size_t)task * a.vstride : nullptr);
+                       TANGENT ? a.wld + (size_t)task * a.vstride : nullptr, a.bl + (size_t)task * a.pstride,
+                       TANGENT ? a.bld + (size_t)task * a.vstride : nullptr, TANGENT ? 0 : a.y[(size_t)task * N + n]);
 }
 
 // dl (primal) or R{dl} (+ dl, tangent) of one task into LDS: s_a [N][WY], s_b [N][WY] (tangent only).  The caller synchronises.

@@ -230,6 +230,7 @@ struct TailArgs {
   double* bpart;        // [T][4][2][c] row-group partials of the BatchNorm-backward sums (tail_bpart_doubles)
   float* scr;           // [T][4][ceil(n/4)][ways + 2] per-row dlogits / loss / hit for the folding workgroup (tail_scr_floats)
   unsigned* counter;    // [T] arrival counters, zero on entry, left at zero
+  unsigned long long* stamps;   // debug (mi_debug_tail_stamps): [T][4][16] wall_clock64() at the stage boundaries, thread 0 of every workgroup; or nullptr
 };
 bool tail_supported(int n, int ho, int wo, int c, int pool, int feat, int ways);
 size_t tail_wpart_floats(int tasks, int feat, int ways);

@@ -145,6 +145,9 @@ int mi_engine_set_fused_tail(mi_engine* e, int on);
  * bit-identical; the BatchNorm-backward sums are the same fp64 terms folded in a fixed order that no longer depends on the tasks per call.  Applies to nets whose last block is a generic (hidden -> hidden) block
  * feeding a flattened head (MiniImagenetCNN; not the mean-pooled OmniglotCNN head) outside the opt-in fp16 operand form. */
 int mi_engine_set_fused_last_block(mi_engine* e, int on);
+/* Debug aid (tools/tail_stamps.py): the 100 MHz wall clock at the stage boundaries of the one-launch tail, thread 0 of each of its four workgroups
+ * per task: buf [tasks][4][16] 64-bit words of device memory, overwritten by every tail launch; NULL = off (the default). */
+int mi_debug_tail_stamps(mi_engine* e, unsigned long long* buf);
 
 /* One meta-batch of ANIL tasks (vision/anil_vision.py:116-122 with features = Sequential(ConvBase, view(-1, fc_neurons)),
  * head = MAML(Linear(fc_neurons, ways)), :86-94): the trunk runs once per task on all 2*shots*ways images (BatchNorm over

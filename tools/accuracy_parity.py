@@ -27,6 +27,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tasks', type=int, default=256)
     ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'accuracy_parity_cfg2'))
+    ap.add_argument('--b1-forms', default='', help='comma-separated operand forms of block 1 (mi_block1_set_split_bf16: 2 = split-bf16 conv1 in the '
+                    'tangent-forward kernel only, the default; 1 = in the forward kernel too; 0 = fp32 pipe everywhere): the engine leg is run once per form, '
+                    'the oracle legs once; every difference comes with its 95 %% confidence interval over the tasks (paired, per task)')
     args = ap.parse_args()
     wl = bench.WORKLOADS['cfg2']
     spec = ModelSpec.mini_imagenet(wl['ways'])
@@ -34,16 +37,30 @@ def main():
     ids = list(range(args.tasks))
     data, labels = bench.make_batch(wl, ids)
     eng = MetaEngine(spec)
-    el, ea = [], []
-    for lo in range(0, args.tasks, 32):
-        d, l = torch.from_numpy(data[lo:lo + 32]).cuda(), torch.from_numpy(labels[lo:lo + 32]).cuda()
-        loss, acc, _, _ = eng.meta_batch(theta0.cuda(), d, l, wl['shots'], wl['steps'], wl['lr'], with_grad=False)
-        el += [float(x) for x in loss.cpu()]
-        ea += [float(x) for x in acc.cpu()]
+
+    def engine_leg():
+        el, ea = [], []
+        for lo in range(0, args.tasks, 32):
+            d, l = torch.from_numpy(data[lo:lo + 32]).cuda(), torch.from_numpy(labels[lo:lo + 32]).cuda()
+            loss, acc, _, _ = eng.meta_batch(theta0.cuda(), d, l, wl['shots'], wl['steps'], wl['lr'], with_grad=False)
+            el += [float(x) for x in loss.cpu()]
+            ea += [float(x) for x in acc.cpu()]
+        return np.array(el), np.array(ea)
+
+    forms = [int(x) for x in args.b1_forms.split(',') if x != '']
+    legs = {}
+    if forms:
+        was = eng.lib.mi_block1_set_split_bf16(-1)
+        for f in forms:
+            eng.lib.mi_block1_set_split_bf16(f)
+            legs[f] = engine_leg()
+        eng.lib.mi_block1_set_split_bf16(was)
+        el, ea = legs[forms[0]]
+    else:
+        el, ea = engine_leg()
     t0 = time.time()
     res = TF.adapt_all(theta0.numpy(), data, labels, wl['shots'], wl['ways'], wl['steps'], wl['lr'], ids)
     dt = time.time() - t0
-    el, ea = np.array(el), np.array(ea)
     l64, a64, l32, a32 = (np.array([r[k] for r in res]) for k in ('loss64', 'acc64', 'loss32', 'acc32'))
     nq = wl['ways'] * wl['shots']
     rows = [('engine (fp32, MI355X)', ea, el), ('reference loop fp32 (oracle)', a32, l32), ('reference loop fp64 (oracle)', a64, l64)]
@@ -60,6 +77,15 @@ def main():
     d_e, d_n = abs(100 * (ea - a64).mean()), abs(100 * (a32 - a64).mean())
     verdict = 'within +-0.2 %' if d_e <= 0.2 else ('within the fp32-vs-fp64 spread' if d_e <= d_n else 'OUTSIDE +-0.2 % and the spread')
     lines += ['', f'|engine - fp64| = {d_e:.4f} % of accuracy (bar: 0.2 %); fp32-vs-fp64 noise floor {d_n:.4f} %: {verdict}.']
+    # paired differences with their 95 % confidence interval over the tasks: a mean accuracy difference is a draw of near-tied predictions
+    # (one flipped prediction = 1 / (tasks x 25)), so a single figure says little without its interval
+    ci = lambda d: 1.96 * 100 * d.std(ddof=1) / np.sqrt(len(d))
+    lines += ['', '| paired difference of accuracy (points of %) | mean | 95 % interval (+-) | n tasks |', '|---|---|---|---|']
+    named = [(f'engine, block-1 form {f} - fp64', legs[f][1] - a64) for f in forms] if forms else [('engine - fp64', ea - a64)]
+    named += [(f'engine form {forms[i]} - engine form {forms[0]}', legs[forms[i]][1] - legs[forms[0]][1]) for i in range(1, len(forms))]
+    named += [('reference fp32 - fp64', a32 - a64)]
+    for name, d in named:
+        lines.append(f'| {name} | {100 * d.mean():+.4f} | {ci(d):.4f} | {len(d)} |')
     print('\n'.join(lines), flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out + '.md', 'w') as f:
