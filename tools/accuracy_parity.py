@@ -59,8 +59,16 @@ def main():
     else:
         el, ea = engine_leg()
     t0 = time.time()
+    import threading
+    done = threading.Event()
+
+    def heartbeat():                              # (the GPU box's watchdog takes minutes of silence for a hang)
+        while not done.wait(60.0):
+            print(f'[accuracy_parity] oracle legs running, {time.time() - t0:.0f} s', file=sys.stderr, flush=True)
+    threading.Thread(target=heartbeat, daemon=True).start()
     res = TF.adapt_all(theta0.numpy(), data, labels, wl['shots'], wl['ways'], wl['steps'], wl['lr'], ids)
     dt = time.time() - t0
+    done.set()
     l64, a64, l32, a32 = (np.array([r[k] for r in res]) for k in ('loss64', 'acc64', 'loss32', 'acc32'))
     nq = wl['ways'] * wl['shots']
     rows = [('engine (fp32, MI355X)', ea, el), ('reference loop fp32 (oracle)', a32, l32), ('reference loop fp64 (oracle)', a64, l64)]
