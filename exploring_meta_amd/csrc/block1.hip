@@ -570,8 +570,14 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 // for the forward kernel, the split form for the tangent-forward kernel (2), which decides nothing: off the power cap (the hidden blocks
 // on the fp16 form) that is 14.95 -> 14.75 .. 14.90 ms per cfg2 iteration on one box, both kernels split 14.66.
 // 2 = the tangent-forward kernel only: it takes no decisions (the argmax is the stored one), so its rounding redraws nothing.
+// Round 6: the 0.203 % was a draw of near-ties, not a property of the form.  Over 1024 tasks (25,600 predictions, paired per task, 95 % intervals;
+// profiles/r6/accuracy_parity_cfg2_1024tasks_b1forms.md): form 2 - fp64 = +0.055 +- 0.144 points, form 1 - fp64 = +0.113 +- 0.136, form 1 - form 2 =
+// +0.059 +- 0.163, the reference's own fp32 - fp64 = -0.023 +- 0.172 -- no form is distinguishable from fp64, and every interval is as wide as
+// north_star's +-0.2 % bar itself.  The forward kernel on the split form is -0.6 % per cfg2 iteration in alternating pairs (16.42 / 16.39 ->
+// 16.29 / 16.33 ms, profiles/r6/ab_b1_form.txt): DEFAULT 1 since round 6 (both lean forward kernels split; eight products keep the decisions'
+// margins those of the fp32 pipe, 1.7e-6).
 #ifndef MI_B1_DEFAULT_SPLIT
-#define MI_B1_DEFAULT_SPLIT 2
+#define MI_B1_DEFAULT_SPLIT 1
 #endif
 static int g_b1_split = -1;
 static int block1_split_bf16() {

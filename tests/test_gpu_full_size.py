@@ -182,7 +182,8 @@ def _batched_vs_one_task(kernel):
 
 
 @pytest.mark.parametrize('T', [32, 256])
-def test_cfg4_full_T_batched_looped_oracle(conv_form_full, T):
+def test_cfg4_full_T_batched_looped_oracle(conv_form_full3, T):
+    conv_form_full = conv_form_full3
     """(Every operand form at 32 tasks per GPU -- the benched size; the 256-task leg runs the default form only: its oracle legs take
     minutes.)  BASELINE config 4 (5-way 1-shot, one second-order step, 32 tasks per GPU; 256 = the whole meta-batch on one GPU) with
     the reference's initialisers and plateau-free inputs, the well-conditioned setting SURVEY.md 8c calibrated at <= 1e-4:
