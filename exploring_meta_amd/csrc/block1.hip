@@ -576,21 +576,26 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 // north_star's +-0.2 % bar itself.  The forward kernel on the split form is -0.6 % per cfg2 iteration in alternating pairs (16.42 / 16.39 ->
 // 16.29 / 16.33 ms, profiles/r6/ab_b1_form.txt): DEFAULT 1 since round 6 (both lean forward kernels split; eight products keep the decisions'
 // margins those of the fp32 pipe, 1.7e-6).
+// Unless set explicitly (environment / mi_block1_set_split_bf16) the forward kernel follows the hidden convolutions' operand form: with those on the
+// fp32 pipe (mi_conv_set_split_bf16(0), the "fp32 pipe" leg of bench.py and of the tests) it stays on the fp32 pipe too (form 2, as in round 5).
 #ifndef MI_B1_DEFAULT_SPLIT
 #define MI_B1_DEFAULT_SPLIT 1
 #endif
-static int g_b1_split = -1;
+static int g_b1_split = -1;      // -1: not set explicitly
+static bool g_b1_env_read = false;
 static int block1_split_bf16() {
-  if (g_b1_split < 0) {
+  if (!g_b1_env_read) {
+    g_b1_env_read = true;
     const char* e = getenv("MI_B1_BF16X3");
-    g_b1_split = e ? (atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e))) : MI_B1_DEFAULT_SPLIT;
+    if (e && g_b1_split < 0) g_b1_split = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
   }
-  return g_b1_split;
+  if (g_b1_split >= 0) return g_b1_split;
+  return conv_operand_form() == 0 ? 2 : MI_B1_DEFAULT_SPLIT;
 }
 int block1_split_form() { return block1_split_bf16(); }
-extern "C" int mi_block1_set_split_bf16(int on) {
+extern "C" int mi_block1_set_split_bf16(int on) {      // on < 0: back to "follow the hidden convolutions' form"; returns the form in force before
   const int was = block1_split_bf16();
-  g_b1_split = on < 0 ? 0 : (on > 2 ? 2 : on);
+  g_b1_split = on < 0 ? -1 : (on > 2 ? 2 : on);
   return was;
 }
 bool block1_supported(int ci, int stride, int pool, int h, int w, int co) {

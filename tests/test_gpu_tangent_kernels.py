@@ -20,14 +20,14 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope='module', params=['split_f16', 'split_bf16_16x16', 'split_bf16_32x32', 'fp32_pipe'])
 def lib(request):
     """Every case runs with both operand forms of the 32-channel stride-1 convolutions (mi_conv_set_split_bf16) -- and, with them, of the
-    lean block-1 forward kernels' conv1 (mi_block1_set_split_bf16; the engine's default splits only the tangent-forward kernel): same bars."""
+    lean block-1 forward kernels' conv1 (mi_block1_set_split_bf16; the engine's default follows the hidden convolutions' form): same bars."""
     lb = _lib.load()
     from conftest import apply_conv_form
     restore = apply_conv_form(lb, request.param)
-    was1 = lb.mi_block1_set_split_bf16(1 if request.param.startswith('split_bf16') else 0)
+    lb.mi_block1_set_split_bf16(1 if request.param.startswith('split_bf16') else 0)
     yield lb
     restore()
-    lb.mi_block1_set_split_bf16(was1)
+    lb.mi_block1_set_split_bf16(-1)             # back to "follow the hidden convolutions' form" (the library's default)
 
 
 def _rand(seed, shape, lo=-1.0, hi=1.0):

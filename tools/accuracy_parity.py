@@ -50,11 +50,10 @@ def main():
     forms = [int(x) for x in args.b1_forms.split(',') if x != '']
     legs = {}
     if forms:
-        was = eng.lib.mi_block1_set_split_bf16(-1)
         for f in forms:
             eng.lib.mi_block1_set_split_bf16(f)
             legs[f] = engine_leg()
-        eng.lib.mi_block1_set_split_bf16(was)
+        eng.lib.mi_block1_set_split_bf16(-1)
         el, ea = legs[forms[0]]
     else:
         el, ea = engine_leg()
