@@ -574,12 +574,14 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 // profiles/r6/accuracy_parity_cfg2_1024tasks_b1forms.md): form 2 - fp64 = +0.055 +- 0.144 points, form 1 - fp64 = +0.113 +- 0.136, form 1 - form 2 =
 // +0.059 +- 0.163, the reference's own fp32 - fp64 = -0.023 +- 0.172 -- no form is distinguishable from fp64, and every interval is as wide as
 // north_star's +-0.2 % bar itself.  The forward kernel on the split form is -0.6 % per cfg2 iteration in alternating pairs (16.42 / 16.39 ->
-// 16.29 / 16.33 ms, profiles/r6/ab_b1_form.txt): DEFAULT 1 since round 6 (both lean forward kernels split; eight products keep the decisions'
-// margins those of the fp32 pipe, 1.7e-6).
-// Unless set explicitly (environment / mi_block1_set_split_bf16) the forward kernel follows the hidden convolutions' operand form: with those on the
-// fp32 pipe (mi_conv_set_split_bf16(0), the "fp32 pipe" leg of bench.py and of the tests) it stays on the fp32 pipe too (form 2, as in round 5).
+// 16.29 / 16.33 ms, profiles/r6/ab_b1_form.txt).  It still stays OPT-IN: as the default it fails four frozen decision-level bars of the GPU
+// suite (profiles/r6/gpu_tests_b1_form1_default.txt: the teacher-forced per-step bar ADJ_H 2e-5 reads 1.2e-4, cfg4's batched-vs-one-task
+// gradient 1.4e-2 without a near-tied decision below TAU to explain it, the K = 2 train + validation bar 2e-3 reads 2.9e-3) -- its rounding
+// moves decisions whose fp32 margins are above the 3e-6 the tests accept as ties, and those bars are not negotiable for 0.6 %.
+// Unless set explicitly (environment / mi_block1_set_split_bf16(0..2)) the form is MI_B1_DEFAULT_SPLIT with the hidden convolutions on a split
+// form and 2 with those on the fp32 pipe (a build with -DMI_B1_DEFAULT_SPLIT=1 keeps the "fp32 pipe" legs of bench.py and of the tests on form 2).
 #ifndef MI_B1_DEFAULT_SPLIT
-#define MI_B1_DEFAULT_SPLIT 1
+#define MI_B1_DEFAULT_SPLIT 2
 #endif
 static int g_b1_split = -1;      // -1: not set explicitly
 static bool g_b1_env_read = false;
