@@ -289,9 +289,29 @@ __global__ __launch_bounds__(256) void wgrad3x3_rows_bf16_kernel(WgradArgs a) {
 struct StripItem { int n, c0, ya, yb; bool ok; };
 struct XRowPl { RowPl e; };                                     // (the odd packing is rebuilt per step: 12 instructions instead of 12 resident registers per row)
 
-template <int C, bool F16>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile))
+// LDSR (round 6; 32 filters, bf16 form): the rows reach the lanes through a per-wave LDS ring filled by LDS-DMA (buffer_load ... lds: no register
+// destination, so nothing limits how far ahead they run but the ring): one "bundle" per step -- x row r + 1 as two 1-KB pieces and one 256-B piece
+// (18 pixels x 128 B), dz row r as two 1-KB pieces -- issued SEVEN steps ahead into 8 + 8 slots (34 KB per wave), and read back as the same 18 dwords per
+// lane (ds_read_b32, conflict-free: a pixel's 32 channels are 32 consecutive words) at the places the register loads used to be.  A wave's own DMA is
+// ordered for its own ds_read by a COUNTED s_waitcnt vmcnt (loads retire in order; hipcc does not track LDS-DMA, so every count here is by hand: 5
+// operations per bundle, the tables next to the macros) -- never by vmcnt(0), which is what made the register ring stall once per loop trip (hipcc
+// turns the first operand wait behind a back edge into vmcnt(0)).  Out-of-range pieces (columns outside the image: offsets past the row descriptor's
+// size; rows outside it or past the strip piece: empty descriptors) arrive as ZEROS in LDS (tools/lds_dma_probe.hip), exactly as they did in registers.
+#define MI_WG_RING 8
+#define MI_WG_XSLOT 576                                          /* floats: 18 pixels x 32 channels */
+#define MI_WG_DSLOT 512                                          /* floats: 16 pixels x 32 channels */
+__device__ __forceinline__ void wg_dma16(mi_rsrc r, float* lds, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ void wg_dma4(mi_rsrc r, float* lds, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 4, voff, 0, 0, 0);
+}
+
+template <int C, bool F16, bool LDSR = false>   // C = filters (32 or 64: blockIdx.z = (ci tile, co tile))
 __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
+  static_assert(!LDSR || (C == 32 && !F16), "the LDS-ring form serves the 32-filter split-bf16 kernel");
   __shared__ float red[4 * 1024];
+  extern __shared__ __attribute__((aligned(16))) float wg_ring[];        // LDSR: [wave][8 x slots | 8 dz slots]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -345,23 +365,54 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
       const bool ok = yy < yb;
       return __builtin_amdgcn_make_buffer_rsrc((void*)(dt + (size_t)(ok ? yy : 0) * W * C), 0, ok ? rowb : 0u, 0x00020000);
     };
-#define ST_LOADX(SET, YY) { const mi_rsrc rr_ = xrow(YY); rawx[SET][0] = buf_ld(rr_, vom);                                  \
-      _Pragma("unroll") for (int c = 1; c < 10; ++c) rawx[SET][c] = buf_ld(rr_, vo + (unsigned)((c - 1) * C * 4)); }
-#define ST_LOADD(SET, YY) { const mi_rsrc rr_ = drow(YY);                                                                  \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) rawd[SET][c] = buf_ld(rr_, vod + (unsigned)(c * C * 4)); }
+    // LDSR: this wave's ring, the lanes' source offsets of the five pieces of a bundle (x: segment = columns s16 * 16 - 1 .. + 16; a negative
+    // offset wraps past the descriptor's size, i.e. reads zeros: the left padding) and this lane's word inside a slot
+    float* const xring = wg_ring + wave * (MI_WG_RING * (MI_WG_XSLOT + MI_WG_DSLOT));
+    float* const dring = xring + MI_WG_RING * MI_WG_XSLOT;
+    const unsigned xseg = (unsigned)((s16 * 16 - 1) * (C * 4));
+    const unsigned vx0 = xseg + (unsigned)(lane * 16), vx1 = xseg + 1024u + (unsigned)(lane * 16), vx2 = xseg + 2048u + (unsigned)(lane * 4);
+    const unsigned vd0 = (unsigned)(s16 * 16 * (C * 4) + lane * 16), vd1 = vd0 + 1024u;
+    const int lane_w = (8 * h) * 32 + j;
+#define WG_XISSUE(R) { const mi_rsrc rr_ = xrow(R); float* s_ = xring + (((R) - ya + 1) & (MI_WG_RING - 1)) * MI_WG_XSLOT;        \
+      wg_dma16(rr_, s_, vx0); wg_dma16(rr_, s_ + 256, vx1); wg_dma4(rr_, s_ + 512, vx2); }
+#define WG_DISSUE(R) { const mi_rsrc rr_ = drow(R); float* s_ = dring + (((R) - ya) & (MI_WG_RING - 1)) * MI_WG_DSLOT;            \
+      wg_dma16(rr_, s_, vd0); wg_dma16(rr_, s_ + 256, vd1); }
+#define WG_BUNDLE(R) { if constexpr (LDSR) { WG_XISSUE((R) + 1) WG_DISSUE(R) } }                 /* 5 operations */
+#define WG_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");
+    // ST_LOADX / ST_LOADD(SET, YY, N): row YY into raw set SET.  Register form: the loads themselves.  LDSR: wait until at most N younger DMA
+    // operations are outstanding (= row YY has landed), then the lane's dwords from the ring.
+#define ST_LOADX(SET, YY, N) { if constexpr (LDSR) { WG_WAIT(N)                                                              \
+        const float* p_ = xring + (((YY) - ya + 1) & (MI_WG_RING - 1)) * MI_WG_XSLOT + lane_w;                                     \
+        _Pragma("unroll") for (int c = 0; c < 10; ++c) rawx[SET][c] = p_[c * 32];                                                 \
+      } else { const mi_rsrc rr_ = xrow(YY); rawx[SET][0] = buf_ld(rr_, vom);                                                      \
+        _Pragma("unroll") for (int c = 1; c < 10; ++c) rawx[SET][c] = buf_ld(rr_, vo + (unsigned)((c - 1) * C * 4)); } }
+#define ST_LOADD(SET, YY, N) { if constexpr (LDSR) { WG_WAIT(N)                                                              \
+        const float* p_ = dring + (((YY) - ya) & (MI_WG_RING - 1)) * MI_WG_DSLOT + lane_w;                                         \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) rawd[SET][c] = p_[c * 32];                                                  \
+      } else { const mi_rsrc rr_ = drow(YY);                                                                                        \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) rawd[SET][c] = buf_ld(rr_, vod + (unsigned)(c * C * 4)); } }
 #define ST_SPLITX(SET, SLOT) { split_x<0, F16>(rawx[SET], xr[SLOT].e, sxi); split_x<1, F16>(rawx[SET], xr[SLOT].e, sxi); split_x<2, F16>(rawx[SET], xr[SLOT].e, sxi); \
       split_x<3, F16>(rawx[SET], xr[SLOT].e, sxi); split_x<4, F16>(rawx[SET], xr[SLOT].e, sxi); }
 #define ST_SPLITD(SET, BUF) { split_dz<0, F16>(rawd[SET], dzp[BUF], sdi); split_dz<1, F16>(rawd[SET], dzp[BUF], sdi); split_dz<2, F16>(rawd[SET], dzp[BUF], sdi); \
       split_dz<3, F16>(rawd[SET], dzp[BUF], sdi); }
     // prologue: x rows ya - 1, ya, ya + 1 (slots 0, 1, 2) and dz row ya; then the ring: x rows ya + 2 .. ya + 4, dz rows ya + 1 .. ya + 3
-    ST_LOADX(0, ya - 1) ST_LOADX(1, ya) ST_LOADX(2, ya + 1) ST_LOADD(0, ya)
+    // LDSR: the previous item's DMA drained, then x rows ya - 1, ya and bundles ya .. ya + 5 on their way (36 operations: the ring's 8 x slots
+    // full); counts below = operations issued AFTER the awaited row's (bundle r = x row r + 1 [3], dz row r [2])
+    if constexpr (LDSR) {
+      WG_WAIT(0)
+      WG_XISSUE(ya - 1) WG_XISSUE(ya)
+      WG_BUNDLE(ya) WG_BUNDLE(ya + 1) WG_BUNDLE(ya + 2) WG_BUNDLE(ya + 3) WG_BUNDLE(ya + 4) WG_BUNDLE(ya + 5)
+    }
+    ST_LOADX(0, ya - 1, 33) ST_LOADX(1, ya, 30) ST_LOADX(2, ya + 1, 27) ST_LOADD(0, ya, 25)
     if constexpr (F16) fs = f16_wgrad_scales(a, fcells);          // (scalar arithmetic on the cells requested at the top of the kernel)
     const float sxi = term ? fs.sx[1] : fs.sx[0], sdi = term ? fs.sd[1] : fs.sd[0];     // (F16) this item's operand scales
     ST_SPLITX(0, 0) ST_SPLITX(1, 1) ST_SPLITX(2, 2) ST_SPLITD(0, 0)
     // The ring.  hipcc turns the FIRST operand wait of every loop trip into vmcnt(0) whatever is in flight across the back edge (its
     // wait-count pass does not carry exact counts around a loop), so the loads are timed such that everything in flight at a trip
     // boundary is at least two steps old: a trip's steps 2 and 3 are loaded at its step 0, the NEXT trip's steps 0 and 1 at its step 2.
-    ST_LOADX(3, ya + 2) ST_LOADD(1, ya + 1) ST_LOADX(0, ya + 3) ST_LOADD(2, ya + 2)
+    if constexpr (LDSR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }      // (x row ya - 1 has left its slot: bundle ya + 6 takes it)
+    WG_BUNDLE(ya + 6)
+    ST_LOADX(3, ya + 2, 27) ST_LOADD(1, ya + 1, 25) ST_LOADX(0, ya + 3, 22) ST_LOADD(2, ya + 2, 20)
     // step T (output row y + T of the trip that starts at row y): x rows in slots T, T+1, T+2 (mod 4), dz planes T & 1; meanwhile x row
     // y + T + 2 (raw set (T + 3) & 3) is split into slot (T + 3) & 3 and dz row y + T + 1 (raw set (T + 1) & 3) into planes (T + 1) & 1
   // (F16: three products -- l b_h, h b_l, h b_h -- with the same preparation slots between them)
@@ -394,8 +445,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
     ST_TAP(3 * (R) + 1, (ot.h), (ot.m), (ot.l), B, V4, V5, V6, V7)                                                \
     ST_TAP(3 * (R) + 2, (X.e.h + 1), (X.e.m + 1), (X.e.l + 1), B, V8, V9, V10, V11)
 #define ST_PREP(X) if (MI_WGRAD_DBG != 2 && MI_WGRAD_DBG != 4) { X; }
+    // LDSR: step T of the trip that starts at row y puts bundle y + T + 7 on its way (x row y + T + 8 into the slot of row y + T, read a trip ago); the
+    // reads of steps 0 / 2 then find: x row y + T + 4 with 22 younger operations (its own bundle's dz [2] + four bundles), dz row y + T + 3 with
+    // 20, x row y + T + 5 with 17, dz row y + T + 4 with 15
 #define ST_STEP(T)                                                                                                \
     {                                                                                                             \
+      WG_BUNDLE(y + (T) + 7)                                                                                      \
       XRowPl& nx = xr[((T) + 3) & 3];                                                                             \
       const float* rx_ = rawx[((T) + 3) & 3];                                                                     \
       const float* rd_ = rawd[((T) + 1) & 3];                                                                     \
@@ -405,11 +460,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
              ST_PREP((split_x<3, F16>(rx_, nx.e, sxi))), ST_PREP((split_x<4, F16>(rx_, nx.e, sxi))), ST_PREP((split_dz<0, F16>(rd_, nd, sdi))), ST_PREP((split_dz<1, F16>(rd_, nd, sdi))), \
              ST_PREP((split_dz<2, F16>(rd_, nd, sdi))), ST_PREP((split_dz<3, F16>(rd_, nd, sdi))))                                \
       ST_ROW(1, xr[((T) + 1) & 3], cd,                                                                            \
-             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADX(1, y + 4) else if ((T) == 2) ST_LOADX(3, y + 6),          \
-             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADD(3, y + 3) else if ((T) == 2) ST_LOADD(1, y + 5),          \
+             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADX(1, y + 4, 22) else if ((T) == 2) ST_LOADX(3, y + 6, 22),          \
+             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADD(3, y + 3, 20) else if ((T) == 2) ST_LOADD(1, y + 5, 20),          \
              (void)0, (void)0,                                                                                    \
-             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADX(2, y + 5) else if ((T) == 2) ST_LOADX(0, y + 7),          \
-             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADD(0, y + 4) else if ((T) == 2) ST_LOADD(2, y + 6),          \
+             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADX(2, y + 5, 17) else if ((T) == 2) ST_LOADX(0, y + 7, 17),          \
+             if (MI_WGRAD_DBG == 3) {} else if ((T) == 0) ST_LOADD(0, y + 4, 15) else if ((T) == 2) ST_LOADD(2, y + 6, 15),          \
              (void)0, (void)0, (void)0)                                                                           \
       ST_ROW(2, xr[((T) + 2) & 3], cd, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0) \
     }
@@ -427,7 +482,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_strip_bf16_kernel(WgradArgs a) {
 #undef ST_SPLITX
 #undef ST_LOADD
 #undef ST_LOADX
+#undef WG_WAIT
+#undef WG_BUNDLE
+#undef WG_DISSUE
+#undef WG_XISSUE
   }
+  if constexpr (LDSR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the last item's run-ahead pieces land before LDS is re-used / the wave ends)
   if constexpr (F16) fs = f16_wgrad_scales(a, fcells);           // (a wave without items has not formed them yet; every thread needs fs.inv below)
 
   // cross-wave reduction, one tap at a time: red[wave][r*64 + lane]
@@ -466,8 +526,26 @@ int wgrad_bf16_strip_items(const ConvGeom& g, int rows) {
   const int rp = wgrad_bf16_strip_rows(g, rows);
   return g.n * ((g.w + 15) / 16) * ((g.h + rp - 1) / rp);
 }
+// the rows-through-LDS form of the strip kernel (32 filters, bf16 form): OPT-IN (MI_WGRAD_LDS=1).  Bit-identical results (same operands, same
+// products, same order: the 100 weight-gradient kernel tests pass with it), but no faster: block 2 of cfg2 in isolation 197.8 us against 185.0 us
+// for the register ring (tools/wgrad_probe.py, one box; profiles/r6/wgrad_lds_ring_ab.txt) -- the launch moves ~1 GB (two terms) in that
+// time, 5 TB/s of the 6.2 a streaming copy reaches, so it was never waiting for latency a deeper run-ahead could hide.
+static bool wgrad_lds_rows() { static const bool v = getenv("MI_WGRAD_LDS") && atoi(getenv("MI_WGRAD_LDS")) != 0; return v; }
 hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid, int rows) {
   a.mpix = wgrad_bf16_strip_rows(a.g, rows);                   // (the kernel takes the rows per piece in this field)
+  if (a.form != 2 && a.g.ci == 32 && wgrad_lds_rows()) {
+    const size_t lds = (size_t)4 * MI_WG_RING * (MI_WG_XSLOT + MI_WG_DSLOT) * sizeof(float);
+    auto k = wgrad3x3_strip_bf16_kernel<32, false, true>;
+    static unsigned attr_done = 0;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (!(attr_done & (1u << (dev & 31)))) {
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+      attr_done |= 1u << (dev & 31);
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+  }
   if (a.form == 2) {
     if (a.g.ci == 64) hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<64, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad3x3_strip_bf16_kernel<32, true>), grid, dim3(256), 0, st, a);

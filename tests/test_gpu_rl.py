@@ -411,6 +411,38 @@ def test_meta_optimize_anil_trpo_matches_oracle():
     assert et <= max(1e-3, es * float(ref['step'].norm()) * P['outer_lr'] / tn * 2)
 
 
+def test_anil_trpo_matches_the_reference_record(golden_rl):
+    """ANIL-TRPO (rl/anil_trpo.py; rl.py:381-382,395-396,409-473 with anil=True) against the record of the REFERENCE's own lines on the stored
+    replays (golden_rl.npz, case anil_tanh): the head-only inner update of fast_adapt_trpo, the surrogate loss / KL at parameters where the
+    re-adapted policies differ from the stored ones, its gradient, and the first product of the exact KL Hessian (the third-derivative
+    terms included).  The conjugate-gradient STEP is not compared: the record holds the reference's own fp32 run beside its fp64 run, and
+    their steps differ by 0.88 of the step's norm (rl_anil_tanh_f32_rel_to_f64[3]) -- ten iterations on a nearly singular, indefinite system."""
+    import rl_cases
+    case = rl_cases.load_case(golden_rl, 'anil_tanh')
+    params, theta, replays, olds = case['params'], case['theta'], case['replays'], case['olds']
+    G = lambda k: golden_rl['rl_anil_tanh_f64_' + k]
+    flat0 = torch.cat([v.reshape(-1) for v in theta.values()]).numpy()
+    pol = _anil_policy(theta)
+    pol.turn_off_body_grads()
+    new = cf.trpo_update(replays[0][0], pol, cf.LinearValue(2, 2), params['inner_lr'], params['gamma'], params['tau'], anil=True)
+    pol.turn_on_body_grads()
+    e_fa = rel_err(new.flat().cpu().numpy() - flat0, G('fa_theta') - flat0)
+    old_pols = [_anil_policy(o) for o in olds]
+    from exploring_meta_amd.core_functions.rl import _SurrogateContext
+    ctx = _SurrogateContext(replays, old_pols, pol, cf.LinearValue(2, 2), params)
+    th = pol.flat()
+    l32, k32, g32 = ctx.evaluate(th, want_grad=True)
+    ctx.prepare_general_kl(th)
+    f32 = ctx.fvp(th, torch.from_numpy(G('surr_grad')).float().cuda())
+    torch.cuda.synchronize()
+    eg, ef = rel_err(g32.cpu().numpy(), G('surr_grad')), rel_err(f32.cpu().numpy(), G('opt_fvp_first'))
+    report('anil_trpo_vs_reference_record', fast_adapt_rel=e_fa, loss=float(l32), loss_ref=float(G('surr_loss_kl')[0]), kl=float(k32),
+           kl_ref=float(G('surr_loss_kl')[1]), grad_rel=eg, fvp_first_rel=ef, reference_fp32_rel_to_its_fp64=golden_rl['rl_anil_tanh_f32_rel_to_f64'].tolist())
+    assert e_fa < 1e-4
+    assert abs(float(l32) - G('surr_loss_kl')[0]) < 1e-6 and abs(float(k32) - G('surr_loss_kl')[1]) < 1e-5 * max(G('surr_loss_kl')[1], 1e-3)
+    assert eg < 1e-4 and ef < 1e-3
+
+
 def test_tanh_surrogate_grad_fvp_match_oracle():
     """MAML-TRPO with DiagNormalPolicy(activation='tanh'): the tanh curvature term of the inner-loss HVP is exercised by the
     surrogate gradient (I - lr H) grad S and by both H products inside the Fisher-vector product."""
