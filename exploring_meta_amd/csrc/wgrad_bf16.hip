@@ -528,8 +528,9 @@ int wgrad_bf16_strip_items(const ConvGeom& g, int rows) {
 }
 // the rows-through-LDS form of the strip kernel (32 filters, bf16 form): OPT-IN (MI_WGRAD_LDS=1).  Bit-identical results (same operands, same
 // products, same order: the 100 weight-gradient kernel tests pass with it), but no faster: block 2 of cfg2 in isolation 197.8 us against 185.0 us
-// for the register ring (tools/wgrad_probe.py, one box; profiles/r6/wgrad_lds_ring_ab.txt) -- the launch moves ~1 GB (two terms) in that
-// time, 5 TB/s of the 6.2 a streaming copy reaches, so it was never waiting for latency a deeper run-ahead could hide.
+// for the register ring (tools/wgrad_probe.py, one box), 16.12 / 16.14 against 16.14 / 16.12 ms per cfg2 iteration (profiles/r6/wgrad_lds_ring_ab.txt):
+// the rows cost the same whichever way they arrive, so the register ring was never waiting for latency a deeper run-ahead could hide -- the
+// launch runs at the socket power cap (and, beside the dgrad on the other stream, at the memory's bandwidth), where bytes moved are clock lost.
 static bool wgrad_lds_rows() { static const bool v = getenv("MI_WGRAD_LDS") && atoi(getenv("MI_WGRAD_LDS")) != 0; return v; }
 hipError_t launch_wgrad_strips_bf16(hipStream_t st, WgradArgs a, dim3 grid, int rows) {
   a.mpix = wgrad_bf16_strip_rows(a.g, rows);                   // (the kernel takes the rows per piece in this field)
