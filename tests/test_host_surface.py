@@ -70,6 +70,9 @@ def test_maml_wrapper_surface():
     learner = maml.clone()
     assert isinstance(learner, cf.MAML) and learner.module is model and learner.lr == 0.5 and learner.first_order is False
     assert maml.clone(first_order=True).first_order is True
+    from exploring_meta_amd.algorithms import MAML as by_l2l_path           # `from learn2learn.algorithms import MAML` with the package swapped
+    from exploring_meta_amd.algorithms.maml import MAML as by_base_path     # reference core_functions/maml.py:8
+    assert by_l2l_path is cf.MAML and by_base_path is cf.MAML
     assert learner.hidden_size == 64                       # attribute forwarding to the wrapped module
     assert set(maml.state_dict().keys()) == {'module.' + k for k in model.state_dict().keys()}
     fw = learner.fast_weights()                            # flat, parameters() order, graph-connected to the base parameters

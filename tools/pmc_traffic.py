@@ -134,6 +134,7 @@ def main():
         # that, the same grid rule for both: a layer the first has taken is not a candidate for the second, whose size classes then count
         # through the remaining layers of that grid)
         taken = {}
+        top_launches = {(k, g): nl for k, g, nl, f, w, c in rows if c == 0}
         for k, g, nl, f, w, c in sorted(rows, key=lambda r: 0 if 'conv3x3_s1_b16_kernel' in r[0] else 1):
             m = re.match(r'conv3x3_s1_mfma_kernel<(\d+), (\d), (\d), (\d)(?:, (true|false))?(?:, (true|false))?>', k)
             m16 = re.match(r'conv3x3_s1_b16_kernel<(\d+), (\d), (\d), (\d)>', k)      # the split-bf16 form on 16x16x32 MFMAs: same grid rule as BF = true
@@ -147,10 +148,15 @@ def main():
             same_grid = [layer for layer in range(1, len(geo))       # blocks launched with this grid, largest maps first
                          if geo[layer][2] == int(m.group(1)) and grid_threads(layer, int(m.group(2)), m.group(5) == 'true') == g
                          and (m16 or layer not in taken.get(op, ()))]
-            if c < len(same_grid):
-                out[f'{args.workload},{op},{same_grid[c]}'] = int((f + w) * 1e6)
+            # (a run may also hold calls on FEWER tasks -- bench.py's 16-task comparison leg -- whose launches of a layer form size classes
+            # of their own between two layers': the workload's own calls launch every layer equally often, so only classes with as many
+            # launches as the largest one count, numbered in order)
+            own = sorted(c2 for k2, g2, nl2, f2, w2, c2 in rows if (k2, g2) == (k, g) and nl2 == top_launches[(k, g)])
+            if c in own and own.index(c) < len(same_grid):
+                layer = same_grid[own.index(c)]
+                out[f'{args.workload},{op},{layer}'] = int((f + w) * 1e6)
                 if m16:
-                    taken.setdefault(op, set()).add(same_grid[c])
+                    taken.setdefault(op, set()).add(layer)
         json.dump(out, open(args.json, 'w'), indent=1)
 
 

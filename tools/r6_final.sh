@@ -18,7 +18,7 @@ if [ "$PART" = a ]; then
   python tools/roofline_table.py $O/event_breakdown_cfg2.csv > $O/roofline_table_cfg2.md 2>/dev/null
   ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/prof_cfg2 -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-clock --no-other --no-sampled --no-dist --no-overlap --pool 2 > $ROOT/$O/prof_cfg2.log 2>&1; echo "trace2 rc=$?" )
   f=$(find $O/prof_cfg2 -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp $f $O/rocprofv3_kernel_stats_cfg2.csv
-  python3 tools/dominant_kernel_trace.py $O/prof_cfg2 --kernel "$DOM" --cycle 1 --bench $O/bench_cfg2.json > $O/rocprofv3_dominant_kernel_cfg2.txt 2>&1
+  python3 tools/dominant_kernel_trace.py $O/prof_cfg2 --kernel "$DOM" --cycle 2 --bench $O/bench_cfg2.json > $O/rocprofv3_dominant_kernel_cfg2.txt 2>&1
   rm -rf $O/prof_cfg2
   for C in cfg1 cfg3 cfg4; do
     timeout -k 10 300 python bench.py --workload $C --steps 20 --warmup 3 --breakdown $O/event_breakdown_$C.csv > $O/bench_$C.json 2> $O/bench_$C.err; echo "$C rc=$?"

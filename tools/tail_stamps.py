@@ -43,11 +43,11 @@ def main():
         torch.cuda.synchronize()
         eng.lib.mi_debug_tail_stamps(eng._h, None)
         s = buf.cpu().numpy().reshape(T, 4, 16).astype(np.int64)
-        t0 = s[:, :, 0].min()
+        t0 = s[0, :, 0].min()
         print(f'# {what}, {T} task(s) per call; microseconds since the first workgroup started (100 MHz clock); task 0')
         for g in range(4):
             row = s[0, g, :10]
-            print(f'workgroup {g}: ' + '  '.join(f'{(v - t0) / 100.0:6.2f}' if v else '     -' for v in row))
+            print(f'workgroup {g}: ' + '  '.join(f'{(v - t0) / 100.0:6.2f}' if v >= t0 else '     -' for v in row))      # (an older launch's last arriver may have been another workgroup: its stamp is stale)
         print('stages: ' + ' | '.join(f'{i}={n}' for i, n in enumerate(NAMES)))
         buf.zero_()
 
