@@ -156,6 +156,7 @@ _SIGS = {
     'mi_conv_get_split_bf16': (C.c_int, [C.POINTER(C.c_uint)]),
     'mi_conv_set_b16': (C.c_int, [C.c_int]),
     'mi_block1_set_split_bf16': (C.c_int, [C.c_int]),
+    'mi_sparse_wgrad_set_split_bf16': (C.c_int, [C.c_int]),
     'mi_trpo_general_workspace_bytes': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     'mi_trpo_kl_prepare': (C.c_int, [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t]),
     'mi_trpo_fvp_general': (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -463,7 +463,11 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
       for (int q = 0; q < 8; ++q) {
         const int i0 = 2 * q, i1 = 2 * q + 1;
         const floatx2 pr = {B1Vec<CI0>::get(o.av[i0 / 3], i0 % 3), i1 < KH ? B1Vec<CI0>::get(o.av[(i1 < KH ? i1 : 0) / 3], (i1 < KH ? i1 : 0) % 3) : 1.f};   // slot 15: the constant 1 (FWD's shift; ARG's weight there is 0)
+#ifdef MI_B1_ABLATE_XSPLIT     // timing probe only (wrong results): what the kernel costs with the patch planes delivered ready-made
+        xh[q] = __builtin_bit_cast(unsigned, pr[0]); xm[q] = __builtin_bit_cast(unsigned, pr[1]); xl[q] = xh[q];
+#else
         bf16_split2(pr, xh[q], xm[q], xl[q]);
+#endif
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {

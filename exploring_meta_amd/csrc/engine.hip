@@ -456,12 +456,12 @@ static void plan_actset(const mi_engine* e, Bump& b, ActSet& A, int T, int n, bo
 }
 
 // Everything that decides WHICH kernels a fused call launches besides the engine's own switches: the operand form of the hidden
-// convolutions, its bisecting mask, the kernel of that form (16x16x32 / 32x32x16) and block 1's operand form.  Part of the hipGraph cache
+// convolutions, its bisecting mask, the kernel of that form (16x16x32 / 32x32x16), block 1's operand form and its sparse weight gradient's.  Part of the hipGraph cache
 // key: a graph captured under one selection must not be replayed under another.
 static unsigned long long kernel_selection_key() {
   unsigned mask = 0;
   const unsigned form = (unsigned)mi_conv_get_split_bf16(&mask);
-  return (unsigned long long)form + 4ull * (unsigned)conv_b16() + 16ull * (unsigned)block1_split_form() + 64ull * (unsigned long long)mask;
+  return (unsigned long long)form + 4ull * (unsigned)conv_b16() + 16ull * (unsigned)block1_split_form() + 64ull * (unsigned)sparse_wgrad_split_form() + 128ull * (unsigned long long)mask;
 }
 
 static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K, int second_order, Plan& pl) {

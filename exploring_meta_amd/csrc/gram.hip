@@ -13,6 +13,7 @@
 #include "mi_common.h"
 #include "kernels.h"
 #include "fold.h"
+#include "bf16_split.h"
 
 typedef double doublex4 __attribute__((ext_vector_type(4)));
 
@@ -366,10 +367,22 @@ __global__ __launch_bounds__(256) void sparse_wgrad_kernel(SparseWgArgs a) {
 // touching memory).  The number of loads in flight at every point is then the same on every path, so the compiler's s_waitcnt
 // counts are exact -- in the work-item loop above the conditional row fetches make it assume the worst and wait for the chunk it
 // has just issued, which exposes a full memory latency per chunk.
-template <int CI0, bool TAN, int CO, int CH, int NCH>
-__global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs a) {
+//
+// BF: the same product on the 16-bit matrix pipe at fp32-equivalent accuracy, with the SIX partial products of the split-bf16 operand form
+// (bf16_split.h: a b = ah bh + am bh + ah bl + al bh + ah bm + am bm up to 2^-24 |a b|) laid out along K.  A window of the pair owns the
+// eight K slots of its lane half of v_mfma_f32_32x32x16_bf16: four for one position of the window, four for the next, each position's four
+// holding A = (ah, am, ah, al).  Two instructions on the same A registers -- B = (bh, bh, bl, bh) and B = (bm, bm, 0, 0) per position, masked
+// by the position's argmax mask -- give all six products of TWO positions: the MFMA count per window is the fp32 kernel's, each an 8-pass
+// bf16 instruction where that is a 16-pass fp32 one, and, unlike the fp32 instruction, it leaves the SIMD's vector lanes to other work.
+// The A side costs nothing in the loop: the input rows are split ONCE, when they are staged into LDS, and stored as the two dwords of a
+// position's slots (P = ah | am << 16, Q = ah | al << 16; two neighbouring values = one ds_read2_b64 straight into the operand registers);
+// the B side is one split per window and channel (shared by the four positions) and three ANDs per position.
+template <int CI0, bool TAN, int CO, int CH, int NCH, bool BF = false>
+__global__ __launch_bounds__(256, BF ? 2 : 4) void sparse_wgrad_rows_kernel(SparseWgArgs a) {
   constexpr int K = 9 * CI0;
   constexpr unsigned RSRC = 0x00020000u;
+  constexpr int EW = BF ? 2 : 1;                 // dwords per staged input value
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
   const int task = blockIdx.y, cbase = blockIdx.z * 32, ch = cbase + j;
   const int H = a.hh, W = a.ww, HP = H >> 1, WP = W >> 1;
   const int RP = a.row_pitch, ROWF = W * CI0;
-  float* rows = lds + wave * 8 * RP;
+  float* rows = lds + wave * 8 * RP * EW;
   const float* x_t = a.x + (size_t)task * a.n * H * W * CI0;
   const size_t p_task = (size_t)a.n * HP * WP * CO;
   const uint8_t* arg_t = a.arg + (size_t)task * p_task;
@@ -386,8 +399,8 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
   const bool kval = j < K;
   const int tap = kval ? j / CI0 : 0, kc = kval ? j % CI0 : 0;
   const int kdy = tap / 3 - 1, kdx = tap % 3 - 1;
-  const float* arow = rows + (kval ? (kdy + 1) * RP + (kdx + 1) * CI0 + kc : 0) + 2 * h * CI0;
-  const float* arow1 = arow + RP;
+  const float* arow = rows + ((kval ? (kdy + 1) * RP + (kdx + 1) * CI0 + kc : 0) + 2 * h * CI0) * EW;
+  const float* arow1 = arow + RP * EW;
   const unsigned lane_b = (unsigned)(h * CO + ch), lane_b4 = lane_b * 4u, lane_x = (unsigned)lane * 4u;
   float sA = 1.f, sB = 0.f;
   if (TAN) {
@@ -395,10 +408,19 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
     sA = a.gammad[(size_t)task * a.vstride + ch] * rs + gm * (-rs * rs * a.m2[(size_t)task * CO + ch]);   // c1
     sB = gm * rs;                                                                                             // gr
   }
-  floatx16 acc, acc2;
+  floatx16 acc, acc2, zero16;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-  for (int e = lane; e < 8 * RP; e += 64) rows[e] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; zero16[r] = 0.f; }
+  // (BF) The sum over the tiles of a wave, of a workgroup's waves and -- in the consumers' folds -- over the workgroups runs in fp64 from each
+  // tile's fp32 result on: what reaches the fold does not depend on how the launch cut the task into shares (to ~1e-16), so a task's
+  // gradient is the same whether it runs alone or beside 31 others -- the fp32 chain over a share's ~1400 MFMAs was this kernel's part of
+  // the engine's sensitivity to launch geometry.
+  double dacc[BF ? 16 : 1];
+  if constexpr (BF) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dacc[r] = 0.0;
+  }
+  for (int e = lane; e < 8 * RP * EW; e += 64) rows[e] = 0.f;
   // this workgroup's share of the task's tiles: an even split (shares differ by at most one tile)
   const int tile_base = (int)((long)blockIdx.x * a.ntiles / gridDim.x);
   const int tile_end = (int)((long)(blockIdx.x + 1) * a.ntiles / gridDim.x);
@@ -417,11 +439,25 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
     }
   };
   auto store_rows = [&](int set) {
-    float* dst = rows + set * 4 * RP + CI0 + lane;
+    if constexpr (BF) {
+      // every staged value split here, once: (P, Q) = (ah | am << 16, ah | al << 16), one ds_write_b64 per value
+      u32x2* dst = reinterpret_cast<u32x2*>(rows) + set * 4 * RP + CI0 + lane;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dst[r * RP + 64 * i] = rbuf[r][i];
+        for (int i = 0; i < 4; i += 2) {
+          unsigned sh, sm, sl;
+          bf16_split2(floatx2{rbuf[r][i], rbuf[r][i + 1]}, sh, sm, sl);
+          dst[r * RP + 64 * i] = u32x2{__builtin_amdgcn_perm(sm, sh, 0x05040100u), __builtin_amdgcn_perm(sl, sh, 0x05040100u)};
+          dst[r * RP + 64 * (i + 1)] = u32x2{__builtin_amdgcn_perm(sm, sh, 0x07060302u), __builtin_amdgcn_perm(sl, sh, 0x07060302u)};
+        }
+    } else {
+      float* dst = rows + set * 4 * RP + CI0 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[r * RP + 64 * i] = rbuf[r][i];
+    }
   };
   auto fetch_b = [&](int tile, int c, SparseB& b) {
     const bool tv = tile < tile_end;
@@ -437,7 +473,49 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
       if (TAN) b.qd[i] = buf_ld(rdd, lane_b4 + (unsigned)((c * CH + i) * 8 * CO));
     }
   };
-  auto compute = [&](int set, int c, const SparseB& b) {
+  // (BF) the A operands of one chunk, read from LDS one chunk ahead of their MFMAs: [K step][top / bottom row of the window]
+  struct SparseA { mi_u32x4 v[CH][2]; };
+  auto fetch_a = [&](int set, int c, SparseA& A) {
+    const u32x2* ac = reinterpret_cast<const u32x2*>(arow) + set * 4 * RP;
+    const u32x2* ac1 = reinterpret_cast<const u32x2*>(arow1) + set * 4 * RP;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int o = 4 * (c * CH + i) * CI0;
+      const u32x2 a0 = ac[o], a1 = ac[o + CI0], a2 = ac1[o], a3 = ac1[o + CI0];
+      A.v[i][0] = mi_u32x4{a0[0], a0[1], a1[0], a1[1]};
+      A.v[i][1] = mi_u32x4{a2[0], a2[1], a3[0], a3[1]};
+    }
+  };
+  auto compute = [&](int set, int c, const SparseB& b, const SparseA& A) {
+    if constexpr (BF) {
+      // One MFMA takes TWO positions of the window (the pair in a row): its A operand is (P, Q) of position q and (P, Q) of position q + 1 --
+      // two staged values CI0 apart, one ds_read2_b64 straight into the operand's register tuple, no moves -- and the six products come from
+      // two instructions on that tuple: B = (bh|bh, bl|bh) per position [ah bh + am bh + ah bl + al bh], then B = (bm|bm, 0) [ah bm + am bm],
+      // each masked by its position's argmax mask.
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        {
+          // the cotangent's three pieces, each as the packed pair the K slots want, straight out of the conversions: cvt_pk(c, c) = bh|bh,
+          // cvt_pk(r, r) = bm|bm with r = c - bh, cvt_pk(r - bm, c) = bl|bh (the subtractions are exact)
+          const float cv = TAN ? fmaf(sB, b.qd[i], sA * b.q[i]) : b.q[i];
+          const unsigned bhh = __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{cv, cv}, bf16x2));
+          const float r1 = bf16_sub(cv, __uint_as_float(bhh & 0xffff0000u));
+          const unsigned bmm = __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{r1, r1}, bf16x2));
+          const float r2 = bf16_sub(r1, __uint_as_float(bmm & 0xffff0000u));
+          const unsigned blh = __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{r2, cv}, bf16x2));
+          const unsigned hot = 1u << b.ag[i];
+          const unsigned m0 = (unsigned)lane_mask_bit<0>(hot), m1 = (unsigned)lane_mask_bit<1>(hot), m2 = (unsigned)lane_mask_bit<2>(hot), m3 = (unsigned)lane_mask_bit<3>(hot);
+          const bf16x8 top = __builtin_bit_cast(bf16x8, A.v[i][0]), bot = __builtin_bit_cast(bf16x8, A.v[i][1]);
+          // (a tile starts from C = 0 -- an inline constant --: its fp32 sum is the same whichever wave of whichever launch geometry computes it)
+          const bool first = c == 0 && i == 0;
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(top, __builtin_bit_cast(bf16x8, (mi_u32x4{bhh & m0, blh & m0, bhh & m1, blh & m1})), first ? zero16 : acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(top, __builtin_bit_cast(bf16x8, (mi_u32x4{bmm & m0, 0u, bmm & m1, 0u})), first ? zero16 : acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bot, __builtin_bit_cast(bf16x8, (mi_u32x4{bhh & m2, blh & m2, bhh & m3, blh & m3})), acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bot, __builtin_bit_cast(bf16x8, (mi_u32x4{bmm & m2, 0u, bmm & m3, 0u})), acc2, 0, 0, 0);
+        }
+      }
+      return;
+    }
     const float* ac = arow + set * 4 * RP, * ac1 = arow1 + set * 4 * RP;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -454,7 +532,48 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
     }
   };
   int tile = tile_base + ((wave + blockIdx.x) & 3);   // this wave's tiles: tile, tile + 4, ... (start rotated per workgroup); pairs per iteration
+  if constexpr (BF) {
+    // The bf16 MFMAs of a chunk take 12 x 32 cycles where the fp32 ones took 12 x 64, and two waves share a SIMD instead of four: one chunk
+    // of run-ahead no longer covers a global load.  The B operands run BD chunks ahead (buffers indexed by the chunk's place in its pooled
+    // row: the same register set for the same place in every tile), the A operands one chunk ahead out of LDS.
+    constexpr int BD = TAN ? 2 : 3;      // (tangent mode loads one more operand per K step: one chunk less of run-ahead keeps it inside the register file)
+    SparseB bb[NCH];
+    SparseA aa[2];
+    fetch_rows(tile);
+    store_rows(0);
+    fetch_rows(tile + 4);
+#pragma unroll
+    for (int c = 0; c < BD; ++c) fetch_b(tile, c, bb[c]);
+    fetch_a(0, 0, aa[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    while (tile < tile_end) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {       // half 0: tile (LDS set 0), half 1: tile + 4 (set 1)
+        const int cur_tile = tile + 4 * half, nxt_tile = cur_tile + 4;
+        store_rows(half ^ 1);                      // rows of the next tile (in registers since the previous half) -> the other set
+        fetch_rows(cur_tile + 8);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int m = half * NCH + c;
+          if (c + BD < NCH) fetch_b(cur_tile, c + BD, bb[c + BD]);
+          else fetch_b(nxt_tile, c + BD - NCH, bb[c + BD - NCH]);
+          if (c + 1 < NCH) fetch_a(half, c + 1, aa[(m + 1) & 1]);
+          else fetch_a(half ^ 1, 0, aa[(m + 1) & 1]);      // (the next tile's rows went into the other set at the top of this half)
+          __builtin_amdgcn_sched_barrier(0);
+          if (cur_tile < tile_end) compute(half, c, bb[c], aa[m & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cur_tile < tile_end) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dacc[r] += (double)(acc[r] + acc2[r]);
+        }
+      }
+      tile += 8;
+    }
+  } else {
   SparseB bb[2];
+  SparseA aa[1];
   fetch_rows(tile);
   store_rows(0);
   fetch_rows(tile + 4);
@@ -473,28 +592,46 @@ __global__ __launch_bounds__(256, 4) void sparse_wgrad_rows_kernel(SparseWgArgs 
         if (c + 1 < NCH) fetch_b(cur_tile, c + 1, bb[(m + 1) & 1]);
         else fetch_b(nxt_tile, 0, bb[(m + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (cur_tile < tile_end) compute(half, c, bb[m & 1]);
+        if (cur_tile < tile_end) compute(half, c, bb[m & 1], aa[0]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     tile += 8;
   }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+  }
   // (lane index and column base re-derived here rather than kept live across the loop: the kernel sits at its 128-register budget)
   const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   __syncthreads();
+  if constexpr (BF) {
+    double* ldsd = reinterpret_cast<double*>(lds);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) lds[wave * 1024 + r * 64 + ln] = acc[r];
+    for (int r = 0; r < 16; ++r) ldsd[wave * 1024 + r * 64 + ln] = dacc[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[wave * 1024 + r * 64 + ln] = acc[r] + acc2[r];
+  }
   __syncthreads();
-  float* pt = a.wpartial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * K * CO + blockIdx.z * 32;
+  float* pt = a.wpartial + ((size_t)blockIdx.y * gridDim.x * (BF ? 2 : 1) + blockIdx.x) * K * CO + blockIdx.z * 32;
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     const int e = wave * 64 + ln + 256 * qq;
-    const float v = lds[e] + lds[1024 + e] + lds[2048 + e] + lds[3072 + e];
+    float v, vlo = 0.f;
+    if constexpr (BF) {
+      // the workgroup's fp64 sum leaves as TWO fp32 partials, v + vlo (vlo in the second half of the task's partial blocks: the consumers fold
+      // 2 * gridDim.x partials in fp64, which restores the sum to 2^-48)
+      const double* ldsd = reinterpret_cast<const double*>(lds);
+      const double d = ((ldsd[e] + ldsd[1024 + e]) + ldsd[2048 + e]) + ldsd[3072 + e];
+      v = (float)d;
+      vlo = (float)(d - (double)v);
+    } else {
+      v = lds[e] + lds[1024 + e] + lds[2048 + e] + lds[3072 + e];
+    }
     const int r = e >> 6;
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = ln & 31;
-    if (row < K) pt[(size_t)row * CO + col] = v;
+    if (row < K) {
+      pt[(size_t)row * CO + col] = v;
+      if constexpr (BF) pt[(size_t)gridDim.x * K * CO + (size_t)row * CO + col] = vlo;
+    }
   }
 }
 
@@ -687,20 +824,41 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a, int ng, in
   gram_stats_body<1024>(gs, ws, vs, qd, ng, kp, co, a.inv_m, tangent, a.out0, a.out1, a.mu_in, a.rstd_in, task);
 }
 
-static int sparse_row_pitch(int w, int ci) {
+static int sparse_row_pitch(int w, int ci, bool bf = false) {
   int rp = (w + 4) * ci;                       // halo pixel + row + halo pixel (+ the pixels an odd row's last half window reaches)
   if (rp < ci + 256) rp = ci + 256;            // a row store writes 4 x 64 lanes (zeros past the row)
-  while (rp % 32 != 12) ++rp;
+  // fp32 rows: pitch = 12 (mod 32) floats, the three tap rows on disjoint banks.  Split rows (8 bytes per value, ds_read_b64: 64 banks per
+  // 32-lane half): the taps of a row span 18 dwords, 2 * pitch = 20 (mod 64) dwords keeps the three rows' spans apart
+  while (rp % 32 != (bf ? 10 : 12)) ++rp;
   return rp;
 }
 // one input row = at most 4 floats per lane; 32 or 64 filters per column tile group; per-task tensors addressable by 32-bit offsets
 bool sparse_wgrad_supported(int w, int ci, int co) { return w * ci <= 256 && (ci == 1 || ci == 3) && (co == 32 || co == 64); }
-static void sparse_wgrad_grid(int n, int h, int w, int co, int tasks, int& ntiles, int& tpw, dim3& grid) {
+// The rows kernel on the split-bf16 operand form (84-wide RGB input).  -1 = follow the hidden blocks' operand form (split forms: on; fp32 pipe:
+// off -- bench.py's fp32_pipe leg and the tests' fp32_pipe parameter stay on fp32-input MFMAs throughout); MI_SPARSE_WGRAD_BF16 = 0 / 1 or
+// mi_sparse_wgrad_set_split_bf16 force it.
+static int g_sparse_bf = -2;
+static bool sparse_wgrad_bf() {
+  if (g_sparse_bf == -2) {
+    const char* e = getenv("MI_SPARSE_WGRAD_BF16");
+    g_sparse_bf = e ? (atoi(e) != 0) : -1;
+  }
+  return g_sparse_bf >= 0 ? g_sparse_bf != 0 : conv_operand_form() != 0;
+}
+extern "C" int mi_sparse_wgrad_set_split_bf16(int on) {      // on < 0: back to following the hidden blocks' form; returns the form in force before
+  const int was = sparse_wgrad_bf() ? 1 : 0;
+  g_sparse_bf = on < 0 ? -1 : (on != 0);
+  return was;
+}
+int sparse_wgrad_split_form() { return sparse_wgrad_bf() ? 1 : 0; }
+static bool sparse_rows_bf(int w, int ci) { return ci == 3 && w == 84 && sparse_wgrad_bf(); }
+static void sparse_wgrad_grid(int n, int h, int w, int co, int tasks, int& ntiles, int& tpw, dim3& grid, bool bf = false) {
   ntiles = n * (h / 2);                       // pooled rows
-  // 4 workgroups of 4 waves are resident per CU (LDS, 128 VGPRs): aim at exactly one resident set (1024 workgroups) with even shares
-  // -- a last, partly filled round of workgroups costs its full time, and so does a share one tile larger on a few SIMDs only
+  // 4 workgroups of 4 waves are resident per CU (LDS, 128 VGPRs; the split form: 2, its rows take twice the LDS): aim at exactly one resident
+  // set (1024 / 512 workgroups) with even shares -- a last, partly filled round of workgroups costs its full time, and so does a share one
+  // tile larger on a few SIMDs only
   const long col_tiles = (long)tasks * (co / 32);
-  long nblk = 1024 / col_tiles;
+  long nblk = (bf ? 512 : 1024) / col_tiles;
   if (nblk < 1) nblk = 1;
   if (nblk > ceil_div(ntiles, 4)) nblk = ceil_div(ntiles, 4);       // at least one tile per wave
   tpw = ceil_div(ceil_div(ntiles, (int)nblk), 4);
@@ -709,33 +867,56 @@ static void sparse_wgrad_grid(int n, int h, int w, int co, int tasks, int& ntile
 int sparse_wgrad_blocks_per_task(int n, int h, int w, int co, int tasks) {
   int ntiles, tpw;
   dim3 grid;
-  sparse_wgrad_grid(n, h, w, co, tasks, ntiles, tpw, grid);
-  return (int)grid.x;
+  sparse_wgrad_grid(n, h, w, co, tasks, ntiles, tpw, grid, false);      // (sizes the partial buffers: the larger of the two forms' needs)
+  const int fp32_blocks = (int)grid.x;
+  sparse_wgrad_grid(n, h, w, co, tasks, ntiles, tpw, grid, true);
+  return fp32_blocks > 2 * (int)grid.x ? fp32_blocks : 2 * (int)grid.x;
+}
+static hipError_t sparse_dynamic_lds(const void* k, size_t lds, unsigned* done_mask) {     // (conv_mfma.hip's ensure_dynamic_lds: once per kernel and device)
+  if (lds <= 64 * 1024) return hipSuccess;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  const unsigned bit = 1u << (dev & 31);
+  if (*done_mask & bit) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+  *done_mask |= bit;
+  return hipSuccess;
+}
+template <bool TAN, int CO>
+static hipError_t launch_sparse_rows_bf(hipStream_t st, dim3 grid, size_t smem, const SparseWgArgs& a) {
+  auto k = sparse_wgrad_rows_kernel<3, TAN, CO, 3, 7, true>;
+  static unsigned attr_done = 0;
+  if (hipError_t e = sparse_dynamic_lds(reinterpret_cast<const void*>(k), smem, &attr_done); e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);
+  return hipGetLastError();
 }
 template <int CI, bool TAN>
-static void launch_sparse_t(hipStream_t st, dim3 grid, size_t smem, const SparseWgArgs& a, bool rows) {
+static hipError_t launch_sparse_t(hipStream_t st, dim3 grid, size_t smem, const SparseWgArgs& a, bool rows, bool bf) {
+  if (CI == 3 && rows && bf) return a.co == 32 ? launch_sparse_rows_bf<TAN, 32>(st, grid, smem, a) : launch_sparse_rows_bf<TAN, 64>(st, grid, smem, a);
   if (CI == 3 && rows && a.co == 32) hipLaunchKernelGGL((sparse_wgrad_rows_kernel<3, TAN, 32, 3, 7>), grid, dim3(256), smem, st, a);
   else if (CI == 3 && rows) hipLaunchKernelGGL((sparse_wgrad_rows_kernel<3, TAN, 64, 3, 7>), grid, dim3(256), smem, st, a);
   else if (a.co == 32) hipLaunchKernelGGL((sparse_wgrad_kernel<CI, TAN, 32, 8>), grid, dim3(256), smem, st, a);
   else hipLaunchKernelGGL((sparse_wgrad_kernel<CI, TAN, 64, 8>), grid, dim3(256), smem, st, a);
+  return hipGetLastError();
 }
 hipError_t launch_sparse_wgrad(hipStream_t st, SparseWgArgs a, int tasks, int ci, int tangent, int* blocks_per_task) {
   int ntiles, tpw;
   dim3 grid;
-  sparse_wgrad_grid(a.n, a.hh, a.ww, a.co, tasks, ntiles, tpw, grid);
-  a.ntiles = ntiles;
-  a.tiles_per_wave = tpw;
-  a.row_pitch = sparse_row_pitch(a.ww, ci);
   if (!sparse_wgrad_supported(a.ww, ci, a.co)) return hipErrorInvalidValue;
   if (a.co != 32 && a.co != 64) return hipErrorInvalidValue;
-  size_t smem = (size_t)a.row_pitch * 32 * sizeof(float);          // 4 waves x 2 sets x 4 rows
-  if (smem < 4 * 1024 * sizeof(float)) smem = 4 * 1024 * sizeof(float);
-  if (blocks_per_task) *blocks_per_task = grid.x;
   const bool rows = ci == 3 && a.ww == 84;       // rows of exactly 7 chunks of 3 steps: the mini-ImageNet input
+  const bool bf = rows && sparse_rows_bf(a.ww, ci);
+  sparse_wgrad_grid(a.n, a.hh, a.ww, a.co, tasks, ntiles, tpw, grid, bf);
+  a.ntiles = ntiles;
+  a.tiles_per_wave = tpw;
+  a.row_pitch = sparse_row_pitch(a.ww, ci, bf);
+  size_t smem = (size_t)a.row_pitch * 32 * sizeof(float) * (bf ? 2 : 1);          // 4 waves x 2 sets x 4 rows
+  if (smem < 4 * 1024 * sizeof(float)) smem = 4 * 1024 * sizeof(float);
+  if (blocks_per_task) *blocks_per_task = bf ? 2 * grid.x : grid.x;        // (the split form writes every workgroup's fp64 sum as two fp32 partials)
   if (ci == 3) {
-    if (tangent) launch_sparse_t<3, true>(st, grid, smem, a, rows); else launch_sparse_t<3, false>(st, grid, smem, a, rows);
+    return tangent ? launch_sparse_t<3, true>(st, grid, smem, a, rows, bf) : launch_sparse_t<3, false>(st, grid, smem, a, rows, bf);
   } else if (ci == 1) {
-    if (tangent) launch_sparse_t<1, true>(st, grid, smem, a, rows); else launch_sparse_t<1, false>(st, grid, smem, a, rows);
+    return tangent ? launch_sparse_t<1, true>(st, grid, smem, a, rows, bf) : launch_sparse_t<1, false>(st, grid, smem, a, rows, bf);
   } else {
     return hipErrorInvalidValue;
   }

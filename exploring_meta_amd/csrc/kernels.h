@@ -81,6 +81,7 @@ hipError_t launch_pooled_reduce(hipStream_t st, const PoolRedArgs& a, int tasks,
 int conv_operand_form();   // 0 fp32 pipe, 1 split-bf16, 2 scaled fp16 planes (mi_conv_set_split_bf16)
 int conv_b16();            // which kernel runs form 1 (mi_conv_set_b16)
 int block1_split_form();   // block1.hip: mi_block1_set_split_bf16
+int sparse_wgrad_split_form();   // gram.hip: mi_sparse_wgrad_set_split_bf16 (1 = the 84-wide rows kernel on the split-bf16 form)
 hipError_t launch_conv3x3(hipStream_t st, ConvArgs a, int tasks, int nterms, int epi, int mode, int* blocks_per_task);
 hipError_t launch_wgrad3x3(hipStream_t st, WgradArgs a, int tasks, int nterms, int* nchunks_out);
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* partial, int nchunks, int nelem, int tasks, float* out, size_t ostride);

@@ -469,6 +469,13 @@ int mi_conv_set_b16(int on);
  * iteration -- but as the default it fails four frozen decision-level bars of the GPU suite, so it stays opt-in: csrc/block1.hip.)
  * Returns the form in force before the call. */
 int mi_block1_set_split_bf16(int on);
+/* Operand form of the sparse part of block 1's weight gradient on 84-wide three-channel inputs (dW1 = sum over pooling windows of the input
+ * patch at the window's argmax times the cotangent: what autograd's conv2d backward computes for ConvBlock 1, reference
+ * core_functions/vision_models.py:188-193, after max-pool and ReLU have zeroed three of every four positions).  1: split-bf16 operands on
+ * the 16-bit matrix pipe with the six partial products of an fp32 product laid out along K (csrc/gram.hip) -- fp32-equivalent, same parity
+ * bars; 0: fp32-input MFMAs.  on < 0 (default; MI_SPARSE_WGRAD_BF16 in the environment sets it): follow mi_conv_set_split_bf16 (fp32 pipe
+ * there -> fp32 here).  Returns the form in force before the call. */
+int mi_sparse_wgrad_set_split_bf16(int on);
 
 /* ANIL-TRPO (rl/anil_trpo.py:104-129, core_functions/rl.py:409-473 with anil=True): the stored old policies were adapted with
  * the body under no_grad (rl.py:381-382) while meta_surrogate_loss re-adapts clone_module(policy) with every parameter

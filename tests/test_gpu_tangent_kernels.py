@@ -4,12 +4,15 @@ restatement in oracle/kernels_ref.py on the same seeded inputs.  Includes cases 
 images): the conv kernels then run their multi-tile loop (tiles_per_wave = 11; 33 with 96 tasks), which
 the small cases never enter.  fp32 kernels vs fp64 oracle: tolerances stated per test."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 import torch
 
 from exploring_meta_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from exploring_meta_amd.utils import synthetic
 from oracle import kernels_ref as KR
 from gpu_utils import dev, ptr, stream, rel_err, max_err, report
@@ -335,6 +338,30 @@ def test_bn_tangent_fwd_bwd(lib, name, T, n, ho, wo, c, pool):
         e['rdz'] = max(e['rdz'], rel_err(rdz[t].cpu().numpy(), rz.numpy()))
     report(f'bn_tangent[{name}]', **e)
     assert e['pd'] < 1e-5 and e['rdgamma'] < 5e-6 and e['rdbeta'] < 5e-6 and e['rdz'] < 5e-6
+
+
+def test_block1_gram_wgrad_is_the_same_bits_at_every_task_count():
+    """Block 1's weight gradient on the engine's default path (input Gram matrix + sparse part + assembly) with the sparse part on the split-bf16
+    form: a task's dW1 and R{dW1} are the SAME BITS whether the task is launched alone or beside 2, 4 or 31 others, although every launch cuts a
+    task into a different number of workgroup shares.  Each pooled row's fp32 sum starts from zero in a fixed order, and everything above it --
+    the rows of a wave, the waves of a workgroup (fp64 registers / LDS), the workgroups (two fp32 partials per workgroup = its fp64 sum to 2^-48,
+    folded in fp64) -- is summed in fp64 (csrc/gram.hip).  The fp32-input form keeps an fp32 chain over each share: 1.6e-7 .. 5e-7 between task
+    counts (tools/sparse_geometry_probe.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('sparse_geometry_probe', os.path.join(REPO, 'tools', 'sparse_geometry_probe.py'))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    lb = _lib.load()
+    lb.mi_sparse_wgrad_set_split_bf16(1)
+    try:
+        ref = probe.run(lb, 1)
+        for T in (3, 5, 32):
+            got = probe.run(lb, T)
+            for name, r, g in zip(('dW', 'RdW', 'dgamma|dbeta'), ref, got):
+                assert np.array_equal(r, g), (T, name, int((r != g).sum()))
+    finally:
+        lb.mi_sparse_wgrad_set_split_bf16(-1)             # back to following the hidden convolutions' form
+
 
 
 # ---------------------------------------------------------------------------------------------------- fused block 1
