@@ -370,13 +370,16 @@ __global__ __launch_bounds__(256) void sparse_wgrad_kernel(SparseWgArgs a) {
 //
 // BF: the same product on the 16-bit matrix pipe at fp32-equivalent accuracy, with the SIX partial products of the split-bf16 operand form
 // (bf16_split.h: a b = ah bh + am bh + ah bl + al bh + ah bm + am bm up to 2^-24 |a b|) laid out along K.  A window of the pair owns the
-// eight K slots of its lane half of v_mfma_f32_32x32x16_bf16: four for one position of the window, four for the next, each position's four
-// holding A = (ah, am, ah, al).  Two instructions on the same A registers -- B = (bh, bh, bl, bh) and B = (bm, bm, 0, 0) per position, masked
-// by the position's argmax mask -- give all six products of TWO positions: the MFMA count per window is the fp32 kernel's, each an 8-pass
-// bf16 instruction where that is a 16-pass fp32 one, and, unlike the fp32 instruction, it leaves the SIMD's vector lanes to other work.
-// The A side costs nothing in the loop: the input rows are split ONCE, when they are staged into LDS, and stored as the two dwords of a
-// position's slots (P = ah | am << 16, Q = ah | al << 16; two neighbouring values = one ds_read2_b64 straight into the operand registers);
-// the B side is one split per window and channel (shared by the four positions) and three ANDs per position.
+// eight K slots of its lane half of v_mfma_f32_32x32x16_bf16.  THREE instructions per K step cover the four positions of the window:
+//   A = (ah, am, ah, al) of position 0 | of position 1,  B = (bh, bh, bl, bh) & mask 0 | & mask 1     [ah bh + am bh + ah bl + al bh]
+//   the same for positions 2 | 3 (the window's lower row),
+//   A = (ah, am) of positions 0 | 1 | 2 | 3,             B = (bm, bm) & mask 0 | 1 | 2 | 3            [ah bm + am bm]
+// -- where the fp32 form needs four 16-pass MFMAs these are three 8-pass ones, and, unlike the fp32 instruction, they leave the SIMD's
+// vector lanes to other work.  The A side costs nothing in the loop: the input rows are split ONCE, when they are staged into LDS, and
+// stored as the two dwords of a position's slots (P = ah | am << 16, Q = ah | al << 16; two neighbouring values = one ds_read2_b64 straight
+// into the operand registers, the four P alone = two ds_read2_b32); the B side is one split per window and channel (shared by the four
+// positions) and three ANDs per position.  What bounds it is the vector port (profiles/r6/mfma_dep_probe.txt: an 8-pass MFMA hides about
+// five vector instructions; this loop has ten per MFMA).
 template <int CI0, bool TAN, int CO, int CH, int NCH, bool BF = false>
 __global__ __launch_bounds__(256, BF ? 2 : 4) void sparse_wgrad_rows_kernel(SparseWgArgs a) {
   constexpr int K = 9 * CI0;
@@ -401,6 +404,9 @@ __global__ __launch_bounds__(256, BF ? 2 : 4) void sparse_wgrad_rows_kernel(Spar
   const int kdy = tap / 3 - 1, kdx = tap % 3 - 1;
   const float* arow = rows + ((kval ? (kdy + 1) * RP + (kdx + 1) * CI0 + kc : 0) + 2 * h * CI0) * EW;
   const float* arow1 = arow + RP * EW;
+  int same = 0;                                               // (BF) a zero the compiler cannot see through: the same rows through registers of their own
+  if constexpr (BF) asm volatile("" : "+v"(same));
+  const float *arow_z = arow + same, *arow1_z = arow1 + same;
   const unsigned lane_b = (unsigned)(h * CO + ch), lane_b4 = lane_b * 4u, lane_x = (unsigned)lane * 4u;
   float sA = 1.f, sB = 0.f;
   if (TAN) {
@@ -474,24 +480,24 @@ __global__ __launch_bounds__(256, BF ? 2 : 4) void sparse_wgrad_rows_kernel(Spar
     }
   };
   // (BF) the A operands of one chunk, read from LDS one chunk ahead of their MFMAs: [K step][top / bottom row of the window]
-  struct SparseA { mi_u32x4 v[CH][2]; };
+  struct SparseA { mi_u32x4 v[CH][3]; };       // per K step: (P, Q) of positions 0 | 1, of positions 2 | 3, and the four P alone
   auto fetch_a = [&](int set, int c, SparseA& A) {
     const u32x2* ac = reinterpret_cast<const u32x2*>(arow) + set * 4 * RP;
     const u32x2* ac1 = reinterpret_cast<const u32x2*>(arow1) + set * 4 * RP;
+    const unsigned* az = reinterpret_cast<const unsigned*>(arow_z) + set * 8 * RP;       // (a second read of the P dwords: LDS cycles instead of
+    const unsigned* az1 = reinterpret_cast<const unsigned*>(arow1_z) + set * 8 * RP;     //  four register moves on the busier vector port)
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int o = 4 * (c * CH + i) * CI0;
       const u32x2 a0 = ac[o], a1 = ac[o + CI0], a2 = ac1[o], a3 = ac1[o + CI0];
       A.v[i][0] = mi_u32x4{a0[0], a0[1], a1[0], a1[1]};
       A.v[i][1] = mi_u32x4{a2[0], a2[1], a3[0], a3[1]};
+      A.v[i][2] = mi_u32x4{az[2 * o], az[2 * (o + CI0)], az1[2 * o], az1[2 * (o + CI0)]};
     }
   };
   auto compute = [&](int set, int c, const SparseB& b, const SparseA& A) {
     if constexpr (BF) {
-      // One MFMA takes TWO positions of the window (the pair in a row): its A operand is (P, Q) of position q and (P, Q) of position q + 1 --
-      // two staged values CI0 apart, one ds_read2_b64 straight into the operand's register tuple, no moves -- and the six products come from
-      // two instructions on that tuple: B = (bh|bh, bl|bh) per position [ah bh + am bh + ah bl + al bh], then B = (bm|bm, 0) [ah bm + am bm],
-      // each masked by its position's argmax mask.
+      // (operand layout: the kernel's header)
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         {
@@ -505,13 +511,12 @@ __global__ __launch_bounds__(256, BF ? 2 : 4) void sparse_wgrad_rows_kernel(Spar
           const unsigned blh = __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{r2, cv}, bf16x2));
           const unsigned hot = 1u << b.ag[i];
           const unsigned m0 = (unsigned)lane_mask_bit<0>(hot), m1 = (unsigned)lane_mask_bit<1>(hot), m2 = (unsigned)lane_mask_bit<2>(hot), m3 = (unsigned)lane_mask_bit<3>(hot);
-          const bf16x8 top = __builtin_bit_cast(bf16x8, A.v[i][0]), bot = __builtin_bit_cast(bf16x8, A.v[i][1]);
+          const bf16x8 top = __builtin_bit_cast(bf16x8, A.v[i][0]), bot = __builtin_bit_cast(bf16x8, A.v[i][1]), pz = __builtin_bit_cast(bf16x8, A.v[i][2]);
           // (a tile starts from C = 0 -- an inline constant --: its fp32 sum is the same whichever wave of whichever launch geometry computes it)
           const bool first = c == 0 && i == 0;
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(top, __builtin_bit_cast(bf16x8, (mi_u32x4{bhh & m0, blh & m0, bhh & m1, blh & m1})), first ? zero16 : acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(top, __builtin_bit_cast(bf16x8, (mi_u32x4{bmm & m0, 0u, bmm & m1, 0u})), first ? zero16 : acc2, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bot, __builtin_bit_cast(bf16x8, (mi_u32x4{bhh & m2, blh & m2, bhh & m3, blh & m3})), acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bot, __builtin_bit_cast(bf16x8, (mi_u32x4{bmm & m2, 0u, bmm & m3, 0u})), acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bot, __builtin_bit_cast(bf16x8, (mi_u32x4{bhh & m2, blh & m2, bhh & m3, blh & m3})), first ? zero16 : acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pz, __builtin_bit_cast(bf16x8, (mi_u32x4{bmm & m0, bmm & m1, bmm & m2, bmm & m3})), acc, 0, 0, 0);
         }
       }
       return;
@@ -535,16 +540,14 @@ __global__ __launch_bounds__(256, BF ? 2 : 4) void sparse_wgrad_rows_kernel(Spar
   if constexpr (BF) {
     // The bf16 MFMAs of a chunk take 12 x 32 cycles where the fp32 ones took 12 x 64, and two waves share a SIMD instead of four: one chunk
     // of run-ahead no longer covers a global load.  The B operands run BD chunks ahead (buffers indexed by the chunk's place in its pooled
-    // row: the same register set for the same place in every tile), the A operands one chunk ahead out of LDS.
+    // row: the same register set for the same place in every tile).
     constexpr int BD = TAN ? 2 : 3;      // (tangent mode loads one more operand per K step: one chunk less of run-ahead keeps it inside the register file)
     SparseB bb[NCH];
-    SparseA aa[2];
     fetch_rows(tile);
     store_rows(0);
     fetch_rows(tile + 4);
 #pragma unroll
     for (int c = 0; c < BD; ++c) fetch_b(tile, c, bb[c]);
-    fetch_a(0, 0, aa[0]);
     __builtin_amdgcn_sched_barrier(0);
     while (tile < tile_end) {
 #pragma unroll
@@ -555,13 +558,12 @@ __global__ __launch_bounds__(256, BF ? 2 : 4) void sparse_wgrad_rows_kernel(Spar
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-          const int m = half * NCH + c;
           if (c + BD < NCH) fetch_b(cur_tile, c + BD, bb[c + BD]);
           else fetch_b(nxt_tile, c + BD - NCH, bb[c + BD - NCH]);
-          if (c + 1 < NCH) fetch_a(half, c + 1, aa[(m + 1) & 1]);
-          else fetch_a(half ^ 1, 0, aa[(m + 1) & 1]);      // (the next tile's rows went into the other set at the top of this half)
+          SparseA aa;                                        // (the chunk's A operands: all nine LDS reads up front; reading them a chunk ahead
+          fetch_a(half, c, aa);                              //  measured the same and costs 36 registers this kernel does not have)
           __builtin_amdgcn_sched_barrier(0);
-          if (cur_tile < tile_end) compute(half, c, bb[c], aa[m & 1]);
+          if (cur_tile < tile_end) compute(half, c, bb[c], aa);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (cur_tile < tile_end) {
