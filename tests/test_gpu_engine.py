@@ -261,14 +261,14 @@ def test_fused_last_block_matches_the_separate_launches(ways, shots, K, fo, task
 
 
 # K = 2 is an ENVELOPE of rounding chaos, not a precision check: the two sides run the same arithmetic in launches of different geometry, the only
-# differences at the first inner step are 5e-7 in block 2's weight gradient and 3e-7 in block 3's dgamma (tools/geometry_noise_probe.py: every
-# other entry of the step-0 gradient is bit-identical between a 3-task and a 5-task call), and two second-order steps at lr 0.4 turn the pooling /
-# ReLU decisions those tip into 3e-4 .. 3e-3 of the meta-gradient -- which decisions tip is a draw that any change of rounding anywhere re-rolls.
-# Round 5: 1.1e-3 (fp32 pipe), 3e-4 .. 7e-4 (split forms), bar 2e-3.  Round 6, block 1's sparse weight gradient on the split-bf16 form (its own
-# contribution to the difference went to exactly zero: test_block1_gram_wgrad_is_the_same_bits_at_every_task_count): 2.9e-3 / 1.0e-3 / 4e-5 / 1.1e-3
-# for split_bf16 / split_f16 / split_bf16_16x16 / fp32_pipe -- the bar moved to 5e-3.  The K = 1 case (no amplification) keeps 1e-4, and what carries
-# parity at K > 1 is the teacher-forced per-step test of tests/test_gpu_full_size.py, whose bars did not move.
-@pytest.mark.parametrize('K,grad_bar', [(1, 1e-4), (2, 5e-3)])
+# difference at the first inner step is 5e-7 in block 2's weight gradient (tools/geometry_noise_probe.py: every other entry of the step-0 gradient
+# is bit-identical between a 3-task and a 5-task call -- block 1's since round 6: test_block1_gram_wgrad_is_the_same_bits_at_every_task_count), and
+# two second-order steps at lr 0.4 turn the pooling / ReLU decisions that tips into up to ~3e-3 of the meta-gradient -- which decisions tip is a
+# draw that any change of rounding anywhere re-rolls.  Round 5: 1.1e-3 (fp32 pipe), 3e-4 .. 7e-4 (split forms).  Round 6 (block 1's sparse weight
+# gradient on the split-bf16 form): 4.6e-6 / 1.8e-3 / 1.2e-6 / 1.1e-3 for split_f16 / split_bf16 / split_bf16_16x16 / fp32_pipe at HEAD; an
+# intermediate form of that kernel (same accuracy, another summation order) drew 2.9e-3 for split_bf16.  The bar is round 5's.  The K = 1 case
+# (no amplification) keeps 1e-4, and what carries parity at K > 1 is the teacher-forced per-step test of tests/test_gpu_full_size.py.
+@pytest.mark.parametrize('K,grad_bar', [(1, 1e-4), (2, 2e-3)])
 def test_train_and_validation_tasks_in_one_call(conv_form, K, grad_bar):
     """mi_meta_batch_maml_tv (reference maml_vision.py:102-124): 3 train + 2 validation tasks through the same launches against the
     two separate calls -- per-task losses / accuracies / logits of both halves, and the meta-gradient summed over the train tasks only.
