@@ -26,6 +26,11 @@ struct Layer {
   size_t off_gamma, off_beta, off_w, off_b;
 };
 
+// Round 6: the query pass's block 1 through a Gram matrix of the QUERY images too (statistics as quadratic forms, weight gradient as sparse
+// part + assembly) instead of the two conv-recompute kernels (0.14 + 0.44 ms per cfg2 iteration): the fp64 Gram launch (0.23 ms) runs on the side
+// stream beside the inner loop.  cfg2 15.84 -> 15.60 ms in alternating pairs (on the caller's stream: 15.71); rounds 2 - 5 had measured no gain
+// from it -- the sparse weight gradient was slower then and the Gram launch sat on the critical path (profiles/r6/ab_gram_query.txt).
+static int gram_query_env() { static const int v = getenv("MI_GRAM_QUERY") ? atoi(getenv("MI_GRAM_QUERY")) : 2; return v; }      // 0: off; 1: on the caller's stream; 2 (default): on the side stream, beside the inner loop
 static bool fork_once_env() { static const bool v = getenv("MI_FORK_ONCE") && atoi(getenv("MI_FORK_ONCE")) != 0; return v; }
 struct mi_engine {
   mi_model_desc d;
@@ -36,6 +41,7 @@ struct mi_engine {
   size_t PS;  // per-task stride of parameter-shaped buffers (P padded so every task's vectors stay 16-B aligned)
   int32_t* perm_dev;
   bool fuse1 = false;   // block 1 runs through the conv-recompute kernels of block1.hip
+  bool gramq = true;    // ... of the QUERY images too (round 6; the backward half's query pass: statistics + weight gradient of block 1)
   bool gram1 = true;    // ... with the statistics of repeated passes from the input Gram matrix (gram.hip) and the BN-backward
                         // reductions from zhat stored at the pooling argmax, instead of further conv-recompute passes
   // Weight gradients of blocks >= 2 run on a side stream: they depend only on dz_l and the block input, nothing downstream of
@@ -249,6 +255,7 @@ extern "C" int mi_engine_set_fused_block1(mi_engine* e, int on) {
   if (!e) return MI_ERR_ARG;
   e->fuse1 = on && block1_supported(e->L[0].ci, e->L[0].stride, e->L[0].pool, e->L[0].ho, e->L[0].wo, e->L[0].co);
   e->gram1 = on != 2;      // 2 = fused kernels, statistics by conv-recompute passes (no Gram matrix)
+  e->gramq = on != 3;      // 3 = the Gram matrix for the support passes only (the query pass by conv-recompute kernels: rounds 2 - 5)
   return MI_OK;
 }
 
@@ -413,6 +420,7 @@ struct Plan {
   float* wgpart_side;   // partials of the weight gradients that run on the side stream
   float* wgpart_l[8];   // fused tail: one partial buffer per block (the folds wait for the pass's advance launch)
   double *gram_part, *gram_s;   // input Gram matrix of the support images (block 1 statistics), or nullptr
+  double *gram_q, *gram_part_q;   // ... of the query images (experiment: MI_GRAM_QUERY), or nullptr
   int half = 0;                 // stream context (engine SideCtx) this plan's side work uses
   float *tmp_loss, *tmp_acc;
   float* hscr;   // head scratch: R{dl} [T][n][ways], row loss [T][n], row hit [T][n]
@@ -522,10 +530,14 @@ static void make_plan(const mi_engine* e, void* ws, int T, int ns, int nq, int K
     if (l == 0 && e->fuse1) { pl.wgpart_l[0] = pl.wgpart; continue; }     // block 1's sparse partials: consumed inside the same advance launch
     pl.wgpart_l[l] = b.take<float>(wgrad_partial_floats(geom(e->L[l], nmax), T));
   }
-  pl.gram_part = pl.gram_s = nullptr;
+  pl.gram_part = pl.gram_s = pl.gram_q = pl.gram_part_q = nullptr;
   if (e->fuse1 && e->gram1 && gram_supported(e->L[0].w, e->L[0].ci) && (K >= 2 || (K >= 1 && second_order))) {   // the support set is swept at least twice
     pl.gram_part = b.take<double>(gram_partial_doubles(T, ns, e->L[0].h, e->L[0].ci));
     pl.gram_s = b.take<double>(gram_doubles(T, e->L[0].ci));
+    if (e->gramq && gram_query_env() && nq == ns) {
+      pl.gram_q = b.take<double>(gram_doubles(T, e->L[0].ci));
+      pl.gram_part_q = b.take<double>(gram_partial_doubles(T, nq, e->L[0].h, e->L[0].ci));
+    }
   }
   if (second_order && K > 0) {
     TanSet& X = pl.tan;
@@ -1242,6 +1254,13 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   LAUNCH(e, st, OP_MISC, 1, launch_gather_params(st, theta, 0, e->perm_dev, (int)e->P, (int)e->PS, T, pl.theta));
   if (pl.gram_s)
     LAUNCH(e, st, OP_GRAM, 0, launch_input_gram(st, pl.xs, T, ns, e->L[0].h, e->L[0].w, e->L[0].ci, pl.gram_part, pl.gram_s));
+  const double* gq = pl.gram_q;          // (also for forward-only calls and tasks: the same query forward whether or not a backward half follows)
+  bool gq_side = false;
+  if (gq && gram_query_env() == 2 && e->overlap) {   // the query images' Gram matrix beside the inner loop
+    hipStream_t ws = side_fork(e, st, pl.half);
+    gq_side = ws != st;
+    LAUNCH(e, ws, OP_GRAM, 0, launch_input_gram(ws, pl.xq, T, nq, e->L[0].h, e->L[0].w, e->L[0].ci, pl.gram_part_q, pl.gram_q));
+  }
   const bool stats0 = tail && pl.gram_s && K > 0;
   if (stats0) {   // block 1's statistics of the first support pass, from theta_0 (nothing folded, nothing written)
     AdvanceArgs a0 = advance_base(e, pl.theta);
@@ -1270,7 +1289,9 @@ static int meta_batch_maml_impl(mi_engine* e, void* stream, const float* theta, 
   }
   float* thK = pl.theta + (size_t)K * TP;
   AdvanceArgs advq = advance_base(e, pl.lam);
-  int rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, nq, T, thK, pl.lam, loss_out, acc_out, logits_out, with_grad != 0, nullptr,
+  if (gq && gq_side) { const int jrc = side_join(e, st, pl.half, true); if (jrc) return jrc; }
+  else if (gq) LAUNCH(e, st, OP_GRAM, 0, launch_input_gram(st, pl.xq, T, nq, e->L[0].h, e->L[0].w, e->L[0].ci, pl.gram_part_q, pl.gram_q));
+  int rc = pass_fwd_bwd(e, st, pl, pl.qry, pl.xq, pl.yq, nq, T, thK, pl.lam, loss_out, acc_out, logits_out, with_grad != 0, gq,
                         (tail && with_grad) ? &advq : nullptr, false, Tg);
   if (rc) return rc;
   if (!with_grad) return MI_OK;
@@ -1483,7 +1504,7 @@ static int meta_batch_entry(MetaBatchFn fn, int which, mi_engine* e, void* strea
       (unsigned long long)shots, (unsigned long long)adapt_steps, (unsigned long long)lr_bits, (unsigned long long)second_order,
       (unsigned long long)with_grad, (unsigned long long)(uintptr_t)loss_out, (unsigned long long)(uintptr_t)acc_out,
       (unsigned long long)(uintptr_t)meta_grad_out, (unsigned long long)(uintptr_t)logits_out, (unsigned long long)(uintptr_t)workspace,
-      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 64ull * e->fork_once + 128ull * e->fuse_last + 256ull * kernel_selection_key()};
+      (unsigned long long)workspace_bytes, (unsigned long long)e->fuse1 + 2ull * e->gram1 + (1ull << 40) * e->gramq + 4ull * e->overlap + 8ull * e->fuse_fin + 16ull * e->fuse_b1red + 32ull * e->fuse_tail + 64ull * e->fork_once + 128ull * e->fuse_last + 256ull * kernel_selection_key()};
   mi_engine::GraphEntry* ent = nullptr;
   for (auto& g : e->graphs)
     if (g.key == key) { ent = &g; break; }

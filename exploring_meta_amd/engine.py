@@ -126,7 +126,8 @@ class MetaEngine:
             self._h = C.c_void_p()
 
     def set_fused_block1(self, on):
-        """Ablation/test switch for the conv-recompute kernels of block 1."""
+        """Ablation/test switch for the conv-recompute kernels of block 1: 0 generic kernels, 1 (default) fused kernels with the Gram-matrix path for
+        the support passes and the query pass, 2 fused kernels without it, 3 the Gram-matrix path for the support passes only."""
         _lib.check(self.lib.mi_engine_set_fused_block1(self._h, int(on)), self._h)
 
     def set_overlap(self, on):

@@ -52,7 +52,9 @@ const char* mi_version(void);
 /* Ablation/test switch: 0 = block 1 through the generic (z-storing) kernels, 1 = fused conv-recompute kernels (default when
  * the geometry allows: Ci in {1,3}, stride-1 conv + pooling, even H/W) with the BatchNorm statistics of repeated support
  * passes taken from the input Gram matrix (mi_input_gram) and the BatchNorm-backward reductions from zhat kept at the pooling
- * argmax, 2 = fused kernels only: every statistic / reduction by a conv-recompute pass. */
+ * argmax, 2 = fused kernels only: every statistic / reduction by a conv-recompute pass.  Since round 6 mode 1 also takes the QUERY pass of a
+ * call with a backward half through a Gram matrix of the query images (formed on the engine's side stream beside the inner loop); 3 = as 1 with
+ * the Gram matrix for the support passes only (the behaviour of rounds 2 - 5: the query pass by conv-recompute kernels). */
 int mi_engine_set_fused_block1(mi_engine* e, int on);
 
 /* 1 (default): the weight gradients of blocks >= 2 run on an engine-owned side stream, forked from the caller's stream once

@@ -526,15 +526,15 @@ def test_fused_block1_odd_pooled_width_rectangular_inputs():
     data = torch.from_numpy(synthetic.hash_uniform(9, (T, 2 * ways * shots, 3, 36, 42)) * 255.0).float().cuda()
     labels = torch.from_numpy(np.stack([synthetic.task_labels(ways, shots)] * T)).cuda()
     outs = []
-    for mode in (1, 2, 0):
+    for mode in (1, 2, 0, 3):        # (3: the Gram matrix for the support passes only -- mode 1 also takes the query pass through one)
         eng = MetaEngine(mspec)
         eng.set_fused_block1(mode)
         loss, acc, grad, _ = eng.meta_batch(theta, data, labels, shots, 2, 0.02, first_order=False)
         torch.cuda.synchronize()
         outs.append((loss.cpu().numpy(), acc.cpu().numpy(), grad.cpu().numpy()))
-    e1, e2 = rel_err(outs[0][2], outs[2][2]), rel_err(outs[1][2], outs[2][2])
-    report('fused_block1_36x42', grad_rel_gram=e1, grad_rel_recompute=e2, loss=[float(x) for x in outs[0][0]])
+    e1, e2, e3 = rel_err(outs[0][2], outs[2][2]), rel_err(outs[1][2], outs[2][2]), rel_err(outs[3][2], outs[2][2])
+    report('fused_block1_36x42', grad_rel_gram=e1, grad_rel_recompute=e2, grad_rel_gram_support_only=e3, loss=[float(x) for x in outs[0][0]])
     assert np.isfinite(outs[0][2]).all() and np.abs(outs[0][2]).sum() > 0
-    for o in outs[:2]:
+    for o in (outs[0], outs[1], outs[3]):
         assert np.allclose(o[0], outs[2][0], rtol=2e-5)
-    assert e1 < 1e-4 and e2 < 1e-4
+    assert e1 < 1e-4 and e2 < 1e-4 and e3 < 1e-4
