@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a few-task meta-iteration spends its time ("if it cannot be done, commit the trace that shows the remaining floor").
 Reads a `rocprofv3 --kernel-trace` of tools/t_sweep.py at one task count and reports, per meta-iteration (iterations are delimited by the
-one input_gram launch each of them starts with): launches, wall span, time with at least one kernel running, idle time between kernels, the
+one prepare_batch launch each of them starts with): launches, wall span, time with at least one kernel running, idle time between kernels, the
 distribution of kernel durations, and the kernels by total time.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/t_sweep.py --workload cfg2 --tasks 4 --steps 6
@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('trace')
     ap.add_argument('--tasks', type=int, default=0)
-    ap.add_argument('--mark', default='input_gram_kernel', help='a kernel launched exactly once per meta-iteration, at its start')
+    ap.add_argument('--mark', default='prepare_batch_kernel', help='a kernel launched exactly once per meta-iteration, at its start')
     a = ap.parse_args()
     path = a.trace if os.path.isfile(a.trace) else sorted(glob.glob(os.path.join(a.trace, '**', '*kernel_trace.csv'), recursive=True))[0]
     rows = []
