@@ -565,27 +565,23 @@ __global__ __launch_bounds__(256) void block1_fwd_kernel(B1Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Operand form of the two lean forward kernels' conv1 (three-channel inputs): 0 (default) = the fp32 matrix pipe, bit-identical to the
-// general block-1 kernel; 1 = split bf16, eight products (mi_block1_set_split_bf16 / MI_B1_BF16X3=1).  Measured on one box at cfg2's
-// size: bn_relu_pool_fwd 0.156 -> 0.139 ms, bn_tangent_fwd 0.147 -> 0.133 ms per launch, the meta-iteration within the run-to-run
-// spread either way (16.45 / 16.36 and 16.60 / 16.79 ms in two A/B pairs: the workload sits at the socket power cap) -- and every change
-// of conv1's rounding redraws which near-tied pooling decisions flip: tools/accuracy_parity.py (6400 predictions) reads 0.016 % from the
-// reference's fp64 accuracy with the fp32 pipe and 0.203 % with this form (profiles/r4/accuracy_parity_cfg2*.md).  Default: the fp32 pipe
-// for the forward kernel, the split form for the tangent-forward kernel (2), which decides nothing: off the power cap (the hidden blocks
-// on the fp16 form) that is 14.95 -> 14.75 .. 14.90 ms per cfg2 iteration on one box, both kernels split 14.66.
-// 2 = the tangent-forward kernel only: it takes no decisions (the argmax is the stored one), so its rounding redraws nothing.
-// Round 6: the 0.203 % was a draw of near-ties, not a property of the form.  Over 1024 tasks (25,600 predictions, paired per task, 95 % intervals;
-// profiles/r6/accuracy_parity_cfg2_1024tasks_b1forms.md): form 2 - fp64 = +0.055 +- 0.144 points, form 1 - fp64 = +0.113 +- 0.136, form 1 - form 2 =
-// +0.059 +- 0.163, the reference's own fp32 - fp64 = -0.023 +- 0.172 -- no form is distinguishable from fp64, and every interval is as wide as
-// north_star's +-0.2 % bar itself.  The forward kernel on the split form is -0.6 % per cfg2 iteration in alternating pairs (16.42 / 16.39 ->
-// 16.29 / 16.33 ms, profiles/r6/ab_b1_form.txt).  It still stays OPT-IN: as the default it fails four frozen decision-level bars of the GPU
-// suite (profiles/r6/gpu_tests_b1_form1_default.txt: the teacher-forced per-step bar ADJ_H 2e-5 reads 1.2e-4, cfg4's batched-vs-one-task
-// gradient 1.4e-2 without a near-tied decision below TAU to explain it, the K = 2 train + validation bar 2e-3 reads 2.9e-3) -- its rounding
-// moves decisions whose fp32 margins are above the 3e-6 the tests accept as ties, and those bars are not negotiable for 0.6 %.
+// Operand form of the two lean forward kernels' conv1 (three-channel inputs): 0 = the fp32 matrix pipe, bit-identical to the general block-1
+// kernel; 1 = split bf16, eight products, in both kernels (mi_block1_set_split_bf16 / MI_B1_BF16X3=1); 2 = in the tangent-forward kernel only (it
+// takes no decisions: the argmax is the stored one, so its rounding redraws nothing).
+// History of the default.  Rounds 4 - 5: 2 -- form 1 read 0.203 % from the reference's fp64 accuracy over 256 tasks (bar 0.2 %).  Round 6 found that
+// figure to be a draw of near-ties: over 1024 tasks (25,600 predictions, paired, 95 % intervals; profiles/r6/accuracy_parity_cfg2_1024tasks_b1forms.md)
+// form 2 - fp64 = +0.055 +- 0.144 points, form 1 - fp64 = +0.113 +- 0.136, the reference's own fp32 - fp64 = -0.023 +- 0.172.  Yet as the default form 1
+// failed four frozen decision-level bars (profiles/r6/gpu_tests_b1_form1_default.txt) -- and the cause was not its accuracy: the QUERY pass ran its
+// backward through the general kernel, which recomputes conv1 on the fp32 pipe and RE-DERIVES the pooling / ReLU decisions, so a forward on another
+// form disagreed with its own backward wherever the two roundings fell on different sides of a tie.  Since the query pass takes the Gram-matrix path
+// (csrc/engine.hip: every later kernel reads the decisions the forward STORED), form 1 is the default wherever a pass has that path -- the whole GPU
+// suite passes with it (569 tests), cfg2 15.69 -> 15.51 ms, cfg3 6.44 -> 6.32 ms in alternating pairs (profiles/r6/ab_b1_form_v2.txt) -- and B1Args::
+// fwd_fp32 keeps the forward on the fp32 pipe for the passes whose backward still recomputes (no Gram matrix: one-step first-order calls, the step-wise
+// learner, mi_engine_set_fused_block1(e, 2 / 3)).
 // Unless set explicitly (environment / mi_block1_set_split_bf16(0..2)) the form is MI_B1_DEFAULT_SPLIT with the hidden convolutions on a split
-// form and 2 with those on the fp32 pipe (a build with -DMI_B1_DEFAULT_SPLIT=1 keeps the "fp32 pipe" legs of bench.py and of the tests on form 2).
+// form and 2 with those on the fp32 pipe (the "fp32 pipe" legs of bench.py and of the tests stay on fp32-input MFMAs in the forward kernel).
 #ifndef MI_B1_DEFAULT_SPLIT
-#define MI_B1_DEFAULT_SPLIT 2
+#define MI_B1_DEFAULT_SPLIT 1
 #endif
 static int g_b1_split = -1;      // -1: not set explicitly
 static bool g_b1_env_read = false;
@@ -648,7 +644,7 @@ hipError_t launch_block1(hipStream_t st, B1Args a, int tasks, int ci, int mode, 
   const size_t x_task_bytes = (size_t)a.n * a.hh * a.ww * ci * 4, p_task_bytes = (size_t)a.n * (a.hh / 2) * (a.ww / 2) * a.co * 4;
   if (!force_general && (mode == B1_FWD || mode == B1_TFWD_ARG) && x_task_bytes < (1u << 24) && p_task_bytes < MI_OOB) {
     const int b1s = block1_split_bf16();
-    if (ci == 3 && (b1s == 1 || (b1s == 2 && mode == B1_TFWD_ARG))) {
+    if (ci == 3 && ((b1s == 1 && !(mode == B1_FWD && a.fwd_fp32)) || (b1s == 2 && mode == B1_TFWD_ARG))) {
       if (mode == B1_FWD) hipLaunchKernelGGL((block1_fwd_kernel<3, false, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((block1_fwd_kernel<3, true, true>), grid, dim3(256), 0, st, a);
     } else if (ci == 3) {

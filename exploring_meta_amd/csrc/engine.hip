@@ -697,6 +697,9 @@ static int trunk_forward(mi_engine* e, hipStream_t st, Plan& pl, ActSet& A, cons
       ba.zh_out = A.zhm;
       ba.arg_out = A.arg0;
       ba.amax_out = cell_bind(e, pl, ba.out);
+      // Without the Gram path this pass's backward (or tangent) kernels recompute conv1 on the fp32 pipe and re-derive the pooling / ReLU decisions
+      // from it: the forward must then round the same way.  With it every later kernel reads the decisions this launch stores.
+      ba.fwd_fp32 = (gram && A.arg0) ? 0 : 1;
       LAUNCH(e, st, OP_BN_FWD, 0, launch_block1(st, ba, T, L.ci, B1_FWD, nullptr));
       continue;
     }

@@ -122,6 +122,8 @@ struct B1Args {
   int n, hh, ww, co;         // images per task, conv output height / width (= input, stride 1), filters
   float inv_m;
   int ntiles, tiles_per_wave;
+  int fwd_fp32;              // FWD: keep conv1 on the fp32 pipe whatever the block-1 form (the pass's backward will RE-DERIVE the pooling / ReLU decisions with the
+                             // general kernel's fp32 conv instead of reading the stored argmax: the two must round alike)
 };
 enum { B1_STATS = 0, B1_FWD = 1, B1_BWD_REDUCE = 2, B1_BWD_WGRAD = 3, B1_TSTATS = 4, B1_TFWD = 5, B1_TBWD_REDUCE = 6, B1_TBWD_WGRAD = 7,
        B1_TFWD_ARG = 8, B1_FORCE_GENERAL = 0x100 };   // tangent forward from the stored argmax / zhat: one conv (with the direction's weights) instead of two

@@ -466,9 +466,12 @@ int mi_conv_set_b16(int on);
  * eight products down to 2^-24 (raw-pixel inputs: the six-product form of the hidden blocks is measurably noisier here) and the
  * BatchNorm normalisation folded into the product.  2: the split form in the tangent-forward kernel only -- it takes no pooling / ReLU
  * decisions (the argmax is the forward pass's stored one), so its rounding cannot re-route anything; the forward kernel stays on the fp32 pipe.
- * Default (on < 0, or never set; MI_B1_BF16X3 in the environment sets it): 2.  (Round 6: post-adaptation accuracy over 1024 tasks cannot tell
- * forms 1 and 2 from fp64 or from each other, profiles/r6/accuracy_parity_cfg2_1024tasks_b1forms.md, and form 1 is 0.6 % faster per cfg2
- * iteration -- but as the default it fails four frozen decision-level bars of the GPU suite, so it stays opt-in: csrc/block1.hip.)
+ * Default (on < 0, or never set; MI_B1_BF16X3 in the environment sets it): 1 since round 6, in every pass whose later kernels read the pooling /
+ * ReLU decisions the forward stored (the Gram-matrix path of block 1: support passes and, since round 6, the query pass); passes whose backward
+ * recomputes conv1 on the fp32 pipe and re-derives the decisions keep the forward on the fp32 pipe, so the two always agree.  (Rounds 4 - 5: 2.
+ * Post-adaptation accuracy over 1024 tasks cannot tell forms 1 and 2 from fp64 or from each other,
+ * profiles/r6/accuracy_parity_cfg2_1024tasks_b1forms.md; form 1 failed decision-level bars only while the query pass's backward re-derived its
+ * decisions: csrc/block1.hip.)  With the hidden blocks on the fp32 pipe (mi_conv_set_split_bf16(0)) the default is 2.
  * Returns the form in force before the call. */
 int mi_block1_set_split_bf16(int on);
 /* Operand form of the sparse part of block 1's weight gradient on 84-wide three-channel inputs (dW1 = sum over pooling windows of the input
