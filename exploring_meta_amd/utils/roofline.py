@@ -32,6 +32,10 @@ def mfma_peak(spec, op, layer, form=1):
     if form and same and ci == 64 and (op in ('conv_fwd_stats', 'dgrad') or (op in SPLIT_BF16_WGRAD_OPS and w >= 16)):
         # one-term forward / dgrad (two terms would need 216 / 144 KB of weight planes); weight gradients as at 32 filters
         return split
+    if form and layer == 0 and ci == 3 and op in ('bn_relu_pool_fwd', 'bn_tangent_fwd'):
+        # block 1's lean forward kernels (csrc/block1.hip): conv1 recomputed with EIGHT bf16 products per multiply-add (raw-pixel inputs: the two
+        # 2^-24 cross terms stay in); the tangent forward since round 4, the forward since the end of round 6
+        return BF16_PEAK_TFLOPS / 8.0, 'bf16 x8 (split operands)'
     if form and layer == 0 and op in SPLIT_BF16_WGRAD_OPS and ci == 3 and w == 84:
         # block 1's sparse weight gradient on 84-wide RGB inputs (csrc/gram.hip sparse_wgrad_rows_kernel<..., BF>): six bf16 products per
         # multiply-add laid out along K, whichever split form the hidden blocks use (round 6)

@@ -54,7 +54,7 @@ def main():
         else:
             bound = 'mfma' if fl and (fl / by) > peak * 1e12 / (PEAK_GBPS * 1e9) else 'hbm'
         if pipe != 'fp32':
-            bound += ' fp16x3' if 'fp16' in pipe else ' bf16x6'
+            bound += ' fp16x3' if 'fp16' in pipe else (' bf16x8' if 'x8' in pipe else ' bf16x6')
         tfs = f'{tf:.1f} ({tf / peak * 100:.0f} %)' if fl else '-'
         print(f'| {op} | {l + 1} | {n} | {avg:.4f} | {share * 100:.1f} % | {fl / 1e9:.2f} | {by / 1e6:.1f} | '
               f'{tfs} | {gb:.0f} ({gb / PEAK_GBPS * 100:.0f} %) | {bound} |')
