@@ -302,6 +302,36 @@ def test_train_and_validation_tasks_in_one_call(conv_form, K, grad_bar):
         eng.meta_batch(theta, d, l, shots, K, lr, grad_tasks=6)
 
 
+def test_block1_forward_form_follows_who_takes_the_decisions():
+    """Block 1's forward kernel runs conv1 on the split-bf16 form only in passes whose later kernels READ the pooling / ReLU decisions it stores (the
+    Gram-matrix path); where the backward recomputes conv1 on the fp32 pipe and re-derives them, the forward stays on the fp32 pipe (B1Args::fwd_fp32).
+    A one-step FIRST-order call has no Gram matrix (the support set is swept once): forms 1 and 2 must then give the same bits.  With two steps the Gram
+    path is on and the two forms differ (by rounding only: the mode tests hold them to the generic kernels)."""
+    from exploring_meta_amd import _lib
+    lb = _lib.load()
+    spec, mspec = _spec('min', 5)
+    theta = R.flatten_params(model_params(spec, 11)).float().cuda().contiguous()
+    data, labels = synthetic.make_meta_batch('min', [2, 3, 4], 5, 1)
+    d, l = torch.from_numpy(data).cuda().contiguous(), torch.from_numpy(labels).cuda().contiguous()
+    outs = {}
+    try:
+        for K in (1, 2):
+            for form in (1, 2):
+                lb.mi_block1_set_split_bf16(form)
+                eng = MetaEngine(mspec)
+                loss, acc, grad, logits = eng.meta_batch(theta, d, l, 1, K, 0.1, first_order=True, return_logits=True)
+                torch.cuda.synchronize()
+                outs[(K, form)] = (loss.cpu().numpy(), grad.cpu().numpy(), logits.cpu().numpy())
+    finally:
+        lb.mi_block1_set_split_bf16(-1)
+    for a, b in zip(outs[(1, 1)], outs[(1, 2)]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(outs[(2, 1)][1], outs[(2, 2)][1])
+    # (1-shot tasks: five support images, so the handful of near-tied pooling decisions the two roundings settle differently re-route a visible share of
+    # the cotangent -- 1.8e-2 of the gradient and 1.8e-4 of one task's loss here)
+    assert rel_err(outs[(2, 1)][1], outs[(2, 2)][1]) < 5e-2 and np.allclose(outs[(2, 1)][0], outs[(2, 2)][0], rtol=1e-3)
+
+
 @pytest.mark.parametrize('dataset,ways,shots,K,tasks', [('min', 5, 5, 2, [3, 4, 5]), ('min', 5, 1, 1, [0, 1, 2, 3, 4, 5, 6])])
 def test_block1_reduce_in_dgrad_epilogue_matches_streaming_pass(dataset, ways, shots, K, tasks):
     """dgamma / dbeta of block 1 (and their tangents in the Hessian-vector product) summed in the epilogue of block 2's dgrad
