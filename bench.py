@@ -674,7 +674,9 @@ def arithmetic_note(eng, tasks_per_call=32):
             'note': 'fp32 tensors and fp32 accumulation throughout (fp64 for statistics and reductions).  Hidden 3x3 convolutions and weight '
                     'gradients: each fp32 operand as the EXACT sum of three bf16 pieces, six bf16 MFMA products per multiply-add, dropped '
                     'cross terms <= 2^-24 of a product (one fp32 rounding): per-kernel errors against the fp64 oracle are the same or smaller '
-                    'than with the fp32 matrix pipe (tests run both forms against the same bars); MI_CONV_BF16X3=0 selects the fp32 pipe'}
+                    'than with the fp32 matrix pipe (tests run both forms against the same bars); MI_CONV_BF16X3=0 selects the fp32 pipe.  '
+                    'Block 1 (three input channels) in the same form since round 6: conv1 of its forward / tangent-forward kernels with eight '
+                    'products (the two 2^-24 cross terms kept: raw-pixel inputs), the sparse part of its weight gradient with six'}
 
 
 def collective_record(dist, world, theta, numel, what):
